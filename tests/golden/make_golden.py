@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE model classes.
+
+Run in the authoring container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+For every case: build the reference nn.Module (src.models.dprnn.DPRNNTasNet,
+src.models.dprnn_spe.DPRNNSpeTasNet, src.models.dprnn_spe_ira.DPRNNSpeIRATasNet), load the
+numpy-recipe weights of oracle.weights.make_state with strict=True (which also pins the
+state_dict key/shape contract), run the recipe input through it on CPU in fp32 and store
+input + output (+ selected intermediates from forward hooks) as a compressed .npz.
+Weights are NOT stored: both sides regenerate them from (kind, cfg, seed).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from oracle.weights import full_cfg, make_mixture, make_state, state_spec  # noqa: E402
+from src.models.dprnn import DPRNNTasNet  # noqa: E402  (reference)
+from src.models.dprnn_spe import DPRNNSpeTasNet  # noqa: E402  (reference)
+from src.models.dprnn_spe_ira import DPRNNSpeIRATasNet  # noqa: E402  (reference)
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+CTOR_KEYS = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length",
+             "n_repeats", "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
+SPE_KEYS = CTOR_KEYS + ["O", "P", "embeddings_size", "num_spks", "fusion_type"]
+
+TINY = dict(input_size=8, feature_size=16, hidden_size=16, chunk_length=10, kernel_size=2, hop_length=5,
+            n_repeats=2)
+TINY_SPE = dict(TINY, O=16, P=24, embeddings_size=12, num_spks=7)
+WIDE = dict(input_size=64, feature_size=128, hidden_size=128, chunk_length=16, kernel_size=2, hop_length=8,
+            n_repeats=2)
+
+CASES = [
+    # name, kind, cfg overrides, batch, samples, seed, taps?, bn_training
+    ("bss_tiny_ln_sigmoid", "bss", dict(TINY), 2, 203, 0, True, False),
+    ("bss_tiny_gln_relu", "bss", dict(TINY, norm_type="gLN", activation_type="relu"), 2, 203, 1, True, False),
+    ("bss_tiny_hop3", "bss", dict(TINY, hop_length=3), 2, 131, 2, False, False),
+    ("bss_tiny_k4s2", "bss", dict(TINY, kernel_size=4), 3, 202, 3, False, False),
+    ("bss_tiny_gru_unidir", "bss", dict(TINY, rnn_type="GRU", bidirectional=False), 2, 97, 4, False, False),
+    ("bss_tiny_rnn", "bss", dict(TINY, rnn_type="RNN"), 2, 97, 5, False, False),
+    ("bss_tiny_b1", "bss", dict(TINY), 1, 64, 6, False, False),
+    ("bss_wide_small", "bss", dict(WIDE), 2, 300, 10, True, False),
+    ("bss_wide_small_gln_relu", "bss", dict(WIDE, norm_type="gLN", activation_type="relu"), 2, 300, 11, False, False),
+    ("bss_wide_b1", "bss", dict(WIDE, n_repeats=1), 1, 257, 12, False, False),
+    ("bss_wide_hop5", "bss", dict(WIDE, chunk_length=16, hop_length=5, n_repeats=1), 3, 211, 13, False, False),
+    ("bss_wide_k250", "bss", dict(WIDE, chunk_length=250, hop_length=125, n_repeats=1), 3, 2000, 14, False, False),
+    ("bss_wide_unidir", "bss", dict(WIDE, bidirectional=False, n_repeats=1), 2, 300, 15, False, False),
+    ("bss_full_b2", "bss", dict(), 2, 24000, 20, False, False),
+    ("spe_tiny_cat", "spe", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 2, 203, 30, True, False),
+    ("spe_tiny_cat_bntrain", "spe", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 3, 203, 31, False, True),
+    ("spe_tiny_add", "spe", dict(TINY_SPE, fusion_type="add", norm_type="ln"), 2, 203, 32, False, False),
+    ("spe_tiny_mul", "spe", dict(TINY_SPE, fusion_type="mul", norm_type="gLN"), 2, 203, 33, False, False),
+    ("spe_tiny_film", "spe", dict(TINY_SPE, fusion_type="film", norm_type="ln"), 2, 203, 34, False, False),
+    ("spe_tiny_att", "spe", dict(TINY_SPE, fusion_type="att", norm_type="ln"), 2, 203, 35, False, False),
+    ("spe_wide_small_cat", "spe", dict(WIDE, fusion_type="cat", norm_type="ln"), 2, 300, 40, True, False),
+    ("spe_wide_small_cat_bntrain", "spe", dict(WIDE, fusion_type="cat", norm_type="ln"), 3, 300, 41, False, True),
+    ("spe_full_b1", "spe", dict(norm_type="ln"), 1, 24000, 42, False, False),
+    ("ira_tiny_cat", "ira", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 2, 203, 50, True, False),
+    ("ira_wide_small_cat", "ira", dict(WIDE, fusion_type="cat", norm_type="ln"), 2, 300, 51, False, False),
+]
+
+
+def build(kind, cfg):
+    if kind == "bss":
+        return DPRNNTasNet(**{k: cfg[k] for k in CTOR_KEYS})
+    cls = DPRNNSpeTasNet if kind == "spe" else DPRNNSpeIRATasNet
+    return cls(**{k: cfg[k] for k in SPE_KEYS})
+
+
+def load_recipe(model, kind, cfg, seed):
+    sd = make_state(kind, cfg, seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return sd
+
+
+def main():
+    contract = {}
+    for name, kind, over, B, T, seed, want_taps, bn_train in CASES:
+        cfg = full_cfg(**over)
+        model = build(kind, cfg)
+        load_recipe(model, kind, cfg, seed)
+        model.eval()
+        if bn_train:   # the reference Inferencer never calls .eval(): BatchNorm in train mode
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.train()
+        taps = {}
+        hooks = []
+        if want_taps:
+            def tap(key):
+                return lambda mod, inp, out: taps.__setitem__(key, out.detach().numpy().copy())
+            hooks.append(model.encoder.register_forward_hook(tap("encoder")))
+            hooks.append(model.separation.bottleneck.register_forward_hook(tap("bottleneck")))
+            for i, blk in enumerate(model.separation.dprnn_blocks):
+                hooks.append(blk.register_forward_hook(tap(f"block{i}")))
+            if kind == "bss":
+                hooks.append(model.separation.register_forward_hook(tap("masks")))
+        mix = make_mixture(B, T, seed=1000 + seed)
+        save = dict(mix=mix)
+        with torch.no_grad():
+            if kind == "bss":
+                out = model(torch.from_numpy(mix))
+                save["out"] = out.numpy()
+            else:
+                aux = make_mixture(B, T, seed=2000 + seed)
+                aux_len = np.float32(T)
+                est, logits = model(torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(float(T)))
+                save.update(aux=aux, aux_len=aux_len, out=est.numpy(), logits=logits.numpy())
+        for h in hooks:
+            h.remove()
+        for k, v in taps.items():
+            save["tap_" + k] = v
+        meta = dict(name=name, kind=kind, cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
+                    bn_training=bn_train, torch=torch.__version__)
+        save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
+        print(f"{name:32s} out {tuple(save['out'].shape)} |out| {np.abs(save['out']).max():.4f}")
+
+    # state_dict key/shape contract at the shipped config, straight from the reference modules
+    for kind, fus in [("bss", "cat"), ("spe", "cat"), ("spe", "add"), ("spe", "mul"), ("spe", "film"),
+                      ("spe", "att"), ("ira", "cat")]:
+        for nt in ("ln", "gLN"):
+            cfg = full_cfg(fusion_type=fus, norm_type=nt)
+            model = build(kind, cfg)
+            ref = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+            mine = [(k, list(s)) for k, s in state_spec(kind, cfg)]
+            assert ref == mine, (kind, fus, nt, [a for a, b in zip(ref, mine) if a != b][:4])
+            contract[f"{kind}/{fus}/{nt}"] = dict(
+                keys=ref, n_params=int(sum(p.numel() for p in model.parameters())))
+    with open(os.path.join(HERE, "state_contract.json"), "w") as f:
+        json.dump(contract, f, indent=0)
+    print("contract ok:", {k: v["n_params"] for k, v in contract.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference classes
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_names, load_golden, rel_l2
+from oracle import dprnn_numpy as onp
+from oracle import dprnn_torch_cpu as otc
+from oracle.weights import full_cfg, make_mixture, make_state, state_spec
+
+TOL = 2e-6      # rel-L2 of an fp32 restatement vs the reference's fp32 CPU output
+SMALL = [n for n in golden_names() if "full" not in n and "k250" not in n]
+
+
+def _run_numpy(g, dtype=np.float32, taps=None):
+    m = g["meta"]
+    sd = make_state(m["kind"], m["cfg"], m["seed"])
+    if m["kind"] == "bss":
+        return onp.tasnet_forward(sd, m["cfg"], g["mix"], dtype, taps), None
+    fn = onp.spe_forward if m["kind"] == "spe" else onp.ira_forward
+    return fn(sd, m["cfg"], g["mix"], g["aux"], g["aux_len"], m["bn_training"], dtype, taps)
+
+
+def _run_torch(g):
+    m = g["meta"]
+    sd = otc.to_torch_state(make_state(m["kind"], m["cfg"], m["seed"]))
+    if m["kind"] == "bss":
+        return otc.tasnet_forward(sd, m["cfg"], torch.from_numpy(g["mix"])).numpy(), None
+    fn = otc.spe_forward if m["kind"] == "spe" else otc.ira_forward
+    est, logits = fn(sd, m["cfg"], torch.from_numpy(g["mix"]), torch.from_numpy(g["aux"]),
+                     torch.tensor(float(g["aux_len"])), m["bn_training"])
+    return est.numpy(), logits.numpy()
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_numpy_oracle_matches_reference(name):
+    g = load_golden(name)
+    out, logits = _run_numpy(g)
+    assert out.shape == g["out"].shape
+    assert rel_l2(out, g["out"]) < TOL
+    if logits is not None:
+        assert rel_l2(logits, g["logits"]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL if "tiny" in n])
+def test_numpy_oracle_fp64_bounds_reference_noise(name):
+    g = load_golden(name)
+    out, _ = _run_numpy(g, np.float64)
+    assert rel_l2(out, g["out"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["bss_tiny_ln_sigmoid", "bss_tiny_gln_relu", "bss_wide_small", "spe_tiny_cat",
+                                  "spe_wide_small_cat"])
+def test_numpy_oracle_intermediates(name):
+    g = load_golden(name)
+    taps = {}
+    _run_numpy(g, np.float32, taps)
+    checked = 0
+    for k in g:
+        if not k.startswith("tap_"):
+            continue
+        key = k[4:]
+        if key not in taps:
+            continue
+        assert taps[key].shape == g[k].shape, key
+        assert rel_l2(taps[key], g[k]) < TOL, key
+        checked += 1
+    assert checked >= 2
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if ("cat" in n or n.startswith("bss")) and
+                                  "gru" not in n and "rnn" not in n or n in ("bss_tiny_gru_unidir", "bss_tiny_rnn")])
+def test_torch_cpu_oracle_matches_reference(name):
+    g = load_golden(name)
+    if g["meta"]["kind"] != "bss" and g["meta"]["cfg"]["fusion_type"] != "cat":
+        pytest.skip("torch-cpu oracle restates cat fusion only")
+    out, logits = _run_torch(g)
+    assert out.shape == g["out"].shape
+    assert rel_l2(out, g["out"]) < TOL
+    if logits is not None:
+        assert rel_l2(logits, g["logits"]) < TOL
+
+
+def test_state_contract_matches_reference():
+    with open(os.path.join(GOLDEN, "state_contract.json")) as f:
+        contract = json.load(f)
+    for tag, c in contract.items():
+        kind, fus, nt = tag.split("/")
+        spec = state_spec(kind, dict(fusion_type=fus, norm_type=nt))
+        assert [(k, list(s)) for k, s in spec] == [(k, list(s)) for k, s in c["keys"]], tag
+    assert contract["bss/cat/ln"]["n_params"] == 3651073
+    assert contract["spe/cat/ln"]["n_params"] == 4038658
+    assert contract["ira/cat/ln"]["n_params"] == 4071554
+
+
+def test_recipe_is_deterministic():
+    a = make_state("bss", dict(n_repeats=1), 7)
+    b = make_state("bss", dict(n_repeats=1), 7)
+    c = make_state("bss", dict(n_repeats=1), 8)
+    k = "separation.dprnn_blocks.0.intra_rnn.rnn.weight_hh_l0"
+    assert np.array_equal(a[k], b[k]) and not np.array_equal(a[k], c[k])
+    assert np.array_equal(make_mixture(2, 50, 3), make_mixture(2, 50, 3))
+    g = load_golden("bss_tiny_b1")
+    assert np.array_equal(g["mix"], make_mixture(1, 64, 1000 + g["meta"]["seed"]))
+
+
+def test_segmentation_overlap_add_identity():
+    """OLA(seg(x)) = 2x when hop = K/2 (dprnn.py:189-217)."""
+    x = np.random.default_rng(0).standard_normal((2, 3, 101)).astype(np.float32)
+    for K, P in [(10, 5), (16, 8), (250, 125)]:
+        seg = onp.segmentation(x, K, P)
+        assert seg.shape[-1] == onp.n_chunks(101, K, P)
+        assert np.array_equal(onp.overlap_add(seg, 101, K, P), 2 * x)
