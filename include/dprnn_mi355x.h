@@ -1,0 +1,130 @@
+/*
+ * dprnn_mi355x.h -- C ABI of libdprnn_mi355x.so: the MI355X (gfx950) forward path of the DPRNN separator.
+ *
+ * The reference (Aleksashka-i/tss-with-dprnn) has no native code; its hot path is the Python
+ * nn.Module code in src/models/.  Each entry point below replaces the reference lines cited next to it
+ * (paths relative to the reference checkout).  All pointers are DEVICE pointers to contiguous fp32
+ * unless stated; `stream` is a hipStream_t passed as void*; every function is asynchronous on that
+ * stream, returns 0 on success or a negative DPRNN_E* code, and records a message for
+ * dprnn_last_error().  No torch types cross this boundary.
+ *
+ * Device-side data layout (channels-last, one layout for both DPRNN paths):
+ *   frames  Y [B][L][F]            F = feature_size (128)
+ *   slab    X [B][S][K][F]         S chunks of K frames, hop P; row (b,s,k) holds F contiguous floats.
+ *                                  intra-chunk sequences walk k, inter-chunk sequences walk s -- both
+ *                                  read whole 512-byte rows, so no transpose is ever materialised.
+ *   rnn out H [B*S*K][ndir*Hd]     same row order as X
+ *   stats     [B][2] double        (sum, sum of squares) per utterance
+ */
+#ifndef DPRNN_MI355X_H
+#define DPRNN_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPRNN_OK            0
+#define DPRNN_EINVAL       -1   /* unsupported size / null pointer */
+#define DPRNN_ELAUNCH      -2   /* HIP launch error */
+
+#define DPRNN_F   128           /* feature_size the kernels are built for (config_bss.yaml:19) */
+#define DPRNN_HD  128           /* hidden_size  (config_bss.yaml:20) */
+
+const char* dprnn_last_error(void);
+int dprnn_abi_version(void);
+/* number of compute units of the current device (grid sizing of the persistent kernels) */
+int dprnn_num_cus(void);
+/* numerics switches (process-wide): 0 = libm-accurate expf/tanhf (default), 1 = v_exp_f32/v_rcp_f32 forms */
+void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
+void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
+
+/* ---- encoder statistics: Encoder.forward (src/models/encoder_decoder.py:25-33) feeding the
+ * bottleneck norm (src/models/dprnn.py:131-136).  enc[b,n,l] = relu(sum_j We[n][j]*wav[b][l*stride+j])
+ * is never stored; this accumulates sum / sum-of-squares of enc over (n,l) into stats[b][0..1]
+ * (stats must be zeroed by the caller on the same stream). */
+int dprnn_encoder_stats(const float* wav, const float* enc_w, double* stats,
+                        int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- per-utterance affine of the bottleneck norm, folded with the 'add'/'mul'/'film' fusions
+ * (dprnn.py:131-136 GroupNorm(1,N) eps 1e-5 / norms.py:6-31 GlobLN eps 1e-8; dprnn_spe.py:194-229):
+ *   a[b,l,c] = enc[b,c,l]*sc[b][c] + sh[b][c],
+ *   sc = gamma[c]*rstd_b*mul[b][c],  sh = (beta[c]-gamma[c]*mean_b*rstd_b)*mul[b][c] + add[b][c]
+ * mul/add may be NULL (1 / 0). */
+int dprnn_bottleneck_prep(const double* stats, const float* gamma, const float* beta, float eps,
+                          const float* mul, const float* add, float* sc, float* sh,
+                          int B, int L, int N, void* stream);
+
+/* ---- bottleneck 1x1 conv on the normalised encoder output (dprnn.py:135-136,169; 'cat' fusion
+ * dprnn_spe.py:186-192 enters as the per-utterance bias row_bias[B][F], may be NULL):
+ *   Y[b][l][f] = sum_c Wb[f][c]*a[b,l,c] + bb[f] + row_bias[b][f]
+ * Wb is [F][ldw] row-major (ldw >= N: the first N input channels are used). */
+int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
+                         const float* Wb, int ldw, const float* bb, const float* row_bias, float* Y,
+                         int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- DPRNN._segmentation (dprnn.py:189-201): X[b][s][k][:] = Y[b][s*P+k-K][:] or 0 outside [0,L) */
+int dprnn_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int S, void* stream);
+
+/* ---- pack one nn.LSTM direction pair for dprnn_bilstm_fwd (SingleRNN, dprnn.py:23-28):
+ * w_ih [4H][F], w_hh [4H][H], b_ih/b_hh [4H] (gate order i,f,g,o), *_r = reverse direction or NULL.
+ * packed: ndir*4*16*8*256 floats, bsum: ndir*4H floats. */
+int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                    const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                    float* packed, float* bsum, void* stream);
+
+/* ---- SingleRNN.forward (dprnn.py:33-37) for one DPRNN path, input projection fused into the
+ * recurrence: for every sequence q < nseq and step t < T
+ *   row(q,t) = (q / inner_n)*outer_stride + (q % inner_n)*inner_stride + t*t_stride
+ * reads X row(q,t) [F], writes H row(q,t) [ndir*Hd] (fwd | bwd).  Zero initial state (dprnn.py:36).
+ * intra path (dprnn.py:84-86): nseq=B*S, T=K, inner_n=nseq, inner_stride=K, t_stride=1
+ * inter path (dprnn.py:94-95): nseq=B*K, T=S, inner_n=K, outer_stride=S*K, inner_stride=1, t_stride=K
+ * seq_tile: sequences per workgroup (16, 32, 48 or 64; 0 = choose). */
+int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
+                     int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                     int64_t t_stride, int ndir, int seq_tile, void* stream);
+
+/* ---- intra_linear / inter_linear (dprnn.py:88,96) + GroupNorm statistics (dprnn.py:90,98):
+ * Z[m][f] = sum_k W[f][k]*H[m][k] + bias[f]; stats[m / rows_per_utt] += (sum Z, sum Z^2).
+ * kdim = 256 (bidirectional) or 128.  stats zeroed by the caller. */
+int dprnn_proj_stats_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
+                         int64_t M, int64_t rows_per_utt, int kdim, void* stream);
+
+/* ---- intra_norm / inter_norm + residual (dprnn.py:90-92,98-99):
+ * Xout = X + ((Z-mean_b)*rstd_b*gamma[f] + beta[f]); count = rows_per_utt*F elements per utterance,
+ * biased variance; eps 1e-5 (ln) or 1e-8 (gLN).  Xout may alias X. */
+int dprnn_norm_residual_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                            const float* beta, float eps, float* Xout, int B, int64_t rows_per_utt,
+                            void* stream);
+
+/* ---- mask head part 1: PReLU -> Conv2d 1x1 (F -> 2F) -> overlap-add (dprnn.py:173-178,203-217),
+ * computed as conv(sum of overlapping prelu rows) + count*bias (the conv is linear):
+ * U[b][l][0:2F], channel block 0 = speaker 0 (dprnn.py:176 reshape). */
+int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W2d, const float* b2d,
+                            float* U, int B, int L, int K, int P, int S, void* stream);
+
+/* ---- mask head part 2: tanh(out conv) * sigmoid(gate conv) (dprnn.py:157-158,180) on rows
+ * (b,l,spk) of U viewed as [B*L*2][F] -> V [B*L*2][F] */
+int dprnn_head_gate_fwd(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
+                        float* V, int64_t rows, void* stream);
+
+/* ---- mask head part 3 + masking + decoder taps: end_conv1x1 (F->N, no bias) -> sigmoid|relu
+ * (dprnn.py:160-164,181-184), mask*enc (dprnn.py:277) and the per-frame decoder dot products of
+ * ConvTranspose1d (encoder_decoder.py:40-42): taps[b][spk][l][j] = sum_n Wd[n][j]*mask*enc,  j<ks.
+ * relu_act: 0 sigmoid, 1 relu.  If masked_out != NULL also stores mask*enc of speaker 0 as
+ * [B][L][N] (DPRNN-Spe-IRA d0/d1, dprnn_spe_ira.py:79-80,106-107). */
+int dprnn_head_mask_decode_fwd(const float* V, const float* Wend, const float* wav, const float* enc_w,
+                               const float* dec_w, float* taps, float* masked_out, int relu_act,
+                               int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- decoder overlap of the transposed conv (encoder_decoder.py:40-42):
+ * out[b][spk][t] = sum_{l*stride+j=t} taps[b][spk][l][j];  nspk speakers are written (2, or 1 for
+ * DPRNN-Spe which decodes speaker 0 only, dprnn_spe.py:325). */
+int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk, int T, int L, int ks, int stride,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol of include/dprnn_mi355x.h,
+the nn.Module mirrors keep the reference's state_dict contract, and the product path refuses to run
+without a HIP device (no fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, build_model
+
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import _lib, engine
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    path = pkg.library_path()
+    if not os.path.exists(path):
+        pkg.build_library()
+    return path
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "dprnn_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dprnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    names = _header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dprnn_mi355x.h but not exported"
+    assert sorted(_lib.ALL_SYMBOLS) == names, "python binding table and header disagree"
+
+
+def test_library_loads_and_reports_abi(lib_path):
+    lib = pkg.load_library()
+    assert lib.dprnn_abi_version() == 1
+    assert lib.dprnn_last_error() is not None
+
+
+def test_null_pointer_is_rejected_without_gpu(lib_path):
+    lib = pkg.load_library()
+    rc = lib.dprnn_segment_fwd(None, None, 1, 10, 4, 2, 8, None)
+    assert rc == -1 and b"null" in lib.dprnn_last_error()
+
+
+@pytest.mark.parametrize("nt", ["ln", "gLN"])
+def test_state_dict_contract_bss(nt):
+    contract = json.load(open(os.path.join(GOLDEN, "state_contract.json")))[f"bss/cat/{nt}"]
+    m = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", nt, "sigmoid", 0)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, list(s)) for k, s in contract["keys"]]
+    assert sum(p.numel() for p in m.parameters()) == contract["n_params"]
+
+
+def test_constructor_defaults_match_reference():
+    m = pkg.DPRNNTasNet(64)                      # dprnn.py:237-241 defaults
+    assert m.cfg["chunk_length"] == 200 and m.cfg["hop_length"] == 100 and m.cfg["stride"] == 1
+    assert m.cfg["norm_type"] == "ln" and m.cfg["activation_type"] == "sigmoid"
+    assert isinstance(m.separation.bottleneck[0], torch.nn.GroupNorm)
+    d = pkg.DPRNN(64)                            # dprnn.py:117-120: default norm is gLN here
+    assert hasattr(d.bottleneck[0], "gamma")
+
+
+def test_recipe_weights_load_strict():
+    model, sd, cfg = build_model("bss", dict(n_repeats=1), 3)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(sd[k])), k
+
+
+def test_cpu_input_fails_loudly():
+    model, _, _ = build_model("bss", dict(n_repeats=1), 3)
+    with pytest.raises(pkg._lib.DprnnError, match="no CPU fallback"):
+        model(torch.zeros(2, 400))
+
+
+def test_unsupported_config_fails_loudly():
+    m = pkg.DPRNNTasNet(8, 16, 16, 10, 2, 5, 1).eval()
+    with pytest.raises(NotImplementedError, match="feature_size"):
+        engine.check_supported(m.cfg)
+    m = pkg.DPRNNTasNet(64, rnn_type="GRU").eval()
+    with pytest.raises(NotImplementedError, match="GRU"):
+        engine.check_supported(m.cfg)
+
+
+def test_training_mode_is_refused_until_backward_exists():
+    m = pkg.DPRNNTasNet(64, n_repeats=1).train()
+    with pytest.raises(NotImplementedError, match="backward"):
+        m(torch.zeros(1, 300))
+
+
+def test_geometry_matches_reference_shapes():
+    g = engine.make_geometry(64, 24000, 64, 250, 125, 2, 1)
+    assert (g.L, g.S, g.T_out, g.rows) == (23999, 194, 24000, 64 * 194 * 250)
+    g = engine.make_geometry(3, 203, 64, 10, 3, 4, 2)
+    assert g.L == 100 and g.S == (100 + 10) // 3 + 1 and g.T_out == 202

@@ -1,0 +1,216 @@
+"""Stage-level GPU tests: each C-ABI entry point against the numpy oracle on seeded inputs, including
+ragged sizes (sequence counts that do not fill a tile, utterance boundaries inside a row tile)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import dprnn_numpy as onp
+from oracle.weights import make_state, full_cfg
+
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import engine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _st():
+    return engine.Stage(torch.device(DEV))
+
+
+_KEEP = []
+
+
+def _t(a):
+    """Host array -> device tensor that stays alive (its data_ptr() is handed to the C ABI)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
+
+
+def _lstm_sd(seed, bidir=True):
+    sd = make_state("bss", dict(n_repeats=1, bidirectional=bidir), seed)
+    p = "separation.dprnn_blocks.0." + ("intra_rnn" if bidir else "inter_rnn")
+    return sd, p
+
+
+@pytest.mark.parametrize("seq_tile", [16, 32, 48, 64])
+@pytest.mark.parametrize("mode", ["intra", "inter"])
+def test_bilstm_matches_oracle(seq_tile, mode):
+    B, S, K = 2, 7, 11                     # 14 / 22 sequences: never a multiple of a tile
+    rng = np.random.default_rng(seq_tile + (0 if mode == "intra" else 1))
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(42)
+    if mode == "intra":
+        seq = X.reshape(B * S, K, 128)
+    else:
+        seq = X.transpose(0, 2, 1, 3).reshape(B * K, S, 128)
+    want = onp.single_rnn(sd, p, seq, "LSTM", True)
+    want = want.reshape(B, S, K, 256) if mode == "intra" else want.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    st.call("dprnn_lstm_pack", *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    Xd = _t(X)
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    if mode == "intra":
+        st.call("dprnn_bilstm_fwd", Xd.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+                B * S, K, B * S, 0, K, 1, 2, seq_tile)
+    else:
+        st.call("dprnn_bilstm_fwd", Xd.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+                B * K, S, K, S * K, 1, K, 2, seq_tile)
+    torch.cuda.synchronize()
+    got = H.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_l2(got, want) < 2e-6
+
+
+def test_bilstm_unidirectional():
+    B, S, K = 1, 5, 9
+    X = np.random.default_rng(3).standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(7, bidir=False)
+    want = onp.single_rnn(sd, p, X.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", False)
+    want = want.reshape(B, K, S, 128).transpose(0, 2, 1, 3)
+    st = _st()
+    packed = torch.empty(engine.PACK_PER_DIR, device=DEV)
+    bsum = torch.empty(512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names]
+    st.call("dprnn_lstm_pack", *[t.data_ptr() for t in w], 0, 0, 0, 0, packed.data_ptr(), bsum.data_ptr())
+    H = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    st.call("dprnn_bilstm_fwd", _t(X).data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+            B * K, S, K, S * K, 1, K, 1, 0)
+    torch.cuda.synchronize()
+    assert rel_l2(H.cpu().numpy(), want) < 2e-6
+
+
+@pytest.mark.parametrize("kdim", [256, 128])
+def test_proj_stats_and_norm_residual(kdim):
+    B, rows_per = 3, 77                    # utterance boundaries fall inside 64-row tiles
+    M = B * rows_per
+    rng = np.random.default_rng(kdim)
+    H = rng.standard_normal((M, kdim)).astype(np.float32)
+    W = (rng.standard_normal((128, kdim)) / np.sqrt(kdim)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    X = rng.standard_normal((M, 128)).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(128)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(128)).astype(np.float32)
+    Zw = H.astype(np.float64) @ W.T.astype(np.float64) + b
+    st = _st()
+    Z = torch.empty(M, 128, device=DEV)
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_proj_stats_fwd", _t(H).data_ptr(), _t(W).data_ptr(), _t(b).data_ptr(), Z.data_ptr(),
+            stats.data_ptr(), M, rows_per, kdim)
+    torch.cuda.synchronize()
+    assert rel_l2(Z.cpu().numpy(), Zw) < 1e-6
+    zb = Zw.reshape(B, -1)
+    assert np.allclose(stats.cpu().numpy()[:, 0], zb.sum(1), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats.cpu().numpy()[:, 1], (zb ** 2).sum(1), rtol=1e-6)
+    for eps in (1e-5, 1e-8):
+        mean = zb.mean(1)[:, None, None]
+        var = zb.var(1)[:, None, None]
+        want = X.reshape(B, rows_per, 128) + ((Zw.reshape(B, rows_per, 128) - mean) / np.sqrt(var + eps)) * gamma + beta
+        Xd = _t(X)
+        st.call("dprnn_norm_residual_fwd", Xd.data_ptr(), Z.data_ptr(), stats.data_ptr(), _t(gamma).data_ptr(),
+                _t(beta).data_ptr(), eps, Xd.data_ptr(), B, rows_per)
+        torch.cuda.synchronize()
+        assert rel_l2(Xd.cpu().numpy().reshape(B, rows_per, 128), want) < 1e-6
+
+
+@pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (8, 8, 40), (250, 125, 700)])
+def test_segment_matches_unfold(K, P, L):
+    B = 2
+    Y = np.random.default_rng(K).standard_normal((B, L, 128)).astype(np.float32)
+    S = onp.n_chunks(L, K, P)
+    want = onp.segmentation(Y.transpose(0, 2, 1), K, P).transpose(0, 3, 2, 1)      # [B,S,K,F]
+    X = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    _st().call("dprnn_segment_fwd", _t(Y).data_ptr(), X.data_ptr(), B, L, K, P, S)
+    torch.cuda.synchronize()
+    assert np.array_equal(X.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (250, 125, 700)])
+def test_head_conv_ola_matches_oracle(K, P, L):
+    B = 2
+    rng = np.random.default_rng(L)
+    S = onp.n_chunks(L, K, P)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    alpha = np.array([0.2], dtype=np.float32)
+    W = (rng.standard_normal((256, 128)) / 11).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    xr = X.transpose(0, 3, 2, 1)                                                    # [B,F,K,S]
+    h = onp.conv1x1(W, b, onp.prelu(alpha, xr), np.float64).reshape(B * 2, 128, K, S)
+    want = onp.overlap_add(h, L, K, P).reshape(B, 256, L).transpose(0, 2, 1)        # [B,L,256]
+    U = torch.empty(B, L, 256, device=DEV)
+    _st().call("dprnn_head_conv_ola_fwd", _t(X).data_ptr(), _t(alpha).data_ptr(), _t(W).data_ptr(), _t(b).data_ptr(),
+               U.data_ptr(), B, L, K, P, S)
+    torch.cuda.synchronize()
+    assert rel_l2(U.cpu().numpy(), want) < 2e-6
+
+
+@pytest.mark.parametrize("ks,stride,T,relu", [(2, 1, 300, 0), (4, 2, 203, 1), (2, 1, 65, 1)])
+def test_encoder_bottleneck_and_decode_chain(ks, stride, T, relu):
+    """encoder stats -> bottleneck and mask/decode chain vs oracle with random V (stage inputs)."""
+    B, N = 3, 64
+    rng = np.random.default_rng(T)
+    cfg = full_cfg(kernel_size=ks, stride=stride, n_repeats=1)
+    wav = (0.1 * rng.standard_normal((B, T))).astype(np.float32)
+    We = (rng.standard_normal((N, 1, ks)) / np.sqrt(ks)).astype(np.float32)
+    Wd = (rng.standard_normal((N, 1, ks)) / 8).astype(np.float32)
+    sd = {"encoder.conv1d.weight": We, "decoder.weight": Wd}
+    enc = onp.encoder(sd, cfg, wav, np.float64)                                    # [B,N,L]
+    L = enc.shape[-1]
+    st = _st()
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_encoder_stats", _t(wav).data_ptr(), _t(We).data_ptr(), stats.data_ptr(), B, T, L, N, ks, stride)
+    torch.cuda.synchronize()
+    s = stats.cpu().numpy()
+    assert np.allclose(s[:, 0], enc.reshape(B, -1).sum(1), rtol=1e-5)
+    assert np.allclose(s[:, 1], (enc.reshape(B, -1) ** 2).sum(1), rtol=1e-5)
+    # bottleneck (ln) with a per-utterance row bias
+    gamma = (1 + 0.1 * rng.standard_normal(N)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    Wb = (rng.standard_normal((128, N)) / 8).astype(np.float32)
+    bb = rng.standard_normal(128).astype(np.float32)
+    rb = rng.standard_normal((B, 128)).astype(np.float32)
+    sdn = {"n.weight": gamma, "n.bias": beta}
+    want = onp.conv1x1(Wb, bb, onp.channel_norm(sdn, "n", enc, "ln", np.float64), np.float64) + rb[:, :, None]
+    sc = torch.empty(B, N, device=DEV); sh = torch.empty(B, N, device=DEV)
+    st.call("dprnn_bottleneck_prep", stats.data_ptr(), _t(gamma).data_ptr(), _t(beta).data_ptr(), 1e-5, 0, 0,
+            sc.data_ptr(), sh.data_ptr(), B, L, N)
+    Y = torch.empty(B, L, 128, device=DEV)
+    st.call("dprnn_bottleneck_fwd", _t(wav).data_ptr(), _t(We).data_ptr(), sc.data_ptr(), sh.data_ptr(), _t(Wb).data_ptr(),
+            N, _t(bb).data_ptr(), _t(rb).data_ptr(), Y.data_ptr(), B, T, L, N, ks, stride)
+    torch.cuda.synchronize()
+    assert rel_l2(Y.cpu().numpy(), want.transpose(0, 2, 1)) < 2e-6
+    # gate -> end conv -> act -> mask*enc -> decoder
+    U = rng.standard_normal((B, L, 2, 128)).astype(np.float32)
+    Wo = (rng.standard_normal((128, 128)) / 11).astype(np.float32); bo = rng.standard_normal(128).astype(np.float32)
+    Wg = (rng.standard_normal((128, 128)) / 11).astype(np.float32); bg = rng.standard_normal(128).astype(np.float32)
+    Wend = (rng.standard_normal((N, 128)) / 11).astype(np.float32)
+    u = U.astype(np.float64)
+    v = np.tanh(u @ Wo.T + bo) * (1 / (1 + np.exp(-(u @ Wg.T + bg))))
+    mk = v @ Wend.T
+    mk = np.maximum(mk, 0) if relu else 1 / (1 + np.exp(-mk))                      # [B,L,2,N]
+    me = mk * enc.transpose(0, 2, 1)[:, :, None, :]
+    want_out = np.stack([onp.decoder(sd, cfg, me[:, :, i].transpose(0, 2, 1), np.float64) for i in range(2)], 1)
+    V = torch.empty(B * L * 2, 128, device=DEV)
+    st.call("dprnn_head_gate_fwd", _t(U).data_ptr(), _t(Wo).data_ptr(), _t(bo).data_ptr(), _t(Wg).data_ptr(),
+            _t(bg).data_ptr(), V.data_ptr(), B * L * 2)
+    taps = torch.empty(B, 2, L, ks, device=DEV)
+    masked = torch.empty(B, L, N, device=DEV)
+    st.call("dprnn_head_mask_decode_fwd", V.data_ptr(), _t(Wend).data_ptr(), _t(wav).data_ptr(), _t(We).data_ptr(),
+            _t(Wd).data_ptr(), taps.data_ptr(), masked.data_ptr(), relu, B, T, L, N, ks, stride)
+    T_out = (L - 1) * stride + ks
+    out = torch.empty(B, 2, T_out, device=DEV)
+    st.call("dprnn_decoder_fwd", taps.data_ptr(), out.data_ptr(), B, 2, T_out, L, ks, stride)
+    torch.cuda.synchronize()
+    assert rel_l2(V.cpu().numpy().reshape(B, L, 2, 128), v) < 2e-6
+    assert rel_l2(masked.cpu().numpy(), me[:, :, 0]) < 2e-6
+    assert rel_l2(out.cpu().numpy(), want_out) < 2e-6

@@ -1,0 +1,118 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the nn.Module mirror
+and the C ABI, against (a) golden vectors produced by the reference classes and (b) the CPU oracle.
+
+Tolerances (fp32 path): rel-L2 <= 1e-5 and max-abs <= 1e-5 * max|y| against the reference's fp32 CPU
+output (its own fp32-vs-fp64 noise is ~2e-7 rel-L2), SI-SDR within 0.01 dB (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_model, golden_names, load_golden, rel_l2
+from oracle import dprnn_numpy as onp
+from oracle import dprnn_torch_cpu as otc
+from oracle.sisdr import si_sdr
+from oracle.weights import make_mixture, make_sources, make_state
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+ABS_TOL = 1e-5
+BSS_GPU_CASES = [n for n in golden_names("bss_wide")] + ["bss_full_b2"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _close(got, want, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), what
+    r = rel_l2(got, want)
+    m = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+    assert r <= REL_TOL and m <= 10 * ABS_TOL, f"{what}: rel-L2 {r:.3e}, max-abs/max {m:.3e}"
+    return r
+
+
+@pytest.mark.parametrize("name", BSS_GPU_CASES)
+def test_tasnet_matches_reference_golden(name):
+    g = load_golden(name)
+    m = g["meta"]
+    model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
+    with torch.no_grad():
+        out = model(torch.from_numpy(g["mix"]).to(_dev()))
+    torch.cuda.synchronize()
+    assert out.shape == g["out"].shape
+    _close(out.cpu().numpy(), g["out"], name)
+
+
+def test_stage_taps_match_reference():
+    g = load_golden("bss_wide_small")
+    m = g["meta"]
+    model, _, cfg = build_model("bss", m["cfg"], m["seed"], _dev())
+    dbg = {}
+    with torch.no_grad():
+        model(torch.from_numpy(g["mix"]).to(_dev()), debug=dbg)
+    # reference layouts: bottleneck [B,F,L]; blocks [B,F,K,S]; ours: [B,L,F] / [B,S,K,F]
+    _close(dbg["bottleneck"].permute(0, 2, 1).cpu().numpy(), g["tap_bottleneck"], "bottleneck")
+    for i in range(cfg["n_repeats"]):
+        _close(dbg[f"block{i}"].permute(0, 3, 2, 1).cpu().numpy(), g[f"tap_block{i}"], f"block{i}")
+
+
+def test_si_sdr_parity_full_size():
+    """BASELINE.json: SI-SDR of the GPU output within +-0.01 dB of the CPU path on identical inputs."""
+    g = load_golden("bss_full_b2")
+    m = g["meta"]
+    model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
+    with torch.no_grad():
+        out = model(torch.from_numpy(g["mix"]).to(_dev())).cpu().numpy()
+    tgt, _ = make_sources(2, 24000, seed=77)
+    a = si_sdr(out, tgt)
+    b = si_sdr(g["out"], tgt)
+    assert np.abs(a - b).max() <= 0.01, (a, b)
+    assert si_sdr(out, g["out"]).min() > 80.0        # GPU vs reference CPU output, dB
+
+
+def test_batch_invariance_and_determinism():
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1)
+    model, _, _ = build_model("bss", cfg, 5, _dev())
+    x = torch.from_numpy(make_mixture(5, 333, seed=9)).to(_dev())
+    with torch.no_grad():
+        full = model(x)
+        again = model(x)
+        one = model(x[3:4])
+    assert torch.equal(full, again), "forward is not run-to-run deterministic"
+    assert one.shape == (1, 2, 333)
+    _close(one[0].cpu().numpy(), full[3].cpu().numpy(), "batch invariance")
+
+
+@pytest.mark.parametrize("B,T", [(1, 24000), (3, 9000)])
+def test_against_cpu_oracle_shipped_config(B, T):
+    """Full-width, full-depth model vs the torch-CPU oracle on fresh seeded input."""
+    model, sd, cfg = build_model("bss", dict(), 123, _dev())
+    x = make_mixture(B, T, seed=4321)
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
+    with torch.no_grad():
+        got = model(torch.from_numpy(x).to(_dev())).cpu().numpy()
+    _close(got, want, f"shipped B={B} T={T}")
+
+
+def test_fast_activations_stay_within_tolerance():
+    import tss_with_dprnn_amd as pkg
+    g = load_golden("bss_full_b2")
+    m = g["meta"]
+    model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
+    lib = pkg.load_library()
+    lib.dprnn_set_fast_activations(1)
+    lib.dprnn_set_fast_head_activations(1)
+    try:
+        with torch.no_grad():
+            out = model(torch.from_numpy(g["mix"]).to(_dev())).cpu().numpy()
+    finally:
+        lib.dprnn_set_fast_activations(0)
+        lib.dprnn_set_fast_head_activations(0)
+    r = rel_l2(out, g["out"])
+    print("fast activations rel-L2", r)
+    assert r <= REL_TOL

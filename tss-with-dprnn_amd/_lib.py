@@ -1,0 +1,106 @@
+"""ctypes binding of libdprnn_mi355x.so (the C ABI in include/dprnn_mi355x.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load,
+``load_library`` raises, and every model forward goes through it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libdprnn_mi355x.so"
+_lock = threading.Lock()
+_lib = None
+
+c_fp = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+
+# name -> argtypes (all return int unless listed in _VOID / _SPECIAL); mirrors include/dprnn_mi355x.h
+SIGNATURES = {
+    "dprnn_encoder_stats": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_bottleneck_prep": [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_bottleneck_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_lstm_pack": [c_fp] * 10 + [c_fp],
+    "dprnn_bilstm_fwd": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp],
+    "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
+    "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
+    "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_head_gate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
+    "dprnn_head_mask_decode_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_decoder_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+}
+_VOID = {
+    "dprnn_set_fast_activations": [c_i],
+    "dprnn_set_fast_head_activations": [c_i],
+}
+_SPECIAL = {
+    "dprnn_last_error": ([], ctypes.c_char_p),
+    "dprnn_abi_version": ([], c_i),
+    "dprnn_num_cus": ([], c_i),
+}
+ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
+
+
+class DprnnError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into tss-with-dprnn_amd/libdprnn_mi355x.so (hipcc cross-compiles
+    without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", csrc, "clean"], check=True, capture_output=not verbose)
+    res = subprocess.run(["make", "-C", csrc, "-j4"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise DprnnError("building libdprnn_mi355x.so failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        print(res.stdout)
+    return library_path()
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the HIP library; raise loudly if it is not there (no CPU / PyTorch fallback exists)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise DprnnError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.join(_HERE, 'csrc')}`. The DPRNN MI355X path has no fallback.")
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:
+            raise DprnnError(f"cannot load {path}: {e}") from e
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = c_i
+        for name, args in _VOID.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = None
+        for name, (args, res) in _SPECIAL.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = lib
+        return lib
+
+
+def check(lib, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.dprnn_last_error()
+        raise DprnnError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,168 @@
+// Bandwidth-bound stages of the DPRNN path (gfx950): everything that is a pure gather / affine / reduction.
+// All loads and stores are 16 bytes per lane over the channels-last rows (512 B per row).
+#include "common.h"
+
+namespace {
+
+constexpr int F = 128;
+constexpr int KSMAX = 8;
+
+// ---- sum / sum-of-squares of enc[b,n,l] = relu(sum_j We[n][j] * wav[b][l*stride + j]) over (n, l)
+// (encoder_decoder.py:25-33 feeding dprnn.py:134).  grid (chunks of 256 frames, B).
+__global__ __launch_bounds__(256) void encoder_stats_kernel(const float* __restrict__ wav, const float* __restrict__ We,
+                                                           double* __restrict__ stats, int T, int L, int N, int ks, int stride) {
+    extern __shared__ float wsh[];                    // We [N][ks]
+    for (int i = threadIdx.x; i < N * ks; i += 256) wsh[i] = We[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    float p1 = 0.f, p2 = 0.f;
+    if (l < L) {
+        const float* x = wav + (long long)b * T + (long long)l * stride;
+        float xv[KSMAX];
+#pragma unroll
+        for (int j = 0; j < KSMAX; ++j) xv[j] = j < ks ? x[j] : 0.f;
+        for (int n = 0; n < N; ++n) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KSMAX; ++j)
+                if (j < ks) s = fmaf(wsh[n * ks + j], xv[j], s);
+            s = fmaxf(s, 0.f);
+            p1 += s; p2 = fmaf(s, s, p2);
+        }
+    }
+    const double s1 = wave_sum((double)p1), s2 = wave_sum((double)p2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[2 * b], s1); atomicAdd(&stats[2 * b + 1], s2); }
+}
+
+__global__ void bottleneck_prep_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float eps, const float* __restrict__ mul,
+                                       const float* __restrict__ add, float* __restrict__ sc, float* __restrict__ sh,
+                                       int B, int L, int N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N) return;
+    const int b = idx / N, c = idx % N;
+    const double cnt = (double)L * (double)N;
+    const double mean = stats[2 * b] / cnt;
+    double var = stats[2 * b + 1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float m = mul ? mul[idx] : 1.f, a = add ? add[idx] : 0.f;
+    const float g = gamma[c] * rstd;
+    sc[idx] = g * m;
+    sh[idx] = (beta[c] - g * (float)mean) * m + a;
+}
+
+// ---- X[b][s][k][:] = Y[b][s*P + k - K][:] or 0 (dprnn.py:189-201); one thread per float4
+__global__ __launch_bounds__(256) void segment_kernel(const f32x4* __restrict__ Y, f32x4* __restrict__ X,
+                                                      long long total4, int L, int K, int P, int S) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i >> 5; const int c4 = (int)(i & 31);
+        const int k = (int)(row % K); const long long bs = row / K;
+        const int s = (int)(bs % S); const long long b = bs / S;
+        const int l = s * P + k - K;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0 && l < L) v = Y[(b * L + l) * 32 + c4];
+        X[i] = v;
+    }
+}
+
+// ---- Xout = X + ((Z - mean_b) * rstd_b * gamma + beta)   (dprnn.py:90-92, 98-99)
+__global__ __launch_bounds__(256) void norm_residual_kernel(const f32x4* __restrict__ X, const f32x4* __restrict__ Z,
+                                                            const double* __restrict__ stats, const f32x4* __restrict__ gamma,
+                                                            const f32x4* __restrict__ beta, float eps, f32x4* __restrict__ Xout,
+                                                            long long total4, long long rows_per_utt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i >> 5; const int c4 = (int)(i & 31);
+        const long long b = row / rows_per_utt;
+        const double cnt = (double)rows_per_utt * (double)F;
+        const double mean = stats[2 * b] / cnt;
+        double var = stats[2 * b + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)mean;
+        const f32x4 x = X[i], z = Z[i], g = gamma[c4], be = beta[c4];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x[e] + ((z[e] - mu) * rstd * g[e] + be[e]);
+        Xout[i] = o;
+    }
+}
+
+// ---- out[b][spk][t] = sum_{l*stride + j = t} taps[b][spk][l][j]   (ConvTranspose1d, encoder_decoder.py:40-42)
+__global__ __launch_bounds__(256) void decoder_kernel(const float* __restrict__ taps, float* __restrict__ out,
+                                                      int B, int nspk, int T, int L, int ks, int stride) {
+    const long long total = (long long)B * nspk * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % T); const long long bs = i / T;
+        const int spk = (int)(bs % nspk); const long long b = bs / nspk;
+        const float* tp = taps + ((b * 2 + spk) * (long long)L) * ks;
+        float s = 0.f;
+        for (int j = 0; j < ks; ++j) {
+            const int d = t - j;
+            if (d >= 0 && d % stride == 0) {
+                const int l = d / stride;
+                if (l < L) s += tp[(long long)l * ks + j];
+            }
+        }
+        out[i] = s;
+    }
+}
+
+inline unsigned grid_for(long long n, int per_block = 256, int cap = 256 * 8) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int dprnn_encoder_stats(const float* wav, const float* enc_w, double* stats,
+                                   int B, int T, int L, int N, int ks, int stride, void* stream) {
+    if (!wav || !enc_w || !stats) { dprnn_set_error("dprnn_encoder_stats: null pointer"); return -1; }
+    if (B < 1 || ks < 1 || ks > KSMAX || stride < 1 || L != (T - ks) / stride + 1 || L < 1) {
+        dprnn_set_error("dprnn_encoder_stats: bad geometry B=%d T=%d L=%d ks=%d stride=%d", B, T, L, ks, stride);
+        return -1;
+    }
+    hipLaunchKernelGGL(encoder_stats_kernel, dim3((L + 255) / 256, B), dim3(256), (size_t)N * ks * sizeof(float),
+                       (hipStream_t)stream, wav, enc_w, stats, T, L, N, ks, stride);
+    return dprnn_check_launch("encoder_stats_kernel");
+}
+
+extern "C" int dprnn_bottleneck_prep(const double* stats, const float* gamma, const float* beta, float eps,
+                                     const float* mul, const float* add, float* sc, float* sh,
+                                     int B, int L, int N, void* stream) {
+    if (!stats || !gamma || !beta || !sc || !sh) { dprnn_set_error("dprnn_bottleneck_prep: null pointer"); return -1; }
+    hipLaunchKernelGGL(bottleneck_prep_kernel, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       stats, gamma, beta, eps, mul, add, sc, sh, B, L, N);
+    return dprnn_check_launch("bottleneck_prep_kernel");
+}
+
+extern "C" int dprnn_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int S, void* stream) {
+    if (!Y || !X) { dprnn_set_error("dprnn_segment_fwd: null pointer"); return -1; }
+    if (K < 1 || P < 1 || S != (L + K) / P + 1) { dprnn_set_error("dprnn_segment_fwd: bad geometry L=%d K=%d P=%d S=%d", L, K, P, S); return -1; }
+    const long long total4 = (long long)B * S * K * 32;
+    hipLaunchKernelGGL(segment_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(Y), reinterpret_cast<f32x4*>(X), total4, L, K, P, S);
+    return dprnn_check_launch("segment_kernel");
+}
+
+extern "C" int dprnn_norm_residual_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                                       const float* beta, float eps, float* Xout, int B, int64_t rows_per_utt, void* stream) {
+    if (!X || !Z || !stats || !gamma || !beta || !Xout) { dprnn_set_error("dprnn_norm_residual_fwd: null pointer"); return -1; }
+    const long long total4 = (long long)B * rows_per_utt * 32;
+    hipLaunchKernelGGL(norm_residual_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(X), reinterpret_cast<const f32x4*>(Z), stats,
+                       reinterpret_cast<const f32x4*>(gamma), reinterpret_cast<const f32x4*>(beta), eps,
+                       reinterpret_cast<f32x4*>(Xout), total4, (long long)rows_per_utt);
+    return dprnn_check_launch("norm_residual_kernel");
+}
+
+extern "C" int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk, int T, int L, int ks, int stride, void* stream) {
+    if (!taps || !out) { dprnn_set_error("dprnn_decoder_fwd: null pointer"); return -1; }
+    if (nspk < 1 || nspk > 2 || T != (L - 1) * stride + ks) { dprnn_set_error("dprnn_decoder_fwd: bad geometry nspk=%d T=%d L=%d ks=%d stride=%d", nspk, T, L, ks, stride); return -1; }
+    hipLaunchKernelGGL(decoder_kernel, dim3(grid_for((long long)B * nspk * T)), dim3(256), 0, (hipStream_t)stream,
+                       taps, out, B, nspk, T, L, ks, stride);
+    return dprnn_check_launch("decoder_kernel");
+}

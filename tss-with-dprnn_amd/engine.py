@@ -1,0 +1,253 @@
+"""Host-side orchestration of the MI355X DPRNN forward path.
+
+Python here only sizes buffers, reads live parameter pointers and enqueues the HIP kernels of
+libdprnn_mi355x.so (include/dprnn_mi355x.h) on torch's current stream; all arithmetic happens in
+those kernels.  Stage order follows the reference forward:
+  DPRNNTasNet.forward   /root/reference/src/models/dprnn.py:271-283
+  DPRNN.forward         dprnn.py:166-187   (bottleneck, segmentation, blocks, mask head)
+  DPRNNBlock.forward    dprnn.py:79-99
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ._lib import DprnnError, check, load_library
+
+F_BUILT = 128      # feature_size / hidden_size the kernels are built for (config_bss.yaml:19-20)
+N_BUILT = 64       # input_size (config_bss.yaml:18)
+KS_MAX = 8
+PACK_PER_DIR = 4 * 16 * 8 * 256
+
+# process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
+SEQ_TILE = {"intra": 0, "inter": 0}
+
+
+@dataclass
+class Geometry:
+    B: int
+    T: int          # input samples
+    L: int          # encoder frames
+    K: int
+    P: int
+    S: int
+    ks: int
+    stride: int
+    N: int
+
+    @property
+    def rows(self) -> int:          # rows of the [B][S][K] slab
+        return self.B * self.S * self.K
+
+    @property
+    def T_out(self) -> int:         # ConvTranspose1d output length (encoder_decoder.py:40-42)
+        return (self.L - 1) * self.stride + self.ks
+
+
+def make_geometry(B: int, T: int, N: int, K: int, P: int, ks: int, stride: int) -> Geometry:
+    if T < ks:
+        raise DprnnError(f"input of {T} samples is shorter than the encoder kernel ({ks})")
+    L = (T - ks) // stride + 1                       # nn.Conv1d output length
+    S = (L + K) // P + 1                             # unfold with padding K (dprnn.py:192-198)
+    return Geometry(B, T, L, K, P, S, ks, stride, N)
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _param(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if t.device != device:
+        raise DprnnError(f"parameter {name} lives on {t.device}, input on {device}: call model.to(device)")
+    if t.dtype != torch.float32:
+        raise DprnnError(f"parameter {name} is {t.dtype}; the MI355X path computes in float32")
+    if not t.is_contiguous():
+        raise DprnnError(f"parameter {name} is not contiguous")
+    return t
+
+
+def check_supported(cfg: dict) -> None:
+    """Fail loudly for constructor settings the HIP kernels are not built for."""
+    bad = []
+    if cfg["feature_size"] != F_BUILT or cfg["hidden_size"] != F_BUILT:
+        bad.append(f"feature_size/hidden_size must be {F_BUILT} (got {cfg['feature_size']}/{cfg['hidden_size']})")
+    if cfg["input_size"] != N_BUILT:
+        bad.append(f"input_size must be {N_BUILT} (got {cfg['input_size']})")
+    if cfg["rnn_type"] != "LSTM":
+        bad.append(f"rnn_type {cfg['rnn_type']!r}: only 'LSTM' has a HIP recurrence kernel")
+    if cfg["kernel_size"] > KS_MAX:
+        bad.append(f"kernel_size must be <= {KS_MAX}")
+    if cfg["norm_type"] not in ("ln", "gLN"):
+        bad.append(f"norm_type {cfg['norm_type']!r} (reference leaves the norms undefined, dprnn.py:72-77)")
+    if cfg["activation_type"] not in ("sigmoid", "relu"):
+        bad.append(f"activation_type {cfg['activation_type']!r} (dprnn.py:161-164)")
+    if cfg.get("dropout", 0) not in (0, 0.0):
+        bad.append("dropout != 0 (a single-layer nn.LSTM ignores it; refusing a silent difference)")
+    if cfg["hop_length"] < 1 or cfg["hop_length"] > cfg["chunk_length"]:
+        bad.append("hop_length must be in [1, chunk_length]")
+    if bad:
+        raise NotImplementedError("DPRNN MI355X path: unsupported configuration: " + "; ".join(bad))
+
+
+def _norm_params(norm: torch.nn.Module):
+    if hasattr(norm, "gamma"):                      # norms.GlobLN (norms.py:20-21), eps 1e-8
+        return norm.gamma, norm.beta, 1e-8
+    return norm.weight, norm.bias, 1e-5             # nn.GroupNorm(1, C), eps 1e-5
+
+
+class Stage:
+    """Thin launcher: stream + error checking around the C ABI."""
+
+    def __init__(self, device):
+        self.lib = load_library()
+        self.device = device
+        self.stream = torch.cuda.current_stream(device).cuda_stream
+
+    def call(self, name: str, *args):
+        rc = getattr(self.lib, name)(*args, self.stream)
+        check(self.lib, rc, name)
+
+
+def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geometry, stats_slot,
+                         mul=None, add=None, row_bias=None):
+    """Encoder -> bottleneck norm -> (fusion) -> bottleneck 1x1 conv, output Y [B][L][F].
+
+    reference: encoder_decoder.py:25-33, dprnn.py:131-136,169; fusion hooks dprnn_spe.py:165-229."""
+    dev = wav.device
+    gamma, beta, eps = _norm_params(bott_norm)
+    st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_slot), geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+    sc = torch.empty(geo.B, geo.N, device=dev, dtype=torch.float32)
+    sh = torch.empty_like(sc)
+    st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(_param(gamma, "bottleneck.0.weight", dev)),
+            _p(_param(beta, "bottleneck.0.bias", dev)), eps, _p(mul), _p(add), _p(sc), _p(sh), geo.B, geo.L, geo.N)
+    w = _param(bott_conv.weight, "bottleneck.1.weight", dev)
+    Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
+    st.call("dprnn_bottleneck_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
+            _p(_param(bott_conv.bias, "bottleneck.1.bias", dev)), _p(row_bias), _p(Y),
+            geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+    return Y
+
+
+def _run_path(st: Stage, X, Hbuf, Z, rnn, lin, norm, stats_slot, packed, bsum, geo: Geometry, intra: bool, dbg):
+    dev = X.device
+    r = rnn.rnn
+    ndir = 2 if r.bidirectional else 1
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    fw = [_param(getattr(r, n), n, dev) for n in names]
+    bw = [_param(getattr(r, n + "_reverse"), n + "_reverse", dev) for n in names] if ndir == 2 else [None] * 4
+    st.call("dprnn_lstm_pack", *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+    B, S, K = geo.B, geo.S, geo.K
+    if intra:       # sequences (b,s) walk k              (dprnn.py:84-86)
+        st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * S, K, B * S, 0, K, 1, ndir,
+                SEQ_TILE["intra"])
+    else:           # sequences (b,k) walk s              (dprnn.py:94-95)
+        st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * K, S, K, S * K, 1, K, ndir,
+                SEQ_TILE["inter"])
+    if dbg is not None:
+        dbg.append(("rnn", Hbuf[: geo.rows * ndir * F_BUILT].view(B, S, K, ndir * F_BUILT).clone()))
+    w = _param(lin.weight, "linear.weight", dev)
+    if w.shape != (F_BUILT, ndir * F_BUILT):
+        raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+    st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
+            geo.rows, S * K, ndir * F_BUILT)
+    gamma, beta, eps = _norm_params(norm)
+    st.call("dprnn_norm_residual_fwd", _p(X), _p(Z), _p(stats_slot), _p(_param(gamma, "norm.weight", dev)),
+            _p(_param(beta, "norm.bias", dev)), eps, _p(X), B, S * K)
+
+
+def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, relu_act: bool,
+                  want_masked: bool = False, debug: Optional[dict] = None):
+    """Segmentation -> DPRNN blocks -> mask head -> mask*enc -> decoder taps.
+
+    reference: dprnn.py:171-186 (== dprnn_spe.py:231-248), dprnn.py:277, encoder_decoder.py:40-42.
+    Returns taps [B][2][L][ks] (and mask*enc of speaker 0 as [B][L][N] if want_masked)."""
+    dev = Y.device
+    B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
+    rows = geo.rows
+    n_blocks = len(sep.dprnn_blocks)
+    # one arena: X [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region
+    head_floats = 2 * B * L * 2 * F_BUILT           # U [B*L][2F] + V [B*L*2][F]
+    h_floats = max(rows * 2 * F_BUILT, head_floats)
+    arena = torch.empty(rows * F_BUILT * 2 + h_floats, device=dev, dtype=torch.float32)
+    X = arena[: rows * F_BUILT]
+    Z = arena[rows * F_BUILT: 2 * rows * F_BUILT]
+    Hbuf = arena[2 * rows * F_BUILT:]
+    packed = torch.empty(2 * PACK_PER_DIR, device=dev, dtype=torch.float32)
+    bsum = torch.empty(2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+
+    st.call("dprnn_segment_fwd", _p(Y), _p(X), B, L, K, P, S)
+    if debug is not None:
+        debug["segmented"] = X.view(B, S, K, F_BUILT).clone()
+    for i, blk in enumerate(sep.dprnn_blocks):
+        dbg = [] if debug is not None else None
+        _run_path(st, X, Hbuf, Z, blk.intra_rnn, blk.intra_linear, blk.intra_norm, stats[1 + 2 * i], packed, bsum,
+                  geo, True, dbg)
+        if debug is not None:
+            debug[f"block{i}.intra_rnn"] = dbg[0][1]
+            debug[f"block{i}.mid"] = X.view(B, S, K, F_BUILT).clone()
+        _run_path(st, X, Hbuf, Z, blk.inter_rnn, blk.inter_linear, blk.inter_norm, stats[2 + 2 * i], packed, bsum,
+                  geo, False, dbg)
+        if debug is not None:
+            debug[f"block{i}"] = X.view(B, S, K, F_BUILT).clone()
+
+    U = Hbuf[: B * L * 2 * F_BUILT]
+    V = Hbuf[B * L * 2 * F_BUILT: 2 * B * L * 2 * F_BUILT]
+    st.call("dprnn_head_conv_ola_fwd", _p(X), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
+            _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
+            _p(U), B, L, K, P, S)
+    st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+            _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
+            _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), B * L * 2)
+    taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
+    masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
+    st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(masked), 1 if relu_act else 0,
+            B, geo.T, L, geo.N, geo.ks, geo.stride)
+    if debug is not None:
+        debug["ola_conv"] = U.view(B, L, 2 * F_BUILT).clone()
+        debug["gated"] = V.view(B, L, 2, F_BUILT).clone()
+    return (taps, masked) if want_masked else taps
+
+
+def decode(st: Stage, taps, geo: Geometry, nspk: int):
+    """ConvTranspose1d overlap (encoder_decoder.py:40-42) -> [B][nspk][T_out]."""
+    out = torch.empty(geo.B, nspk, geo.T_out, device=taps.device, dtype=torch.float32)
+    st.call("dprnn_decoder_fwd", _p(taps), _p(out), geo.B, nspk, geo.T_out, geo.L, geo.ks, geo.stride)
+    return out
+
+
+def check_input(x: torch.Tensor, what: str = "input") -> torch.Tensor:
+    if not isinstance(x, torch.Tensor) or x.dim() != 2:
+        raise DprnnError(f"{what} must be a [batch, samples] tensor")
+    if not x.is_cuda:
+        raise DprnnError(
+            f"{what} is on {x.device}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback); "
+            "move the model and the input to 'cuda'")
+    if x.dtype != torch.float32:
+        raise DprnnError(f"{what} must be float32 (got {x.dtype})")
+    return x.contiguous()
+
+
+def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
+    """DPRNNTasNet.forward (dprnn.py:271-283): [B, T] -> [B, 2, T_out]."""
+    cfg = model.cfg
+    check_supported(cfg)
+    wav = check_input(wav)
+    dev = wav.device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        geo = make_geometry(wav.shape[0], wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                            cfg["kernel_size"], cfg["stride"])
+        if geo.T_out < 2:
+            raise DprnnError("utterance too short")
+        sep = model.separation
+        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
+        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), geo.B, 2, device=dev, dtype=torch.float64)
+        Y = frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0])
+        if debug is not None:
+            debug["bottleneck"] = Y.clone()
+        taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
+        return decode(st, taps, geo, 2)
