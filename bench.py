@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DPRNN-TasNet forward throughput (utterances/sec, 3 s @ 8 kHz, batch 64 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one forward of the HIP path over one batch of 64 synthetic 3-second mixtures already
+resident in HBM (BASELINE.json configs[1]).  Utterances are independent, so ranks shard the batch with
+no data-path collective (weak scaling: 64 utterances per GPU).  Rank 0 prints ONE JSON line with
+  roofline     : the dominant kernel (fused BiLSTM recurrence, dprnn_bilstm_fwd) timed with HIP events
+                 on its launch stream inside the timed region; achieved = algorithmic FLOPs per launch
+                 (rows * 2 dirs * 2*256*512) / mean launch time; peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline : the reference's CPU path (oracle/dprnn_torch_cpu.py: the same ATen CPU ops the
+                 reference dispatches to) timed on this host's cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLES = 24000          # 3 s @ 8 kHz
+PER_GPU_BATCH = 64       # BASELINE.json configs[1]
+FLOP_PER_UTT = 350.80e9
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length", "n_repeats",
+        "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
+
+
+def cpu_baseline(sd, cfg, threads, batch=4, iters=3):
+    from oracle import dprnn_torch_cpu as otc
+    from oracle.weights import make_mixture
+    torch.set_num_threads(threads)
+    tsd = otc.to_torch_state(sd)
+    x = torch.from_numpy(make_mixture(batch, SAMPLES, seed=1234))
+    otc.tasnet_forward(tsd, cfg, x[:1])                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        otc.tasnet_forward(tsd, cfg, x)
+    dt = time.perf_counter() - t0
+    return dict(value=batch * iters / dt, unit="utt/s", cores=threads, kind="port",
+                sample=f"{iters} forwards of batch {batch} x 3 s @ 8 kHz, oracle/dprnn_torch_cpu.py "
+                       f"(stock torch CPU ops), {threads} threads of {os.cpu_count()} logical CPUs, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast-act", type=int, default=0)
+    ap.add_argument("--seq-tile-intra", type=int, default=0)
+    ap.add_argument("--seq-tile-inter", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import tss_with_dprnn_amd as pkg
+    from tss_with_dprnn_amd import engine
+    from oracle.weights import full_cfg, make_mixture, make_state
+
+    cfg = full_cfg()
+    model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
+    sd = make_state("bss", cfg, 0)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev)
+    lib = pkg.load_library()
+    lib.dprnn_set_fast_activations(args.fast_act)
+    lib.dprnn_set_fast_head_activations(args.fast_act)
+    engine.SEQ_TILE["intra"], engine.SEQ_TILE["inter"] = args.seq_tile_intra, args.seq_tile_inter
+
+    B = args.batch
+    x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(x)
+        sync()
+        engine.PROFILE = {"names": {"dprnn_bilstm_fwd"}, "events": {}}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x)
+        sync()
+        elapsed = time.perf_counter() - t0
+        prof, engine.PROFILE = engine.PROFILE, None
+    assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ev = prof["events"].get("dprnn_bilstm_fwd", [])
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    geo = engine.make_geometry(B, SAMPLES, cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                               cfg["kernel_size"], cfg["stride"])
+    flop_per_launch = geo.rows * 2 * (2 * 256 * 512)
+    achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd", "value": value, "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DPRNN-TasNet BSS inference, synthetic 3 s @ 8 kHz, batch=64 per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
+                       "fast_activations": bool(args.fast_act)},
+            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_bilstm_fwd)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms, "launches_timed": len(ev),
+                         "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(sd, cfg, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,10 @@ PACK_PER_DIR = 4 * 16 * 8 * 256
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
 SEQ_TILE = {"intra": 0, "inter": 0}
 
+# optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
+# HIP events are recorded on the stream the kernels are launched on (torch's current stream).
+PROFILE = None
+
 
 @dataclass
 class Geometry:
@@ -106,7 +110,15 @@ class Stage:
         self.stream = torch.cuda.current_stream(device).cuda_stream
 
     def call(self, name: str, *args):
-        rc = getattr(self.lib, name)(*args, self.stream)
+        prof = PROFILE
+        if prof is not None and name in prof["names"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            rc = getattr(self.lib, name)(*args, self.stream)
+            e1.record(torch.cuda.current_stream(self.device))
+            prof["events"].setdefault(name, []).append((e0, e1))
+        else:
+            rc = getattr(self.lib, name)(*args, self.stream)
         check(self.lib, rc, name)
 
 
