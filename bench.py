@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fast-act", type=int, default=0)
+    ap.add_argument("--fast-act", type=int, default=1)
+    ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
     args = ap.parse_args()
@@ -85,6 +86,8 @@ def main():
     lib.dprnn_set_fast_activations(args.fast_act)
     lib.dprnn_set_fast_head_activations(args.fast_act)
     engine.SEQ_TILE["intra"], engine.SEQ_TILE["inter"] = args.seq_tile_intra, args.seq_tile_inter
+    if args.groups is not None:
+        engine.STREAM_GROUPS = args.groups
 
     B = args.batch
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
@@ -130,7 +133,7 @@ def main():
             "config": {"workload": "DPRNN-TasNet BSS inference, synthetic 3 s @ 8 kHz, batch=64 per GPU "
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
-                       "fast_activations": bool(args.fast_act)},
+                       "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS},
             "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_bilstm_fwd)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

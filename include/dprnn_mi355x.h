@@ -36,7 +36,8 @@ const char* dprnn_last_error(void);
 int dprnn_abi_version(void);
 /* number of compute units of the current device (grid sizing of the persistent kernels) */
 int dprnn_num_cus(void);
-/* numerics switches (process-wide): 0 = libm-accurate expf/tanhf (default), 1 = v_exp_f32/v_rcp_f32 forms */
+/* numerics switches (process-wide): 1 = v_exp_f32/v_rcp_f32 forms of sigmoid/tanh (default; measured
+ * 2e-7 rel-L2 against the reference output end to end, tests/test_gpu_parity.py), 0 = libm expf/tanhf */
 void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
 void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
 
@@ -84,6 +85,12 @@ int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
 int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                      int64_t t_stride, int ndir, int seq_tile, void* stream);
+
+/* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][4] u64 =
+ * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles}; used by tools/bench_recur.py only. */
+int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
+                             int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                             int64_t t_stride, int ndir, int seq_tile, unsigned long long* stamps, void* stream);
 
 /* ---- intra_linear / inter_linear (dprnn.py:88,96) + GroupNorm statistics (dprnn.py:90,98):
  * Z[m][f] = sum_k W[f][k]*H[m][k] + bias[f]; stats[m / rows_per_utt] += (sum Z, sum Z^2).

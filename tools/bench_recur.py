@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of dprnn_bilstm_fwd alone (MI355X): isolates per-step cost from grid quantisation.
+usage: python tools/bench_recur.py [--fast 1]  -> table of (seq_tile, workgroups, T) -> us/step, TFLOP/s"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tss_with_dprnn_amd as pkg  # noqa: E402
+from tss_with_dprnn_amd import engine  # noqa: E402
+
+
+def run(st, seq_tile, nwg, T, ndir=2, iters=3):
+    nseq = nwg * seq_tile // ndir
+    X = torch.randn(nseq * T, 128, device="cuda") * 0.5
+    H = torch.empty(nseq * T, ndir * 128, device="cuda")
+    packed = torch.randn(ndir * engine.PACK_PER_DIR, device="cuda") * 0.08
+    bsum = torch.randn(ndir * 512, device="cuda") * 0.1
+    args = (X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T, nseq, 0, T, 1, ndir, seq_tile)
+    st.call("dprnn_bilstm_fwd", *args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        st.call("dprnn_bilstm_fwd", *args)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = nseq * T * ndir * 2 * 256 * 512
+    return ms, flops / ms / 1e9
+
+
+def stamps(st, seq_tile, per_cu, T, ndir=2):
+    ncu = st.lib.dprnn_num_cus()
+    nwg = ncu * per_cu
+    nseq = nwg * seq_tile // ndir
+    X = torch.randn(nseq * T, 128, device="cuda") * 0.5
+    H = torch.empty(nseq * T, ndir * 128, device="cuda")
+    packed = torch.randn(ndir * engine.PACK_PER_DIR, device="cuda") * 0.08
+    bsum = torch.randn(ndir * 512, device="cuda") * 0.1
+    buf = torch.zeros(nwg, 4, device="cuda", dtype=torch.int64)
+    for _ in range(3):      # warm clocks
+        st.call("dprnn_bilstm_fwd_stamped", X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T,
+                nseq, 0, T, 1, ndir, seq_tile, buf.data_ptr())
+    torch.cuda.synchronize()
+    b = buf.cpu().double()
+    cyc, ticks, kloop, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
+    clk = cyc / ticks * 100.0
+    print(f"stamps seq_tile={seq_tile} wgs/CU={per_cu}: in-kernel clock {clk:.0f} MHz; per step: total {cyc / T:.0f} cyc, "
+          f"k-loop {kloop / T:.0f}, cell+stores {cell / T:.0f}, barrier/other {(cyc - kloop - cell) / T:.0f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fast", type=int, default=1)
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--stamps", type=int, default=0)
+    a = ap.parse_args()
+    lib = pkg.load_library()
+    lib.dprnn_set_fast_activations(a.fast)
+    st = engine.Stage(torch.device("cuda:0"))
+    ncu = lib.dprnn_num_cus()
+    print(f"CUs {ncu} fast={a.fast} T={a.T}")
+    if a.stamps:
+        for seq_tile, per_cu in ((32, 1), (32, 2), (64, 1)):
+            stamps(st, seq_tile, per_cu, a.T)
+        return
+    print("seq_tile  wgs/CU   ms     us/step  TFLOP/s  mfma-cycles/step/SIMD(ideal)  implied-util@2.4GHz")
+    for seq_tile in (16, 32, 48, 64):
+        for per_cu in (1, 2, 3, 4):
+            lds = 2 * seq_tile * 257 * 4
+            if per_cu * lds > 160 * 1024 or (seq_tile > 32 and per_cu > 1):
+                continue
+            ms, tf = run(st, seq_tile, ncu * per_cu, a.T)
+            us_step = ms * 1e3 / a.T
+            ideal_cycles = per_cu * (seq_tile // 16) * 512 * 32
+            util = ideal_cycles / 2.4e3 / us_step
+            print(f"{seq_tile:8d} {per_cu:7d} {ms:7.3f} {us_step:8.2f} {tf:8.1f} {ideal_cycles:12d} {util:22.3f}")
+
+
+if __name__ == "__main__":
+    main()

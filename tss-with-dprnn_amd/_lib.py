@@ -28,6 +28,7 @@ SIGNATURES = {
     "dprnn_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp],
+    "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],

@@ -37,6 +37,7 @@ struct RecurArgs {
     float* H;
     int nseq, T, inner_n, ndir;
     long long outer_stride, inner_stride, t_stride;   // in rows
+    unsigned long long* stamps;                       // diagnostic build only: [wg][4] cycle counters
 };
 
 // packed[dir][wave][grp][gate*2+u][lane][i] = Wcat[dir][gate*128 + 32*wave + 16*u + (lane&15)][k]
@@ -62,7 +63,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __
     }
 }
 
-template <int NT, bool FAST>
+template <int NT, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
     constexpr int NS = 16 * NT;
@@ -136,7 +137,11 @@ void bilstm_kernel(RecurArgs a) {
     for (int x = 0; x < 8; ++x) w[0][x] = wbase[x * 64];
     __syncthreads();
 
+    unsigned long long st_t0 = 0, st_r0 = 0, st_mfma = 0, st_act = 0;
+    if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int step = 0; step < T; ++step) {
+        unsigned long long st_a = 0, st_b = 0;
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const int cur = step & 1, nxt = cur ^ 1;
         const long long t = dir ? (T - 1 - step) : step;
         const bool more = step + 1 < T;
@@ -187,6 +192,7 @@ void bilstm_kernel(RecurArgs a) {
             }
         }
 
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); st_mfma += st_b - st_a; }
         // ---- LSTM cell (gate order i,f,g,o), lane-local
         float* const Hn = XH + nxt * NS * XS + HD;
 #pragma unroll
@@ -213,7 +219,17 @@ void bilstm_kernel(RecurArgs a) {
                 d[0] = xr[m][0]; d[1] = xr[m][1]; d[2] = xr[m][2]; d[3] = xr[m][3];
             }
         }
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_act += __builtin_amdgcn_s_memtime() - st_b; __builtin_amdgcn_sched_barrier(0); }
         __syncthreads();
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + 4 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = __builtin_amdgcn_s_memtime() - st_t0;          // shader cycles, whole step loop
+            o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;      // 100 MHz ticks
+            o[2] = st_mfma;                                       // cycles inside the k-loop (wave 0)
+            o[3] = st_act;                                        // cycles in cell update + stores, before the barrier
+        }
     }
 }
 
@@ -247,7 +263,7 @@ extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float
     return dprnn_check_launch("lstm_pack_kernel");
 }
 
-static int g_fast_act = 0;
+static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L2 end to end, same as the libm forms
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
 
 extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
@@ -259,7 +275,7 @@ extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float
         return -1;
     }
     if (seq_tile == 0) seq_tile = nseq <= 16 ? 16 : 32;
-    RecurArgs a{X, packed, bsum, H, nseq, T, inner_n, ndir, outer_stride, inner_stride, t_stride};
+    RecurArgs a{X, packed, bsum, H, nseq, T, inner_n, ndir, outer_stride, inner_stride, t_stride, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const bool fast = g_fast_act != 0;
     switch (seq_tile) {
@@ -268,5 +284,27 @@ extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float
         case 48: return fast ? launch_bilstm<3, true>(a, st) : launch_bilstm<3, false>(a, st);
         case 64: return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
         default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,32,48,64 (got %d)", seq_tile); return -1;
+    }
+}
+
+// Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][4] u64
+// {cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles}.  Not part of the product path.
+extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
+                                        int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                        int64_t t_stride, int ndir, int seq_tile, unsigned long long* stamps, void* stream) {
+    if (!X || !packed || !bsum || !H || !stamps) { dprnn_set_error("dprnn_bilstm_fwd_stamped: null pointer"); return -1; }
+    RecurArgs a{X, packed, bsum, H, nseq, T, inner_n, ndir, outer_stride, inner_stride, t_stride, stamps};
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto kern, int NS) {
+        const size_t lds = (size_t)2 * NS * XS * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
+        hipLaunchKernelGGL(kern, dim3((nseq + NS - 1) / NS, ndir), dim3(256), lds, st, a);
+        return dprnn_check_launch("bilstm_kernel(stamped)");
+    };
+    switch (seq_tile) {
+        case 32: return go(&bilstm_kernel<2, true, true>, 32);
+        case 64: return go(&bilstm_kernel<4, true, true>, 64);
+        default: dprnn_set_error("dprnn_bilstm_fwd_stamped: seq_tile 32 or 64"); return -1;
     }
 }

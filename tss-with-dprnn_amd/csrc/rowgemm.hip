@@ -369,7 +369,7 @@ int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const f
 
 extern "C" int dprnn_num_cus(void) { return num_cus(); }
 
-static int g_fast_head = 0;
+static int g_fast_head = 1;
 extern "C" void dprnn_set_fast_head_activations(int on) { g_fast_head = on; }
 
 extern "C" int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,

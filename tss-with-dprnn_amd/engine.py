@@ -24,6 +24,13 @@ PACK_PER_DIR = 4 * 16 * 8 * 256
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
 SEQ_TILE = {"intra": 0, "inter": 0}
 
+# utterance groups run on separate HIP streams (0/1 = everything on the current stream).  Utterances are
+# independent, so each group is a complete pipeline of its own: while one group's recurrence kernel drains
+# its last workgroups (grid quantisation) or runs a bandwidth-bound stage, the other group's kernels fill
+# the idle CUs.
+STREAM_GROUPS = 4
+MIN_GROUP_BATCH = 8          # do not split batches smaller than 2 * this
+
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
 PROFILE = None
@@ -104,18 +111,19 @@ def _norm_params(norm: torch.nn.Module):
 class Stage:
     """Thin launcher: stream + error checking around the C ABI."""
 
-    def __init__(self, device):
+    def __init__(self, device, stream: Optional[torch.cuda.Stream] = None):
         self.lib = load_library()
         self.device = device
-        self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.tstream = stream if stream is not None else torch.cuda.current_stream(device)
+        self.stream = self.tstream.cuda_stream
 
     def call(self, name: str, *args):
         prof = PROFILE
         if prof is not None and name in prof["names"]:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(self.device))
+            e0.record(self.tstream)
             rc = getattr(self.lib, name)(*args, self.stream)
-            e1.record(torch.cuda.current_stream(self.device))
+            e1.record(self.tstream)
             prof["events"].setdefault(name, []).append((e0, e1))
         else:
             rc = getattr(self.lib, name)(*args, self.stream)
@@ -142,14 +150,35 @@ def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geome
     return Y
 
 
-def _run_path(st: Stage, X, Hbuf, Z, rnn, lin, norm, stats_slot, packed, bsum, geo: Geometry, intra: bool, dbg):
-    dev = X.device
+def _rnn_tensors(rnn, dev):
     r = rnn.rnn
     ndir = 2 if r.bidirectional else 1
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
     fw = [_param(getattr(r, n), n, dev) for n in names]
     bw = [_param(getattr(r, n + "_reverse"), n + "_reverse", dev) for n in names] if ndir == 2 else [None] * 4
-    st.call("dprnn_lstm_pack", *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+    return ndir, fw, bw
+
+
+class _Group:
+    """One utterance group [b0, b1): its own stream, slab arena and geometry."""
+
+    def __init__(self, st: Stage, geo: Geometry, b0: int, b1: int, dev):
+        self.st, self.b0, self.b1 = st, b0, b1
+        self.geo = Geometry(b1 - b0, geo.T, geo.L, geo.K, geo.P, geo.S, geo.ks, geo.stride, geo.N)
+        rows, B, L = self.geo.rows, self.geo.B, geo.L
+        # one arena: X [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region
+        head_floats = 2 * B * L * 2 * F_BUILT           # U [B*L][2F] + V [B*L*2][F]
+        h_floats = max(rows * 2 * F_BUILT, head_floats)
+        self.arena = torch.empty(rows * F_BUILT * 2 + h_floats, device=dev, dtype=torch.float32)
+        self.X = self.arena[: rows * F_BUILT]
+        self.Z = self.arena[rows * F_BUILT: 2 * rows * F_BUILT]
+        self.H = self.arena[2 * rows * F_BUILT:]
+
+
+def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg):
+    st, geo, X, Z, Hbuf = g.st, g.geo, g.X, g.Z, g.H
+    dev = X.device
+    ndir = 2 if rnn.rnn.bidirectional else 1
     B, S, K = geo.B, geo.S, geo.K
     if intra:       # sequences (b,s) walk k              (dprnn.py:84-86)
         st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * S, K, B * S, 0, K, 1, ndir,
@@ -158,7 +187,7 @@ def _run_path(st: Stage, X, Hbuf, Z, rnn, lin, norm, stats_slot, packed, bsum, g
         st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * K, S, K, S * K, 1, K, ndir,
                 SEQ_TILE["inter"])
     if dbg is not None:
-        dbg.append(("rnn", Hbuf[: geo.rows * ndir * F_BUILT].view(B, S, K, ndir * F_BUILT).clone()))
+        dbg.append(Hbuf[: geo.rows * ndir * F_BUILT].view(B, S, K, ndir * F_BUILT).clone())
     w = _param(lin.weight, "linear.weight", dev)
     if w.shape != (F_BUILT, ndir * F_BUILT):
         raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
@@ -169,57 +198,86 @@ def _run_path(st: Stage, X, Hbuf, Z, rnn, lin, norm, stats_slot, packed, bsum, g
             _p(_param(beta, "norm.bias", dev)), eps, _p(X), B, S * K)
 
 
+def _split(B: int):
+    n = STREAM_GROUPS if (STREAM_GROUPS > 1 and B >= 2 * MIN_GROUP_BATCH) else 1
+    n = min(n, B)
+    cuts = [round(i * B / n) for i in range(n + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
+
+
 def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, relu_act: bool,
                   want_masked: bool = False, debug: Optional[dict] = None):
     """Segmentation -> DPRNN blocks -> mask head -> mask*enc -> decoder taps.
 
     reference: dprnn.py:171-186 (== dprnn_spe.py:231-248), dprnn.py:277, encoder_decoder.py:40-42.
-    Returns taps [B][2][L][ks] (and mask*enc of speaker 0 as [B][L][N] if want_masked)."""
+    Returns taps [B][2][L][ks] (and mask*enc of speaker 0 as [B][L][N] if want_masked).
+    stats: [1 + 2*n_blocks][B][2] float64, zeroed; slot 0 belongs to the bottleneck."""
     dev = Y.device
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
-    rows = geo.rows
-    n_blocks = len(sep.dprnn_blocks)
-    # one arena: X [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region
-    head_floats = 2 * B * L * 2 * F_BUILT           # U [B*L][2F] + V [B*L*2][F]
-    h_floats = max(rows * 2 * F_BUILT, head_floats)
-    arena = torch.empty(rows * F_BUILT * 2 + h_floats, device=dev, dtype=torch.float32)
-    X = arena[: rows * F_BUILT]
-    Z = arena[rows * F_BUILT: 2 * rows * F_BUILT]
-    Hbuf = arena[2 * rows * F_BUILT:]
-    packed = torch.empty(2 * PACK_PER_DIR, device=dev, dtype=torch.float32)
-    bsum = torch.empty(2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+    blocks = list(sep.dprnn_blocks)
 
-    st.call("dprnn_segment_fwd", _p(Y), _p(X), B, L, K, P, S)
-    if debug is not None:
-        debug["segmented"] = X.view(B, S, K, F_BUILT).clone()
-    for i, blk in enumerate(sep.dprnn_blocks):
-        dbg = [] if debug is not None else None
-        _run_path(st, X, Hbuf, Z, blk.intra_rnn, blk.intra_linear, blk.intra_norm, stats[1 + 2 * i], packed, bsum,
-                  geo, True, dbg)
-        if debug is not None:
-            debug[f"block{i}.intra_rnn"] = dbg[0][1]
-            debug[f"block{i}.mid"] = X.view(B, S, K, F_BUILT).clone()
-        _run_path(st, X, Hbuf, Z, blk.inter_rnn, blk.inter_linear, blk.inter_norm, stats[2 + 2 * i], packed, bsum,
-                  geo, False, dbg)
-        if debug is not None:
-            debug[f"block{i}"] = X.view(B, S, K, F_BUILT).clone()
+    # pack every LSTM once, on the caller's stream, before the groups fork
+    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR, device=dev, dtype=torch.float32)
+    bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+    for i, blk in enumerate(blocks):
+        for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
+            _, fw, bw = _rnn_tensors(rnn, dev)
+            st.call("dprnn_lstm_pack", *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
-    U = Hbuf[: B * L * 2 * F_BUILT]
-    V = Hbuf[B * L * 2 * F_BUILT: 2 * B * L * 2 * F_BUILT]
-    st.call("dprnn_head_conv_ola_fwd", _p(X), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
-            _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
-            _p(U), B, L, K, P, S)
-    st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
-            _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
-            _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), B * L * 2)
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
-    st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
-            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(masked), 1 if relu_act else 0,
-            B, geo.T, L, geo.N, geo.ks, geo.stride)
+
+    parts = _split(B) if debug is None else [(0, B)]
+    if len(parts) == 1:
+        groups = [_Group(st, geo, 0, B, dev)]
+    else:
+        fork = torch.cuda.Event()
+        fork.record(st.tstream)
+        groups = []
+        for b0, b1 in parts:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_event(fork)
+            groups.append(_Group(Stage(dev, side), geo, b0, b1, dev))
+
+    for g in groups:
+        g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
-        debug["ola_conv"] = U.view(B, L, 2 * F_BUILT).clone()
-        debug["gated"] = V.view(B, L, 2, F_BUILT).clone()
+        debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()
+    for i, blk in enumerate(blocks):
+        for intra in (True, False):
+            rnn, lin, norm = (blk.intra_rnn, blk.intra_linear, blk.intra_norm) if intra else \
+                (blk.inter_rnn, blk.inter_linear, blk.inter_norm)
+            slot = 1 + 2 * i + (0 if intra else 1)
+            dbg = [] if debug is not None else None
+            for g in groups:            # interleaved submission: every group advances one path at a time
+                _run_path(g, rnn, lin, norm, stats[slot][g.b0:], packed[2 * i + (0 if intra else 1)],
+                          bsum[2 * i + (0 if intra else 1)], intra, dbg)
+            if debug is not None:
+                debug[f"block{i}." + ("intra_rnn" if intra else "inter_rnn")] = dbg[0]
+                debug[f"block{i}" + (".mid" if intra else "")] = groups[0].X.view(B, S, K, F_BUILT).clone()
+
+    for g in groups:
+        gB = g.geo.B
+        U = g.H[: gB * L * 2 * F_BUILT]
+        V = g.H[gB * L * 2 * F_BUILT: 2 * gB * L * 2 * F_BUILT]
+        g.st.call("dprnn_head_conv_ola_fwd", _p(g.X), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
+                  _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
+                  _p(U), gB, L, K, P, S)
+        g.st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+                  _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
+                  _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), gB * L * 2)
+        g.st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+                  _p(wav[g.b0:]), _p(enc_w), _p(dec_w), _p(taps[g.b0:]), _p(masked[g.b0:] if want_masked else None),
+                  1 if relu_act else 0, gB, geo.T, L, geo.N, geo.ks, geo.stride)
+        if debug is not None:
+            debug["ola_conv"] = U.view(B, L, 2 * F_BUILT).clone()
+            debug["gated"] = V.view(B, L, 2, F_BUILT).clone()
+    if len(groups) > 1:             # join: the caller's stream continues only after every group is done
+        for g in groups:
+            done = torch.cuda.Event()
+            done.record(g.st.tstream)
+            st.tstream.wait_event(done)
+            g.arena.record_stream(g.st.tstream)
     return (taps, masked) if want_masked else taps
 
 
