@@ -111,10 +111,8 @@ def main():
         prof, engine.PROFILE = engine.PROFILE, None
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from tss_with_dprnn_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step time
 
     ev = prof["events"].get("dprnn_bilstm_fwd", [])
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
