@@ -58,6 +58,24 @@ def test_state_dict_contract_bss(nt):
     assert sum(p.numel() for p in m.parameters()) == contract["n_params"]
 
 
+@pytest.mark.parametrize("tag", ["spe/cat/ln", "spe/add/gLN", "spe/mul/ln", "spe/film/ln", "spe/att/ln", "ira/cat/ln", "ira/cat/gLN"])
+def test_state_dict_contract_spe_ira(tag):
+    from tss_with_dprnn_amd.dprnn_spe import DPRNNSpeTasNet
+    from tss_with_dprnn_amd.dprnn_spe_ira import DPRNNSpeIRATasNet
+    kind, fus, nt = tag.split("/")
+    contract = json.load(open(os.path.join(GOLDEN, "state_contract.json")))[tag]
+    cls = DPRNNSpeTasNet if kind == "spe" else DPRNNSpeIRATasNet
+    m = cls(64, 128, 128, 250, 2, 125, 6, True, "LSTM", nt, "sigmoid", 0, None, 128, 256, 128, 251, fus)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, list(s)) for k, s in contract["keys"]]
+    assert sum(p.numel() for p in m.parameters()) == contract["n_params"]
+
+
+def test_dprnn_spe_module_reexports_tasnet():
+    """scripts/test/config_bss.yaml:12 targets src.models.dprnn_spe.DPRNNTasNet."""
+    from tss_with_dprnn_amd import dprnn_spe
+    assert dprnn_spe.DPRNNTasNet is pkg.DPRNNTasNet
+
+
 def test_constructor_defaults_match_reference():
     m = pkg.DPRNNTasNet(64)                      # dprnn.py:237-241 defaults
     assert m.cfg["chunk_length"] == 200 and m.cfg["hop_length"] == 100 and m.cfg["stride"] == 1

@@ -1,0 +1,104 @@
+"""GPU parity of the DPRNN-Spe / DPRNN-Spe-IRA path (speaker encoder, fusion, two-pass IRA) against the
+reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_model, load_golden, rel_l2
+from oracle import dprnn_numpy as onp
+from oracle.weights import make_mixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL_TOL = 1e-5
+
+
+def _run(model, g, bn_train=False):
+    if bn_train:        # the reference Inferencer leaves BatchNorm in train mode
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.train()
+    with torch.no_grad():
+        est, logits = model(torch.from_numpy(g["mix"]).to(DEV), torch.from_numpy(g["aux"]).to(DEV),
+                            torch.tensor(float(g["aux_len"])))
+    torch.cuda.synchronize()
+    return est.cpu().numpy(), logits.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["spe_wide_small_cat", "spe_wide_small_cat_bntrain", "spe_full_b1", "ira_wide_small_cat"])
+def test_spe_matches_reference_golden(name):
+    g = load_golden(name)
+    m = g["meta"]
+    model, _, _ = build_model(m["kind"], m["cfg"], m["seed"], DEV)
+    bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    est, logits = _run(model, g, m["bn_training"])
+    assert est.shape == g["out"].shape and logits.shape == g["logits"].shape
+    assert np.isfinite(est).all()
+    assert rel_l2(logits, g["logits"]) <= REL_TOL, rel_l2(logits, g["logits"])
+    assert rel_l2(est, g["out"]) <= REL_TOL, rel_l2(est, g["out"])
+    sd = model.state_dict()
+    for k, v in bn0.items():
+        if m["bn_training"]:     # torch semantics: running buffers move, the counter increments (twice per IRA pass)
+            assert not torch.equal(sd[k], v), k
+        else:
+            assert torch.equal(sd[k], v), k
+
+
+def test_bn_train_running_stats_follow_torch():
+    """One ResBlock-sized check of the in-place running-statistics update against nn.BatchNorm1d itself."""
+    import tss_with_dprnn_amd as pkg
+    from tss_with_dprnn_amd import engine
+    st = engine.Stage(torch.device(DEV))
+    C, n = 128, 777
+    y = torch.randn(n, C, device=DEV) * 1.7 + 0.3
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    ref = torch.nn.BatchNorm1d(C).to(DEV)
+    ref.load_state_dict(bn.state_dict())
+    ref.train()
+    want = ref(y.t().unsqueeze(0)).squeeze(0).t()
+    cs = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)], dim=1).contiguous()
+    scale = torch.empty(C, device=DEV); shift = torch.empty(C, device=DEV)
+    st.call("dprnn_bn_prep", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+            bn.num_batches_tracked.data_ptr(), cs.data_ptr(), n, 0.1, 1e-5, scale.data_ptr(), shift.data_ptr(), C)
+    torch.cuda.synchronize()
+    got = y * scale + shift
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().cpu().numpy()) < 1e-6
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-6, atol=1e-7)
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("fusion,nt", [("add", "ln"), ("mul", "gLN"), ("film", "ln"), ("cat", "gLN")])
+def test_fusions_match_cpu_oracle(fusion, nt):
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type=fusion, norm_type=nt)
+    model, sd, cfg = build_model("spe", cfg, 70, DEV)
+    B, T = 3, 400
+    mix, aux = make_mixture(B, T, seed=1), make_mixture(B, 350, seed=2)
+    want, wlog = onp.spe_forward(sd, cfg, mix, aux, np.float32(350.0))
+    with torch.no_grad():
+        est, logits = model(torch.from_numpy(mix).to(DEV), torch.from_numpy(aux).to(DEV), torch.tensor(350.0))
+    assert rel_l2(logits.cpu().numpy(), wlog) <= REL_TOL
+    assert rel_l2(est.cpu().numpy(), want) <= REL_TOL
+
+
+def test_ira_fusion_mul_matches_cpu_oracle():
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="mul", norm_type="ln")
+    model, sd, cfg = build_model("ira", cfg, 71, DEV)
+    B, T = 2, 400
+    mix, aux = make_mixture(B, T, seed=3), make_mixture(B, T, seed=4)
+    want, wlog = onp.ira_forward(sd, cfg, mix, aux, np.float32(T))
+    with torch.no_grad():
+        est, logits = model(torch.from_numpy(mix).to(DEV), torch.from_numpy(aux).to(DEV), torch.tensor(float(T)))
+    assert rel_l2(logits.cpu().numpy(), wlog) <= REL_TOL
+    assert rel_l2(est.cpu().numpy(), want) <= REL_TOL
+
+
+def test_att_fusion_is_refused_loudly():
+    model, _, _ = build_model("spe", dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="att", norm_type="ln"), 5, DEV)
+    x = torch.zeros(1, 300, device=DEV)
+    with pytest.raises(NotImplementedError, match="att"):
+        with torch.no_grad():
+            model(x, x, torch.tensor(300.0))

@@ -35,6 +35,12 @@ SIGNATURES = {
     "dprnn_head_gate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
     "dprnn_head_mask_decode_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_decoder_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_pointwise_fwd": [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i64, c_fp],
+    "dprnn_bn_prep": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp, c_fp, c_i, c_fp],
+    "dprnn_resblock_pool_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_time_mean_fwd": [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_linear_small_fwd": [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_rows_stats": [c_fp, c_fp, c_i, c_i64, c_i, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],

@@ -1,371 +1,6 @@
-// Row GEMMs of the DPRNN path: every 1x1 conv / Linear is out[row][0:ND] = A[row][0:KD] @ W^T with a
-// fused prologue (how A rows are produced) and epilogue (what happens to the ND outputs of a row).
-//
-// Structure (gfx950): persistent workgroups (one per CU, 4 waves).  The whole fp32 weight matrix
-// (KD*ND <= 32768 floats = 128 KB) is staged ONCE per workgroup into LDS, already in
-// v_mfma_f32_16x16x4_f32 B-fragment order ([k-group][col-tile][lane] float4 -> one conflict-free
-// ds_read_b128 per fragment), straight from the row-major torch parameter: no packed weight copies.
-// Each wave then walks its own tiles of 16*RT rows: A fragments come straight from HBM as 16-byte
-// loads in fragment order (lane (r,q) reads floats 16g+4q..+3 of row r: k = 16g + 4q + i for MFMA
-// sub-step i), one k-group prefetched ahead; accumulators stay in registers; no barrier in the loop.
-//
-// Instances (reference lines):
-//   bottleneck   KD=64  ND=128  A generated from the waveform (encoder + norm affine)   dprnn.py:131-136,169
-//   proj+stats   KD=256/128 ND=128  intra/inter Linear + GroupNorm sums                 dprnn.py:88,96 (+90,98)
-//   head conv    KD=128 ND=256  A = overlap-add of PReLU rows                           dprnn.py:173-178
-//   head gate    KD=128 ND=256  tanh(out) * sigmoid(gate)                               dprnn.py:157-158,180
-//   mask+decode  KD=128 ND=64   end conv, activation, mask*enc, decoder taps            dprnn.py:181-184,277
-#include "common.h"
-
-namespace {
-
-constexpr int F = 128;
-constexpr int KSMAX = 8;     // max encoder kernel_size supported by the generated-A / decode paths
-
-struct Geo {                 // shared row -> (b, l) geometry
-    int B, T, L, N, ks, stride;
-};
-
-// ------------------------------------------------------------------------------------------------ A loaders
-// Each loader is initialised per wave-tile with the global row of this lane for every row tile rt and
-// returns the lane's float4 of k-group g.
-
-template <int RT>
-struct PlainRows {
-    const float* A; int pitch;
-    const float* p[RT];
-    __device__ void init(long long row0, int r, int q, long long M) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            long long row = row0 + 16 * rt + r;
-            if (row >= M) row = M - 1;
-            p[rt] = A + row * pitch + 4 * q;
-        }
-    }
-    __device__ f32x4 load(int rt, int g) const { return *reinterpret_cast<const f32x4*>(p[rt] + 16 * g); }
-};
-
-// a[b,l,c] = relu(sum_j We[c][j]*wav[b][l*stride+j]) * sc[b][c] + sh[b][c]
-template <int RT>
-struct GenBottleneck {
-    const float* wav; const float* We; const float* sc; const float* sh; Geo geo;
-    float xv[RT][KSMAX];
-    int boff[RT];
-    int q4;
-    __device__ void init(long long row0, int r, int q, long long M) {
-        q4 = 4 * q;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            long long row = row0 + 16 * rt + r;
-            if (row >= M) row = M - 1;
-            const int b = (int)(row / geo.L), l = (int)(row % geo.L);
-            boff[rt] = b * geo.N;
-            const float* x = wav + (long long)b * geo.T + (long long)l * geo.stride;
-#pragma unroll
-            for (int j = 0; j < KSMAX; ++j) xv[rt][j] = (j < geo.ks) ? x[j] : 0.f;
-        }
-    }
-    __device__ f32x4 load(int rt, int g) const {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int cch = 16 * g + q4 + e;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < KSMAX; ++j)
-                if (j < geo.ks) s = fmaf(We[cch * geo.ks + j], xv[rt][j], s);
-            s = fmaxf(s, 0.f);
-            v[e] = fmaf(s, sc[boff[rt] + cch], sh[boff[rt] + cch]);
-        }
-        return v;
-    }
-};
-
-// a[(b,l)][f] = sum over chunks s covering frame l of prelu(X[b][s][l+K-s*P][f])   (dprnn.py:173,203-217)
-template <int RT>
-struct OlaGather {
-    const float* X; float alpha; int L, K, P, S;
-    const float* p0[RT];       // row of the first term
-    int nterm[RT];
-    __device__ static int s_lo(int l, int P) { return (l + P) / P; }                       // ceil((l+1)/P)
-    __device__ static int s_hi(int l, int K, int P, int S) { int s = (l + K) / P; return s < S - 1 ? s : S - 1; }
-    __device__ void init(long long row0, int r, int q, long long M) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            long long row = row0 + 16 * rt + r;
-            if (row >= M) row = M - 1;
-            const int b = (int)(row / L), l = (int)(row % L);
-            const int lo = s_lo(l, P), hi = s_hi(l, K, P, S);
-            nterm[rt] = hi - lo + 1;
-            // term s: row ((b*S + s)*K + (l + K - s*P)); successive s differ by (K - P) rows
-            p0[rt] = X + (((long long)b * S + lo) * K + (l + K - lo * P)) * F + 4 * q;
-        }
-    }
-    __device__ f32x4 load(int rt, int g) const {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* p = p0[rt] + 16 * g;
-        for (int s = 0; s < nterm[rt]; ++s, p += (long long)(K - P) * F) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += v[e] >= 0.f ? v[e] : alpha * v[e];
-        }
-        return acc;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ epilogues
-// acc[rt][ct][e]: row = row0 + 16*rt + 4*q + e, col = 16*ct + r.
-
-template <int RT, int NCT>
-struct EpBiasStore {            // out[row][col] = acc + bias[col] (+ row_bias[row / rows_per_b][col])
-    float* out; const float* bias; const float* row_bias; long long rows_per_b;
-    __device__ void begin() {}
-    __device__ void end(int lane) {}
-    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int col = 16 * ct + r;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const long long row = row0 + 16 * rt + 4 * q + e;
-                    if (row < M) {
-                        float v = acc[rt][ct][e] + bv;
-                        if (row_bias) v += row_bias[(row / rows_per_b) * (16 * NCT) + col];
-                        out[row * (16 * NCT) + col] = v;
-                    }
-                }
-        }
-    }
-};
-
-template <int RT, int NCT>
-struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in double
-    float* Z; const float* bias; double* stats; long long rows_per_b;
-    double d1, d2; long long cur_b;
-    __device__ void begin() { d1 = 0.0; d2 = 0.0; cur_b = -1; }
-    __device__ void flush(int lane) {
-        if (cur_b >= 0) {
-            const double s1 = wave_sum(d1), s2 = wave_sum(d2);
-            if (lane == 0) { atomicAdd(&stats[2 * cur_b], s1); atomicAdd(&stats[2 * cur_b + 1], s2); }
-        }
-        d1 = 0.0; d2 = 0.0;
-    }
-    __device__ void end(int lane) { flush(lane); cur_b = -1; }
-    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
-        float bv[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) bv[ct] = bias[16 * ct + r];
-        const long long last = (row0 + 16 * RT - 1 < M ? row0 + 16 * RT - 1 : M - 1);
-        const long long b_first = row0 / rows_per_b, b_last = last / rows_per_b;
-        // store + per-row-tile partial sums, one utterance at a time (a tile spans <= 2 in practice)
-        for (long long b = b_first; b <= b_last; ++b) {
-            if (b != cur_b) { flush(lane); cur_b = b; }
-            float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const long long row = row0 + 16 * rt + 4 * q + e;
-                    if (row < M && row / rows_per_b == b) {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) {
-                            const float v = acc[rt][ct][e] + bv[ct];
-                            Z[row * (16 * NCT) + 16 * ct + r] = v;
-                            p1 += v; p2 = fmaf(v, v, p2);
-                        }
-                    }
-                }
-            d1 += (double)p1; d2 += (double)p2;
-        }
-    }
-};
-
-template <int RT>
-struct EpHeadConv {             // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 columns
-    float* U; const float* bias; int L, K, P, S;
-    __device__ void begin() {}
-    __device__ void end(int lane) {}
-    __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int r, int q, int lane, long long M) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long long row = row0 + 16 * rt + 4 * q + e;
-                if (row < M) {
-                    const int l = (int)(row % L);
-                    const float cnt = (float)(OlaGather<1>::s_hi(l, K, P, S) - OlaGather<1>::s_lo(l, P) + 1);
-#pragma unroll
-                    for (int ct = 0; ct < 16; ++ct)
-                        U[row * 256 + 16 * ct + r] = fmaf(cnt, bias[16 * ct + r], acc[rt][ct][e]);
-                }
-            }
-    }
-};
-
-template <int RT, bool FAST>
-struct EpGate {                 // V[row][col] = tanh(acc[col]+bo[col]) * sigmoid(acc[128+col]+bg[col])
-    float* V; const float* bo; const float* bg;
-    __device__ void begin() {}
-    __device__ void end(int lane) {}
-    __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int r, int q, int lane, long long M) {
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const float b1 = bo[16 * ct + r], b2 = bg[16 * ct + r];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const long long row = row0 + 16 * rt + 4 * q + e;
-                    if (row < M)
-                        V[row * F + 16 * ct + r] = tanh_f<FAST>(acc[rt][ct][e] + b1) * sigmoid_f<FAST>(acc[rt][ct + 8][e] + b2);
-                }
-        }
-    }
-};
-
-// rows are (b, l, spk): mask = act(acc[n]); me = mask*enc[b,n,l]; taps[b][spk][l][j] = sum_n Wd[n][j]*me
-template <int RT, int NCT, bool FAST>
-struct EpMaskDecode {
-    const float* wav; const float* We; const float* Wd; float* taps; float* masked; int relu_act; Geo geo;
-    __device__ void begin() {}
-    __device__ void end(int lane) {}
-    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
-        const int ks = geo.ks;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                long long row = row0 + 16 * rt + 4 * q + e;
-                const bool ok = row < M;
-                if (!ok) row = M - 1;
-                const int spk = (int)(row & 1);
-                const long long bl = row >> 1;
-                const int b = (int)(bl / geo.L), l = (int)(bl % geo.L);
-                const float* x = wav + (long long)b * geo.T + (long long)l * geo.stride;
-                float xv[KSMAX];
-#pragma unroll
-                for (int j = 0; j < KSMAX; ++j) xv[j] = j < ks ? x[j] : 0.f;
-                float tp[KSMAX];
-#pragma unroll
-                for (int j = 0; j < KSMAX; ++j) tp[j] = 0.f;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const int n = 16 * ct + r;
-                    float en = 0.f;
-#pragma unroll
-                    for (int j = 0; j < KSMAX; ++j)
-                        if (j < ks) en = fmaf(We[n * ks + j], xv[j], en);
-                    en = fmaxf(en, 0.f);
-                    const float a = acc[rt][ct][e];
-                    const float m = relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a);
-                    const float me = m * en;
-                    if (masked && ok && spk == 0) masked[bl * geo.N + n] = me;
-#pragma unroll
-                    for (int j = 0; j < KSMAX; ++j)
-                        if (j < ks) tp[j] = fmaf(Wd[n * ks + j], me, tp[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < KSMAX; ++j)
-                    if (j < ks) {
-                        float v = tp[j];
-                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                        if (ok && r == 0) taps[(((long long)b * 2 + spk) * geo.L + l) * ks + j] = v;
-                    }
-            }
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ kernel
-template <int KD, int ND, int RT, class AL, class EP>
-__global__ __launch_bounds__(256, 1)
-void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
-                    long long M, AL al, EP ep) {
-    constexpr int NCT = ND / 16, NG = KD / 16, K4 = KD / 4;
-    extern __shared__ __attribute__((aligned(16))) f32x4 wl[];          // [NG][NCT][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-
-    for (int idx = tid; idx < ND * K4; idx += 256) {
-        const int col = idx / K4, k4 = idx % K4;
-        const float* src = col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * k4);
-        wl[((k4 >> 2) * NCT + (col >> 4)) * 64 + (k4 & 3) * 16 + (col & 15)] = v;
-    }
-    __syncthreads();
-
-    constexpr int ROWS_IT = 4 * RT * 16;
-    const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
-    const long long per = (nchunk + gridDim.x - 1) / gridDim.x;
-    long long c0 = per * blockIdx.x, c1 = c0 + per;
-    if (c1 > nchunk) c1 = nchunk;
-    ep.begin();
-    for (long long ch = c0; ch < c1; ++ch) {
-        const long long row0 = ch * ROWS_IT + wave * RT * 16;
-        if (row0 >= M) break;
-        al.init(row0, r, q, M);
-        f32x4 acc[RT][NCT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 a[2][RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[0][rt] = al.load(rt, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int cb = g & 1;
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[cb ^ 1][rt] = al.load(rt, g + 1);
-            }
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const f32x4 b = wl[(g * NCT + ct) * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma16(a[cb][rt][i], b[i], acc[rt][ct]);
-            }
-        }
-        ep(acc, row0, r, q, lane, M);
-    }
-    ep.end(lane);
-}
-
-int g_num_cus = 0;
-int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0; (void)hipGetDevice(&dev);
-        hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, dev);
-        g_num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    }
-    return g_num_cus;
-}
-
-template <int KD, int ND, int RT, class AL, class EP>
-int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
-                   const AL& al, const EP& ep, hipStream_t st) {
-    const size_t lds = (size_t)KD * ND * sizeof(float);
-    auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
-        attr_set = true;
-    }
-    constexpr int ROWS_IT = 4 * RT * 16;
-    long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
-    long long grid = nchunk < num_cus() ? nchunk : num_cus();
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
-    return dprnn_check_launch(what);
-}
-
-}  // namespace
+// Main-path instances of the row GEMM (rowgemm_core.h): bottleneck, Linear+GroupNorm sums, mask head.
+#include "rowgemm_core.h"
+using namespace rg;
 
 extern "C" int dprnn_num_cus(void) { return num_cus(); }
 

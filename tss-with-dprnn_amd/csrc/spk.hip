@@ -1,0 +1,264 @@
+// Speaker-encoder branch of DPRNN-Spe / DPRNN-Spe-IRA (reference src/models/dprnn_spe.py:8-42,115-123,156-163):
+// 1x1 convs as row GEMMs (rowgemm_core.h) with BatchNorm/PReLU folded into the next GEMM's A loader, MaxPool1d(3)
+// fused with the residual add, the time mean and the small per-utterance Linears.
+#include "rowgemm_core.h"
+using namespace rg;
+
+namespace {
+
+// A[row][k] -> prelu(a * s[u*aff_stride + k] + t[...]), u = row / rows_per_utt; every piece optional.
+template <int RT>
+struct AffineRows {
+    const float* A; int pitch;
+    const float* sc; const float* sh; int aff_stride; long long rows_per_utt;
+    const float* prelu_p;
+    const float* p[RT];
+    const float* ps[RT];
+    const float* pt[RT];
+    float alpha;
+    __device__ void init(long long row0, int r, int q, long long M) {
+        alpha = prelu_p ? *prelu_p : 1.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            long long row = row0 + 16 * rt + r;
+            if (row >= M) row = M - 1;
+            p[rt] = A + row * pitch + 4 * q;
+            const long long u = aff_stride ? row / rows_per_utt : 0;
+            ps[rt] = sc ? sc + u * aff_stride + 4 * q : nullptr;
+            pt[rt] = sc ? sh + u * aff_stride + 4 * q : nullptr;
+        }
+    }
+    __device__ f32x4 load(int rt, int g) const {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p[rt] + 16 * g);
+        if (sc) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(ps[rt] + 16 * g);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(pt[rt] + 16 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], s[e], t[e]);
+        }
+        if (prelu_p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : alpha * v[e];
+        }
+        return v;
+    }
+};
+
+// out[row*pitch + col0 + col] = acc + bias[col0+col]; optional per-channel (sum, sumsq) in fp64 (BatchNorm batch stats)
+template <int RT>
+struct EpStoreColStats {
+    float* out; int pitch; int col0; const float* bias; double* col_stats;
+    double d1[8], d2[8];
+    __device__ void begin() {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) { d1[ct] = 0.0; d2[ct] = 0.0; }
+    }
+    __device__ void end(int lane) {
+        if (!col_stats) return;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {      // reduce the 4 lane quarters that share a column
+            double a = d1[ct], b = d2[ct];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 16) {
+                atomicAdd(&col_stats[2 * (col0 + 16 * ct + lane)], a);
+                atomicAdd(&col_stats[2 * (col0 + 16 * ct + lane) + 1], b);
+            }
+        }
+    }
+    __device__ void operator()(f32x4 (&acc)[RT][8], long long row0, int r, int q, int lane, long long M) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int col = col0 + 16 * ct + r;
+            const float bv = bias ? bias[col] : 0.f;
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long row = row0 + 16 * rt + 4 * q + e;
+                    if (row < M) {
+                        const float v = acc[rt][ct][e] + bv;
+                        out[row * pitch + col] = v;
+                        p1 += v; p2 = fmaf(v, v, p2);
+                    }
+                }
+            d1[ct] += (double)p1; d2[ct] += (double)p2;
+        }
+    }
+};
+
+// BatchNorm1d folded to y*scale + shift (eps 1e-5).  col_stats == NULL: running statistics (eval).
+// Otherwise batch statistics (biased variance) and the running buffers are updated in place exactly as
+// nn.BatchNorm1d does in train mode (momentum, unbiased variance, num_batches_tracked += 1).
+__global__ void bn_prep_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                               float* running_var, long long* nbt, const double* __restrict__ col_stats, long long count,
+                               float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (col_stats) {
+        const double m = col_stats[2 * c] / (double)count;
+        double v = col_stats[2 * c + 1] / (double)count - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m; var = (float)v;
+        const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        if (c == 0 && nbt) *nbt += 1;
+    } else {
+        mean = running_mean[c]; var = running_var[c];
+    }
+    const float s = gamma[c] / sqrtf(var + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - mean * s;
+}
+
+// out[b][t3][c] = max_{j<3} prelu(y[b][3*t3+j][c]*scale[c] + shift[c] + res[b][3*t3+j][c])   (dprnn_spe.py:35-42)
+__global__ __launch_bounds__(256) void resblock_pool_kernel(const f32x4* __restrict__ Y, const f32x4* __restrict__ scale,
+                                                            const f32x4* __restrict__ shift, const f32x4* __restrict__ res,
+                                                            const float* __restrict__ prelu_w, f32x4* __restrict__ out,
+                                                            long long total4, int T_in, int T_out, int C4) {
+    const float alpha = *prelu_w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4); const long long bt = i / C4;
+        const int t3 = (int)(bt % T_out); const long long b = bt / T_out;
+        const f32x4 s = scale[c4], t = shift[c4];
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const long long src = (b * T_in + 3 * t3 + j) * C4 + c4;
+            const f32x4 y = Y[src], rr = res[src];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(y[e], s[e], t[e]) + rr[e];
+                v = v >= 0.f ? v : alpha * v;
+                m[e] = fmaxf(m[e], v);
+            }
+        }
+        out[i] = m;
+    }
+}
+
+// emb[b][c] = sum_t E[b][t][c] / aux_T,  aux_T = ((((len - ks) // (ks//2)) + 1) // 3 // 3 // 3)   (dprnn_spe.py:156-163)
+__global__ void time_mean_kernel(const float* __restrict__ E, const float* __restrict__ aux_len, int n_len,
+                                 float* __restrict__ emb, int T3, int C, int ks) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    const float len = aux_len[n_len > 1 ? b : 0];
+    float aT = floorf((len - (float)ks) / (float)(ks / 2)) + 1.f;
+    aT = floorf(floorf(floorf(aT / 3.f) / 3.f) / 3.f);
+    float s = 0.f;
+    const float* p = E + (long long)b * T3 * C + c;
+    for (int t = 0; t < T3; ++t) s += p[(long long)t * C];
+    emb[b * C + c] = s / aT;
+}
+
+// out[b][o] = sum_k W[o*ldw + k0 + k] * in[b*in_pitch + k] + bias[o]
+__global__ void linear_small_kernel(const float* __restrict__ in, int in_pitch, const float* __restrict__ W, int ldw,
+                                    int k0, int K, const float* __restrict__ bias, float* __restrict__ out, int out_pitch,
+                                    int B, int O) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * O) return;
+    const int b = idx / O, o = idx % O;
+    const float* w = W + (long long)o * ldw + k0;
+    const float* x = in + (long long)b * in_pitch;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(w[k], x[k], s);
+    out[(long long)b * out_pitch + o] = s + (bias ? bias[o] : 0.f);
+}
+
+// per-utterance (sum, sumsq) over a materialised [B][rows_per_utt][C] tensor (GroupNorm(1,C) of d0, dprnn_spe_ira.py:84)
+__global__ __launch_bounds__(256) void rows_stats_kernel(const f32x4* __restrict__ A, double* __restrict__ stats,
+                                                         long long per_utt4) {
+    const int b = blockIdx.y;
+    const f32x4* p = A + (long long)b * per_utt4;
+    float p1 = 0.f, p2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+    int n = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_utt4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = p[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p1 += v[e]; p2 = fmaf(v[e], v[e], p2); }
+        if (++n == 32) { d1 += p1; d2 += p2; p1 = p2 = 0.f; n = 0; }
+    }
+    d1 += p1; d2 += p2;
+    d1 = wave_sum(d1); d2 = wave_sum(d2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[2 * b], d1); atomicAdd(&stats[2 * b + 1], d2); }
+}
+
+template <int KD>
+int launch_pointwise(const AffineRows<4>& al, const EpStoreColStats<4>& ep, const float* W, int ldw, long long M, hipStream_t st) {
+    return launch_rowgemm<KD, 128, 4>("pointwise", W, ldw, 128, nullptr, 0, M, al, ep, st);
+}
+
+}  // namespace
+
+extern "C" int dprnn_pointwise_fwd(const float* A, int a_pitch, int kdim, const float* in_scale, const float* in_shift,
+                                   int aff_stride, int64_t rows_per_utt, const float* in_prelu, const float* W, int ldw,
+                                   const float* bias, float* out, int out_pitch, int col0, double* col_stats, int64_t M,
+                                   void* stream) {
+    if (!A || !W || !out || M <= 0) { dprnn_set_error("dprnn_pointwise_fwd: null pointer / M"); return -1; }
+    if ((kdim != 64 && kdim != 128 && kdim != 256) || a_pitch < kdim || (a_pitch % 4) || ldw < kdim || (ldw % 4) ||
+        (col0 % 16) || out_pitch < col0 + 128 || (aff_stride && rows_per_utt <= 0) || ((in_scale == nullptr) != (in_shift == nullptr))) {
+        dprnn_set_error("dprnn_pointwise_fwd: unsupported kdim=%d a_pitch=%d ldw=%d col0=%d out_pitch=%d", kdim, a_pitch, ldw, col0, out_pitch);
+        return -1;
+    }
+    AffineRows<4> al{A, a_pitch, in_scale, in_shift, aff_stride, (long long)(rows_per_utt > 0 ? rows_per_utt : 1), in_prelu};
+    EpStoreColStats<4> ep{out, out_pitch, col0, bias, col_stats};
+    const float* Wc = W + (long long)col0 * ldw;
+    // the epilogue indexes bias/out/stats with col0 + col, the weight rows are pre-offset
+    ep.col0 = col0;
+    hipStream_t st = (hipStream_t)stream;
+    if (kdim == 64) return launch_pointwise<64>(al, ep, Wc, ldw, M, st);
+    if (kdim == 128) return launch_pointwise<128>(al, ep, Wc, ldw, M, st);
+    return launch_pointwise<256>(al, ep, Wc, ldw, M, st);
+}
+
+extern "C" int dprnn_bn_prep(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, const double* col_stats, int64_t count, float momentum,
+                             float eps, float* scale, float* shift, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) { dprnn_set_error("dprnn_bn_prep: null pointer"); return -1; }
+    hipLaunchKernelGGL(bn_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, (long long*)num_batches_tracked, col_stats, (long long)count, momentum, eps, scale, shift, C);
+    return dprnn_check_launch("bn_prep_kernel");
+}
+
+extern "C" int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, const float* shift, const float* res,
+                                       const float* prelu_w, float* out, int B, int T_in, int C, void* stream) {
+    if (!Y2 || !scale || !shift || !res || !prelu_w || !out) { dprnn_set_error("dprnn_resblock_pool_fwd: null pointer"); return -1; }
+    if (C % 4 || T_in < 3) { dprnn_set_error("dprnn_resblock_pool_fwd: bad sizes T_in=%d C=%d", T_in, C); return -1; }
+    const int T_out = T_in / 3;
+    const long long total4 = (long long)B * T_out * (C / 4);
+    long long g = (total4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(resblock_pool_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(Y2), reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
+                       reinterpret_cast<const f32x4*>(res), prelu_w, reinterpret_cast<f32x4*>(out), total4, T_in, T_out, C / 4);
+    return dprnn_check_launch("resblock_pool_kernel");
+}
+
+extern "C" int dprnn_time_mean_fwd(const float* E, const float* aux_len, int n_len, float* emb, int B, int T3, int C, int ks,
+                                   void* stream) {
+    if (!E || !aux_len || !emb) { dprnn_set_error("dprnn_time_mean_fwd: null pointer"); return -1; }
+    if (C > 1024 || ks < 2 || (n_len != 1 && n_len != B)) { dprnn_set_error("dprnn_time_mean_fwd: bad sizes C=%d ks=%d n_len=%d", C, ks, n_len); return -1; }
+    hipLaunchKernelGGL(time_mean_kernel, dim3(B), dim3(((C + 63) / 64) * 64), 0, (hipStream_t)stream, E, aux_len, n_len, emb, T3, C, ks);
+    return dprnn_check_launch("time_mean_kernel");
+}
+
+extern "C" int dprnn_linear_small_fwd(const float* in, int in_pitch, const float* W, int ldw, int k0, int K, const float* bias,
+                                      float* out, int out_pitch, int B, int O, void* stream) {
+    if (!in || !W || !out) { dprnn_set_error("dprnn_linear_small_fwd: null pointer"); return -1; }
+    hipLaunchKernelGGL(linear_small_kernel, dim3((B * O + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, in_pitch, W, ldw,
+                       k0, K, bias, out, out_pitch, B, O);
+    return dprnn_check_launch("linear_small_kernel");
+}
+
+extern "C" int dprnn_rows_stats(const float* A, double* stats, int B, int64_t rows_per_utt, int C, void* stream) {
+    if (!A || !stats) { dprnn_set_error("dprnn_rows_stats: null pointer"); return -1; }
+    if (C % 4) { dprnn_set_error("dprnn_rows_stats: C must be a multiple of 4"); return -1; }
+    const long long per4 = (long long)rows_per_utt * C / 4;
+    long long g = (per4 + 256 * 16 - 1) / (256 * 16); if (g > 256) g = 256; if (g < 1) g = 1;
+    hipLaunchKernelGGL(rows_stats_kernel, dim3((unsigned)g, B), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(A), stats, per4);
+    return dprnn_check_launch("rows_stats_kernel");
+}

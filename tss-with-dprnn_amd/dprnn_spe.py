@@ -1,0 +1,120 @@
+"""DPRNN-Spe on the MI355X path: API mirror of the reference's src/models/dprnn_spe.py.
+
+Same class names, constructor signatures, registration order and state_dict keys (incl. the BatchNorm
+buffers) as the reference; the modules hold parameters, ``DPRNNSpeTasNet.forward`` enqueues the HIP kernels
+(engine.spe_forward).  BatchNorm1d follows ``module.training`` exactly like torch: the reference's
+Inferencer never calls ``.eval()`` (src/inferencers/inferencer_spe.py:20-32), so batch statistics -- and the
+in-place running-statistics update -- are supported too.  ``DPRNNTasNet`` is re-exported because
+scripts/test/config_bss.yaml:12 targets ``src.models.dprnn_spe.DPRNNTasNet``.
+"""
+import torch
+from torch import nn
+
+from . import engine, norms
+from ._lib import DprnnError
+from .dprnn import DPRNN, DPRNNTasNet  # noqa: F401  (DPRNNTasNet: see module docstring)
+from .encoder_decoder import Decoder, Encoder
+
+
+class ResBlock(nn.Module):
+    """ResNet block of the speaker encoder (dprnn_spe.py:8-42): 1x1 conv, BN, PReLU, 1x1 conv, BN, (+x | +conv(x)),
+    PReLU, MaxPool1d(3).  Evaluated by dprnn_pointwise_fwd / dprnn_bn_prep / dprnn_resblock_pool_fwd."""
+
+    def __init__(self, in_dims, out_dims):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_dims, out_dims, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(out_dims, out_dims, kernel_size=1, bias=False)
+        self.batch_norm1 = nn.BatchNorm1d(out_dims)
+        self.batch_norm2 = nn.BatchNorm1d(out_dims)
+        self.prelu1 = nn.PReLU()
+        self.prelu2 = nn.PReLU()
+        self.maxpool = nn.MaxPool1d(3)
+        self.downsample = in_dims != out_dims
+        if self.downsample:
+            self.conv_downsample = nn.Conv1d(in_dims, out_dims, kernel_size=1, bias=False)
+
+    def forward(self, x):
+        raise DprnnError("ResBlock is evaluated by the fused MI355X kernels; call the TasNet wrapper")
+
+
+class DPRNNSpe(DPRNN):
+    """DPRNN with speaker-embedding fusion (dprnn_spe.py:44-248) -- parameter holder."""
+
+    def __init__(self, input_size, feature_size=128, hidden_size=128, chunk_length=200, hop_length=None,
+                 n_repeats=6, bidirectional=True, rnn_type='LSTM', norm_type='gLN', activation_type='sigmoid',
+                 dropout=0, O=128, P=256, embeddings_size=128, num_spks=251, kernel_size=2, fusion_type='cat'):
+        super().__init__(input_size, feature_size, hidden_size, chunk_length, hop_length, n_repeats, bidirectional,
+                         rnn_type, norm_type, activation_type, dropout=dropout)
+        self.kernel_size = kernel_size
+        self.fusion_type = fusion_type
+        start_conv1d = None
+        if fusion_type == 'cat':
+            start_conv1d = nn.Conv1d(input_size + embeddings_size, feature_size, 1)
+        if fusion_type in ('add', 'mul'):
+            self.fusion_linear = nn.Linear(embeddings_size, input_size)
+            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+        if fusion_type == 'film':
+            self.fusion_linear_1 = nn.Linear(embeddings_size, input_size)
+            self.fusion_linear_2 = nn.Linear(embeddings_size, input_size)
+            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+        if fusion_type == 'att':
+            self.fusion_linear = nn.Linear(embeddings_size, input_size)
+            self.average = nn.Conv1d(input_size, input_size, kernel_size, kernel_size, groups=input_size)
+            self.average.weight = nn.Parameter(torch.ones(input_size, 1, kernel_size) / kernel_size)
+            self.average.bias = nn.Parameter(torch.zeros(input_size))
+            for p in self.average.parameters():
+                p.requires_grad = False
+            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+        if start_conv1d is None:
+            raise UnboundLocalError("local variable 'start_conv1d' referenced before assignment")   # as the reference does
+        linear_norm = norms.GlobLN(input_size) if norm_type == 'gLN' else nn.GroupNorm(1, input_size)   # dprnn_spe.py:108-111
+        self.bottleneck = nn.Sequential(linear_norm, start_conv1d)
+        self.spk_encoder = nn.Sequential(
+            nn.GroupNorm(1, input_size),
+            nn.Conv1d(input_size, O, 1),
+            ResBlock(O, O),
+            ResBlock(O, P),
+            ResBlock(P, P),
+            nn.Conv1d(P, embeddings_size, 1),
+        )
+        self.pred_linear = nn.Linear(embeddings_size, num_spks)
+
+    def forward(self, input, aux, aux_len):
+        raise DprnnError("DPRNNSpe consumes raw waveforms on the MI355X path; call DPRNNSpeTasNet / DPRNNSpeIRATasNet")
+
+
+def _refuse_training(module, name):
+    if torch.is_grad_enabled() and module.training and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            f"{name} (MI355X): backward kernels are not built yet; run the forward under torch.no_grad() "
+            "(BatchNorm train-mode statistics are honoured under no_grad)")
+
+
+class DPRNNSpeTasNet(nn.Module):
+    """DPRNN-Spe-TasNet (dprnn_spe.py:250-327): forward(input[B,T], aux[B,Ta], aux_len) -> (est[B,T], logits)."""
+
+    _separator_cls = DPRNNSpe
+
+    def __init__(self, input_size, feature_size=128, hidden_size=128, chunk_length=200, kernel_size=2,
+                 hop_length=None, n_repeats=6, bidirectional=True, rnn_type='LSTM', norm_type='gLN',
+                 activation_type='sigmoid', dropout=0, stride=None, O=128, P=256, embeddings_size=128,
+                 num_spks=251, fusion_type='cat'):
+        super().__init__()
+        self.stride = stride if stride is not None else kernel_size // 2
+        self.encoder = Encoder(kernel_size, input_size, stride=self.stride, bias=False)
+        self.separation = self._separator_cls(input_size, feature_size, hidden_size, chunk_length, hop_length,
+                                              n_repeats, bidirectional, rnn_type, norm_type, activation_type, dropout,
+                                              O, P, embeddings_size, num_spks, kernel_size, fusion_type)
+        self.decoder = Decoder(in_channels=input_size, out_channels=1, kernel_size=kernel_size, stride=self.stride,
+                               bias=False)
+        self.cfg = dict(input_size=input_size, feature_size=feature_size, hidden_size=hidden_size,
+                        chunk_length=chunk_length, kernel_size=kernel_size, hop_length=self.separation.hop_length,
+                        n_repeats=n_repeats, bidirectional=bool(bidirectional), rnn_type=rnn_type, norm_type=norm_type,
+                        activation_type=activation_type, dropout=dropout, stride=self.stride, O=O, P=P,
+                        embeddings_size=embeddings_size, num_spks=num_spks, fusion_type=fusion_type)
+
+    _ira = False
+
+    def forward(self, input, aux, aux_len, debug=None):
+        _refuse_training(self, type(self).__name__)
+        return engine.spe_forward(self, input, aux, aux_len, ira=self._ira, debug=debug)

@@ -130,24 +130,37 @@ class Stage:
         check(self.lib, rc, name)
 
 
-def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geometry, stats_slot,
-                         mul=None, add=None, row_bias=None):
-    """Encoder -> bottleneck norm -> (fusion) -> bottleneck 1x1 conv, output Y [B][L][F].
-
-    reference: encoder_decoder.py:25-33, dprnn.py:131-136,169; fusion hooks dprnn_spe.py:165-229."""
+def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slot, mul=None, add=None):
+    """Per-utterance affine (sc, sh) of the bottleneck norm, with the add/mul/film fusions folded in.
+    reference: encoder_decoder.py:25-33 (stats of the encoder output), dprnn.py:131-136, dprnn_spe.py:194-229."""
     dev = wav.device
     gamma, beta, eps = _norm_params(bott_norm)
     st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_slot), geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
     sc = torch.empty(geo.B, geo.N, device=dev, dtype=torch.float32)
     sh = torch.empty_like(sc)
-    st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(_param(gamma, "bottleneck.0.weight", dev)),
-            _p(_param(beta, "bottleneck.0.bias", dev)), eps, _p(mul), _p(add), _p(sc), _p(sh), geo.B, geo.L, geo.N)
-    w = _param(bott_conv.weight, "bottleneck.1.weight", dev)
+    st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(_param(gamma, "norm.weight", dev)),
+            _p(_param(beta, "norm.bias", dev)), eps, _p(mul), _p(add), _p(sc), _p(sh), geo.B, geo.L, geo.N)
+    return sc, sh
+
+
+def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None):
+    """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias)."""
+    dev = wav.device
+    w = _param(conv.weight, "conv.weight", dev)
+    if w.shape[0] != F_BUILT or w.shape[1] < geo.N:
+        raise DprnnError(f"1x1 conv weight {tuple(w.shape)} does not fit the {geo.N}->{F_BUILT} kernel")
     Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
     st.call("dprnn_bottleneck_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
-            _p(_param(bott_conv.bias, "bottleneck.1.bias", dev)), _p(row_bias), _p(Y),
+            _p(_param(conv.bias, "conv.bias", dev)), _p(row_bias), _p(Y),
             geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
     return Y
+
+
+def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geometry, stats_slot,
+                         mul=None, add=None, row_bias=None):
+    """Encoder -> bottleneck norm -> (fusion) -> bottleneck 1x1 conv, output Y [B][L][F]."""
+    sc, sh = bottleneck_affine(st, wav, enc_w, bott_norm, geo, stats_slot, mul, add)
+    return bottleneck_frames(st, wav, enc_w, sc, sh, bott_conv, geo, row_bias)
 
 
 def _rnn_tensors(rnn, dev):
@@ -321,3 +334,177 @@ def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> to
             debug["bottleneck"] = Y.clone()
         taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
         return decode(st, taps, geo, 2)
+
+
+# ------------------------------------------------------------------------------------------------ DPRNN-Spe / IRA
+def check_supported_spe(cfg: dict) -> None:
+    check_supported(cfg)
+    bad = []
+    if cfg["O"] != 128 or cfg["P"] != 256 or cfg["embeddings_size"] != 128:
+        bad.append(f"speaker encoder must be O=128, P=256, embeddings_size=128 (got {cfg['O']}, {cfg['P']}, {cfg['embeddings_size']})")
+    if cfg["fusion_type"] not in ("cat", "add", "mul", "film"):
+        bad.append(f"fusion_type {cfg['fusion_type']!r}: 'att' has no HIP kernel yet; 'cat', 'add', 'mul', 'film' do")
+    if cfg["kernel_size"] < 2:
+        bad.append("kernel_size must be >= 2 (aux_T divides by kernel_size // 2, dprnn_spe.py:159)")
+    if bad:
+        raise NotImplementedError("DPRNN-Spe MI355X path: unsupported configuration: " + "; ".join(bad))
+
+
+def _linear_small(st: Stage, lin_w, lin_b, x, k0: int = 0, K: Optional[int] = None):
+    dev = x.device
+    w = _param(lin_w, "linear.weight", dev)
+    w2 = w.reshape(w.shape[0], -1)
+    K = w2.shape[1] - k0 if K is None else K
+    out = torch.empty(x.shape[0], w2.shape[0], device=dev, dtype=torch.float32)
+    st.call("dprnn_linear_small_fwd", _p(x), x.shape[1], _p(w2), w2.shape[1], k0, K,
+            _p(_param(lin_b, "linear.bias", dev)) if lin_b is not None else 0, _p(out), out.shape[1], x.shape[0], w2.shape[0])
+    return out
+
+
+def _pointwise(st: Stage, A, rows, kdim, conv_w, conv_b, cout, in_scale=None, in_shift=None, aff_stride=0,
+               rows_per_utt=0, in_prelu=None, col_stats=None):
+    dev = A.device
+    w = _param(conv_w, "conv.weight", dev)
+    out = torch.empty(rows, cout, device=dev, dtype=torch.float32)
+    for col0 in range(0, cout, 128):
+        st.call("dprnn_pointwise_fwd", _p(A), kdim, kdim, _p(in_scale), _p(in_shift), aff_stride, rows_per_utt,
+                _p(in_prelu), _p(w), kdim, _p(_param(conv_b, "conv.bias", dev)) if conv_b is not None else 0,
+                _p(out), cout, col0, _p(col_stats), rows)
+    return out
+
+
+def _bn_fold(st: Stage, bn, col_stats, count, dev):
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not supported")
+    C = bn.num_features
+    scale = torch.empty(C, device=dev, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    st.call("dprnn_bn_prep", _p(_param(bn.weight, "bn.weight", dev)), _p(_param(bn.bias, "bn.bias", dev)),
+            _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(col_stats), count,
+            float(bn.momentum), float(bn.eps), _p(scale), _p(shift), C)
+    return scale, shift
+
+
+def _resblock(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
+    """ResBlock.forward (dprnn_spe.py:31-42) on channels-last rows [B*T][cin] -> [B][T//3][cout]."""
+    dev = Xin.device
+    rows = B * T
+    tr1, tr2 = blk.batch_norm1.training, blk.batch_norm2.training
+    cs1 = torch.zeros(cout, 2, device=dev, dtype=torch.float64) if tr1 else None
+    y1 = _pointwise(st, Xin, rows, cin, blk.conv1.weight, None, cout, col_stats=cs1)
+    s1, t1 = _bn_fold(st, blk.batch_norm1, cs1, rows, dev)
+    cs2 = torch.zeros(cout, 2, device=dev, dtype=torch.float64) if tr2 else None
+    y2 = _pointwise(st, y1, rows, cout, blk.conv2.weight, None, cout, in_scale=s1, in_shift=t1,
+                    in_prelu=_param(blk.prelu1.weight, "prelu1.weight", dev), col_stats=cs2)
+    s2, t2 = _bn_fold(st, blk.batch_norm2, cs2, rows, dev)
+    res = _pointwise(st, Xin, rows, cin, blk.conv_downsample.weight, None, cout) if blk.downsample else Xin
+    out = torch.empty(B, T // 3, cout, device=dev, dtype=torch.float32)
+    st.call("dprnn_resblock_pool_fwd", _p(y2), _p(s2), _p(t2), _p(res), _p(_param(blk.prelu2.weight, "prelu2.weight", dev)),
+            _p(out), B, T, cout)
+    return out, T // 3
+
+
+def speaker_embedding(st: Stage, sep, A0, B: int, T: int, aux_len_dev, ks: int):
+    """spk_encoder[2:] + time mean (dprnn_spe.py:117-122,156-163) from the first conv's output A0 [B*T][128]."""
+    se = sep.spk_encoder
+    h, t = _resblock(st, se[2], A0, B, T, 128, 128)
+    h, t = _resblock(st, se[3], h, B, t, 128, 256)
+    h, t = _resblock(st, se[4], h, B, t, 256, 256)
+    if t < 1:
+        raise DprnnError("reference utterance too short for three MaxPool1d(3) stages")
+    E = _pointwise(st, h, B * t, 256, se[5].weight, se[5].bias, 128)
+    emb = torch.empty(B, 128, device=A0.device, dtype=torch.float32)
+    st.call("dprnn_time_mean_fwd", _p(E), _p(aux_len_dev), aux_len_dev.numel(), _p(emb), B, t, 128, ks)
+    return emb
+
+
+def _aux_len_tensor(aux_len, B: int, dev):
+    t = torch.as_tensor(aux_len, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    if t.numel() not in (1, B):
+        raise DprnnError(f"aux_len must be a scalar or hold one value per utterance (got {t.numel()} for batch {B})")
+    return t
+
+
+def _fusion_operands(st: Stage, sep, cfg, emb):
+    """(mul, add, row_bias) of the bottleneck for every supported fusion (dprnn_spe.py:165-229)."""
+    ft = cfg["fusion_type"]
+    if ft == "cat":          # conv over cat([x, emb]) = conv_x(x) + W[:, N:] @ emb  (dprnn_spe.py:186-192)
+        return None, None, _linear_small(st, sep.bottleneck[1].weight, None, emb, k0=cfg["input_size"])
+    if ft == "add":
+        return None, _linear_small(st, sep.fusion_linear.weight, sep.fusion_linear.bias, emb), None
+    if ft == "mul":
+        return _linear_small(st, sep.fusion_linear.weight, sep.fusion_linear.bias, emb), None, None
+    if ft == "film":
+        return (_linear_small(st, sep.fusion_linear_1.weight, sep.fusion_linear_1.bias, emb),
+                _linear_small(st, sep.fusion_linear_2.weight, sep.fusion_linear_2.bias, emb), None)
+    raise NotImplementedError(ft)
+
+
+def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
+    """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) / DPRNNSpeIRATasNet.forward (dprnn_spe_ira.py:179-190):
+    (mix [B,T], aux [B,Ta], aux_len) -> (estimate [B,T_out], speaker logits [B,num_spks])."""
+    cfg = model.cfg
+    check_supported_spe(cfg)
+    wav, aux = check_input(wav), check_input(aux, "aux")
+    if aux.shape[0] != wav.shape[0]:
+        raise DprnnError("mixture and reference batch sizes differ")
+    dev = wav.device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
+        geo = make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+        geo_a = make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+        B = geo.B
+        sep = model.separation
+        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
+        n_blocks = len(sep.dprnn_blocks)
+        n_pass = 2 if ira else 1
+        stats = torch.zeros(n_pass * (1 + 2 * n_blocks) + 2, B, 2, device=dev, dtype=torch.float64)
+        aux_len_dev = _aux_len_tensor(aux_len, B, dev)
+        se = sep.spk_encoder
+
+        # speaker embedding of the reference utterance (dprnn_spe.py:156-163)
+        sc_a, sh_a = bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats[-1])
+        A0 = bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
+        v0 = speaker_embedding(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
+        if debug is not None:
+            debug["emb"] = v0.clone()
+
+        # first (only) separation pass
+        mul, add, row_bias = _fusion_operands(st, sep, cfg, v0)
+        sc, sh = bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], mul, add)
+        Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias)
+        relu_act = cfg["activation_type"] == "relu"
+        v_last = v0
+        if not ira:
+            taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[: 1 + 2 * n_blocks], relu_act, debug=debug)
+        else:
+            taps, d0 = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[: 1 + 2 * n_blocks], relu_act,
+                                     want_masked=True)
+            # second embedding from the first estimate d0 = mask0 * enc  (dprnn_spe_ira.py:79-92)
+            st.call("dprnn_rows_stats", _p(d0), _p(stats[-2]), B, geo.L, N)
+            g0, b0, _ = _norm_params(se[0])
+            sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
+            sh_d = torch.empty_like(sc_d)
+            st.call("dprnn_bottleneck_prep", _p(stats[-2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
+                    _p(_param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, _p(sc_d), _p(sh_d), B, geo.L, N)
+            A0d = _pointwise(st, d0.view(B * geo.L, N), B * geo.L, N, se[1].weight, se[1].bias, 128,
+                             in_scale=sc_d, in_shift=sh_d, aff_stride=N, rows_per_utt=geo.L)
+            v1 = speaker_embedding(st, sep, A0d, B, geo.L, aux_len_dev, ks)
+            v1 = _linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0, v1), dim=1).contiguous())
+            if debug is not None:
+                debug["v1"] = v1.clone()
+            # second pass re-uses the cached norm output (dprnn_spe_ira.py:96): same sc/sh, new fusion operands
+            mul2, add2, row_bias2 = _fusion_operands(st, sep, cfg, v1)
+            if mul2 is not None or add2 is not None:
+                g, b_, eps = _norm_params(sep.bottleneck[0])
+                st.call("dprnn_bottleneck_prep", _p(stats[0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh),
+                        B, geo.L, N)
+            Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2)
+            taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[1 + 2 * n_blocks: 2 * (1 + 2 * n_blocks)],
+                                 relu_act, debug=debug)
+            v_last = v1
+        logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last)
+        est = decode(st, taps, geo, 1)                    # speaker 0 only (dprnn_spe.py:325)
+        return est[:, 0, :], logits

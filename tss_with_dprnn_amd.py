@@ -12,3 +12,5 @@ __version__ = "0.1.0"
 from tss_with_dprnn_amd._lib import build_library, load_library, library_path  # noqa: E402,F401
 from tss_with_dprnn_amd.dprnn import DPRNN, DPRNNBlock, DPRNNTasNet, SingleRNN  # noqa: E402,F401
 from tss_with_dprnn_amd.encoder_decoder import Decoder, Encoder  # noqa: E402,F401
+from tss_with_dprnn_amd.dprnn_spe import DPRNNSpe, DPRNNSpeTasNet, ResBlock  # noqa: E402,F401
+from tss_with_dprnn_amd.dprnn_spe_ira import DPRNNSpeIRA, DPRNNSpeIRATasNet  # noqa: E402,F401
