@@ -102,7 +102,7 @@ def main():
         for _ in range(args.warmup):
             out = model(x)
         sync()
-        engine.PROFILE = {"names": {"dprnn_bilstm_fwd"}, "events": {}}
+        engine.PROFILE = {"names": {"dprnn_bilstm_fwd", "dprnn_bilstm_norm_fwd"}, "events": {}}
         t_ref = torch.cuda.Event(enable_timing=True)
         t_ref.record()
         t0 = time.perf_counter()
@@ -119,7 +119,7 @@ def main():
     # dominant kernel: per-launch HIP-event durations on the launch streams.  With utterance groups on several
     # streams the launches overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch
     # intervals); kernel_ms is the plain mean launch duration (what rocprofv3 --stats reports).
-    ev = prof["events"].get("dprnn_bilstm_fwd", [])
+    ev = prof["events"].get("dprnn_bilstm_fwd", []) + prof["events"].get("dprnn_bilstm_norm_fwd", [])
     spans = sorted((t_ref.elapsed_time(a), t_ref.elapsed_time(b)) for a, b in ev)
     kern_ms = float(np.mean([e - s for s, e in spans])) if spans else float("nan")
     union_ms, cur_s, cur_e = 0.0, None, None
@@ -157,11 +157,11 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS},
-            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_bilstm_fwd)",
+            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_bilstm_fwd / dprnn_bilstm_norm_fwd)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
-                         "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 * 4 / 1e9,
+                         "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 * (4 + (3 if engine.FUSE_NORM else 0)) / 1e9,
                          "kernel_ms": kern_ms, "launches_timed": len(ev), "launches_per_step": launches_per_step,
                          "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},

@@ -40,6 +40,9 @@ int dprnn_num_cus(void);
  * 2e-7 rel-L2 against the reference output end to end, tests/test_gpu_parity.py), 0 = libm expf/tanhf */
 void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
 void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
+/* seq_tile 64 of dprnn_bilstm_fwd: 1 = software-pipelined kernel (cell update hidden under the other half's
+ * gate GEMM, recur64.hip), 0 = plain 64-sequence tile */
+void dprnn_set_recur_pipelined(int on);
 
 /* ---- encoder statistics: Encoder.forward (src/models/encoder_decoder.py:25-33) feeding the
  * bottleneck norm (src/models/dprnn.py:131-136).  enc[b,n,l] = relu(sum_j We[n][j]*wav[b][l*stride+j])
@@ -86,8 +89,19 @@ int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, flo
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                      int64_t t_stride, int ndir, int seq_tile, void* stream);
 
-/* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][4] u64 =
- * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles}; used by tools/bench_recur.py only. */
+/* ---- dprnn_bilstm_fwd with the previous path's norm + residual folded into the x loader
+ * (DPRNNBlock.forward, dprnn.py:90-92 feeding :94-95, and :98-99 feeding the next block's :84-86):
+ * the kernel consumes x' = X + ((Z - mean_b)*rstd_b*gamma + beta) (b = sequence / seqs_per_utt, statistics over
+ * rows_per_utt*F elements, eps 1e-5|1e-8) and writes x' once to Xout (must differ from X: both directions read X).
+ * Saves the separate dprnn_norm_residual_fwd pass over the slab. */
+int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                          const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                          const float* packed, const float* bsum, float* H,
+                          int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                          int64_t t_stride, int ndir, int seq_tile, void* stream);
+
+/* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
+ * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; used by tools/bench_recur.py only. */
 int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
                              int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                              int64_t t_stride, int ndir, int seq_tile, unsigned long long* stamps, void* stream);
@@ -110,6 +124,12 @@ int dprnn_norm_residual_fwd(const float* X, const float* Z, const double* stats,
  * U[b][l][0:2F], channel block 0 = speaker 0 (dprnn.py:176 reshape). */
 int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W2d, const float* b2d,
                             float* U, int B, int L, int K, int P, int S, void* stream);
+
+/* same with the last path's norm + residual still pending (see dprnn_bilstm_norm_fwd): rows are read as
+ * X + ((Z - mean_b)*rstd_b*gamma + beta) before the PReLU */
+int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                                 const float* beta, float eps, const float* prelu_w, const float* W2d,
+                                 const float* b2d, float* U, int B, int L, int K, int P, int S, void* stream);
 
 /* ---- mask head part 2: tanh(out conv) * sigmoid(gate conv) (dprnn.py:157-158,180) on rows
  * (b,l,spk) of U viewed as [B*L*2][F] -> V [B*L*2][F] */

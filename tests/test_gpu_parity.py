@@ -120,6 +120,27 @@ def test_both_activation_forms_stay_within_tolerance(fast):
     assert r <= REL_TOL
 
 
+def test_fused_and_explicit_norm_agree():
+    """engine.FUSE_NORM folds every norm+residual into the consumer's loader; the explicit pass must agree."""
+    from tss_with_dprnn_amd import engine
+    g = load_golden("bss_wide_k250")
+    m = g["meta"]
+    model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
+    x = torch.from_numpy(g["mix"]).to(_dev())
+    old = engine.FUSE_NORM
+    try:
+        outs = []
+        for f in (True, False):
+            engine.FUSE_NORM = f
+            with torch.no_grad():
+                outs.append(model(x).cpu().numpy())
+    finally:
+        engine.FUSE_NORM = old
+    _close(outs[0], g["out"], "fused")
+    _close(outs[1], g["out"], "explicit")
+    assert rel_l2(outs[0], outs[1]) < 1e-6
+
+
 def test_stream_groups_do_not_change_results():
     """Utterance groups on separate HIP streams (engine.STREAM_GROUPS) must be bit-identical to one stream."""
     from tss_with_dprnn_amd import engine

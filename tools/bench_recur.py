@@ -40,15 +40,35 @@ def stamps(st, seq_tile, per_cu, T, ndir=2):
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
     packed = torch.randn(ndir * engine.PACK_PER_DIR, device="cuda") * 0.08
     bsum = torch.randn(ndir * 512, device="cuda") * 0.1
-    buf = torch.zeros(nwg, 4, device="cuda", dtype=torch.int64)
-    for _ in range(3):      # warm clocks
+    buf = torch.zeros(nwg, 8, device="cuda", dtype=torch.int64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(12):      # long enough for the clock to settle; time the last 8
+        if it == 4:
+            e0.record()
         st.call("dprnn_bilstm_fwd_stamped", X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T,
                 nseq, 0, T, 1, ndir, seq_tile, buf.data_ptr())
+    e1.record()
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 8
+    tf = nseq * T * ndir * 2 * 256 * 512 / ms / 1e9
     b = buf.cpu().double()
     cyc, ticks, kloop, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
     clk = cyc / ticks * 100.0
-    print(f"stamps seq_tile={seq_tile} wgs/CU={per_cu}: in-kernel clock {clk:.0f} MHz; per step: total {cyc / T:.0f} cyc, "
+    start = (b[:, 4] - b[:, 4].min()) / 100.0          # us
+    end = (b[:, 5] - b[:, 4].min()) / 100.0
+    import collections
+    late = int((start > 50).sum())
+    q = torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], dtype=torch.float64)
+    print("   end-time percentiles (us) [0,10,25,50,75,90,99,100]:", [int(v) for v in torch.quantile(end, q).tolist()])
+    for x in range(8):
+        sel = (b[:, 6].long() & 0xF) == x
+        if sel.any():
+            print(f"   xcc {x}: {int(sel.sum())} wgs, end median {end[sel].median():.0f} max {end[sel].max():.0f}, clock {float((b[sel, 0] / b[sel, 1]).median()) * 100:.0f} MHz")
+    print(f"   dispatch: {nwg} wgs, start us min/median/max {start.min():.0f}/{start.median():.0f}/{start.max():.0f}, "
+          f"end us min/median/max {end.min():.0f}/{end.median():.0f}/{end.max():.0f}, started later than 50 us: {late}")
+    cu = collections.Counter((int(x) & 0xF, (int(h) >> 8) & 0xF, (int(h) >> 13) & 0x7, (int(h) >> 16) & 0xF) for x, h in zip(b[:, 6].tolist(), b[:, 7].tolist()))
+    print(f"   distinct (xcc, cu, sh?, se) ids {len(cu)}, workgroups per id histogram {sorted(collections.Counter(cu.values()).items())}")
+    print(f"stamps DIAG={os.environ.get('DPRNN_DIAG', '0')} seq_tile={seq_tile} wgs/CU={per_cu}: {tf:.1f} TFLOP/s, in-kernel clock {clk:.0f} MHz; per step: total {cyc / T:.0f} cyc, "
           f"k-loop {kloop / T:.0f}, cell+stores {cell / T:.0f}, barrier/other {(cyc - kloop - cell) / T:.0f}")
 
 
@@ -57,15 +77,23 @@ def main():
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
+    ap.add_argument("--pipelined", type=int, default=0, help="seq_tile 64 uses the software-pipelined kernel")
+    ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
     lib.dprnn_set_fast_activations(a.fast)
+    lib.dprnn_set_recur_pipelined(a.pipelined)
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
     if a.stamps:
         for seq_tile, per_cu in ((32, 1), (32, 2), (64, 1)):
             stamps(st, seq_tile, per_cu, a.T)
+        return
+    if a.only:
+        seq_tile, per_cu = (int(v) for v in a.only.split(","))
+        ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
+        print(f"only seq_tile={seq_tile} wgs/CU={per_cu}: {ms:.3f} ms {tf:.1f} TFLOP/s")
         return
     print("seq_tile  wgs/CU   ms     us/step  TFLOP/s  mfma-cycles/step/SIMD(ideal)  implied-util@2.4GHz")
     for seq_tile in (16, 32, 48, 64):

@@ -28,10 +28,13 @@ SIGNATURES = {
     "dprnn_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp],
+    "dprnn_bilstm_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
+                              c_i64, c_i, c_i, c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_head_conv_ola_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_head_gate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
     "dprnn_head_mask_decode_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_decoder_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -45,6 +48,7 @@ SIGNATURES = {
 _VOID = {
     "dprnn_set_fast_activations": [c_i],
     "dprnn_set_fast_head_activations": [c_i],
+    "dprnn_set_recur_pipelined": [c_i],
 }
 _SPECIAL = {
     "dprnn_last_error": ([], ctypes.c_char_p),

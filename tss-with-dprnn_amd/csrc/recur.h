@@ -1,0 +1,35 @@
+// Shared declarations of the recurrence kernels (recur.hip, recur64.hip).
+#pragma once
+#include "common.h"
+
+namespace recur {
+constexpr int F = 128;      // input features of the LSTM
+constexpr int HD = 128;     // hidden units
+constexpr int XS = 257;     // LDS row stride in floats: [x(128) | h(128)] + 1 pad (odd => conflict-free)
+constexpr int NGRP = 16;    // k-groups of 16 per step: 0..7 over x, 8..15 over h
+constexpr int PACK_PER_DIR = 4 * NGRP * 8 * 256;   // floats
+
+struct RecurArgs {
+    const float* X;
+    const float* Wp;
+    const float* bsum;
+    float* H;
+    int nseq, T, inner_n, ndir;
+    long long outer_stride, inner_stride, t_stride;   // in rows
+    unsigned long long* stamps;                       // diagnostic build only: [wg][8] counters
+    float* dump;                                      // recur64: landing zone for rows past nseq
+    // optional fused "pending norm + residual" of the previous path (dprnn.py:90-92,98-99): when Z != nullptr the
+    // kernel reads x' = X + (Z - mean_b)*rstd_b*gamma + beta, and direction 0 also writes x' to Xout (!= X)
+    const float* Z;
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    float* Xout;
+    float eps;
+    int seqs_per_utt;
+    long long rows_per_utt;
+};
+
+// software-pipelined 64-sequence variant (recur64.hip)
+int launch_bilstm64(const RecurArgs& a, bool fast, hipStream_t st);
+}  // namespace recur

@@ -20,25 +20,11 @@
 //     are 16 floats apart (bank = (row + 16*(q&1)) mod 32: a bijection).
 //   * c stays in registers for the whole sequence; h goes registers -> LDS (next step's operand) and
 //     registers -> HBM (64-byte segments, merged in L2).
-#include "common.h"
+#include "recur.h"
+#include <stdlib.h>
+using namespace recur;
 
 namespace {
-
-constexpr int F = 128;      // input features of the LSTM
-constexpr int HD = 128;     // hidden units
-constexpr int XS = 257;     // LDS row stride in floats: [x(128) | h(128)] + 1 pad (odd => conflict-free)
-constexpr int NGRP = 16;    // k-groups of 16 per step: 0..7 over x, 8..15 over h
-constexpr int PACK_PER_DIR = 4 * NGRP * 8 * 256;   // floats
-
-struct RecurArgs {
-    const float* X;
-    const float* Wp;
-    const float* bsum;
-    float* H;
-    int nseq, T, inner_n, ndir;
-    long long outer_stride, inner_stride, t_stride;   // in rows
-    unsigned long long* stamps;                       // diagnostic build only: [wg][4] cycle counters
-};
 
 // packed[dir][wave][grp][gate*2+u][lane][i] = Wcat[dir][gate*128 + 32*wave + 16*u + (lane&15)][k]
 __global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
@@ -63,7 +49,10 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __
     }
 }
 
-template <int NT, bool FAST, bool STAMP = false>
+// DIAG (diagnostic builds only, wrong results on purpose): 1 = every k-group re-reads weight group 0 (L1-resident:
+// no L2 weight stream), 2 = A fragments read once per step instead of per k-group (no LDS operand traffic),
+// 3 = cell update skipped (h = gate pre-activation), 4 = no HBM store of h.
+template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
     constexpr int NS = 16 * NT;
@@ -77,22 +66,30 @@ void bilstm_kernel(RecurArgs a) {
     const int seq0 = blockIdx.x * NS;
     const int T = a.T;
 
+    // Addressing: every row this workgroup touches is (first row of the workgroup) + a small per-lane offset, and all
+    // rows advance by the same amount per step, so per-lane offsets are 32-bit constants and the per-step part is a
+    // scalar base (SGPR adds, saddr-form global_load/store): no vector ALU work for addresses inside the step loop
+    // -- fp32 VALU instructions are not hidden by fp32 MFMAs on gfx950, every one of them costs matrix time.
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);          // uniform
+    const int hpitch = a.ndir * HD;
     // ---- x staging descriptors: float4 f = tid + 256*m covers row f>>5, floats 4*(f&31)..+3
-    const float* xptr[NXV];
+    unsigned xoff[NXV];                               // byte offset from X + row0*F
     int xlds[NXV];
     bool xval[NXV];
+    const int c4 = tid & 31;
 #pragma unroll
     for (int m = 0; m < NXV; ++m) {
-        const int f = tid + 256 * m, row = f >> 5, c4 = f & 31;
+        const int f = tid + 256 * m, row = f >> 5;
         const int seq = seq0 + row;
         xval[m] = seq < a.nseq;
-        const int sq = xval[m] ? seq : 0;
-        const long long base = (long long)(sq / a.inner_n) * a.outer_stride + (long long)(sq % a.inner_n) * a.inner_stride;
-        xptr[m] = a.X + base * F + c4 * 4;
+        xoff[m] = (unsigned)((rowbase(xval[m] ? seq : seq0) - row0) * F + c4 * 4) * 4u;
         xlds[m] = row * XS + c4 * 4;
     }
     // ---- rows of the accumulator tile this lane owns: seq row 16*nt + 4*q + reg
-    long long hbase[NT][4];
+    unsigned hoff[NT][4];                             // byte offset from H + row0*hpitch
     bool hval[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -100,11 +97,38 @@ void bilstm_kernel(RecurArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
             hval[nt][e] = seq < a.nseq;
-            const int sq = hval[nt][e] ? seq : 0;
-            hbase[nt][e] = (long long)(sq / a.inner_n) * a.outer_stride + (long long)(sq % a.inner_n) * a.inner_stride;
+            hoff[nt][e] = (unsigned)((rowbase(hval[nt][e] ? seq : seq0) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u;
         }
-    const int hpitch = a.ndir * HD;
-    float* const hout = a.H + dir * HD + 32 * wave + r;
+    // ---- pending norm of the previous path, applied while x is staged
+    const bool fuse = a.Z != nullptr;
+    f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f};
+    float mu[NXV], rs[NXV];
+#pragma unroll
+    for (int m = 0; m < NXV; ++m) { mu[m] = 0.f; rs[m] = 0.f; }
+    if (fuse) {
+        gam = *reinterpret_cast<const f32x4*>(a.gamma + 4 * c4);
+        bet = *reinterpret_cast<const f32x4*>(a.beta + 4 * c4);
+#pragma unroll
+        for (int m = 0; m < NXV; ++m) {
+            const int seq = seq0 + (tid >> 5) + 8 * m;
+            const int b = (seq < a.nseq ? seq : seq0) / a.seqs_per_utt;
+            const double cnt = (double)a.rows_per_utt * (double)F;
+            const double mean = a.stats[2 * b] / cnt;
+            double var = a.stats[2 * b + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mu[m] = (float)mean;
+            rs[m] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+    }
+    // x' of one staged float4 (identity when nothing is pending)
+    auto fix = [&](f32x4 x, f32x4 z, int m) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x[e] + ((z[e] - mu[m]) * rs[m] * gam[e] + bet[e]);
+        return o;
+    };
+    // time index -> scalar bases
+    auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
 
     float bias[4][2];
 #pragma unroll
@@ -117,10 +141,19 @@ void bilstm_kernel(RecurArgs a) {
     // ---- prologue: x_{t0} -> Xs[0], zeros -> Hs[0]
     {
         const long long t0 = dir ? (T - 1) : 0;
+        const char* xs = reinterpret_cast<const char*>(a.X + tbase(t0) * F);
+        const char* zs = reinterpret_cast<const char*>(a.Z + tbase(t0) * F);
+        char* os = reinterpret_cast<char*>(a.Xout + tbase(t0) * F);
 #pragma unroll
         for (int m = 0; m < NXV; ++m) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xval[m]) v = *reinterpret_cast<const f32x4*>(xptr[m] + t0 * a.t_stride * F);
+            if (xval[m]) {
+                v = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
+                if (fuse) {
+                    v = fix(v, *reinterpret_cast<const f32x4*>(zs + xoff[m]), m);
+                    if (dir == 0) *reinterpret_cast<f32x4*>(os + xoff[m]) = v;
+                }
+            }
             float* d = XH + xlds[m];
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
@@ -146,13 +179,19 @@ void bilstm_kernel(RecurArgs a) {
         const long long t = dir ? (T - 1 - step) : step;
         const bool more = step + 1 < T;
         // prefetch x_{t+1} into registers
-        f32x4 xr[NXV];
+        f32x4 xr[NXV], zr[NXV];
+        const long long tn = dir ? (t - 1) : (t + 1);
         if (more) {
-            const long long tn = dir ? (t - 1) : (t + 1);
+            const char* xs = reinterpret_cast<const char*>(a.X + tbase(tn) * F);
+            const char* zs = reinterpret_cast<const char*>(a.Z + tbase(tn) * F);
 #pragma unroll
             for (int m = 0; m < NXV; ++m) {
                 xr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xval[m]) xr[m] = *reinterpret_cast<const f32x4*>(xptr[m] + tn * a.t_stride * F);
+                zr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (xval[m]) {
+                    xr[m] = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
+                    if (fuse) zr[m] = *reinterpret_cast<const f32x4*>(zs + xoff[m]);
+                }
             }
         }
         f32x4 acc[NT][4][2];
@@ -164,6 +203,7 @@ void bilstm_kernel(RecurArgs a) {
                 for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{bias[g][u], bias[g][u], bias[g][u], bias[g][u]};
 
         const float* const Ac = XH + cur * NS * XS + r * XS + 16 * q;
+        if constexpr (SCHED == 0) {
         // 16 k-groups, two per trip; the weights of group g+1 are in flight while group g computes
 #pragma unroll 1
         for (int gp = 0; gp < NGRP / 2; ++gp) {
@@ -171,10 +211,10 @@ void bilstm_kernel(RecurArgs a) {
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
                 // weights of the next k-group (wraps to group 0 of the next step: same bytes every step)
-                const f32x4* wn = wbase + (((grp + 1) & 15) * 8) * 64;
+                const f32x4* wn = wbase + (DIAG == 1 ? 0 : (((grp + 1) & 15) * 8) * 64);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
-                const float* src = Ac + 64 * (grp >> 2) + 4 * (grp & 3);
+                const float* src = Ac + (DIAG == 2 ? 0 : 64 * (grp >> 2) + 4 * (grp & 3));
                 float av[NT][4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -191,32 +231,85 @@ void bilstm_kernel(RecurArgs a) {
                                 acc[nt][gt][u] = mfma16(av[nt][i], w[half][gt * 2 + u][i], acc[nt][gt][u]);
             }
         }
+        } else {
+        // Interleaved schedule: weights AND A fragments of group g+1 are requested while group g computes, and
+        // sched_group_barrier spreads the 8 VMEM + 2*NT DS instructions one per MFMA cluster instead of leaving
+        // them bunched at the group boundary (each MFMA gap hides only a few other instructions).
+        float av[2][NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[0][nt][i] = Ac[nt * 16 * XS + i];
+#pragma unroll 1
+        for (int gp = 0; gp < NGRP / 2; ++gp) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int grp = 2 * gp + half;
+                const f32x4* wn = wbase + ((((grp + 1) & 15) * 8) * 64);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
+                const int gn = (grp + 1) & 15;             // group 15 prefetches group 0 of the old image: unused
+                const float* src = Ac + 64 * (gn >> 2) + 4 * (gn & 3);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[half ^ 1][nt][i] = src[nt * 16 * XS + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                acc[nt][gt][u] = mfma16(av[half][nt][i], w[half][gt * 2 + u][i], acc[nt][gt][u]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 // 1 VMEM read
+                    if (k < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);            // 4*NT MFMA
+                }
+            }
+        }
+        }
 
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); st_mfma += st_b - st_a; }
         // ---- LSTM cell (gate order i,f,g,o), lane-local
         float* const Hn = XH + nxt * NS * XS + HD;
+        char* const hs = reinterpret_cast<char*>(a.H + tbase(t) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float ig = sigmoid_f<FAST>(acc[nt][0][u][e]);
-                    const float fg = sigmoid_f<FAST>(acc[nt][1][u][e]);
-                    const float gg = tanh_f<FAST>(acc[nt][2][u][e]);
-                    const float og = sigmoid_f<FAST>(acc[nt][3][u][e]);
-                    const float cn = fg * c[nt][u][e] + ig * gg;
-                    c[nt][u][e] = cn;
-                    const float h = og * tanh_f<FAST>(cn);
+                    float h;
+                    if constexpr (DIAG == 3) {
+                        h = acc[nt][0][u][e] + acc[nt][1][u][e] + acc[nt][2][u][e] + acc[nt][3][u][e];
+                    } else {
+                        const float ig = sigmoid_f<FAST>(acc[nt][0][u][e]);
+                        const float fg = sigmoid_f<FAST>(acc[nt][1][u][e]);
+                        const float gg = tanh_f<FAST>(acc[nt][2][u][e]);
+                        const float og = sigmoid_f<FAST>(acc[nt][3][u][e]);
+                        const float cn = fg * c[nt][u][e] + ig * gg;
+                        c[nt][u][e] = cn;
+                        h = og * tanh_f<FAST>(cn);
+                    }
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
-                    if (hval[nt][e]) hout[(hbase[nt][e] + t * a.t_stride) * hpitch + 16 * u] = h;
+                    if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
                 }
         if (more) {
             float* const Xn = XH + nxt * NS * XS;
+            char* os = reinterpret_cast<char*>(a.Xout + tbase(tn) * F);
 #pragma unroll
             for (int m = 0; m < NXV; ++m) {
+                f32x4 v = xr[m];
+                if (fuse && xval[m]) {
+                    v = fix(v, zr[m], m);
+                    if (dir == 0) *reinterpret_cast<f32x4*>(os + xoff[m]) = v;
+                }
                 float* d = Xn + xlds[m];
-                d[0] = xr[m][0]; d[1] = xr[m][1]; d[2] = xr[m][2]; d[3] = xr[m][3];
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_act += __builtin_amdgcn_s_memtime() - st_b; __builtin_amdgcn_sched_barrier(0); }
@@ -224,11 +317,16 @@ void bilstm_kernel(RecurArgs a) {
     }
     if constexpr (STAMP) {
         if (tid == 0 && a.stamps) {
-            unsigned long long* o = a.stamps + 4 * (blockIdx.y * gridDim.x + blockIdx.x);
+            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
             o[0] = __builtin_amdgcn_s_memtime() - st_t0;          // shader cycles, whole step loop
             o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;      // 100 MHz ticks
             o[2] = st_mfma;                                       // cycles inside the k-loop (wave 0)
             o[3] = st_act;                                        // cycles in cell update + stores, before the barrier
+            o[4] = st_r0;                                         // absolute start (100 MHz)
+            o[5] = __builtin_amdgcn_s_memrealtime();              // absolute end
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[6] = xcc; o[7] = hwid;
         }
     }
 }
@@ -236,16 +334,19 @@ void bilstm_kernel(RecurArgs a) {
 template <int NT, bool FAST>
 int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     constexpr int NS = 16 * NT;
+    // one workgroup per CU (NT >= 3): prefetch A fragments a k-group ahead and spread the memory instructions
+    // between the MFMAs (measured +6 % at NT = 4); with two co-resident workgroups (NT <= 2) the plain loop is as fast
+    constexpr int SCHED = NT >= 3 ? 1 : 0;
     const size_t lds = (size_t)2 * NS * XS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
-    hipLaunchKernelGGL((bilstm_kernel<NT, FAST>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED>), grid, dim3(256), lds, st, a);
     return dprnn_check_launch("bilstm_kernel");
 }
 
@@ -263,37 +364,66 @@ extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float
     return dprnn_check_launch("lstm_pack_kernel");
 }
 
+static int g_pipelined64 = 0;
+extern "C" void dprnn_set_recur_pipelined(int on) { g_pipelined64 = on; }
 static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L2 end to end, same as the libm forms
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
 
-extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
-                                int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
-                                int64_t t_stride, int ndir, int seq_tile, void* stream) {
-    if (!X || !packed || !bsum || !H) { dprnn_set_error("dprnn_bilstm_fwd: null pointer"); return -1; }
-    if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2)) {
-        dprnn_set_error("dprnn_bilstm_fwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d", nseq, T, inner_n, ndir);
+static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
+    if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_bilstm_fwd: null pointer"); return -1; }
+    if (a.nseq <= 0 || a.T <= 0 || a.inner_n <= 0 || (a.ndir != 1 && a.ndir != 2)) {
+        dprnn_set_error("dprnn_bilstm_fwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d", a.nseq, a.T, a.inner_n, a.ndir);
         return -1;
     }
-    if (seq_tile == 0) seq_tile = nseq <= 16 ? 16 : 32;
-    RecurArgs a{X, packed, bsum, H, nseq, T, inner_n, ndir, outer_stride, inner_stride, t_stride, nullptr};
-    hipStream_t st = (hipStream_t)stream;
+    if (a.Z && (!a.stats || !a.gamma || !a.beta || !a.Xout || a.Xout == a.X || a.seqs_per_utt <= 0 || a.rows_per_utt <= 0)) {
+        dprnn_set_error("dprnn_bilstm_norm_fwd: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
+        return -1;
+    }
+    if (seq_tile == 0) seq_tile = a.nseq <= 16 ? 16 : 32;
     const bool fast = g_fast_act != 0;
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
         case 32: return fast ? launch_bilstm<2, true>(a, st) : launch_bilstm<2, false>(a, st);
         case 48: return fast ? launch_bilstm<3, true>(a, st) : launch_bilstm<3, false>(a, st);
-        case 64: return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
+        case 64:
+            if (g_pipelined64 && !a.Z) return launch_bilstm64(a, fast, st);
+            return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
         default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,32,48,64 (got %d)", seq_tile); return -1;
     }
 }
 
-// Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][4] u64
+extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
+                                int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                int64_t t_stride, int ndir, int seq_tile, void* stream) {
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
+    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+}
+
+extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                                     const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                     const float* packed, const float* bsum, float* H,
+                                     int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                     int64_t t_stride, int ndir, int seq_tile, void* stream) {
+    if (!Z) { dprnn_set_error("dprnn_bilstm_norm_fwd: Z is null (use dprnn_bilstm_fwd)"); return -1; }
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
+    a.rows_per_utt = rows_per_utt; a.Xout = Xout;
+    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+}
+
+// Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][8] u64
 // {cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles}.  Not part of the product path.
 extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
                                         int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                                         int64_t t_stride, int ndir, int seq_tile, unsigned long long* stamps, void* stream) {
     if (!X || !packed || !bsum || !H || !stamps) { dprnn_set_error("dprnn_bilstm_fwd_stamped: null pointer"); return -1; }
-    RecurArgs a{X, packed, bsum, H, nseq, T, inner_n, ndir, outer_stride, inner_stride, t_stride, stamps};
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
     auto go = [&](auto kern, int NS) {
         const size_t lds = (size_t)2 * NS * XS * sizeof(float);
@@ -302,9 +432,31 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
         hipLaunchKernelGGL(kern, dim3((nseq + NS - 1) / NS, ndir), dim3(256), lds, st, a);
         return dprnn_check_launch("bilstm_kernel(stamped)");
     };
-    switch (seq_tile) {
-        case 32: return go(&bilstm_kernel<2, true, true>, 32);
-        case 64: return go(&bilstm_kernel<4, true, true>, 64);
-        default: dprnn_set_error("dprnn_bilstm_fwd_stamped: seq_tile 32 or 64"); return -1;
+    const char* dg = getenv("DPRNN_DIAG");
+    const int diag = dg ? atoi(dg) : 0;
+    const char* sc = getenv("DPRNN_SCHED");
+    if (sc && atoi(sc) == 1) {
+        if (seq_tile == 32) return go(&bilstm_kernel<2, true, true, 0, 1>, 32);
+        if (seq_tile == 64) return go(&bilstm_kernel<4, true, true, 0, 1>, 64);
     }
+    if (seq_tile == 32) {
+        switch (diag) {
+            case 1: return go(&bilstm_kernel<2, true, true, 1>, 32);
+            case 2: return go(&bilstm_kernel<2, true, true, 2>, 32);
+            case 3: return go(&bilstm_kernel<2, true, true, 3>, 32);
+            case 4: return go(&bilstm_kernel<2, true, true, 4>, 32);
+            default: return go(&bilstm_kernel<2, true, true, 0>, 32);
+        }
+    }
+    if (seq_tile == 64) {
+        switch (diag) {
+            case 1: return go(&bilstm_kernel<4, true, true, 1>, 64);
+            case 2: return go(&bilstm_kernel<4, true, true, 2>, 64);
+            case 3: return go(&bilstm_kernel<4, true, true, 3>, 64);
+            case 4: return go(&bilstm_kernel<4, true, true, 4>, 64);
+            default: return go(&bilstm_kernel<4, true, true, 0>, 64);
+        }
+    }
+    dprnn_set_error("dprnn_bilstm_fwd_stamped: seq_tile 32 or 64");
+    return -1;
 }

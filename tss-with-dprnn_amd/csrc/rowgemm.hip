@@ -45,17 +45,31 @@ struct OlaGatherP {             // OlaGather with the PReLU slope behind a devic
 };
 }
 
-extern "C" int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W2d, const float* b2d,
-                                       float* U, int B, int L, int K, int P, int S, void* stream) {
+static int head_conv_ola(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta, float eps,
+                         const float* prelu_w, const float* W2d, const float* b2d, float* U, int B, int L, int K, int P, int S,
+                         void* stream) {
     if (!X || !prelu_w || !W2d || !b2d || !U) { dprnn_set_error("dprnn_head_conv_ola_fwd: null pointer"); return -1; }
+    if (Z && (!stats || !gamma || !beta)) { dprnn_set_error("dprnn_head_conv_ola_norm_fwd: pending norm needs stats, gamma, beta"); return -1; }
     if (K < 1 || P < 1 || P > K || S != (L + K) / P + 1) {
         dprnn_set_error("dprnn_head_conv_ola_fwd: bad geometry L=%d K=%d P=%d S=%d", L, K, P, S);
         return -1;
     }
     constexpr int RT = 2;
-    OlaGatherP<RT> al{OlaGather<RT>{X, 0.f, L, K, P, S}, prelu_w};
+    OlaGatherP<RT> al{OlaGather<RT>{X, 0.f, L, K, P, S, Z, stats, gamma, beta, eps}, prelu_w};
     EpHeadConv<RT> ep{U, b2d, L, K, P, S};
     return launch_rowgemm<128, 256, RT>("head_conv_ola", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
+}
+
+extern "C" int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W2d, const float* b2d,
+                                       float* U, int B, int L, int K, int P, int S, void* stream) {
+    return head_conv_ola(X, nullptr, nullptr, nullptr, nullptr, 0.f, prelu_w, W2d, b2d, U, B, L, K, P, S, stream);
+}
+
+extern "C" int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
+                                            const float* beta, float eps, const float* prelu_w, const float* W2d,
+                                            const float* b2d, float* U, int B, int L, int K, int P, int S, void* stream) {
+    if (!Z) { dprnn_set_error("dprnn_head_conv_ola_norm_fwd: Z is null (use dprnn_head_conv_ola_fwd)"); return -1; }
+    return head_conv_ola(X, Z, stats, gamma, beta, eps, prelu_w, W2d, b2d, U, B, L, K, P, S, stream);
 }
 
 extern "C" int dprnn_head_gate_fwd(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,

@@ -82,15 +82,20 @@ struct GenBottleneck {
     }
 };
 
-// a[(b,l)][f] = sum over chunks s covering frame l of prelu(X[b][s][l+K-s*P][f])   (dprnn.py:173,203-217)
+// a[(b,l)][f] = sum over chunks s covering frame l of prelu(x'[b][s][l+K-s*P][f])   (dprnn.py:173,203-217)
+// x' = X, or X + ((Z - mean_b)*rstd_b*gamma + beta) when the last path's norm + residual is still pending (Z != null)
 template <int RT>
 struct OlaGather {
     const float* X; float alpha; int L, K, P, S;
+    const float* Z; const double* stats; const float* gamma; const float* beta; float eps;
     const float* p0[RT];       // row of the first term
     int nterm[RT];
+    float mu[RT], rs[RT];
+    int q4;
     __device__ static int s_lo(int l, int P) { return (l + P) / P; }                       // ceil((l+1)/P)
     __device__ static int s_hi(int l, int K, int P, int S) { int s = (l + K) / P; return s < S - 1 ? s : S - 1; }
     __device__ void init(long long row0, int r, int q, long long M) {
+        q4 = 4 * q;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             long long row = row0 + 16 * rt + r;
@@ -100,13 +105,32 @@ struct OlaGather {
             nterm[rt] = hi - lo + 1;
             // term s: row ((b*S + s)*K + (l + K - s*P)); successive s differ by (K - P) rows
             p0[rt] = X + (((long long)b * S + lo) * K + (l + K - lo * P)) * F + 4 * q;
+            mu[rt] = 0.f; rs[rt] = 0.f;
+            if (Z) {
+                const double cnt = (double)S * (double)K * (double)F;
+                const double mean = stats[2 * b] / cnt;
+                double var = stats[2 * b + 1] / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                mu[rt] = (float)mean;
+                rs[rt] = (float)(1.0 / sqrt(var + (double)eps));
+            }
         }
     }
     __device__ f32x4 load(int rt, int g) const {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* p = p0[rt] + 16 * g;
+        f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+        if (Z) {
+            gm = *reinterpret_cast<const f32x4*>(gamma + 16 * g + q4);
+            bt = *reinterpret_cast<const f32x4*>(beta + 16 * g + q4);
+        }
         for (int s = 0; s < nterm[rt]; ++s, p += (long long)(K - P) * F) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            if (Z) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(Z + (p - X));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((z[e] - mu[rt]) * rs[rt] * gm[e] + bt[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e] >= 0.f ? v[e] : alpha * v[e];
         }

@@ -31,6 +31,10 @@ SEQ_TILE = {"intra": 0, "inter": 0}
 STREAM_GROUPS = 4
 MIN_GROUP_BATCH = 8          # do not split batches smaller than 2 * this
 
+# Fold every GroupNorm + residual into the loader of the stage that consumes it (the next recurrence kernel, or the
+# mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
+FUSE_NORM = True
+
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
 PROFILE = None
@@ -179,26 +183,35 @@ class _Group:
         self.st, self.b0, self.b1 = st, b0, b1
         self.geo = Geometry(b1 - b0, geo.T, geo.L, geo.K, geo.P, geo.S, geo.ks, geo.stride, geo.N)
         rows, B, L = self.geo.rows, self.geo.B, geo.L
-        # one arena: X [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region
+        # one arena: X [rows][F] | X2 [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region.
+        # X / X2 ping-pong when the norm is folded into the next recurrence (both directions read the old slab).
         head_floats = 2 * B * L * 2 * F_BUILT           # U [B*L][2F] + V [B*L*2][F]
         h_floats = max(rows * 2 * F_BUILT, head_floats)
-        self.arena = torch.empty(rows * F_BUILT * 2 + h_floats, device=dev, dtype=torch.float32)
-        self.X = self.arena[: rows * F_BUILT]
-        self.Z = self.arena[rows * F_BUILT: 2 * rows * F_BUILT]
-        self.H = self.arena[2 * rows * F_BUILT:]
+        n = rows * F_BUILT
+        self.arena = torch.empty(3 * n + h_floats, device=dev, dtype=torch.float32)
+        self.X = self.arena[:n]
+        self.X2 = self.arena[n: 2 * n]
+        self.Z = self.arena[2 * n: 3 * n]
+        self.H = self.arena[3 * n:]
+        self.pending = None           # (stats_slot, gamma, beta, eps) of a norm not yet applied to X
 
 
-def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg):
-    st, geo, X, Z, Hbuf = g.st, g.geo, g.X, g.Z, g.H
-    dev = X.device
+def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool):
+    st, geo, Z, Hbuf = g.st, g.geo, g.Z, g.H
+    dev = Z.device
     ndir = 2 if rnn.rnn.bidirectional else 1
     B, S, K = geo.B, geo.S, geo.K
-    if intra:       # sequences (b,s) walk k              (dprnn.py:84-86)
-        st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * S, K, B * S, 0, K, 1, ndir,
-                SEQ_TILE["intra"])
-    else:           # sequences (b,k) walk s              (dprnn.py:94-95)
-        st.call("dprnn_bilstm_fwd", _p(X), _p(packed), _p(bsum), _p(Hbuf), B * K, S, K, S * K, 1, K, ndir,
-                SEQ_TILE["inter"])
+    # intra: sequences (b,s) walk k (dprnn.py:84-86); inter: sequences (b,k) walk s (dprnn.py:94-95)
+    addr = (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
+    tile = SEQ_TILE["intra" if intra else "inter"]
+    if g.pending is None:
+        st.call("dprnn_bilstm_fwd", _p(g.X), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
+    else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
+        pstats, pg, pb, peps = g.pending
+        st.call("dprnn_bilstm_norm_fwd", _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
+                _p(g.X2), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
+        g.X, g.X2 = g.X2, g.X
+        g.pending = None
     if dbg is not None:
         dbg.append(Hbuf[: geo.rows * ndir * F_BUILT].view(B, S, K, ndir * F_BUILT).clone())
     w = _param(lin.weight, "linear.weight", dev)
@@ -207,8 +220,11 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
             geo.rows, S * K, ndir * F_BUILT)
     gamma, beta, eps = _norm_params(norm)
-    st.call("dprnn_norm_residual_fwd", _p(X), _p(Z), _p(stats_slot), _p(_param(gamma, "norm.weight", dev)),
-            _p(_param(beta, "norm.bias", dev)), eps, _p(X), B, S * K)
+    gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
+    if fuse:
+        g.pending = (stats_slot, gamma, beta, eps)
+    else:
+        st.call("dprnn_norm_residual_fwd", _p(g.X), _p(Z), _p(stats_slot), _p(gamma), _p(beta), eps, _p(g.X), B, S * K)
 
 
 def _split(B: int):
@@ -240,6 +256,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
 
+    fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
     parts = _split(B) if debug is None else [(0, B)]
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
@@ -264,7 +281,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             dbg = [] if debug is not None else None
             for g in groups:            # interleaved submission: every group advances one path at a time
                 _run_path(g, rnn, lin, norm, stats[slot][g.b0:], packed[2 * i + (0 if intra else 1)],
-                          bsum[2 * i + (0 if intra else 1)], intra, dbg)
+                          bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse)
             if debug is not None:
                 debug[f"block{i}." + ("intra_rnn" if intra else "inter_rnn")] = dbg[0]
                 debug[f"block{i}" + (".mid" if intra else "")] = groups[0].X.view(B, S, K, F_BUILT).clone()
@@ -273,9 +290,15 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
         gB = g.geo.B
         U = g.H[: gB * L * 2 * F_BUILT]
         V = g.H[gB * L * 2 * F_BUILT: 2 * gB * L * 2 * F_BUILT]
-        g.st.call("dprnn_head_conv_ola_fwd", _p(g.X), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
-                  _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
-                  _p(U), gB, L, K, P, S)
+        head_w = (_p(_param(sep.prelu.weight, "prelu.weight", dev)), _p(_param(sep.conv2d.weight, "conv2d.weight", dev)),
+                  _p(_param(sep.conv2d.bias, "conv2d.bias", dev)))
+        if g.pending is None:
+            g.st.call("dprnn_head_conv_ola_fwd", _p(g.X), *head_w, _p(U), gB, L, K, P, S)
+        else:
+            pstats, pg, pb, peps = g.pending
+            g.st.call("dprnn_head_conv_ola_norm_fwd", _p(g.X), _p(g.Z), _p(pstats), _p(pg), _p(pb), peps, *head_w,
+                      _p(U), gB, L, K, P, S)
+            g.pending = None
         g.st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
                   _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
                   _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), gB * L * 2)
