@@ -63,7 +63,8 @@ class DprnnError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # DPRNN_LIB: alternative build of the same ABI (A/B timing of kernel variants inside one process pool / one GPU box)
+    return os.environ.get("DPRNN_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

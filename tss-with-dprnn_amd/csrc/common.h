@@ -30,6 +30,17 @@ template <bool FAST> __device__ __forceinline__ float tanh_f(float x) {
     if constexpr (FAST) return tanh_fast(x); else return tanh_acc(x);
 }
 
+// activation of (x + b) with the bias pre-scaled for the FAST forms: bk = -log2e*b (sigmoid), 2*log2e*b (tanh);
+// for the libm forms bk is the plain bias.
+template <bool FAST> __device__ __forceinline__ float sigmoid_b(float x, float bk) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x, -1.4426950408889634f, bk)));
+    else return sigmoid_acc(x + bk);
+}
+template <bool FAST> __device__ __forceinline__ float tanh_b(float x, float bk) {
+    if constexpr (FAST) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(x, 2.8853900817779268f, bk)) + 1.0f);
+    else return tanh_acc(x + bk);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

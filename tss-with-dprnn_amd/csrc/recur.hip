@@ -22,9 +22,12 @@
 //     registers -> HBM (64-byte segments, merged in L2).
 #include "recur.h"
 #include <stdlib.h>
+#include <type_traits>
 using namespace recur;
 
 namespace {
+
+typedef const f32x4 __attribute__((address_space(1)))* gw_ptr;   // global address space pointer to packed weights
 
 // packed[dir][wave][grp][gate*2+u][lane][i] = Wcat[dir][gate*128 + 32*wave + 16*u + (lane&15)][k]
 __global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
@@ -130,13 +133,21 @@ void bilstm_kernel(RecurArgs a) {
     // time index -> scalar bases
     auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
 
+    // bias enters through the activation's own first instruction (x*k + b*k is one v_fma), so the accumulators
+    // start from an inline-constant zero instead of 64 v_mov per step
     float bias[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) bias[g][u] = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+        for (int u = 0; u < 2; ++u) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+            bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+        }
 
-    const f32x4* const wbase = reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave) * NGRP * 8 * 64 + lane;
+    // wave-uniform weight slice (SGPR base, global address space) + lane index: saddr-form loads, scalar address math
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const gw_ptr wsl = (gw_ptr)(reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NGRP * 8 * 64);
+    const gw_ptr wbase = wsl + lane;
 
     // ---- prologue: x_{t0} -> Xs[0], zeros -> Hs[0]
     {
@@ -184,34 +195,32 @@ void bilstm_kernel(RecurArgs a) {
         if (more) {
             const char* xs = reinterpret_cast<const char*>(a.X + tbase(tn) * F);
             const char* zs = reinterpret_cast<const char*>(a.Z + tbase(tn) * F);
+            // rows past nseq alias the tile's first row (xoff), so every lane loads unconditionally: no exec-mask
+            // branches, no zero fills -- their h is never stored and a duplicated x' store carries identical bytes
 #pragma unroll
-            for (int m = 0; m < NXV; ++m) {
-                xr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                zr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xval[m]) {
-                    xr[m] = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
-                    if (fuse) zr[m] = *reinterpret_cast<const f32x4*>(zs + xoff[m]);
-                }
+            for (int m = 0; m < NXV; ++m) xr[m] = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
+            if (fuse) {
+#pragma unroll
+                for (int m = 0; m < NXV; ++m) zr[m] = *reinterpret_cast<const f32x4*>(zs + xoff[m]);
             }
         }
         f32x4 acc[NT][4][2];
+        const float* const Ac = XH + cur * NS * XS + r * XS + 16 * q;
+        if constexpr (SCHED == 0) {
+        // 16 k-groups, two per trip; the weights of group g+1 are in flight while group g computes
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{bias[g][u], bias[g][u], bias[g][u], bias[g][u]};
-
-        const float* const Ac = XH + cur * NS * XS + r * XS + 16 * q;
-        if constexpr (SCHED == 0) {
-        // 16 k-groups, two per trip; the weights of group g+1 are in flight while group g computes
+                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int gp = 0; gp < NGRP / 2; ++gp) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
                 // weights of the next k-group (wraps to group 0 of the next step: same bytes every step)
-                const f32x4* wn = wbase + (DIAG == 1 ? 0 : (((grp + 1) & 15) * 8) * 64);
+                const gw_ptr wn = wbase + (DIAG == 1 ? 0 : (((grp + 1) & 15) * 8) * 64);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
                 const float* src = Ac + (DIAG == 2 ? 0 : 64 * (grp >> 2) + 4 * (grp & 3));
@@ -232,6 +241,12 @@ void bilstm_kernel(RecurArgs a) {
             }
         }
         } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
         // Interleaved schedule: weights AND A fragments of group g+1 are requested while group g computes, and
         // sched_group_barrier spreads the 8 VMEM + 2*NT DS instructions one per MFMA cluster instead of leaving
         // them bunched at the group boundary (each MFMA gap hides only a few other instructions).
@@ -245,7 +260,7 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
-                const f32x4* wn = wbase + ((((grp + 1) & 15) * 8) * 64);
+                const gw_ptr wn = wbase + ((((grp + 1) & 15) * 8) * 64);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
                 const int gn = (grp + 1) & 15;             // group 15 prefetches group 0 of the old image: unused
@@ -285,12 +300,12 @@ void bilstm_kernel(RecurArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float h;
                     if constexpr (DIAG == 3) {
-                        h = acc[nt][0][u][e] + acc[nt][1][u][e] + acc[nt][2][u][e] + acc[nt][3][u][e];
+                        h = acc[nt][0][u][e] + acc[nt][1][u][e] + acc[nt][2][u][e] + acc[nt][3][u][e] + bias[0][u];
                     } else {
-                        const float ig = sigmoid_f<FAST>(acc[nt][0][u][e]);
-                        const float fg = sigmoid_f<FAST>(acc[nt][1][u][e]);
-                        const float gg = tanh_f<FAST>(acc[nt][2][u][e]);
-                        const float og = sigmoid_f<FAST>(acc[nt][3][u][e]);
+                        const float ig = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
+                        const float fg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
+                        const float gg = tanh_b<FAST>(acc[nt][2][u][e], bias[2][u]);
+                        const float og = sigmoid_b<FAST>(acc[nt][3][u][e], bias[3][u]);
                         const float cn = fg * c[nt][u][e] + ig * gg;
                         c[nt][u][e] = cn;
                         h = og * tanh_f<FAST>(cn);
@@ -304,7 +319,7 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
             for (int m = 0; m < NXV; ++m) {
                 f32x4 v = xr[m];
-                if (fuse && xval[m]) {
+                if (fuse) {
                     v = fix(v, zr[m], m);
                     if (dir == 0) *reinterpret_cast<f32x4*>(os + xoff[m]) = v;
                 }
