@@ -184,17 +184,40 @@ struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) bv[ct] = bias[16 * ct + r];
         const long long last = (row0 + 16 * RT - 1 < M ? row0 + 16 * RT - 1 : M - 1);
-        const long long b_first = row0 / rows_per_b, b_last = last / rows_per_b;
-        // store + per-row-tile partial sums, one utterance at a time (a tile spans <= 2 in practice)
+        const long long b_first = row0 / rows_per_b;
+        const long long next_start = (b_first + 1) * rows_per_b;
+        if (row0 + 16 * RT <= M && last < next_start) {
+            // fast path (almost every tile): all 16*RT rows exist and belong to one utterance -- no per-row tests,
+            // one base pointer per row, immediate column offsets (fp32 VALU work costs matrix time on gfx950)
+            if (b_first != cur_b) { flush(lane); cur_b = b_first; }
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* zr = Z + (row0 + 16 * rt + 4 * q + e) * (16 * NCT) + r;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const float v = acc[rt][ct][e] + bv[ct];
+                        zr[16 * ct] = v;
+                        p1 += v; p2 = fmaf(v, v, p2);
+                    }
+                }
+            d1 += (double)p1; d2 += (double)p2;
+            return;
+        }
+        // general path: ragged last tile and tiles that straddle utterances (one utterance at a time)
+        const long long b_last = last / rows_per_b;
         for (long long b = b_first; b <= b_last; ++b) {
             if (b != cur_b) { flush(lane); cur_b = b; }
+            const long long lo = b * rows_per_b, hi = lo + rows_per_b;
             float p1 = 0.f, p2 = 0.f;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long row = row0 + 16 * rt + 4 * q + e;
-                    if (row < M && row / rows_per_b == b) {
+                    if (row < M && row >= lo && row < hi) {
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) {
                             const float v = acc[rt][ct][e] + bv[ct];
