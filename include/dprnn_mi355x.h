@@ -151,6 +151,12 @@ int dprnn_head_mask_decode_fwd(const float* V, const float* Wend, const float* w
 int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk, int T, int L, int ks, int stride,
                       void* stream);
 
+/* ---- pairwise SI-SDR in fp64 (asteroid==0.7.0 pairwise_neg_sisdr, negated: reference call sites
+ * src/trainers/trainer.py:39,104, src/inferencers/inferencer.py:30,60): out[b][i][j] in dB for estimate i vs
+ * target j; est [B][n_est][T], tgt [B][n_tgt][T], out [B][n_est][n_tgt] double. */
+int dprnn_pairwise_sisdr(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
+                         void* stream);
+
 /* =====================  DPRNN-Spe / DPRNN-Spe-IRA speaker branch (src/models/dprnn_spe.py)  ===================== */
 
 /* ---- generic 1x1 conv on channels-last rows (spk_encoder convs, ResBlock convs: dprnn_spe.py:18-19,27,115-122):

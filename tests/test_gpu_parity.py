@@ -146,7 +146,8 @@ def test_stream_groups_do_not_change_results():
     from tss_with_dprnn_amd import engine
     model, _, _ = build_model("bss", dict(chunk_length=50, hop_length=25, n_repeats=2), 11, _dev())
     x = torch.from_numpy(make_mixture(19, 3000, seed=3)).to(_dev())
-    old = engine.STREAM_GROUPS
+    old, old_min = engine.STREAM_GROUPS, engine.MIN_GROUP_BATCH
+    engine.MIN_GROUP_BATCH = 4
     try:
         outs = []
         for n in (1, 2, 3):
@@ -154,6 +155,7 @@ def test_stream_groups_do_not_change_results():
             with torch.no_grad():
                 outs.append(model(x))
             torch.cuda.synchronize()
+        assert len(engine._split(19)) == 3
     finally:
         engine.STREAM_GROUPS = old
     # not bit-identical by construction: the fp64 GroupNorm sums are accumulated in a different grouping
@@ -167,5 +169,5 @@ def test_stream_groups_do_not_change_results():
         with torch.no_grad():
             again = model(x)
     finally:
-        engine.STREAM_GROUPS = old
+        engine.STREAM_GROUPS, engine.MIN_GROUP_BATCH = old, old_min
     assert torch.equal(again, outs[2]), "multi-stream forward is not run-to-run deterministic"

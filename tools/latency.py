@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Forward latency / throughput of DPRNN-TasNet at small batches (config 1: B=1) for the sequence-tile choices."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import engine
+from oracle.weights import full_cfg, make_mixture, make_state
+
+CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length", "n_repeats",
+        "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
+cfg = full_cfg()
+model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
+sd = make_state("bss", cfg, 0)
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model = model.to("cuda:0")
+for B in (1, 2, 4, 8, 16):
+    x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
+    for tile in (0, 16, 32):
+        engine.SEQ_TILE["intra"] = engine.SEQ_TILE["inter"] = tile
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                model(x)
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        print(f"B={B:2d} seq_tile={tile:2d}: {ms:7.2f} ms/forward  {B / ms * 1e3:7.1f} utt/s")

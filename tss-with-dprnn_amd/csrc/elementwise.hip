@@ -166,3 +166,44 @@ extern "C" int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk,
                        taps, out, B, nspk, T, L, ks, stride);
     return dprnn_check_launch("decoder_kernel");
 }
+
+// ---- pairwise SI-SDR (the metric/loss core of asteroid's pairwise_neg_sisdr that the reference calls at
+// src/trainers/trainer.py:39,104 and src/inferencers/inferencer.py:30,60), fp64 accumulation:
+// out[b][i][j] = 10 log10( |s|^2 / (|e - s|^2 + eps) + eps ),  e = est[b][i] - mean, t = tgt[b][j] - mean,
+// s = <e,t> t / (|t|^2 + eps), eps = 1e-8.  One workgroup per (b, i, j).
+namespace {
+__global__ __launch_bounds__(256) void pairwise_sisdr_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                             double* __restrict__ out, int n_est, int n_tgt, int T) {
+    const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x;
+    const float* e = est + ((long long)b * n_est + i) * T;
+    const float* t = tgt + ((long long)b * n_tgt + j) * T;
+    double se = 0, st = 0, see = 0, stt = 0, set = 0;
+    for (int k = threadIdx.x; k < T; k += 256) {
+        const double x = e[k], y = t[k];
+        se += x; st += y; see += x * x; stt += y * y; set += x * y;
+    }
+    __shared__ double red[5][4];
+    se = wave_sum(se); st = wave_sum(st); see = wave_sum(see); stt = wave_sum(stt); set = wave_sum(set);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = se; red[1][w] = st; red[2][w] = see; red[3][w] = stt; red[4][w] = set; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v[5];
+        for (int k = 0; k < 5; ++k) v[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+        const double n = (double)T, eps = 1e-8;
+        const double ee = v[2] - v[0] * v[0] / n, tt = v[3] - v[1] * v[1] / n, et = v[4] - v[0] * v[1] / n;   // zero-mean moments
+        const double alpha = et / (tt + eps);
+        const double s2 = alpha * alpha * tt;                       // |s|^2
+        const double n2 = ee - 2.0 * alpha * et + alpha * alpha * tt;   // |e - s|^2
+        out[((long long)b * n_est + i) * n_tgt + j] = 10.0 * log10(s2 / (n2 + eps) + eps);
+    }
+}
+}  // namespace
+
+extern "C" int dprnn_pairwise_sisdr(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
+                                    void* stream) {
+    if (!est || !tgt || !out) { dprnn_set_error("dprnn_pairwise_sisdr: null pointer"); return -1; }
+    if (B < 1 || n_est < 1 || n_tgt < 1 || T < 2) { dprnn_set_error("dprnn_pairwise_sisdr: bad sizes"); return -1; }
+    hipLaunchKernelGGL(pairwise_sisdr_kernel, dim3(n_tgt, n_est, B), dim3(256), 0, (hipStream_t)stream, est, tgt, out, n_est, n_tgt, T);
+    return dprnn_check_launch("pairwise_sisdr_kernel");
+}

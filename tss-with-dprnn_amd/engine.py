@@ -29,7 +29,7 @@ SEQ_TILE = {"intra": 0, "inter": 0}
 # its last workgroups (grid quantisation) or runs a bandwidth-bound stage, the other group's kernels fill
 # the idle CUs.
 STREAM_GROUPS = 4
-MIN_GROUP_BATCH = 8          # do not split batches smaller than 2 * this
+MIN_GROUP_BATCH = 16         # utterances per group at least (smaller groups lose more per kernel than overlap wins)
 
 # Fold every GroupNorm + residual into the loader of the stage that consumes it (the next recurrence kernel, or the
 # mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
@@ -194,6 +194,7 @@ class _Group:
         self.Z = self.arena[2 * n: 3 * n]
         self.H = self.arena[3 * n:]
         self.pending = None           # (stats_slot, gamma, beta, eps) of a norm not yet applied to X
+        self.n_concurrent = 1         # utterance groups in flight together (set by dprnn_process)
 
 
 def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool):
@@ -204,6 +205,12 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     # intra: sequences (b,s) walk k (dprnn.py:84-86); inter: sequences (b,k) walk s (dprnn.py:94-95)
     addr = (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
     tile = SEQ_TILE["intra" if intra else "inter"]
+    if tile == 0:
+        # 32 sequences per workgroup when that still gives every CU its two workgroups (counting the utterance groups
+        # that run concurrently on other streams); otherwise 16, which doubles the workgroups at small batches
+        # (B=1: 28 ms instead of 48 ms per forward)
+        wgs32 = -(-addr[0] // 32) * ndir * g.n_concurrent
+        tile = 32 if wgs32 >= 2 * st.lib.dprnn_num_cus() else 16
     if g.pending is None:
         st.call("dprnn_bilstm_fwd", _p(g.X), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
@@ -228,8 +235,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
 
 
 def _split(B: int):
-    n = STREAM_GROUPS if (STREAM_GROUPS > 1 and B >= 2 * MIN_GROUP_BATCH) else 1
-    n = min(n, B)
+    n = max(1, min(STREAM_GROUPS, B // MIN_GROUP_BATCH))
     cuts = [round(i * B / n) for i in range(n + 1)]
     return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
 
@@ -270,6 +276,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             groups.append(_Group(Stage(dev, side), geo, b0, b1, dev))
 
     for g in groups:
+        g.n_concurrent = len(groups)
         g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
         debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()

@@ -1,0 +1,101 @@
+"""Batched / multi-stream inference harness around the MI355X forward path.
+
+The reference evaluates one full-length utterance per call (src/inferencers/inferencer.py:54-58,
+inferencer_spe.py:27-32): the serial depth of 2 664 LSTM steps then bounds throughput.  Utterances are
+independent, so here
+
+* utterances of equal length are stacked into one batch (zero-padding to a common length is NOT done: it would
+  change the per-utterance GroupNorm statistics, dprnn.py:76-77),
+* every length bucket runs as its own pipeline on a HIP stream from a small pool, most work first, so the short
+  kernels of different utterances fill the chip together,
+* across GPUs the utterance list is dealt by length with sharding.shard_by_length, no collective on the path.
+
+pairwise_si_sdr / pit_si_sdr evaluate the reference's metric (asteroid pairwise_neg_sisdr + PITLossWrapper
+'pw_mtx', trainer.py:39, inferencer.py:30,60) on the device in fp64 (dprnn_pairwise_sisdr).
+"""
+from __future__ import annotations
+
+import itertools
+from collections import defaultdict
+from typing import List, Sequence
+
+import torch
+
+from ._lib import DprnnError, check, load_library
+
+
+def separate_many(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, extra_inputs=None) -> List:
+    """Run `model` over utterances of arbitrary (different) lengths; returns one output per utterance, in order.
+
+    wavs: 1-D float32 device tensors.  For DPRNN-Spe / IRA models pass extra_inputs = [(aux 1-D tensor, aux_len)]
+    and each output is (estimate, logits)."""
+    if len(wavs) == 0:
+        return []
+    dev = wavs[0].device
+    if not all(w.is_cuda and w.dim() == 1 and w.dtype == torch.float32 for w in wavs):
+        raise DprnnError("separate_many expects 1-D float32 tensors on a HIP device")
+    buckets = defaultdict(list)
+    for i, w in enumerate(wavs):
+        key = (w.numel(),) if extra_inputs is None else (w.numel(), extra_inputs[i][0].numel(), float(extra_inputs[i][1]))
+        buckets[key].append(i)
+    order = sorted(buckets.items(), key=lambda kv: -kv[0][0] * len(kv[1]))     # most work first
+    main = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(max_streams, len(order))))]
+    fork = torch.cuda.Event()
+    fork.record(main)
+    outs: List = [None] * len(wavs)
+    with torch.no_grad():
+        for n, (key, idxs) in enumerate(order):
+            s = pool[n % len(pool)]
+            s.wait_event(fork)
+            with torch.cuda.stream(s):
+                x = torch.stack([wavs[i] for i in idxs])
+                if extra_inputs is None:
+                    y = model(x)
+                    parts = [y[j] for j in range(len(idxs))]
+                else:
+                    aux = torch.stack([extra_inputs[i][0] for i in idxs])
+                    est, logits = model(x, aux, torch.tensor(key[2]))
+                    parts = [(est[j], logits[j]) for j in range(len(idxs))]
+                for j, i in enumerate(idxs):
+                    outs[i] = parts[j]
+                    for t in (parts[j] if isinstance(parts[j], tuple) else (parts[j],)):
+                        t.record_stream(main)
+    for s in pool:
+        done = torch.cuda.Event()
+        done.record(s)
+        main.wait_event(done)
+    return outs
+
+
+def pairwise_si_sdr(est: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+    """est [B, n_est, T], tgt [B, n_tgt, T] (float32, device) -> [B, n_est, n_tgt] float64 SI-SDR in dB."""
+    if not (est.is_cuda and tgt.is_cuda):
+        raise DprnnError("pairwise_si_sdr runs on the HIP device only")
+    est, tgt = est.contiguous().float(), tgt.contiguous().float()
+    B, ne, T = est.shape
+    nt = tgt.shape[1]
+    if tgt.shape[0] != B or tgt.shape[2] != T:
+        raise DprnnError("estimate / target shapes differ")
+    out = torch.empty(B, ne, nt, device=est.device, dtype=torch.float64)
+    lib = load_library()
+    rc = lib.dprnn_pairwise_sisdr(est.data_ptr(), tgt.data_ptr(), out.data_ptr(), B, ne, nt, T,
+                                  torch.cuda.current_stream(est.device).cuda_stream)
+    check(lib, rc, "dprnn_pairwise_sisdr")
+    return out
+
+
+def pit_si_sdr(est: torch.Tensor, tgt: torch.Tensor):
+    """Permutation-invariant mean SI-SDR (PITLossWrapper pit_from='pw_mtx' semantics, maximising SI-SDR):
+    returns (best mean SI-SDR per item [B] float64, best permutation [B, n_src] = target of estimate i,
+    estimates reordered to the targets' order)."""
+    pw = pairwise_si_sdr(est, tgt)                       # [B, est, tgt]
+    n = pw.shape[1]
+    perms = torch.tensor(list(itertools.permutations(range(n))), device=pw.device)      # [n!, n]
+    ar = torch.arange(n, device=pw.device)
+    scores = torch.stack([pw[:, ar, p].mean(dim=1) for p in perms], dim=1)              # [B, n!]
+    best = scores.argmax(dim=1)
+    perm = perms[best]                                   # [B, n]
+    inv = torch.argsort(perm, dim=1)                     # estimate index for each target
+    reordered = torch.gather(est, 1, inv.unsqueeze(-1).expand(-1, -1, est.shape[-1]))
+    return scores.gather(1, best[:, None])[:, 0], perm, reordered
