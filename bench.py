@@ -161,7 +161,10 @@ def main():
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
-                         "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 * (4 + (3 if engine.FUSE_NORM else 0)) / 1e9,
+                         # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
+                         # the previous norm is folded in: all launches of a forward but the first]
+                         "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 *
+                         ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
                          "kernel_ms": kern_ms, "launches_timed": len(ev), "launches_per_step": launches_per_step,
                          "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
