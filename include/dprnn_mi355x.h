@@ -68,6 +68,20 @@ int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, 
                          const float* Wb, int ldw, const float* bb, const float* row_bias, float* Y,
                          int B, int T, int L, int N, int ks, int stride, void* stream);
 
+/* same for the 'att' fusion (dprnn_spe.py:178-183): Y = row_scale[b][l] * (W a) + bias, where a already carries the
+ * per-channel factor fusion_linear(emb) through sc/sh (mul) and row_scale = upsampled attention + 1 */
+int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
+                             const float* Wb, int ldw, const float* bb, const float* row_scale, float* Y,
+                             int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- attention weights of the 'att' fusion (dprnn_spe.py:98-105,214-222): depth-wise averaging conv
+ * (avg_w [N][ks_a], avg_b [N], stride ks_a) of the normalised encoder output (sc0/sh0 = plain norm affine from
+ * dprnn_bottleneck_prep with mul = add = NULL), scores[b][t] = sum_c a[b][c]*avg[b][c][t], softmax over t,
+ * nearest upsampling to L: row_scale[b][l] = att[b][min(floor(l*La/L), La-1)] + 1.  scores: [B][La] scratch. */
+int dprnn_att_row_scale(const float* wav, const float* enc_w, const float* sc0, const float* sh0,
+                        const float* avg_w, const float* avg_b, const float* a, float* scores, float* row_scale,
+                        int B, int T, int L, int N, int ks, int stride, int ks_a, void* stream);
+
 /* ---- DPRNN._segmentation (dprnn.py:189-201): X[b][s][k][:] = Y[b][s*P+k-K][:] or 0 outside [0,L) */
 int dprnn_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int S, void* stream);
 

@@ -68,6 +68,9 @@ CASES = [
     ("spe_wide_small_cat", "spe", dict(WIDE, fusion_type="cat", norm_type="ln"), 2, 300, 40, True, False),
     ("spe_wide_small_cat_bntrain", "spe", dict(WIDE, fusion_type="cat", norm_type="ln"), 3, 300, 41, False, True),
     ("spe_full_b1", "spe", dict(norm_type="ln"), 1, 24000, 42, False, False),
+    ("spe_wide_small_att", "spe", dict(WIDE, fusion_type="att", norm_type="ln"), 2, 301, 43, False, False),
+    ("spe_full_att_b1", "spe", dict(norm_type="ln", fusion_type="att"), 1, 24000, 44, False, False),   # example.ipynb cell 5 model
+    ("spe_wide_small_film", "spe", dict(WIDE, fusion_type="film", norm_type="gLN"), 2, 300, 45, False, False),
     ("ira_tiny_cat", "ira", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 2, 203, 50, True, False),
     ("ira_wide_small_cat", "ira", dict(WIDE, fusion_type="cat", norm_type="ln"), 2, 300, 51, False, False),
 ]
@@ -88,7 +91,10 @@ def load_recipe(model, kind, cfg, seed):
 
 def main():
     contract = {}
+    only = set(sys.argv[1:])          # optional: regenerate just the named cases (keeps the other files byte-identical)
     for name, kind, over, B, T, seed, want_taps, bn_train in CASES:
+        if only and name not in only:
+            continue
         cfg = full_cfg(**over)
         model = build(kind, cfg)
         load_recipe(model, kind, cfg, seed)
@@ -129,6 +135,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
         print(f"{name:32s} out {tuple(save['out'].shape)} |out| {np.abs(save['out']).max():.4f}")
 
+    if only:
+        return
     # state_dict key/shape contract at the shipped config, straight from the reference modules
     for kind, fus in [("bss", "cat"), ("spe", "cat"), ("spe", "add"), ("spe", "mul"), ("spe", "film"),
                       ("spe", "att"), ("ira", "cat")]:

@@ -25,7 +25,8 @@ def _run(model, g, bn_train=False):
     return est.cpu().numpy(), logits.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["spe_wide_small_cat", "spe_wide_small_cat_bntrain", "spe_full_b1", "ira_wide_small_cat"])
+@pytest.mark.parametrize("name", ["spe_wide_small_cat", "spe_wide_small_cat_bntrain", "spe_full_b1", "ira_wide_small_cat",
+                                  "spe_wide_small_att", "spe_full_att_b1", "spe_wide_small_film"])
 def test_spe_matches_reference_golden(name):
     g = load_golden(name)
     m = g["meta"]
@@ -71,7 +72,7 @@ def test_bn_train_running_stats_follow_torch():
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("fusion,nt", [("add", "ln"), ("mul", "gLN"), ("film", "ln"), ("cat", "gLN")])
+@pytest.mark.parametrize("fusion,nt", [("add", "ln"), ("mul", "gLN"), ("film", "ln"), ("cat", "gLN"), ("att", "ln"), ("att", "gLN")])
 def test_fusions_match_cpu_oracle(fusion, nt):
     cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type=fusion, norm_type=nt)
     model, sd, cfg = build_model("spe", cfg, 70, DEV)
@@ -96,9 +97,13 @@ def test_ira_fusion_mul_matches_cpu_oracle():
     assert rel_l2(est.cpu().numpy(), want) <= REL_TOL
 
 
-def test_att_fusion_is_refused_loudly():
-    model, _, _ = build_model("spe", dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="att", norm_type="ln"), 5, DEV)
-    x = torch.zeros(1, 300, device=DEV)
-    with pytest.raises(NotImplementedError, match="att"):
-        with torch.no_grad():
-            model(x, x, torch.tensor(300.0))
+def test_ira_att_matches_cpu_oracle():
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="att", norm_type="ln")
+    model, sd, cfg = build_model("ira", cfg, 72, DEV)
+    B, T = 2, 401
+    mix, aux = make_mixture(B, T, seed=5), make_mixture(B, 377, seed=6)
+    want, wlog = onp.ira_forward(sd, cfg, mix, aux, np.float32(377))
+    with torch.no_grad():
+        est, logits = model(torch.from_numpy(mix).to(DEV), torch.from_numpy(aux).to(DEV), torch.tensor(377.0))
+    assert rel_l2(logits.cpu().numpy(), wlog) <= REL_TOL
+    assert rel_l2(est.cpu().numpy(), want) <= REL_TOL

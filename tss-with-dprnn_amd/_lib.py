@@ -25,6 +25,8 @@ SIGNATURES = {
     "dprnn_encoder_stats": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_bottleneck_prep": [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_bottleneck_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_bottleneck_att_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_att_row_scale": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp],

@@ -7,9 +7,9 @@ extern "C" int dprnn_num_cus(void) { return num_cus(); }
 static int g_fast_head = 1;
 extern "C" void dprnn_set_fast_head_activations(int on) { g_fast_head = on; }
 
-extern "C" int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
-                                    const float* Wb, int ldw, const float* bb, const float* row_bias, float* Y,
-                                    int B, int T, int L, int N, int ks, int stride, void* stream) {
+static int bottleneck(const float* wav, const float* enc_w, const float* sc, const float* sh,
+                      const float* Wb, int ldw, const float* bb, const float* row_bias, const float* row_scale, float* Y,
+                      int B, int T, int L, int N, int ks, int stride, void* stream) {
     if (!wav || !enc_w || !sc || !sh || !Wb || !bb || !Y) { dprnn_set_error("dprnn_bottleneck_fwd: null pointer"); return -1; }
     if (N != 64 || ks < 1 || ks > KSMAX || ldw < N || (ldw % 4) != 0 || L != (T - ks) / stride + 1) {
         dprnn_set_error("dprnn_bottleneck_fwd: unsupported N=%d ks=%d ldw=%d L=%d T=%d stride=%d (built for input_size 64, ks<=8)", N, ks, ldw, L, T, stride);
@@ -17,8 +17,21 @@ extern "C" int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const 
     }
     constexpr int RT = 4;
     GenBottleneck<RT> al{wav, enc_w, sc, sh, Geo{B, T, L, N, ks, stride}};
-    EpBiasStore<RT, 8> ep{Y, bb, row_bias, (long long)L};
+    EpBiasStore<RT, 8> ep{Y, bb, row_bias, (long long)L, row_scale};
     return launch_rowgemm<64, 128, RT>("bottleneck", Wb, ldw, 128, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
+}
+
+extern "C" int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
+                                    const float* Wb, int ldw, const float* bb, const float* row_bias, float* Y,
+                                    int B, int T, int L, int N, int ks, int stride, void* stream) {
+    return bottleneck(wav, enc_w, sc, sh, Wb, ldw, bb, row_bias, nullptr, Y, B, T, L, N, ks, stride, stream);
+}
+
+extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
+                                        const float* Wb, int ldw, const float* bb, const float* row_scale, float* Y,
+                                        int B, int T, int L, int N, int ks, int stride, void* stream) {
+    if (!row_scale) { dprnn_set_error("dprnn_bottleneck_att_fwd: row_scale is null"); return -1; }
+    return bottleneck(wav, enc_w, sc, sh, Wb, ldw, bb, nullptr, row_scale, Y, B, T, L, N, ks, stride, stream);
 }
 
 extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,

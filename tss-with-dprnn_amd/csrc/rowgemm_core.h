@@ -142,8 +142,8 @@ struct OlaGather {
 // acc[rt][ct][e]: row = row0 + 16*rt + 4*q + e, col = 16*ct + r.
 
 template <int RT, int NCT>
-struct EpBiasStore {            // out[row][col] = acc + bias[col] (+ row_bias[row / rows_per_b][col])
-    float* out; const float* bias; const float* row_bias; long long rows_per_b;
+struct EpBiasStore {            // out[row][col] = acc*row_scale[row] + bias[col] (+ row_bias[row / rows_per_b][col])
+    float* out; const float* bias; const float* row_bias; long long rows_per_b; const float* row_scale;
     __device__ void begin() {}
     __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
@@ -157,7 +157,9 @@ struct EpBiasStore {            // out[row][col] = acc + bias[col] (+ row_bias[r
                 for (int e = 0; e < 4; ++e) {
                     const long long row = row0 + 16 * rt + 4 * q + e;
                     if (row < M) {
-                        float v = acc[rt][ct][e] + bv;
+                        float v = acc[rt][ct][e];
+                        if (row_scale) v *= row_scale[row];
+                        v += bv;
                         if (row_bias) v += row_bias[(row / rows_per_b) * (16 * NCT) + col];
                         out[row * (16 * NCT) + col] = v;
                     }

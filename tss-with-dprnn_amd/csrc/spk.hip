@@ -187,6 +187,65 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(const f32x4* __restrict
     if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[2 * b], d1); atomicAdd(&stats[2 * b + 1], d2); }
 }
 
+// ---- 'att' fusion (dprnn_spe.py:98-105,178-183,214-222).  scores[b][t] = sum_c a[b][c] * avg[b][c][t] with
+// avg = depth-wise Conv1d(k=ks_a, stride=ks_a) of the normalised encoder output xn[b,c,l] = enc*sc0[b][c] + sh0[b][c].
+__global__ __launch_bounds__(256) void att_scores_kernel(const float* __restrict__ wav, const float* __restrict__ We,
+                                                         const float* __restrict__ sc0, const float* __restrict__ sh0,
+                                                         const float* __restrict__ avg_w, const float* __restrict__ avg_b,
+                                                         const float* __restrict__ a, float* __restrict__ scores,
+                                                         int T, int La, int N, int ks, int stride, int ks_a) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= La) return;
+    float s = 0.f;
+    for (int c = 0; c < N; ++c) {
+        float av = avg_b[c];
+        for (int j = 0; j < ks_a; ++j) {
+            const float* x = wav + (long long)b * T + (long long)(t * ks_a + j) * stride;
+            float e = 0.f;
+            for (int jj = 0; jj < ks; ++jj) e = fmaf(We[c * ks + jj], x[jj], e);
+            e = fmaxf(e, 0.f);
+            av = fmaf(avg_w[c * ks_a + j], fmaf(e, sc0[b * N + c], sh0[b * N + c]), av);
+        }
+        s = fmaf(av, a[b * N + c], s);
+    }
+    scores[(long long)b * La + t] = s;
+}
+
+// softmax over time per utterance, then nearest-neighbour upsampling to L frames (nn.Upsample(size=L), float index
+// arithmetic as torch: src = min(floor(l * (La / L)), La - 1)); row_scale[b][l] = att[b][src] + 1  (att*a + a = a*(att+1))
+__global__ __launch_bounds__(256) void att_softmax_upsample_kernel(const float* __restrict__ scores, float* __restrict__ row_scale,
+                                                                   int La, int L) {
+    const int b = blockIdx.x;
+    const float* s = scores + (long long)b * La;
+    __shared__ float red[4];
+    __shared__ float stat[2];
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < La; t += 256) m = fmaxf(m, s[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = stat[0];
+    float z = 0.f;
+    for (int t = threadIdx.x; t < La; t += 256) z += expf(s[t] - m);
+    z = wave_sum(z);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = z;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[1] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float inv = 1.f / stat[1];
+    const float scale = (float)La / (float)L;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        int src = (int)floorf((float)l * scale);
+        if (src > La - 1) src = La - 1;
+        row_scale[(long long)b * L + l] = expf(s[src] - m) * inv + 1.f;
+    }
+}
+
 template <int KD>
 int launch_pointwise(const AffineRows<4>& al, const EpStoreColStats<4>& ep, const float* W, int ldw, long long M, hipStream_t st) {
     return launch_rowgemm<KD, 128, 4>("pointwise", W, ldw, 128, nullptr, 0, M, al, ep, st);
@@ -261,4 +320,18 @@ extern "C" int dprnn_rows_stats(const float* A, double* stats, int B, int64_t ro
     hipLaunchKernelGGL(rows_stats_kernel, dim3((unsigned)g, B), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(A), stats, per4);
     return dprnn_check_launch("rows_stats_kernel");
+}
+
+extern "C" int dprnn_att_row_scale(const float* wav, const float* enc_w, const float* sc0, const float* sh0,
+                                   const float* avg_w, const float* avg_b, const float* a, float* scores, float* row_scale,
+                                   int B, int T, int L, int N, int ks, int stride, int ks_a, void* stream) {
+    if (!wav || !enc_w || !sc0 || !sh0 || !avg_w || !avg_b || !a || !scores || !row_scale) { dprnn_set_error("dprnn_att_row_scale: null pointer"); return -1; }
+    if (ks_a < 1 || L < ks_a || ks < 1) { dprnn_set_error("dprnn_att_row_scale: bad sizes L=%d ks_a=%d", L, ks_a); return -1; }
+    const int La = (L - ks_a) / ks_a + 1;
+    hipLaunchKernelGGL(att_scores_kernel, dim3((La + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, wav, enc_w, sc0, sh0,
+                       avg_w, avg_b, a, scores, T, La, N, ks, stride, ks_a);
+    int rc = dprnn_check_launch("att_scores_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(att_softmax_upsample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, row_scale, La, L);
+    return dprnn_check_launch("att_softmax_upsample_kernel");
 }

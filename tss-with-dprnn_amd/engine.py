@@ -147,13 +147,19 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
     return sc, sh
 
 
-def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None):
-    """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias)."""
+def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None):
+    """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias,
+    'att' fusion as row_scale)."""
     dev = wav.device
     w = _param(conv.weight, "conv.weight", dev)
     if w.shape[0] != F_BUILT or w.shape[1] < geo.N:
         raise DprnnError(f"1x1 conv weight {tuple(w.shape)} does not fit the {geo.N}->{F_BUILT} kernel")
     Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
+    if row_scale is not None:
+        st.call("dprnn_bottleneck_att_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
+                _p(_param(conv.bias, "conv.bias", dev)), _p(row_scale), _p(Y),
+                geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+        return Y
     st.call("dprnn_bottleneck_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
             _p(_param(conv.bias, "conv.bias", dev)), _p(row_bias), _p(Y),
             geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
@@ -372,8 +378,8 @@ def check_supported_spe(cfg: dict) -> None:
     bad = []
     if cfg["O"] != 128 or cfg["P"] != 256 or cfg["embeddings_size"] != 128:
         bad.append(f"speaker encoder must be O=128, P=256, embeddings_size=128 (got {cfg['O']}, {cfg['P']}, {cfg['embeddings_size']})")
-    if cfg["fusion_type"] not in ("cat", "add", "mul", "film"):
-        bad.append(f"fusion_type {cfg['fusion_type']!r}: 'att' has no HIP kernel yet; 'cat', 'add', 'mul', 'film' do")
+    if cfg["fusion_type"] not in ("cat", "add", "mul", "film", "att"):
+        bad.append(f"fusion_type {cfg['fusion_type']!r} (dprnn_spe.py:88-105 knows cat, add, mul, film, att)")
     if cfg["kernel_size"] < 2:
         bad.append("kernel_size must be >= 2 (aux_T divides by kernel_size // 2, dprnn_spe.py:159)")
     if bad:
@@ -456,8 +462,11 @@ def _aux_len_tensor(aux_len, B: int, dev):
 
 
 def _fusion_operands(st: Stage, sep, cfg, emb):
-    """(mul, add, row_bias) of the bottleneck for every supported fusion (dprnn_spe.py:165-229)."""
+    """(mul, add, row_bias) of the bottleneck for every fusion (dprnn_spe.py:165-229); 'att' additionally needs the
+    per-frame row scale from _att_row_scale."""
     ft = cfg["fusion_type"]
+    if ft == "att":          # output * (att*a + a) = output * a * (att + 1): a is the per-channel mul  (dprnn_spe.py:214-222)
+        return _linear_small(st, sep.fusion_linear.weight, sep.fusion_linear.bias, emb), None, None
     if ft == "cat":          # conv over cat([x, emb]) = conv_x(x) + W[:, N:] @ emb  (dprnn_spe.py:186-192)
         return None, None, _linear_small(st, sep.bottleneck[1].weight, None, emb, k0=cfg["input_size"])
     if ft == "add":
@@ -468,6 +477,26 @@ def _fusion_operands(st: Stage, sep, cfg, emb):
         return (_linear_small(st, sep.fusion_linear_1.weight, sep.fusion_linear_1.bias, emb),
                 _linear_small(st, sep.fusion_linear_2.weight, sep.fusion_linear_2.bias, emb), None)
     raise NotImplementedError(ft)
+
+
+def _att_row_scale(st: Stage, sep, cfg, wav, enc_w, geo: Geometry, stats_slot, a_vec):
+    """Per-frame factor of the 'att' fusion: softmax attention over the averaged, normalised encoder output,
+    nearest-upsampled to L, plus one (dprnn_spe.py:98-105,178-183,214-222)."""
+    dev = wav.device
+    g, b_, eps = _norm_params(sep.bottleneck[0])
+    sc0 = torch.empty(geo.B, geo.N, device=dev, dtype=torch.float32)
+    sh0 = torch.empty_like(sc0)
+    st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(g), _p(b_), eps, 0, 0, _p(sc0), _p(sh0), geo.B, geo.L, geo.N)
+    ks_a = sep.average.kernel_size[0]
+    if sep.average.stride[0] != ks_a or sep.average.groups != geo.N:
+        raise DprnnError("unexpected averaging conv geometry in the 'att' fusion")
+    La = (geo.L - ks_a) // ks_a + 1
+    scores = torch.empty(geo.B, La, device=dev, dtype=torch.float32)
+    row_scale = torch.empty(geo.B, geo.L, device=dev, dtype=torch.float32)
+    st.call("dprnn_att_row_scale", _p(wav), _p(enc_w), _p(sc0), _p(sh0), _p(_param(sep.average.weight, "average.weight", dev)),
+            _p(_param(sep.average.bias, "average.bias", dev)), _p(a_vec), _p(scores), _p(row_scale),
+            geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride, ks_a)
+    return row_scale
 
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
@@ -504,7 +533,8 @@ def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dic
         # first (only) separation pass
         mul, add, row_bias = _fusion_operands(st, sep, cfg, v0)
         sc, sh = bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], mul, add)
-        Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias)
+        row_scale = _att_row_scale(st, sep, cfg, wav, enc_w, geo, stats[0], mul) if cfg["fusion_type"] == "att" else None
+        Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias, row_scale)
         relu_act = cfg["activation_type"] == "relu"
         v_last = v0
         if not ira:
@@ -531,7 +561,8 @@ def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dic
                 g, b_, eps = _norm_params(sep.bottleneck[0])
                 st.call("dprnn_bottleneck_prep", _p(stats[0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh),
                         B, geo.L, N)
-            Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2)
+            row_scale2 = _att_row_scale(st, sep, cfg, wav, enc_w, geo, stats[0], mul2) if cfg["fusion_type"] == "att" else None
+            Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2)
             taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[1 + 2 * n_blocks: 2 * (1 + 2 * n_blocks)],
                                  relu_act, debug=debug)
             v_last = v1
