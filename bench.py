@@ -67,11 +67,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): DPRNN_BENCH_BACKEND=gloo DPRNN_BENCH_SHARE_GPU=1
+    backend = os.environ.get("DPRNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("DPRNN_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     import tss_with_dprnn_amd as pkg
     from tss_with_dprnn_amd import engine
@@ -114,7 +121,7 @@ def main():
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
 
     from tss_with_dprnn_amd import sharding
-    elapsed = sharding.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step time
+    elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
 
     # dominant kernel: per-launch HIP-event durations on the launch streams.  With utterance groups on several
     # streams the launches overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch
