@@ -171,3 +171,32 @@ def test_stream_groups_do_not_change_results():
     finally:
         engine.STREAM_GROUPS, engine.MIN_GROUP_BATCH = old, old_min
     assert torch.equal(again, outs[2]), "multi-stream forward is not run-to-run deterministic"
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (2, 3), (1, 100), (3, 251), (2, 1000), (65, 600)])
+def test_edge_lengths_and_batches_vs_cpu_oracle(B, T):
+    """Utterances shorter than a chunk (L < K, a single frame), odd lengths, and a batch that splits unevenly
+    into stream groups (65) -- shipped chunk geometry K=250/P=125, two blocks."""
+    model, sd, cfg = build_model("bss", dict(n_repeats=2), 31, _dev())
+    x = make_mixture(B, T, seed=T)
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
+    with torch.no_grad():
+        got = model(torch.from_numpy(x).to(_dev())).cpu().numpy()
+    assert got.shape == want.shape
+    _close(got, want, f"edge B={B} T={T}")
+
+
+def test_input_validation_messages():
+    import tss_with_dprnn_amd as pkg
+    model, _, _ = build_model("bss", dict(n_repeats=1), 32, _dev())
+    with pytest.raises(pkg._lib.DprnnError, match="float32"):
+        model(torch.zeros(1, 500, device=_dev(), dtype=torch.float64))
+    with pytest.raises(pkg._lib.DprnnError, match="batch, samples"):
+        model(torch.zeros(500, device=_dev()))
+    with pytest.raises(pkg._lib.DprnnError, match="shorter than the encoder kernel"):
+        model(torch.zeros(1, 1, device=_dev()))
+    x = torch.randn(4, 1200, device=_dev())[:, ::2]            # non-contiguous view is accepted (made contiguous)
+    with torch.no_grad():
+        a = model(x)
+        b = model(x.contiguous())
+    assert torch.equal(a, b)
