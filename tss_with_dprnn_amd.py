@@ -6,6 +6,7 @@ directly; this module turns itself into that package by pointing ``__path__`` at
 """
 import os as _os
 
+
 __path__ = [_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tss-with-dprnn_amd")]
 __version__ = "0.1.0"
 
