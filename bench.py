@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
+    ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
     args = ap.parse_args()
@@ -95,6 +96,8 @@ def main():
     engine.SEQ_TILE["intra"], engine.SEQ_TILE["inter"] = args.seq_tile_intra, args.seq_tile_inter
     if args.groups is not None:
         engine.STREAM_GROUPS = args.groups
+    if args.min_group is not None:
+        engine.MIN_GROUP_BATCH = args.min_group
 
     B = args.batch
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing

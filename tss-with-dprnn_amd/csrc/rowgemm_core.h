@@ -362,15 +362,20 @@ void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 a[2][RT];
+        // A fragments come straight from HBM: keep PF k-groups in flight (one group of MFMAs is ~4096 cycles, about one
+        // loaded HBM latency, so a single group of lookahead leaves the wave waiting)
+        constexpr int PF = (NG >= 4) ? 2 : 1;
+        f32x4 a[PF + 1][RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[0][rt] = al.load(rt, 0);
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[p][rt] = al.load(rt, p);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int cb = g & 1;
-            if (g + 1 < NG) {
+            const int cb = g % (PF + 1);
+            if (g + PF < NG) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[cb ^ 1][rt] = al.load(rt, g + 1);
+                for (int rt = 0; rt < RT; ++rt) a[(g + PF) % (PF + 1)][rt] = al.load(rt, g + PF);
             }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
