@@ -212,11 +212,17 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     addr = (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
     tile = SEQ_TILE["intra" if intra else "inter"]
     if tile == 0:
-        # 32 sequences per workgroup when that still gives every CU its two workgroups (counting the utterance groups
-        # that run concurrently on other streams); otherwise 16, which doubles the workgroups at small batches
-        # (B=1: 28 ms instead of 48 ms per forward)
-        wgs32 = -(-addr[0] // 32) * ndir * g.n_concurrent
-        tile = 32 if wgs32 >= 2 * st.lib.dprnn_num_cus() else 16
+        # Sequences per workgroup, from measurements on MI355X (profiles/): 32 (two workgroups per CU) when that still
+        # gives every CU its two workgroups, counting the utterance groups that run concurrently on other streams;
+        # 16 below that (B=1: 28 ms instead of 48 ms per forward); the inter-chunk path, whose 64 sequences are one
+        # contiguous 32 KB run of rows per step, takes 64 (one workgroup per CU, half the L2 weight bytes per FLOP)
+        # when there are enough of those: +1.8 % at B=64.
+        ncu = st.lib.dprnn_num_cus()
+        wgs = lambda t: -(-addr[0] // t) * ndir * g.n_concurrent
+        if not intra and wgs(64) >= 1.5 * ncu:
+            tile = 64
+        else:
+            tile = 32 if wgs(32) >= 2 * ncu else 16
     if g.pending is None:
         st.call("dprnn_bilstm_fwd", _p(g.X), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
