@@ -112,7 +112,7 @@ def main():
         for _ in range(args.warmup):
             out = model(x)
         sync()
-        engine.PROFILE = {"names": {"dprnn_bilstm_fwd", "dprnn_bilstm_norm_fwd"}, "events": {}}
+        engine.PROFILE = {"names": {"dprnn_rnn_fwd"}, "events": {}}
         t_ref = torch.cuda.Event(enable_timing=True)
         t_ref.record()
         t0 = time.perf_counter()
@@ -129,7 +129,7 @@ def main():
     # dominant kernel: per-launch HIP-event durations on the launch streams.  With utterance groups on several
     # streams the launches overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch
     # intervals); kernel_ms is the plain mean launch duration (what rocprofv3 --stats reports).
-    ev = prof["events"].get("dprnn_bilstm_fwd", []) + prof["events"].get("dprnn_bilstm_norm_fwd", [])
+    ev = prof["events"].get("dprnn_rnn_fwd", [])
     spans = sorted((t_ref.elapsed_time(a), t_ref.elapsed_time(b)) for a, b in ev)
     kern_ms = float(np.mean([e - s for s, e in spans])) if spans else float("nan")
     union_ms, cur_s, cur_e = 0.0, None, None
@@ -167,7 +167,7 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS},
-            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_bilstm_fwd / dprnn_bilstm_norm_fwd)",
+            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_rnn_fwd, LSTM cell)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_gflop_per_launch": flop_per_launch / 1e9,

@@ -114,6 +114,19 @@ int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const double* stats, c
                           int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                           int64_t t_stride, int ndir, int seq_tile, void* stream);
 
+/* ---- the same two entry points for every rnn_type the reference accepts (getattr(nn, rnn_type), dprnn.py:23):
+ * cell 0 = LSTM (gates i,f,g,o), 1 = GRU (r,z,n with n = tanh(W_in x + b_in + r*(W_hn h + b_hn))), 2 = RNN (tanh).
+ * Weight shapes as torch: w_ih [G*H][F], w_hh [G*H][H], biases [G*H], G = 4 | 3 | 1.  dprnn_rnn_fwd: Z == NULL means
+ * no pending norm (then stats/gamma/beta/Xout are ignored).  GRU / RNN use 16- or 32-sequence tiles. */
+int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                   float* packed, float* bsum, void* stream);
+int dprnn_rnn_fwd(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                  const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                  const float* packed, const float* bsum, float* H,
+                  int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                  int64_t t_stride, int ndir, int seq_tile, void* stream);
+
 /* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
  * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; used by tools/bench_recur.py only. */
 int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,

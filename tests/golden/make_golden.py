@@ -58,6 +58,9 @@ CASES = [
     ("bss_wide_hop5", "bss", dict(WIDE, chunk_length=16, hop_length=5, n_repeats=1), 3, 211, 13, False, False),
     ("bss_wide_k250", "bss", dict(WIDE, chunk_length=250, hop_length=125, n_repeats=1), 3, 2000, 14, False, False),
     ("bss_wide_unidir", "bss", dict(WIDE, bidirectional=False, n_repeats=1), 2, 300, 15, False, False),
+    ("bss_wide_gru", "bss", dict(WIDE, rnn_type="GRU"), 2, 300, 16, False, False),
+    ("bss_wide_gru_unidir", "bss", dict(WIDE, rnn_type="GRU", bidirectional=False, n_repeats=1), 3, 211, 17, False, False),
+    ("bss_wide_rnn", "bss", dict(WIDE, rnn_type="RNN", norm_type="gLN"), 2, 300, 18, False, False),
     ("bss_full_b2", "bss", dict(), 2, 24000, 20, False, False),
     ("spe_tiny_cat", "spe", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 2, 203, 30, True, False),
     ("spe_tiny_cat_bntrain", "spe", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 3, 203, 31, False, True),

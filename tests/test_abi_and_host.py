@@ -101,9 +101,9 @@ def test_unsupported_config_fails_loudly():
     m = pkg.DPRNNTasNet(8, 16, 16, 10, 2, 5, 1).eval()
     with pytest.raises(NotImplementedError, match="feature_size"):
         engine.check_supported(m.cfg)
-    m = pkg.DPRNNTasNet(64, rnn_type="GRU").eval()
-    with pytest.raises(NotImplementedError, match="GRU"):
-        engine.check_supported(m.cfg)
+    engine.check_supported(pkg.DPRNNTasNet(64, rnn_type="GRU").eval().cfg)      # GRU and RNN have kernels too
+    with pytest.raises(AttributeError):
+        pkg.DPRNNTasNet(64, rnn_type="QRNN")                                       # getattr(nn, rnn_type) in the reference
 
 
 def test_training_mode_is_refused_until_backward_exists():

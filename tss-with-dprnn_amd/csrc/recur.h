@@ -28,6 +28,7 @@ struct RecurArgs {
     float eps;
     int seqs_per_utt;
     long long rows_per_utt;
+    int cell;                                         // 0 LSTM, 1 GRU, 2 Elman RNN (tanh)
 };
 
 // software-pipelined 64-sequence variant (recur64.hip)

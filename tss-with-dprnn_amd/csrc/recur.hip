@@ -29,36 +29,59 @@ namespace {
 
 typedef const f32x4 __attribute__((address_space(1)))* gw_ptr;   // global address space pointer to packed weights
 
-// packed[dir][wave][grp][gate*2+u][lane][i] = Wcat[dir][gate*128 + 32*wave + 16*u + (lane&15)][k]
-__global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
-                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
-                                 const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
-                                 const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
-                                 float* __restrict__ packed, float* __restrict__ bsum, int ndir) {
+// packed[dir][wave][grp][slot*2+u][lane][i] = Wslot[dir][slot][32*wave + 16*u + (lane&15)][k], k over [x(128) | h(128)].
+// The four accumulator slots per hidden unit are
+//   LSTM (cell 0): i, f, g, o            rows slot*128+unit of [W_ih | W_hh], bias b_ih + b_hh
+//   GRU  (cell 1): r, z, n_x, n_h        r, z as above; n_x = [W_in | 0] + b_in; n_h = [0 | W_hn] + b_hn
+//                                        (n = tanh(n_x + r * n_h) keeps the two halves apart, torch.nn.GRU semantics)
+//   RNN  (cell 2): a, -, -, -            [W_ih | W_hh], bias sum; slots 1..3 are not computed
+__global__ void rnn_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
+                                const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
+                                float* __restrict__ packed, float* __restrict__ bsum, int ndir, int cell) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ndir * PACK_PER_DIR) return;
     const int i = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, grp = (idx >> 11) & 15;
     const int wave = (idx >> 15) & 3, dir = idx >> 17;
-    const int gate = gu >> 1, u = gu & 1, j = lane & 15, q = lane >> 4;
-    const int row = gate * HD + 32 * wave + 16 * u + j;
+    const int slot = gu >> 1, u = gu & 1, j = lane & 15, q = lane >> 4;
+    const int unit = 32 * wave + 16 * u + j;
     const int g = grp & 7;
     const int k = 64 * (g >> 2) + 16 * q + 4 * (g & 3) + i;
     const float* wi = dir ? w_ih_r : w_ih;
     const float* wh = dir ? w_hh_r : w_hh;
-    packed[idx] = (grp < 8) ? wi[row * F + k] : wh[row * HD + k];
+    const bool xpart = grp < 8;
+    float v = 0.f;
+    if (cell == 0) {
+        v = xpart ? wi[(slot * HD + unit) * F + k] : wh[(slot * HD + unit) * HD + k];
+    } else if (cell == 1) {
+        const int gate = slot < 2 ? slot : 2;
+        const bool use = slot < 2 || (slot == 2 && xpart) || (slot == 3 && !xpart);
+        if (use) v = xpart ? wi[(gate * HD + unit) * F + k] : wh[(gate * HD + unit) * HD + k];
+    } else {
+        if (slot == 0) v = xpart ? wi[unit * F + k] : wh[unit * HD + k];
+    }
+    packed[idx] = v;
     if (idx < ndir * 4 * HD) {
-        const int d = idx / (4 * HD), n = idx % (4 * HD);
-        bsum[idx] = (d ? b_ih_r : b_ih)[n] + (d ? b_hh_r : b_hh)[n];
+        const int d = idx / (4 * HD), n = idx % (4 * HD), sl = n / HD, un = n % HD;
+        const float* bi = d ? b_ih_r : b_ih;
+        const float* bh = d ? b_hh_r : b_hh;
+        float b = 0.f;
+        if (cell == 0) b = bi[n] + bh[n];
+        else if (cell == 1) b = sl < 2 ? bi[n] + bh[n] : (sl == 2 ? bi[2 * HD + un] : bh[2 * HD + un]);
+        else b = sl == 0 ? bi[un] + bh[un] : 0.f;
+        bsum[idx] = b;
     }
 }
 
 // DIAG (diagnostic builds only, wrong results on purpose): 1 = every k-group re-reads weight group 0 (L1-resident:
 // no L2 weight stream), 2 = A fragments read once per step instead of per k-group (no LDS operand traffic),
 // 3 = cell update skipped (h = gate pre-activation), 4 = no HBM store of h.
-template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0>
+template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
     constexpr int NS = 16 * NT;
+    constexpr int NGA = CELL == 2 ? 1 : 4;            // accumulator slots in use (see rnn_pack_kernel)
     constexpr int NXV = NS / 8;                       // float4 x loads per thread per step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const XH = smem;                           // [2][NS][XS]: row = x_t (128) | h_{t-1} (128)
@@ -141,7 +164,11 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
-            bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+            // pre-scaled for the activation that consumes the slot directly (sigmoid: -log2e, tanh: 2*log2e);
+            // the GRU candidate slots (2, 3) enter a product first and keep the plain bias
+            const bool is_tanh = (CELL == 0 && g == 2) || CELL == 2;
+            const bool plain = CELL == 1 && g >= 2;
+            bias[g][u] = (FAST && !plain) ? b * (is_tanh ? 2.8853900817779268f : -1.4426950408889634f) : b;
         }
 
     // wave-uniform weight slice (SGPR base, global address space) + lane index: saddr-form loads, scalar address math
@@ -178,7 +205,7 @@ void bilstm_kernel(RecurArgs a) {
 
     f32x4 w[2][8];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) w[0][x] = wbase[x * 64];
+    for (int x = 0; x < 2 * NGA; ++x) w[0][x] = wbase[x * 64];
     __syncthreads();
 
     unsigned long long st_t0 = 0, st_r0 = 0, st_mfma = 0, st_act = 0;
@@ -222,7 +249,7 @@ void bilstm_kernel(RecurArgs a) {
                 // weights of the next k-group (wraps to group 0 of the next step: same bytes every step)
                 const gw_ptr wn = wbase + (DIAG == 1 ? 0 : (((grp + 1) & 15) * 8) * 64);
 #pragma unroll
-                for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
+                for (int x = 0; x < 2 * NGA; ++x) w[half ^ 1][x] = wn[x * 64];
                 const float* src = Ac + (DIAG == 2 ? 0 : 64 * (grp >> 2) + 4 * (grp & 3));
                 float av[NT][4];
 #pragma unroll
@@ -234,13 +261,14 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int gt = 0; gt < 4; ++gt)
+                        for (int gt = 0; gt < NGA; ++gt)
 #pragma unroll
                             for (int u = 0; u < 2; ++u)
                                 acc[nt][gt][u] = mfma16(av[nt][i], w[half][gt * 2 + u][i], acc[nt][gt][u]);
             }
         }
         } else {
+        static_assert(SCHED == 0 || CELL == 0, "the interleaved schedule is instantiated for the LSTM cell only");
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -301,7 +329,7 @@ void bilstm_kernel(RecurArgs a) {
                     float h;
                     if constexpr (DIAG == 3) {
                         h = acc[nt][0][u][e] + acc[nt][1][u][e] + acc[nt][2][u][e] + acc[nt][3][u][e] + bias[0][u];
-                    } else {
+                    } else if constexpr (CELL == 0) {     // LSTM, gate order i,f,g,o (torch.nn.LSTM)
                         const float ig = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
                         const float fg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
                         const float gg = tanh_b<FAST>(acc[nt][2][u][e], bias[2][u]);
@@ -309,6 +337,14 @@ void bilstm_kernel(RecurArgs a) {
                         const float cn = fg * c[nt][u][e] + ig * gg;
                         c[nt][u][e] = cn;
                         h = og * tanh_f<FAST>(cn);
+                    } else if constexpr (CELL == 1) {     // GRU: n = tanh(n_x + r*n_h), h' = (1-z)*n + z*h (c holds h)
+                        const float rg = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
+                        const float zg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
+                        const float ng = tanh_f<FAST>((acc[nt][2][u][e] + bias[2][u]) + rg * (acc[nt][3][u][e] + bias[3][u]));
+                        h = (1.f - zg) * ng + zg * c[nt][u][e];
+                        c[nt][u][e] = h;
+                    } else {                              // Elman RNN, tanh
+                        h = tanh_b<FAST>(acc[nt][0][u][e], bias[0][u]);
                     }
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
                     if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
@@ -346,37 +382,44 @@ void bilstm_kernel(RecurArgs a) {
     }
 }
 
-template <int NT, bool FAST>
+template <int NT, bool FAST, int CELL = 0>
 int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     constexpr int NS = 16 * NT;
     // one workgroup per CU (NT >= 3): prefetch A fragments a k-group ahead and spread the memory instructions
     // between the MFMAs (measured +6 % at NT = 4); with two co-resident workgroups (NT <= 2) the plain loop is as fast
-    constexpr int SCHED = NT >= 3 ? 1 : 0;
+    constexpr int SCHED = (NT >= 3 && CELL == 0) ? 1 : 0;
     const size_t lds = (size_t)2 * NS * XS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
-    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL>), grid, dim3(256), lds, st, a);
     return dprnn_check_launch("bilstm_kernel");
 }
 
 }  // namespace
 
+extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                              const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                              float* packed, float* bsum, void* stream) {
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_rnn_pack: null pointer"); return -1; }
+    if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    const int ndir = w_ih_r ? 2 : 1;
+    if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_rnn_pack: incomplete reverse direction"); return -1; }
+    const int n = ndir * PACK_PER_DIR;
+    hipLaunchKernelGGL(rnn_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, ndir, cell);
+    return dprnn_check_launch("rnn_pack_kernel");
+}
+
 extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                                const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                                float* packed, float* bsum, void* stream) {
-    if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_lstm_pack: null pointer"); return -1; }
-    const int ndir = w_ih_r ? 2 : 1;
-    if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_lstm_pack: incomplete reverse direction"); return -1; }
-    const int n = ndir * PACK_PER_DIR;
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, ndir);
-    return dprnn_check_launch("lstm_pack_kernel");
+    return dprnn_rnn_pack(0, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
 }
 
 static int g_pipelined64 = 0;
@@ -396,6 +439,16 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
     }
     if (seq_tile == 0) seq_tile = a.nseq <= 16 ? 16 : 32;
     const bool fast = g_fast_act != 0;
+    if (a.cell == 1 || a.cell == 2) {       // GRU / Elman: 16- or 32-sequence tiles
+        const bool small = seq_tile == 16;
+        if (a.cell == 1) {
+            if (small) return fast ? launch_bilstm<1, true, 1>(a, st) : launch_bilstm<1, false, 1>(a, st);
+            return fast ? launch_bilstm<2, true, 1>(a, st) : launch_bilstm<2, false, 1>(a, st);
+        }
+        if (small) return fast ? launch_bilstm<1, true, 2>(a, st) : launch_bilstm<1, false, 2>(a, st);
+        return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
+    }
+    if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
         case 32: return fast ? launch_bilstm<2, true>(a, st) : launch_bilstm<2, false>(a, st);
@@ -413,6 +466,19 @@ extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float
     RecurArgs a{};
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
+    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+}
+
+extern "C" int dprnn_rnn_fwd(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                             const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                             const float* packed, const float* bsum, float* H,
+                             int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                             int64_t t_stride, int ndir, int seq_tile, void* stream) {
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
+    a.rows_per_utt = rows_per_utt; a.Xout = Xout;
     return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
 }
 

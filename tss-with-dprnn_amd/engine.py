@@ -20,6 +20,7 @@ F_BUILT = 128      # feature_size / hidden_size the kernels are built for (confi
 N_BUILT = 64       # input_size (config_bss.yaml:18)
 KS_MAX = 8
 PACK_PER_DIR = 4 * 16 * 8 * 256
+CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
 SEQ_TILE = {"intra": 0, "inter": 0}
@@ -90,8 +91,8 @@ def check_supported(cfg: dict) -> None:
         bad.append(f"feature_size/hidden_size must be {F_BUILT} (got {cfg['feature_size']}/{cfg['hidden_size']})")
     if cfg["input_size"] != N_BUILT:
         bad.append(f"input_size must be {N_BUILT} (got {cfg['input_size']})")
-    if cfg["rnn_type"] != "LSTM":
-        bad.append(f"rnn_type {cfg['rnn_type']!r}: only 'LSTM' has a HIP recurrence kernel")
+    if cfg["rnn_type"] not in CELL_ID:
+        bad.append(f"rnn_type {cfg['rnn_type']!r}: torch.nn has LSTM, GRU and RNN recurrences")
     if cfg["kernel_size"] > KS_MAX:
         bad.append(f"kernel_size must be <= {KS_MAX}")
     if cfg["norm_type"] not in ("ln", "gLN"):
@@ -223,11 +224,14 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
             tile = 64
         else:
             tile = 32 if wgs(32) >= 2 * ncu else 16
+    cell = CELL_ID[rnn.rnn.mode]
+    if cell != 0 and tile > 32:
+        tile = 32
     if g.pending is None:
-        st.call("dprnn_bilstm_fwd", _p(g.X), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
+        st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
         pstats, pg, pb, peps = g.pending
-        st.call("dprnn_bilstm_norm_fwd", _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
+        st.call("dprnn_rnn_fwd", cell, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
                 _p(g.X2), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
         g.X, g.X2 = g.X2, g.X
         g.pending = None
@@ -269,7 +273,8 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
             _, fw, bw = _rnn_tensors(rnn, dev)
-            st.call("dprnn_lstm_pack", *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
+            st.call("dprnn_rnn_pack", CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
+                    _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
