@@ -56,8 +56,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
+    ap.add_argument("--gemm-mode", type=int, default=0,
+                    help="0 exact fp32 MFMA (headline); 1/2 = optional bf16-split gate GEMM with 6/3 products")
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
@@ -98,6 +101,7 @@ def main():
         engine.STREAM_GROUPS = args.groups
     if args.min_group is not None:
         engine.MIN_GROUP_BATCH = args.min_group
+    engine.GEMM_MODE = args.gemm_mode
 
     B = args.batch
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
@@ -156,17 +160,38 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # Optional arithmetic modes of the gate GEMM, timed AFTER (and outside) the headline region: same batch, same
+    # protocol, 3 steps each; deviation is measured against the exact-fp32 output of this very run.
+    optional = None
+    if world == 1 and args.gemm_mode == 0 and not args.no_optional_modes:
+        optional = {}
+        ref_out = out.double()
+        with torch.no_grad():
+            for mode, name in ((1, "bf16_split_6_products"), (2, "bf16_split_3_products")):
+                engine.GEMM_MODE = mode
+                o = model(x)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    o = model(x)
+                sync()
+                dt = (time.perf_counter() - t1) / 3
+                optional[name] = {"value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt,
+                                  "rel_l2_vs_exact_fp32_path": float((o.double() - ref_out).norm() / ref_out.norm())}
+            engine.GEMM_MODE = 0
     if rank == 0:
         value = world * B * args.steps / elapsed
         line = {
             "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.gemm_mode == 0 else "f32 via bf16-split operands, f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": "DPRNN-TasNet BSS inference, synthetic 3 s @ 8 kHz, batch=64 per GPU "
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
-                       "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS},
+                       "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS,
+                       "gemm_mode": ["exact fp32 MFMA", "bf16-split x6 on bf16 MFMA (opt-in)", "bf16-split x3 on bf16 MFMA (opt-in)"][args.gemm_mode]},
             "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_rnn_fwd, LSTM cell)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01_pmc_traffic.json)",
@@ -179,6 +204,9 @@ def main():
                          "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
+        if optional is not None:
+            line["optional_gemm_modes"] = dict(optional, note="opt-in (engine.GEMM_MODE / dprnn_set_gemm_mode): LSTM gate GEMM with "
+                                               "bf16-split operands on the bf16 MFMA, fp32 accumulate; NOT part of `value`")
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(sd, cfg, threads)

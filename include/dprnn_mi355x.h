@@ -40,6 +40,17 @@ int dprnn_num_cus(void);
  * 2e-7 rel-L2 against the reference output end to end, tests/test_gpu_parity.py), 0 = libm expf/tanhf */
 void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
 void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
+/* OPTIONAL arithmetic mode of the LSTM gate GEMM (process-wide, read by dprnn_rnn_pack / dprnn_lstm_pack and by the
+ * recurrence entry points, so set it before packing): 0 = exact fp32 operands on the fp32 MFMA (default, what every
+ * parity claim and the bench headline refer to); 1 = operands split into three bf16 pieces, the six cross products of
+ * order <= 2^-16 on the bf16 MFMA with fp32 accumulation (product error ~2^-24: end-to-end deviation identical to the
+ * fp32 path's own rounding noise); 2 = two pieces / three products (product error ~2^-16).  recur_split.hip. */
+void dprnn_set_gemm_mode(int mode);
+int dprnn_get_gemm_mode(void);
+/* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order) */
+int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                          const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                          void* packed, float* bsum, void* stream);
 /* seq_tile 64 of dprnn_bilstm_fwd: 1 = software-pipelined kernel (cell update hidden under the other half's
  * gate GEMM, recur64.hip), 0 = plain 64-sequence tile */
 void dprnn_set_recur_pipelined(int on);
@@ -87,7 +98,7 @@ int dprnn_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int 
 
 /* ---- pack one nn.LSTM direction pair for dprnn_bilstm_fwd (SingleRNN, dprnn.py:23-28):
  * w_ih [4H][F], w_hh [4H][H], b_ih/b_hh [4H] (gate order i,f,g,o), *_r = reverse direction or NULL.
- * packed: ndir*4*16*8*256 floats, bsum: ndir*4H floats. */
+ * packed: ndir*4*16*8*256 floats (ndir*196608 when a split gemm mode is active), bsum: ndir*4H floats. */
 int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                     const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                     float* packed, float* bsum, void* stream);

@@ -144,6 +144,43 @@ def test_bilstm_with_pending_norm(mode, seq_tile):
     assert rel_l2(H.cpu().numpy(), want) < 2e-6
 
 
+@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("path", ["intra", "inter"])
+def test_bilstm_split_gemm_modes(mode, tol, path):
+    """Optional bf16-split gate GEMM (recur_split.hip): 6 products ~ fp32 accuracy, 3 products ~ 2^-16."""
+    B, S, K = 2, 9, 21
+    rng = np.random.default_rng(mode)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(45)
+    if path == "intra":
+        want = onp.single_rnn(sd, p, X.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    else:
+        want = onp.single_rnn(sd, p, X.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
+        want = want.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    Xd = _t(X)
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    st.lib.dprnn_set_gemm_mode(mode)
+    try:
+        assert st.lib.dprnn_get_gemm_mode() == mode
+        st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+        st.call("dprnn_rnn_fwd", 0, Xd.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+                *addr, 2, 0)
+        torch.cuda.synchronize()
+    finally:
+        st.lib.dprnn_set_gemm_mode(0)
+    got = H.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = rel_l2(got, want)
+    print(f"split mode {mode} {path}: rel-L2 {err:.2e}")
+    assert err < tol
+
+
 def test_bilstm_unidirectional():
     B, S, K = 1, 5, 9
     X = np.random.default_rng(3).standard_normal((B, S, K, 128)).astype(np.float32)

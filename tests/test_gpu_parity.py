@@ -141,6 +141,30 @@ def test_fused_and_explicit_norm_agree():
     assert rel_l2(outs[0], outs[1]) < 1e-6
 
 
+@pytest.mark.parametrize("mode,tol", [(1, 1e-6), (2, 1e-5)])
+def test_optional_split_gemm_modes_full_size(mode, tol):
+    """engine.GEMM_MODE 1 / 2 (bf16-split gate GEMM, opt-in): the 6-product form must sit at the fp32 path's own
+    noise level against the reference output, the 3-product form inside the 1e-5 parity tolerance."""
+    from tss_with_dprnn_amd import engine
+    g = load_golden("bss_full_b2")
+    m = g["meta"]
+    model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
+    x = torch.from_numpy(g["mix"]).to(_dev())
+    engine.GEMM_MODE = mode
+    try:
+        with torch.no_grad():
+            out = model(x).cpu().numpy()
+    finally:
+        engine.GEMM_MODE = 0
+    with torch.no_grad():
+        exact = model(x).cpu().numpy()
+    r = rel_l2(out, g["out"])
+    tgt, _ = make_sources(2, 24000, seed=77)
+    d = np.abs(si_sdr(out, tgt) - si_sdr(g["out"], tgt)).max()
+    print(f"gemm mode {mode}: rel-L2 vs reference {r:.2e} (exact fp32 path {rel_l2(exact, g['out']):.2e}), |dSI-SDR| {d:.1e} dB")
+    assert r <= tol and d <= 0.01
+
+
 def test_stream_groups_do_not_change_results():
     """Utterance groups on separate HIP streams (engine.STREAM_GROUPS) must be bit-identical to one stream."""
     from tss_with_dprnn_amd import engine

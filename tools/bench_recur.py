@@ -16,15 +16,19 @@ def run(st, seq_tile, nwg, T, ndir=2, iters=3):
     nseq = nwg * seq_tile // ndir
     X = torch.randn(nseq * T, 128, device="cuda") * 0.5
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
-    packed = torch.randn(ndir * engine.PACK_PER_DIR, device="cuda") * 0.08
-    bsum = torch.randn(ndir * 512, device="cuda") * 0.1
-    args = (X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T, nseq, 0, T, 1, ndir, seq_tile)
-    st.call("dprnn_bilstm_fwd", *args)
+    packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
+    bsum = torch.empty(ndir * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    args = (0, X.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T, nseq, 0, T, 1,
+            ndir, seq_tile)
+    st.call("dprnn_rnn_fwd", *args)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        st.call("dprnn_bilstm_fwd", *args)
+        st.call("dprnn_rnn_fwd", *args)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -77,12 +81,14 @@ def main():
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3")
     ap.add_argument("--pipelined", type=int, default=0, help="seq_tile 64 uses the software-pipelined kernel")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
     lib.dprnn_set_fast_activations(a.fast)
     lib.dprnn_set_recur_pipelined(a.pipelined)
+    lib.dprnn_set_gemm_mode(a.gemm_mode)
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")

@@ -33,4 +33,6 @@ struct RecurArgs {
 
 // software-pipelined 64-sequence variant (recur64.hip)
 int launch_bilstm64(const RecurArgs& a, bool fast, hipStream_t st);
+// optional bf16-split gate GEMM (recur_split.hip): products = 6 or 3
+int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
 }  // namespace recur

@@ -1,0 +1,310 @@
+// OPTIONAL gate-GEMM mode of the BiLSTM recurrence: bf16-split operands on the bf16 MFMA, fp32 accumulate.
+//
+// Off by default (dprnn_set_gemm_mode).  The default path (recur.hip) multiplies exact fp32 operands on
+// v_mfma_f32_16x16x4_f32, which runs at the fp32 *vector* rate and -- measured, profiles/r01_mfma_valu_coissue.txt --
+// shares that datapath with every VALU instruction.  v_mfma_f32_16x16x32_bf16 is 16x faster per FLOP and leaves the
+// vector ALU free, so this kernel writes every fp32 operand v as a sum of bf16 pieces v = v1 + v2 (+ v3) and sums
+// the cross products of order <= 2^-16 with fp32 accumulation inside the MFMA:
+//     mode 1 (6 products: v1w1, v1w2, v2w1, v1w3, v2w2, v3w1): product error ~2^-24 -- end to end the same
+//            1.4e-7 rel-L2 against fp64 as the exact fp32 path (tools/split_precision_study.py),
+//     mode 2 (3 products: v1w1, v1w2, v2w1):                   product error ~2^-16 -- 1.2e-6 rel-L2.
+// Everything else (cell arithmetic, state, layout, addressing, pending-norm loader) is the fp32 code of recur.hip.
+//
+// Layout differences: x/h live in LDS as three bf16 planes [plane][seq][x(128)|h(128)] (row pitch 528 B so that the
+// 16-byte fragment reads of 16 rows spread over the banks), single-buffered with two barriers per step; weights are
+// pre-split by dprnn_lstm_pack_split into [dir][wave][k-slab 8][gate 4][u 2][piece 3][lane 64] 16-byte fragments
+// (lane (r, q) = unit row r, k = 32*slab + 8*q .. +7: the B operand of v_mfma_f32_16x16x32_bf16).
+#include "recur.h"
+using namespace recur;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef const u32x4 __attribute__((address_space(1)))* gfrag_ptr;
+
+constexpr int NSLAB = 8;                       // k-slabs of 32 over [x | h]
+constexpr int PITCH = 528;                     // bytes per LDS row (256 bf16 + 16 B pad)
+constexpr int SPLIT_PACK_PER_DIR = 4 * NSLAB * 8 * 3 * 64 * 4;     // u32 per direction
+
+__device__ __forceinline__ unsigned bf16_bits(float v) {            // round-to-nearest-even bf16 of v, in the low 16 bits
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = __builtin_convertvector(f32x2{v, 0.f}, bf16x2);
+    return __builtin_bit_cast(unsigned, p) & 0xFFFFu;
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned bits16) { return __builtin_bit_cast(float, bits16 << 16); }
+
+// v -> three bf16 pieces (bits), v ~= p1 + p2 + p3 with |p2| <= 2^-8 |v|, |p3| <= 2^-16 |v|
+__device__ __forceinline__ void split3(float v, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = bf16_bits(v);
+    const float r1 = v - bf16_to_f32(p1);
+    p2 = bf16_bits(r1);
+    const float r2 = r1 - bf16_to_f32(p2);
+    p3 = bf16_bits(r2);
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// packed[dir][wave][slab][gate*2+u][piece][lane][4 u32] : bf16 piece `piece` of Wcat[gate*128 + 32*wave + 16*u + r][32*slab + 8*q + j]
+__global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                       const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
+                                       const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
+                                       unsigned* __restrict__ packed, float* __restrict__ bsum, int ndir) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (.., lane, dword) of piece 0
+    const int per_dir = 4 * NSLAB * 8 * 64 * 4;
+    if (idx >= ndir * per_dir) return;
+    const int dw = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, slab = (idx >> 11) & 7;
+    const int wave = (idx >> 14) & 3, dir = idx >> 16;
+    const int gate = gu >> 1, u = gu & 1, r = lane & 15, q = lane >> 4;
+    const int row = gate * HD + 32 * wave + 16 * u + r;
+    const float* wi = dir ? w_ih_r : w_ih;
+    const float* wh = dir ? w_hh_r : w_hh;
+    unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int k = 32 * slab + 8 * q + 2 * dw + half;            // 0..255 over [x | h]
+        const float v = k < F ? wi[row * F + k] : wh[row * HD + (k - F)];
+        unsigned p1, p2, p3;
+        split3(v, p1, p2, p3);
+        out[0] |= p1 << (16 * half); out[1] |= p2 << (16 * half); out[2] |= p3 << (16 * half);
+    }
+    const size_t base = ((((size_t)(dir * 4 + wave) * NSLAB + slab) * 8 + gu) * 3) * 256 + lane * 4 + dw;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) packed[base + (size_t)p * 256] = out[p];
+    if (idx < ndir * 4 * HD) {
+        const int d = idx / (4 * HD), n = idx % (4 * HD);
+        bsum[idx] = (d ? b_ih_r : b_ih)[n] + (d ? b_hh_r : b_hh)[n];
+    }
+}
+
+template <int NT, int NP, bool FAST>
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
+void bilstm_split_kernel(RecurArgs a) {
+    constexpr int NS = 16 * NT, NXV = NS / 8;
+    constexpr int NPC = NP == 6 ? 3 : 2;               // pieces actually needed per operand
+    constexpr int PLANE = NS * PITCH;                  // bytes
+    extern __shared__ __attribute__((aligned(16))) char img[];       // [3][NS][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * NS;
+    const int T = a.T;
+
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);
+    const int hpitch = a.ndir * HD;
+    unsigned xoff[NXV];
+    int xlds[NXV];
+    const int c4 = tid & 31;
+#pragma unroll
+    for (int m = 0; m < NXV; ++m) {
+        const int row = (tid >> 5) + 8 * m;
+        const int seq = seq0 + row;
+        xoff[m] = (unsigned)((rowbase(seq < a.nseq ? seq : seq0) - row0) * F + c4 * 4) * 4u;
+        xlds[m] = row * PITCH + c4 * 8;                // 4 bf16 = 8 bytes
+    }
+    unsigned hoff[NT][4];
+    bool hval[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int seq = seq0 + 16 * nt + 4 * q + e;
+            hval[nt][e] = seq < a.nseq;
+            hoff[nt][e] = (unsigned)((rowbase(hval[nt][e] ? seq : seq0) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u;
+        }
+    const bool fuse = a.Z != nullptr;
+    f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f};
+    float mu[NXV], rs[NXV];
+#pragma unroll
+    for (int m = 0; m < NXV; ++m) { mu[m] = 0.f; rs[m] = 0.f; }
+    if (fuse) {
+        gam = *reinterpret_cast<const f32x4*>(a.gamma + 4 * c4);
+        bet = *reinterpret_cast<const f32x4*>(a.beta + 4 * c4);
+#pragma unroll
+        for (int m = 0; m < NXV; ++m) {
+            const int seq = seq0 + (tid >> 5) + 8 * m;
+            const int b = (seq < a.nseq ? seq : seq0) / a.seqs_per_utt;
+            const double cnt = (double)a.rows_per_utt * (double)F;
+            const double mean = a.stats[2 * b] / cnt;
+            double var = a.stats[2 * b + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mu[m] = (float)mean;
+            rs[m] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+    }
+    auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
+
+    float bias[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+            bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+        }
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const gfrag_ptr wsl = (gfrag_ptr)(reinterpret_cast<const u32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NSLAB * 8 * 3 * 64) + lane;
+
+    // stage one time step of x (with the pending norm applied) as bf16 pieces into the image
+    auto stage_x = [&](long long t) __attribute__((always_inline)) {
+        const char* xs = reinterpret_cast<const char*>(a.X + tbase(t) * F);
+        const char* zs = reinterpret_cast<const char*>(a.Z + tbase(t) * F);
+        char* os = reinterpret_cast<char*>(a.Xout + tbase(t) * F);
+#pragma unroll
+        for (int m = 0; m < NXV; ++m) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
+            if (fuse) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(zs + xoff[m]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((z[e] - mu[m]) * rs[m] * gam[e] + bet[e]);
+                if (dir == 0) *reinterpret_cast<f32x4*>(os + xoff[m]) = v;
+            }
+            unsigned p[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc)
+                *reinterpret_cast<u32x2*>(img + pc * PLANE + xlds[m]) = u32x2{p[pc][0] | (p[pc][1] << 16), p[pc][2] | (p[pc][3] << 16)};
+        }
+    };
+
+    // ---- prologue: x(t0) pieces, h = 0
+    stage_x(dir ? (T - 1) : 0);
+    for (int i = tid; i < 3 * NS * 64; i += 256) {     // h region of every plane: 128 bf16 = 64 dwords per row (NS rows)
+        const int pl = i / (NS * 64), rem = i % (NS * 64);
+        *reinterpret_cast<unsigned*>(img + pl * PLANE + (rem >> 6) * PITCH + 256 + 4 * (rem & 63)) = 0u;
+    }
+    f32x4 c[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // B fragments of one k-slab: [gate][u][piece]; slab s+1 of a gate is requested as soon as slab s of it is consumed
+    u32x4 bfr[4][2][NPC];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bfr[g][u][pc] = wsl[((0 * 8 + g * 2 + u) * 3 + pc) * 64];
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const long long t = dir ? (T - 1 - step) : step;
+        const bool more = step + 1 < T;
+        f32x4 acc[NT][4][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const char* const Aim = img + r * PITCH + 16 * q;
+#pragma unroll 1
+        for (int s = 0; s < NSLAB; ++s) {
+            u32x4 afr[NT][NPC];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc)
+                    afr[nt][pc] = *reinterpret_cast<const u32x4*>(Aim + pc * PLANE + nt * 16 * PITCH + 64 * s);
+            const int sn = (s + 1) & 7;               // wraps to slab 0 of the next step (same bytes every step)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // products outermost: consecutive MFMAs go to different accumulators (no dependent-issue stalls),
+                // smallest cross terms first
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int pr = (NP == 6 ? 0 : 3); pr < 6; ++pr)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt][g][u] = mfma_bf16(afr[nt][PA[pr]], bfr[g][u][PB[pr]], acc[nt][g][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) bfr[g][u][pc] = wsl[((sn * 8 + g * 2 + u) * 3 + pc) * 64];
+            }
+        }
+        __syncthreads();                              // every wave is done reading the image of this step
+
+        // ---- LSTM cell, lane-local; h -> bf16 pieces in the image (next step's operand) and fp32 to HBM
+        char* const hs = reinterpret_cast<char*>(a.H + tbase(t) * hpitch);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ig = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
+                    const float fg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
+                    const float gg = tanh_b<FAST>(acc[nt][2][u][e], bias[2][u]);
+                    const float og = sigmoid_b<FAST>(acc[nt][3][u][e], bias[3][u]);
+                    const float cn = fg * c[nt][u][e] + ig * gg;
+                    c[nt][u][e] = cn;
+                    const float h = og * tanh_f<FAST>(cn);
+                    unsigned p1, p2, p3;
+                    split3(h, p1, p2, p3);
+                    char* d = img + (16 * nt + 4 * q + e) * PITCH + 2 * (HD + 32 * wave + 16 * u + r);
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p1;
+                    *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)p2;
+                    if (NPC == 3) *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)p3;
+                    if (hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
+                }
+        if (more) stage_x(dir ? (t - 1) : (t + 1));
+        __syncthreads();
+    }
+}
+
+template <int NT, int NP, bool FAST>
+int launch_split(const RecurArgs& a, hipStream_t st) {
+    constexpr int NS = 16 * NT;
+    const size_t lds = (size_t)3 * NS * PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_kernel<NT, NP, FAST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split): %s", hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
+    hipLaunchKernelGGL((bilstm_split_kernel<NT, NP, FAST>), grid, dim3(256), lds, st, a);
+    return dprnn_check_launch("bilstm_split_kernel");
+}
+
+}  // namespace
+
+int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st) {
+    // the weight stream from L2 (~70 GB/s per CU) bounds this kernel: 64 sequences per workgroup halve its bytes per FLOP
+    if (seq_tile == 64) {
+        if (products == 6) return fast ? launch_split<4, 6, true>(a, st) : launch_split<4, 6, false>(a, st);
+        return fast ? launch_split<4, 3, true>(a, st) : launch_split<4, 3, false>(a, st);
+    }
+    if (products == 6) return fast ? launch_split<2, 6, true>(a, st) : launch_split<2, 6, false>(a, st);
+    return fast ? launch_split<2, 3, true>(a, st) : launch_split<2, 3, false>(a, st);
+}
+
+extern "C" int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                     const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                                     void* packed, float* bsum, void* stream) {
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_lstm_pack_split: null pointer"); return -1; }
+    const int ndir = w_ih_r ? 2 : 1;
+    if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_lstm_pack_split: incomplete reverse direction"); return -1; }
+    const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
+    hipLaunchKernelGGL(lstm_pack_split_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
+    return dprnn_check_launch("lstm_pack_split_kernel");
+}

@@ -19,7 +19,8 @@ from ._lib import DprnnError, check, load_library
 F_BUILT = 128      # feature_size / hidden_size the kernels are built for (config_bss.yaml:19-20)
 N_BUILT = 64       # input_size (config_bss.yaml:18)
 KS_MAX = 8
-PACK_PER_DIR = 4 * 16 * 8 * 256
+PACK_PER_DIR = 4 * 16 * 8 * 256            # fp32 fragments of one direction (floats)
+PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4   # the optional bf16-split modes need three piece planes (u32 words)
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
@@ -35,6 +36,11 @@ MIN_GROUP_BATCH = 16         # utterances per group at least (smaller groups los
 # Fold every GroupNorm + residual into the loader of the stage that consumes it (the next recurrence kernel, or the
 # mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
 FUSE_NORM = True
+
+# OPTIONAL arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).  0 = exact fp32
+# operands on the fp32 MFMA: the default, and what the parity claims and the bench headline refer to.  1 / 2 = bf16-split
+# operands (6 / 3 cross products) on the bf16 MFMA with fp32 accumulation: opt-in, reported separately.
+GEMM_MODE = 0
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
@@ -227,6 +233,8 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     cell = CELL_ID[rnn.rnn.mode]
     if cell != 0 and tile > 32:
         tile = 32
+    if cell == 0 and st.lib.dprnn_get_gemm_mode() != 0:
+        tile = 32                # the split kernel is L2-weight-stream bound: two 32-sequence workgroups per CU
     if g.pending is None:
         st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
@@ -267,8 +275,9 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
     blocks = list(sep.dprnn_blocks)
 
+    st.lib.dprnn_set_gemm_mode(GEMM_MODE if all(b.intra_rnn.rnn.mode == "LSTM" for b in blocks) else 0)
     # pack every LSTM once, on the caller's stream, before the groups fork
-    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR, device=dev, dtype=torch.float32)
+    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
     bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
