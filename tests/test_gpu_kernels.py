@@ -144,11 +144,11 @@ def test_bilstm_with_pending_norm(mode, seq_tile):
     assert rel_l2(H.cpu().numpy(), want) < 2e-6
 
 
-@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5), (3, 2e-6), (4, 3e-5)])
 @pytest.mark.parametrize("path", ["intra", "inter"])
 def test_bilstm_split_gemm_modes(mode, tol, path):
     """Optional bf16-split gate GEMM (recur_split.hip): 6 products ~ fp32 accuracy, 3 products ~ 2^-16."""
-    B, S, K = 2, 9, 21
+    B, S, K = 3, 9, 23              # 27 / 69 sequences: ragged against 32- and 64-sequence tiles
     rng = np.random.default_rng(mode)
     X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
     sd, p = _lstm_sd(45)

@@ -35,4 +35,6 @@ struct RecurArgs {
 int launch_bilstm64(const RecurArgs& a, bool fast, hipStream_t st);
 // optional bf16-split gate GEMM (recur_split.hip): products = 6 or 3
 int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
+// same arithmetic, GEMM-like structure: waves split the sequences, weights shared through an LDS ring (recur_split3.hip)
+int launch_bilstm_split3(const RecurArgs& a, int products, bool fast, hipStream_t st);
 }  // namespace recur

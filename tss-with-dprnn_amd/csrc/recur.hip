@@ -403,18 +403,24 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
 
 }  // namespace
 
-static int g_gemm_mode = 0;       // 0 exact fp32 MFMA (default), 1 bf16-split 6 products, 2 bf16-split 3 products
-extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
+// 0 exact fp32 MFMA (default); bf16-split: 1 = 6 products, 2 = 3 products (per-wave weight stream, recur_split.hip);
+// 3 = 6 products, 4 = 3 products (weights shared through an LDS ring, recur_split3.hip)
+static int g_gemm_mode = 0;
+extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode >= 1 && mode <= 4) ? mode : 0; }
 extern "C" int dprnn_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" int dprnn_lstm_pack_split(const float*, const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, void*, float*, void*);
+extern "C" int dprnn_lstm_pack_split3(const float*, const float*, const float*, const float*, const float*, const float*,
+                                      const float*, const float*, void*, float*, void*);
 
 extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                               const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                               float* packed, float* bsum, void* stream) {
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_rnn_pack: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (cell == 0 && g_gemm_mode != 0)      // optional split mode: bf16 piece planes instead of fp32 fragments
+    if (cell == 0 && g_gemm_mode >= 3)      // optional split modes: bf16 piece planes instead of fp32 fragments
+        return dprnn_lstm_pack_split3(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
+    if (cell == 0 && g_gemm_mode != 0)
         return dprnn_lstm_pack_split(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_rnn_pack: incomplete reverse direction"); return -1; }
@@ -457,6 +463,7 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
     }
     if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    if (g_gemm_mode >= 3) return launch_bilstm_split3(a, g_gemm_mode == 3 ? 6 : 3, fast, st);
     if (g_gemm_mode != 0) return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, seq_tile, fast, st);
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);

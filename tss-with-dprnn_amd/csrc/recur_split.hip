@@ -83,7 +83,7 @@ __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const flo
 }
 
 template <int NT, int NP, bool FAST>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
+__global__ __launch_bounds__(256, (NT <= 3 ? 2 : 1))
 void bilstm_split_kernel(RecurArgs a) {
     constexpr int NS = 16 * NT, NXV = NS / 8;
     constexpr int NPC = NP == 6 ? 3 : 2;               // pieces actually needed per operand
@@ -292,6 +292,10 @@ int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, b
     if (seq_tile == 64) {
         if (products == 6) return fast ? launch_split<4, 6, true>(a, st) : launch_split<4, 6, false>(a, st);
         return fast ? launch_split<4, 3, true>(a, st) : launch_split<4, 3, false>(a, st);
+    }
+    if (seq_tile == 48) {       // two 48-sequence workgroups still fit one CU (2 x 76 KB of LDS): 2/3 of the weight bytes per FLOP
+        if (products == 6) return fast ? launch_split<3, 6, true>(a, st) : launch_split<3, 6, false>(a, st);
+        return fast ? launch_split<3, 3, true>(a, st) : launch_split<3, 3, false>(a, st);
     }
     if (products == 6) return fast ? launch_split<2, 6, true>(a, st) : launch_split<2, 6, false>(a, st);
     return fast ? launch_split<2, 3, true>(a, st) : launch_split<2, 3, false>(a, st);
