@@ -4,11 +4,11 @@
 //   * the four waves split the 64 SEQUENCES (16 each) and every wave computes all 4 x 128 gate columns of its rows,
 //     so h of a row is produced and consumed by the same wave: the x|h image is wave-private (fp32, split into bf16
 //     pieces when the A fragment is read) and needs no workgroup barrier;
-//   * the weights are shared: one stage = (k-slab of 32, gate) = 8 unit tiles x NPC pieces x 1 KB is brought into a
-//     3-deep LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, already in B-fragment order), each
-//     byte once per workgroup-step instead of once per wave -- half the L2 bytes per FLOP of the 32-sequence kernel;
-//   * one s_barrier per stage orders the ring: wait (counted vmcnt) for my part of stage i, barrier, request stage
-//     i+2 into the buffer whose readers have all passed the barrier, compute stage i.
+//   * the weights are shared: one stage = (k-slab of 32, gate) = 8 unit tiles x NPC pieces x 1 KB goes through a
+//     3-deep LDS ring (each wave copies a quarter of it: global_load_dwordx4 one stage ahead, ds_write_b128 after the
+//     barrier; already in B-fragment order), each byte once per workgroup-step instead of once per wave -- half the
+//     L2 bytes per FLOP of the 32-sequence kernel;
+//   * one barrier per stage orders the ring: barrier, publish stage i+1, request stage i+2, compute stage i.
 #include "recur.h"
 using namespace recur;
 
@@ -165,17 +165,23 @@ void bilstm_split3_kernel(RecurArgs a) {
         }
     };
 
-    // weight stream: stage st (0..31 within a step, same bytes every step) -> ring buffer buf
+    // weight stream: stage st (0..31 within a step, same bytes every step).  Register-staged: this wave's DPW 1-KB
+    // pieces of a stage are loaded to VGPRs one stage ahead and written to the ring right after the barrier
+    // (an LDS-DMA version of the same ring cost ~100 issue cycles per piece and was slower).
     const char* const wsrc = reinterpret_cast<const char*>(a.Wp) + (size_t)dir * NSLAB * 4 * 8 * 3 * 1024;
-    auto dma_stage = [&](int st, int buf) __attribute__((always_inline)) {
+    u32x4 wreg[DPW];
+    auto load_stage = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
-            const int piece_idx = wave * DPW + i;                  // 0 .. STAGE_KB-1 : (tile j, piece p) = divmod by NPC
+            const int piece_idx = wave * DPW + i;                  // (tile j, piece p) = divmod by NPC
             const int j = piece_idx / NPC, p = piece_idx % NPC;
-            const char* src = wsrc + ((size_t)(st * 8 + j) * 3 + p) * 1024 + lane * 16;
-            char* dst = ring + buf * RING_BYTES + piece_idx * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
+            wreg[i] = *reinterpret_cast<const u32x4*>(wsrc + ((size_t)(st * 8 + j) * 3 + p) * 1024 + lane * 16);
         }
+    };
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            *reinterpret_cast<u32x4*>(ring + buf * RING_BYTES + (wave * DPW + i) * 1024 + lane * 16) = wreg[i];
     };
 
     // ---- prologue
@@ -185,8 +191,9 @@ void bilstm_split3_kernel(RecurArgs a) {
     f32x4 c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dma_stage(0, 0);
-    dma_stage(1, 1);
+    load_stage(0);
+    store_stage(0);
+    load_stage(1);                                       // written to the ring after the first barrier
     int gst = 0;                                         // global stage counter (ring position), wave-uniform
 
     for (int step = 0; step < T; ++step) {
@@ -222,14 +229,11 @@ void bilstm_split3_kernel(RecurArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int buf = gst % 3;
-                // my DMA pieces of this stage have landed once at most the DPW pieces of the next stage are outstanding
-                // (and my LDS reads of the previous stage have returned before anyone may overwrite that buffer)
-                if constexpr (DPW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // everyone is past compute(gst-1): its buffer is free -> request stage gst+2 (wraps within the step pattern)
-                dma_stage((s * 4 + g + 2) & 31, (gst + 2) % 3);
+                // barrier: every wave has finished compute(gst-1) and has written its pieces of stage gst (previous trip);
+                // then publish stage gst+1 (its buffer was last read in compute(gst-2)) and request stage gst+2
+                __syncthreads();
+                store_stage((gst + 1) % 3);
+                load_stage((s * 4 + g + 2) & 31);
                 const u32x4* bp = reinterpret_cast<const u32x4*>(ring + buf * RING_BYTES) + lane;
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
                 // four unit tiles at a time: the products of one accumulator are spaced by three other accumulators
@@ -269,7 +273,6 @@ void bilstm_split3_kernel(RecurArgs a) {
             }
         if (more) stage_x(dir ? (t - 1) : (t + 1));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA left in flight when the workgroup retires
 }
 
 template <int NP, bool FAST>
