@@ -1,0 +1,150 @@
+"""Stage-level GPU tests of the training (backward) kernels against torch CPU autograd of the same stock operators
+the reference dispatches to (nn.LSTM, F.linear): test infrastructure only, the product never calls them."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle.weights import make_state
+
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import engine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+_KEEP = []
+
+
+def _st():
+    return engine.Stage(torch.device(DEV))
+
+
+def _t(a):
+    t = (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).contiguous().to(DEV)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _cpu_lstm(seed):
+    sd = make_state("bss", dict(n_repeats=1), seed)
+    p = "separation.dprnn_blocks.0.intra_rnn.rnn."
+    lstm = torch.nn.LSTM(128, 128, 1, batch_first=True, bidirectional=True)
+    with torch.no_grad():
+        for n, prm in lstm.named_parameters():
+            prm.copy_(torch.from_numpy(sd[p + n]))
+    return lstm
+
+
+NAMES = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+
+
+@pytest.mark.parametrize("path,B,S,K", [("intra", 3, 9, 23), ("inter", 2, 11, 37), ("intra", 1, 40, 5)])
+def test_lstm_backward_matches_autograd(path, B, S, K):
+    """dprnn_lstm_fwd_train + dprnn_lstm_bwd + dprnn_wgrad vs autograd of nn.LSTM (dprnn.py:23-37 under
+    trainer.py:106): dX, dW_ih, dW_hh, db of both directions; ragged against the 32-sequence tile."""
+    rng = np.random.default_rng(B * 100 + S)
+    lstm = _cpu_lstm(7)
+    X = torch.from_numpy(rng.standard_normal((B, S, K, 128)).astype(np.float32))
+    dH = torch.from_numpy(rng.standard_normal((B, S, K, 256)).astype(np.float32))
+    Xr = X.clone().requires_grad_(True)
+    if path == "intra":
+        out = lstm(Xr.reshape(B * S, K, 128))[0].reshape(B, S, K, 256)
+    else:
+        out = lstm(Xr.permute(0, 2, 1, 3).reshape(B * K, S, 128))[0].reshape(B, K, S, 256).permute(0, 2, 1, 3)
+    out.backward(dH)
+
+    st = _st()
+    lib = st.lib
+    w = [_t(getattr(lstm, n).detach()) for n in NAMES] + [_t(getattr(lstm, n + "_reverse").detach()) for n in NAMES]
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    packedT = torch.empty(2 * 512 * 256, device=DEV)
+    rows = B * S * K
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    nseq, T = addr[0], addr[1]
+    tape = torch.empty(lib.dprnn_lstm_tape_floats(nseq, T, 2), device=DEV)
+    Xd, dHd = _t(X), _t(dH)
+    H = torch.full((rows, 256), float("nan"), device=DEV)
+    dXd = torch.full((2, rows, 128), float("nan"), device=DEV)
+    dG = torch.full((rows, 1024), float("nan"), device=DEV)
+    st.call("dprnn_rnn_pack", 0, *[_p(t) for t in w], _p(packed), _p(bsum))
+    st.call("dprnn_lstm_pack_bwd", _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
+    st.call("dprnn_lstm_fwd_train", _p(Xd), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), _p(tape), *addr, 2)
+    st.call("dprnn_lstm_bwd", _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2)
+    torch.cuda.synchronize()
+    assert rel_l2(H.cpu().numpy().reshape(B, S, K, 256), out.detach().numpy()) < 2e-6
+    dX = (dXd[0] + dXd[1]).cpu().numpy().reshape(B, S, K, 128)
+    assert np.isfinite(dX).all()
+    err = rel_l2(dX, Xr.grad.numpy())
+    print(f"lstm bwd {path}: dX rel-L2 {err:.2e}")
+    assert err < 5e-6
+
+    # weight gradients: dW = dG^T [x | h_prev]
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(512, 256, rows), device=DEV)
+    t_stride = addr[5]
+    for d, suf in enumerate(["", "_reverse"]):
+        dW = torch.full((512, 256), float("nan"), device=DEV)
+        db0 = torch.full((512,), float("nan"), device=DEV)
+        db1 = torch.full((512,), float("nan"), device=DEV)
+        st.call("dprnn_wgrad", dG.data_ptr() + 4 * 512 * d, 1024, 512, _p(Xd), 128, 128, 0,
+                H.data_ptr() + 4 * 128 * d, 256, 128, 1 if d == 0 else -1, rows, t_stride, T,
+                _p(dW), 256, 1, _p(db0), _p(db1), 0, _p(ws))
+        torch.cuda.synchronize()
+        g_ih = getattr(lstm, "weight_ih_l0" + suf).grad.numpy()
+        g_hh = getattr(lstm, "weight_hh_l0" + suf).grad.numpy()
+        g_b = getattr(lstm, "bias_ih_l0" + suf).grad.numpy()
+        dWn = dW.cpu().numpy()
+        e1, e2 = rel_l2(dWn[:, :128], g_ih), rel_l2(dWn[:, 128:], g_hh)
+        e3, e4 = rel_l2(db0.cpu().numpy(), g_b), rel_l2(db1.cpu().numpy(), g_b)
+        print(f"  dir {d}: dW_ih {e1:.2e} dW_hh {e2:.2e} db {e3:.2e}")
+        assert max(e1, e2, e3, e4) < 1e-5
+
+
+@pytest.mark.parametrize("kd,nd", [(128, 256), (128, 128), (64, 128), (256, 128), (128, 64)])
+def test_dgrad_matches_matmul(kd, nd):
+    rng = np.random.default_rng(kd + nd)
+    rows = 1000 + kd
+    dOut = rng.standard_normal((rows, kd)).astype(np.float32)
+    k0 = kd if kd != 256 else 128
+    W0 = rng.standard_normal((k0, nd)).astype(np.float32)
+    W1 = rng.standard_normal((kd - k0, nd)).astype(np.float32) if k0 < kd else None
+    W = W0 if W1 is None else np.concatenate([W0, W1], 0)
+    want = dOut.astype(np.float64) @ W.astype(np.float64)
+    st = _st()
+    dA = torch.full((rows, nd), float("nan"), device=DEV)
+    st.call("dprnn_dgrad", _p(_t(dOut)), kd, _p(_t(W0)), nd, k0, _p(_t(W1)) if W1 is not None else 0, nd, _p(dA), nd, rows)
+    torch.cuda.synchronize()
+    assert rel_l2(dA.cpu().numpy(), want) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,rows,acc", [(512, 256, 5000, 0), (256, 128, 777, 1), (64, 128, 4099, 0), (128, 64, 130, 1), (128, 256, 3000, 0)])
+def test_wgrad_matches_matmul(M, N, rows, acc):
+    """dW (+)= P^T Q with column sums of P, ragged row counts, 64-wide operands, transposed destination."""
+    rng = np.random.default_rng(M + N + rows)
+    ldp, ldq = M + 8, 128
+    P = rng.standard_normal((rows, ldp)).astype(np.float32)
+    Q0 = rng.standard_normal((rows, ldq)).astype(np.float32)
+    Q1 = rng.standard_normal((rows, ldq)).astype(np.float32) if N > 128 else None
+    n0 = min(N, 128)
+    Qf = Q0[:, :n0] if Q1 is None else np.concatenate([Q0, Q1[:, :N - 128]], 1)
+    want = P[:, :M].astype(np.float64).T @ Qf.astype(np.float64)
+    wb = P[:, :M].astype(np.float64).sum(0)
+    st = _st()
+    init = rng.standard_normal((N, M)).astype(np.float32)          # destination stored transposed: dW[m][n] at n*M + m
+    dW = _t(init.copy())
+    db = _t(np.ones(M, np.float32))
+    ws = torch.empty(st.lib.dprnn_wgrad_workspace_floats(M, N, rows), device=DEV)
+    st.call("dprnn_wgrad", _p(_t(P)), ldp, M, _p(_t(Q0)), ldq, n0, 0, _p(_t(Q1)) if Q1 is not None else 0, ldq, N - 128 if Q1 is not None else 0, 0,
+            rows, 1, 1, _p(dW), 1, M, _p(db), 0, acc, _p(ws))
+    torch.cuda.synchronize()
+    got = dW.cpu().numpy().T.astype(np.float64) - (init.T if acc else 0)
+    gb = db.cpu().numpy().astype(np.float64) - (1 if acc else 0)
+    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(gb, wb) < 2e-6

@@ -52,6 +52,14 @@ SIGNATURES = {
     "dprnn_time_mean_fwd": [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_linear_small_fwd": [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_rows_stats": [c_fp, c_fp, c_i, c_i64, c_i, c_fp],
+    # ---- training path (include/dprnn_mi355x_train.h)
+    "dprnn_lstm_fwd_train": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
+                             c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_lstm_pack_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
+                    c_fp, c_fp, c_i, c_fp, c_fp],
+    "dprnn_dgrad": [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i64, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],
@@ -64,6 +72,8 @@ _SPECIAL = {
     "dprnn_abi_version": ([], c_i),
     "dprnn_num_cus": ([], c_i),
     "dprnn_get_gemm_mode": ([], c_i),
+    "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
+    "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
 

@@ -29,6 +29,7 @@ struct RecurArgs {
     int seqs_per_utt;
     long long rows_per_utt;
     int cell;                                         // 0 LSTM, 1 GRU, 2 Elman RNN (tanh)
+    float* tape;                                      // training forward only: activated gates + cell state per step
 };
 
 // software-pipelined 64-sequence variant (recur64.hip)

@@ -77,9 +77,14 @@ __global__ void rnn_pack_kernel(const float* __restrict__ w_ih, const float* __r
 // DIAG (diagnostic builds only, wrong results on purpose): 1 = every k-group re-reads weight group 0 (L1-resident:
 // no L2 weight stream), 2 = A fragments read once per step instead of per k-group (no LDS operand traffic),
 // 3 = cell update skipped (h = gate pre-activation), 4 = no HBM store of h.
-template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0>
+// SAVE (training forward, LSTM only): every step also writes the activated gates and the new cell state to a.tape in
+// this kernel's own fragment order -- [dir][workgroup][step][wave][nt][u][i,f,g,o,c][lane] float4 over the lane's four
+// sequences -- which lstm_bwd_kernel (train_recur.hip) reads back with the same thread mapping: 16-byte coalesced
+// stores and loads, no transposition.
+template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0, bool SAVE = false>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
+    static_assert(!SAVE || CELL == 0, "the gate tape is defined for the LSTM cell");
     constexpr int NS = 16 * NT;
     constexpr int NGA = CELL == 2 ? 1 : 4;            // accumulator slots in use (see rnn_pack_kernel)
     constexpr int NXV = NS / 8;                       // float4 x loads per thread per step
@@ -320,10 +325,15 @@ void bilstm_kernel(RecurArgs a) {
         // ---- LSTM cell (gate order i,f,g,o), lane-local
         float* const Hn = XH + nxt * NS * XS + HD;
         char* const hs = reinterpret_cast<char*>(a.H + tbase(t) * hpitch);
+        f32x4* tp = nullptr;
+        if constexpr (SAVE)
+            tp = reinterpret_cast<f32x4*>(a.tape) +
+                 ((((size_t)dir * gridDim.x + blockIdx.x) * T + step) * 4 + wave) * (NT * 2 * 5 * 64) + lane;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                f32x4 sv[5];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float h;
@@ -337,6 +347,7 @@ void bilstm_kernel(RecurArgs a) {
                         const float cn = fg * c[nt][u][e] + ig * gg;
                         c[nt][u][e] = cn;
                         h = og * tanh_f<FAST>(cn);
+                        if constexpr (SAVE) { sv[0][e] = ig; sv[1][e] = fg; sv[2][e] = gg; sv[3][e] = og; sv[4][e] = cn; }
                     } else if constexpr (CELL == 1) {     // GRU: n = tanh(n_x + r*n_h), h' = (1-z)*n + z*h (c holds h)
                         const float rg = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
                         const float zg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
@@ -349,6 +360,11 @@ void bilstm_kernel(RecurArgs a) {
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
                     if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
                 }
+                if constexpr (SAVE) {
+#pragma unroll
+                    for (int x = 0; x < 5; ++x) tp[((nt * 2 + u) * 5 + x) * 64] = sv[x];
+                }
+            }
         if (more) {
             float* const Xn = XH + nxt * NS * XS;
             char* os = reinterpret_cast<char*>(a.Xout + tbase(tn) * F);
@@ -382,7 +398,7 @@ void bilstm_kernel(RecurArgs a) {
     }
 }
 
-template <int NT, bool FAST, int CELL = 0>
+template <int NT, bool FAST, int CELL = 0, bool SAVE = false>
 int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     constexpr int NS = 16 * NT;
     // one workgroup per CU (NT >= 3): prefetch A fragments a k-group ahead and spread the memory instructions
@@ -391,13 +407,13 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NS * XS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
-    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE>), grid, dim3(256), lds, st, a);
     return dprnn_check_launch("bilstm_kernel");
 }
 
@@ -510,6 +526,36 @@ extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const doubl
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
     a.rows_per_utt = rows_per_utt; a.Xout = Xout;
     return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+}
+
+// ---- training forward: dprnn_rnn_fwd for the LSTM cell on 32-sequence tiles, plus the gate tape for dprnn_lstm_bwd
+extern "C" int64_t dprnn_lstm_tape_floats(int nseq, int T, int ndir) {
+    return (int64_t)ndir * ((nseq + 31) / 32) * T * (32 * HD * 5);
+}
+
+extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double* stats, const float* gamma,
+                                    const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                    const float* packed, const float* bsum, float* H, float* tape,
+                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                    int64_t t_stride, int ndir, void* stream) {
+    if (!tape) { dprnn_set_error("dprnn_lstm_fwd_train: tape is null"); return -1; }
+    if (g_gemm_mode != 0) { dprnn_set_error("dprnn_lstm_fwd_train: the training path uses the exact fp32 gate GEMM (gemm mode 0)"); return -1; }
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = 0;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
+    a.rows_per_utt = rows_per_utt; a.Xout = Xout; a.tape = tape;
+    if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_lstm_fwd_train: null pointer"); return -1; }
+    if (a.nseq <= 0 || a.T <= 0 || a.inner_n <= 0 || (a.ndir != 1 && a.ndir != 2)) {
+        dprnn_set_error("dprnn_lstm_fwd_train: bad sizes nseq=%d T=%d inner_n=%d ndir=%d", a.nseq, a.T, a.inner_n, a.ndir);
+        return -1;
+    }
+    if (a.Z && (!a.stats || !a.gamma || !a.beta || !a.Xout || a.Xout == a.X || a.seqs_per_utt <= 0 || a.rows_per_utt <= 0)) {
+        dprnn_set_error("dprnn_lstm_fwd_train: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
+        return -1;
+    }
+    return g_fast_act ? launch_bilstm<2, true, 0, true>(a, (hipStream_t)stream)
+                      : launch_bilstm<2, false, 0, true>(a, (hipStream_t)stream);
 }
 
 // Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][8] u64

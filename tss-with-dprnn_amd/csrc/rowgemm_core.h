@@ -330,7 +330,10 @@ struct EpMaskDecode {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel
-template <int KD, int ND, int RT, class AL, class EP>
+// WT = false: out = A @ W^T with W [ND][ldw] row-major (W0: columns < nd0, W1: the rest) -- the forward products.
+// WT = true (backward, data gradients): out = A @ W with W [KD][ldw] row-major (W0: k < nd0, W1: the rest), i.e. the
+// same torch parameter read transposed while it is staged.
+template <int KD, int ND, int RT, class AL, class EP, bool WT = false>
 __global__ __launch_bounds__(256, 1)
 void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
                     long long M, AL al, EP ep) {
@@ -339,11 +342,24 @@ void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
 
-    for (int idx = tid; idx < ND * K4; idx += 256) {
-        const int col = idx / K4, k4 = idx % K4;
-        const float* src = col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * k4);
-        wl[((k4 >> 2) * NCT + (col >> 4)) * 64 + (k4 & 3) * 16 + (col & 15)] = v;
+    if constexpr (!WT) {
+        for (int idx = tid; idx < ND * K4; idx += 256) {
+            const int col = idx / K4, k4 = idx % K4;
+            const float* src = col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * k4);
+            wl[((k4 >> 2) * NCT + (col >> 4)) * 64 + (k4 & 3) * 16 + (col & 15)] = v;
+        }
+    } else {
+        for (int idx = tid; idx < ND * K4; idx += 256) {
+            const int col = idx % ND, k4 = idx / ND;            // consecutive threads read consecutive columns
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * k4 + e;
+                v[e] = k < nd0 ? W0[(long long)k * ldw0 + col] : W1[(long long)(k - nd0) * ldw1 + col];
+            }
+            wl[((k4 >> 2) * NCT + (col >> 4)) * 64 + (k4 & 3) * 16 + (col & 15)] = v;
+        }
     }
     __syncthreads();
 
@@ -401,11 +417,11 @@ inline int num_cus() {
     return g_num_cus;
 }
 
-template <int KD, int ND, int RT, class AL, class EP>
+template <int KD, int ND, int RT, bool WT = false, class AL, class EP>
 int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
                    const AL& al, const EP& ep, hipStream_t st) {
     const size_t lds = (size_t)KD * ND * sizeof(float);
-    auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP>;
+    auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP, WT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,236 @@
+// Generic GEMMs of the training backward pass: the gradients autograd forms for the
+// Linear / 1x1-conv / LSTM weights of the reference model when src/trainers/trainer.py:106 calls backward().
+//
+// dprnn_wgrad    dW[m][n] (+)= sum_rows P[row][m] * Q[row][n]      weight gradients: a reduction over ALL rows of the slab
+// dprnn_dgrad_*  dA[row][:] = dOut[row][:] @ W                     data gradients: the forward row GEMM with W read transposed
+//
+// wgrad structure (gfx950): the row index is the MFMA k dimension.  A workgroup of 8 waves owns a 256 x 128 block of
+// dW and a contiguous range of rows; chunks of 16 rows of P (256 columns) and Q (128 columns) go HBM -> registers ->
+// LDS (double-buffered, one barrier per chunk) and every wave multiplies its 64 x 64 sub-block out of LDS with
+// v_mfma_f32_16x16x4_f32: a lane's 16-byte LDS read of four consecutive columns feeds four different 16x16 tiles (tile j
+// owns columns 4c + j), so one ds_read_b128 of P and one of Q feed 16 MFMAs.  Row ranges are split over blockIdx.z;
+// the partial blocks are written to a workspace and summed by wgrad_reduce_kernel in a fixed order, so the result
+// does not depend on scheduling (no floating-point atomics).  The column sums of P (bias gradients) ride along in the
+// staging registers of the workgroups with blockIdx.y == 0.
+#include "rowgemm_core.h"
+using namespace rg;
+
+namespace {
+
+constexpr int WG_MB = 256, WG_NB = 128, WG_R = 16, WG_THREADS = 512;
+
+struct QDesc {                 // one 128-column block of Q
+    const float* p; int ld; int cols;      // cols valid in this block (<= 128), the rest reads as zero
+    int dt;                                // row shift in time steps: Q row = row - dt*t_stride, zero where t - dt is outside [0, T)
+};
+struct WgradArgs {
+    const float* P; int ldp; int M;        // P [rows][ldp], M valid columns
+    QDesc q[2];
+    long long rows;
+    long long t_stride; int T;             // time structure of the rows for shifted Q blocks: t = (row / t_stride) % T
+    long long rows_per_split;              // multiple of WG_R
+    float* part;                           // [splits][Mpad][Npad]
+    float* part_b;                         // [splits][Mpad] or null
+    int Mpad, Npad;
+};
+
+__global__ __launch_bounds__(WG_THREADS)
+void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ps[2][WG_R][WG_MB];
+    __shared__ __attribute__((aligned(16))) float Qs[2][WG_R][WG_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mb = blockIdx.x, nb = blockIdx.y, ks = blockIdx.z;
+    const QDesc qd = a.q[nb];
+    const long long r0 = (long long)ks * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > a.rows) r1 = a.rows;
+
+    // staging assignment: P chunk = 16 rows x 64 float4 -> 2 per thread (fixed column chunk), Q chunk = 16 x 32 -> 1
+    const int pc4 = tid & 63, prow = tid >> 6;          // rows prow, prow + 8
+    const int qc4 = tid & 31, qrow = tid >> 5;
+    const int pcol = mb * WG_MB + 4 * pc4;
+    const bool pok = pcol < a.M;                         // M is a multiple of 4
+    const bool qok = 4 * qc4 < qd.cols;
+    f32x4 pv[2], qv, psum = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](long long row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long row = row0 + prow + 8 * j;
+            pv[j] = (pok && row < r1) ? *reinterpret_cast<const f32x4*>(a.P + row * a.ldp + pcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const long long row = row0 + qrow;
+        bool ok = qok && row < r1;
+        long long src = row;
+        if (qd.dt != 0) {
+            const long long t = (row / a.t_stride) % a.T - qd.dt;
+            ok = ok && t >= 0 && t < a.T;
+            src = row - (long long)qd.dt * a.t_stride;
+        }
+        qv = ok ? *reinterpret_cast<const f32x4*>(qd.p + src * qd.ld + 4 * qc4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<f32x4*>(&Ps[buf][prow + 8 * j][4 * pc4]) = pv[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) psum[e] += pv[j][e];
+        }
+        *reinterpret_cast<f32x4*>(&Qs[buf][qrow][4 * qc4]) = qv;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (r0 < r1) {
+        load(r0);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long row0 = r0; row0 < r1; row0 += WG_R, buf ^= 1) {
+            const bool more = row0 + WG_R < r1;
+            if (more) load(row0 + WG_R);
+#pragma unroll
+            for (int kk = 0; kk < WG_R / 4; ++kk) {
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(&Ps[buf][4 * kk + q][64 * wm + 4 * r]);
+                const f32x4 qb = *reinterpret_cast<const f32x4*>(&Qs[buf][4 * kk + q][64 * wn + 4 * r]);
+#pragma unroll
+                for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) acc[jm][jn] = mfma16(pa[jm], qb[jn], acc[jm][jn]);
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // acc[jm][jn][e] = dW[m][n], m = 256*mb + 64*wm + 4*(4q+e) + jm, n = 128*nb + 64*wn + 4*r + jn
+    float* const out = a.part + (long long)ks * a.Mpad * a.Npad;
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = WG_MB * mb + 64 * wm + 4 * (4 * q + e) + jm;
+            const int n = WG_NB * nb + 64 * wn + 4 * r;
+            *reinterpret_cast<f32x4*>(out + (long long)m * a.Npad + n) =
+                f32x4{acc[jm][0][e], acc[jm][1][e], acc[jm][2][e], acc[jm][3][e]};
+        }
+    if (a.part_b && nb == 0) {
+        // column sums of P: threads tid and tid + 64*j hold the same column chunk
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(&Ps[0][0][0]);          // 512 float4 <= 2*16*256/4
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 64) {
+            f32x4 s = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const f32x4 v = red[tid + 64 * j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += v[e];
+            }
+            *reinterpret_cast<f32x4*>(a.part_b + (long long)ks * a.Mpad + WG_MB * mb + 4 * tid) = s;
+        }
+    }
+}
+
+// dW[m*ldm + n*ldn] = (accumulate ? dW : 0) + sum_s part[s][m][n];  db likewise (two optional destinations: the
+// LSTM's b_ih and b_hh receive the same gradient)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int splits,
+                                    int Mpad, int Npad, int M, int N, float* __restrict__ dW, long long ldm,
+                                    long long ldn, float* __restrict__ db0, float* __restrict__ db1, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < M * N) {
+        const int m = idx / N, n = idx % N;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[((long long)k * Mpad + m) * Npad + n];
+        float* d = dW + m * ldm + n * ldn;
+        *d = accumulate ? *d + s : s;
+    }
+    if (part_b && idx < M) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part_b[(long long)k * Mpad + idx];
+        if (db0) db0[idx] = accumulate ? db0[idx] + s : s;
+        if (db1) db1[idx] = accumulate ? db1[idx] + s : s;
+    }
+}
+
+}  // namespace
+
+// row ranges: about two workgroups per CU, at least 64 rows each
+static void wgrad_plan(int M, int N, long long rows, int& mblocks, int& nblocks, long long& splits, long long& per) {
+    mblocks = (M + WG_MB - 1) / WG_MB;
+    nblocks = (N + WG_NB - 1) / WG_NB;
+    splits = (2LL * num_cus() + mblocks * nblocks - 1) / (mblocks * nblocks);
+    const long long max_splits = (rows + 63) / 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    per = (rows + splits - 1) / splits;
+    per = (per + WG_R - 1) / WG_R * WG_R;
+    splits = (rows + per - 1) / per;
+}
+
+extern "C" int64_t dprnn_wgrad_workspace_floats(int M, int N, int64_t rows) {
+    int mblocks, nblocks; long long splits, per;
+    wgrad_plan(M, N, rows > 0 ? rows : 1, mblocks, nblocks, splits, per);
+    return splits * ((int64_t)mblocks * WG_MB * nblocks * WG_NB + mblocks * WG_MB);
+}
+
+extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
+                           const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
+                           float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
+                           float* workspace, void* stream) {
+    if (!P || !Q0 || !dW || !workspace) { dprnn_set_error("dprnn_wgrad: null pointer"); return -1; }
+    const int N = n0 + (Q1 ? n1 : 0);
+    if (rows <= 0 || M <= 0 || (M % 4) || n0 <= 0 || n0 > WG_NB || (n0 % 4) || (Q1 && (n1 <= 0 || n1 > WG_NB || (n1 % 4) || n0 != WG_NB)) ||
+        (ldp % 4) || (ldq0 % 4) || (Q1 && (ldq1 % 4)) || ((dt0 || dt1) && (t_stride <= 0 || T <= 0))) {
+        dprnn_set_error("dprnn_wgrad: unsupported shapes M=%d n0=%d n1=%d ldp=%d ldq0=%d rows=%lld", M, n0, n1, ldp, ldq0, (long long)rows);
+        return -1;
+    }
+    WgradArgs a{};
+    a.P = P; a.ldp = ldp; a.M = M;
+    a.q[0] = QDesc{Q0, ldq0, n0, dt0};
+    a.q[1] = QDesc{Q1, ldq1, Q1 ? n1 : 0, dt1};
+    a.rows = rows; a.t_stride = t_stride > 0 ? t_stride : 1; a.T = T > 0 ? T : 1;
+    int mblocks, nblocks; long long splits, per;
+    wgrad_plan(M, N, rows, mblocks, nblocks, splits, per);
+    a.Mpad = mblocks * WG_MB; a.Npad = nblocks * WG_NB;
+    a.rows_per_split = per;
+    a.part = workspace;
+    a.part_b = (db0 || db1) ? workspace + splits * (long long)a.Mpad * a.Npad : nullptr;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    int rc = dprnn_check_launch("wgrad_kernel");
+    if (rc) return rc;
+    const int n = M * N > M ? M * N : M;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       a.part, a.part_b, (int)splits, a.Mpad, a.Npad, M, N, dW, (long long)ldm, (long long)ldn, db0, db1, accumulate);
+    return dprnn_check_launch("wgrad_reduce_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ data gradients
+// dA[row][0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1] row-major [kd][ldw]: (kd, nd) in {(128,256), (128,128),
+// (64,128), (256,128), (128,64)} -- intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out+gate convs (:157-158),
+// bottleneck conv (:135).
+extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
+                           float* dA, int nd, int64_t rows, void* stream) {
+    if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1)) { dprnn_set_error("dprnn_dgrad: null pointer / rows"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int RT = 4;
+    PlainRows<RT> al{dOut, kd};
+#define DG_CASE(KD, ND)                                                                                              \
+    if (kd == KD && nd == ND) {                                                                                      \
+        EpBiasStore<RT, ND / 16> ep{dA, nullptr, nullptr, 1, nullptr};                                               \
+        return launch_rowgemm<KD, ND, RT, true>("dgrad" #KD "x" #ND, W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st); \
+    }
+    DG_CASE(128, 256)
+    DG_CASE(128, 128)
+    DG_CASE(64, 128)
+    DG_CASE(256, 128)
+    DG_CASE(128, 64)
+#undef DG_CASE
+    dprnn_set_error("dprnn_dgrad: unsupported (kd, nd) = (%d, %d)", kd, nd);
+    return -1;
+}

@@ -1,0 +1,241 @@
+// Backward of the fused BiLSTM recurrence (training path).
+//
+// Gradient of SingleRNN.forward = nn.LSTM(128,128,bidirectional) (reference src/models/dprnn.py:23-37) as autograd
+// computes it for `epoch_loss.backward()` (src/trainers/trainer.py:106).  The forward (bilstm_kernel<.., SAVE>,
+// recur.hip) left a tape of the activated gates i,f,g,o and the cell state c of every step.  One workgroup (4 waves)
+// owns the same 32 sequences of one direction as in the forward and walks the steps in reverse order:
+//
+//   da_t = gate derivatives of (dH_t + dh_rec, dc_rec) from the tape                 lane-local, same lane mapping
+//   [dx_t | dh_rec] (32 x 256) = da_t (32 x 512) @ [W_ih | W_hh] (512 x 256)         v_mfma_f32_16x16x4_f32
+//
+// i.e. the same FLOPs and the same structure as the forward step with K and N exchanged: da_t goes through LDS as
+// the A operand ([seq][512 + 1 pad], conflict-free fragment reads with the forward's k-permutation), the transposed
+// weights are streamed from L2 as pre-packed B fragments (dprnn_lstm_pack_bwd), wave w owns input columns and hidden
+// units [32w, 32w+32) so dh_rec and dc_rec never leave registers.  da_t is also written to HBM ([row][dir][4*128]):
+// the weight gradients dW_ih = da^T x, dW_hh = da^T h_{t-1}, db = sum da are one large GEMM over all rows
+// (dprnn_wgrad, train_gemm.hip) outside the serial loop.  dx of the two directions goes to two slabs that the
+// consumer adds (no atomics: the result does not depend on scheduling).
+#include "recur.h"
+using namespace recur;
+
+namespace {
+
+typedef const f32x4 __attribute__((address_space(1)))* gw_ptr;
+
+constexpr int GS = 513;                    // LDS row stride of the da image (floats): 512 + 1 pad
+constexpr int NGB = 32;                    // k-groups of 16 over the 512 gate rows
+constexpr int PACKT_PER_DIR = 4 * NGB * 4 * 256;   // floats: [wave][grp][col tile 4][lane][4]
+
+// packedT[dir][wave][grp][j][lane][i] = Wcat[k][col],  k = 64*(grp>>2) + 16*q + 4*(grp&3) + i (gate row, 0..511),
+// col: j < 2 -> input column 32*wave + 16*j + r (W_ih), j >= 2 -> hidden column 32*wave + 16*(j-2) + r (W_hh)
+__global__ void lstm_pack_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                     const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
+                                     float* __restrict__ packedT, int ndir) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ndir * PACKT_PER_DIR) return;
+    const int i = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 3, grp = (idx >> 10) & 31;
+    const int wave = (idx >> 15) & 3, dir = idx >> 17;
+    const int r = lane & 15, q = lane >> 4;
+    const int k = 64 * (grp >> 2) + 16 * q + 4 * (grp & 3) + i;
+    const float* wi = dir ? w_ih_r : w_ih;
+    const float* wh = dir ? w_hh_r : w_hh;
+    packedT[idx] = j < 2 ? wi[k * F + 32 * wave + 16 * j + r] : wh[k * HD + 32 * wave + 16 * (j - 2) + r];
+}
+
+struct BwdArgs {
+    const float* dH;          // [rows][ndir*128] gradient of the recurrence output
+    const float* tape;        // forward tape
+    const float* WpT;         // dprnn_lstm_pack_bwd
+    float* dX;                // [ndir][rows_total][128]
+    float* dG;                // [rows][ndir*512] gate pre-activation gradients (i,f,g,o)
+    long long rows_total;
+    int nseq, T, inner_n, ndir;
+    long long outer_stride, inner_stride, t_stride;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2)
+void lstm_bwd_kernel(BwdArgs a) {
+    constexpr int NS = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float DA[];        // [NS][GS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * NS;
+    const int T = a.T;
+
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);
+    const int hpitch = a.ndir * HD, gpitch = a.ndir * 4 * HD;
+    // rows of the accumulator tile this lane owns: seq 16*nt + 4*q + e; rows past nseq alias the tile's first row for
+    // loads and are never stored
+    unsigned roff[NT][4];                  // row offset from row0 (rows)
+    bool val[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int seq = seq0 + 16 * nt + 4 * q + e;
+            val[nt][e] = seq < a.nseq;
+            roff[nt][e] = (unsigned)(rowbase(val[nt][e] ? seq : seq0) - row0);
+        }
+    const int ucol = 32 * wave + r;        // + 16*u
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const gw_ptr wbase = (gw_ptr)(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * NGB * 4 * 64) + lane;
+    const f32x4* const tape0 = reinterpret_cast<const f32x4*>(a.tape) +
+                               (((size_t)dir * gridDim.x + blockIdx.x) * T * 4 + wave) * (NT * 2 * 5 * 64) + lane;
+    auto tape_at = [&](int fs) { return tape0 + (size_t)fs * 4 * (NT * 2 * 5 * 64); };
+    auto t_of = [&](int fs) { return (long long)(dir ? (T - 1 - fs) : fs); };      // forward step -> time index
+
+    f32x4 gi[NT][2], gf[NT][2], gg[NT][2], go[NT][2], cc[NT][2], cp[NT][2], dho[NT][2];
+    f32x4 dh[NT][2], dc[NT][2];
+    auto load_step = [&](int fs) __attribute__((always_inline)) {     // gates of step fs, c of step fs-1, dH of step fs
+        const f32x4* tp = tape_at(fs);
+        const f32x4* tq = tape_at(fs > 0 ? fs - 1 : 0);
+        const float* dhs = a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch + dir * HD + ucol;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int b = (nt * 2 + u) * 5;
+                gi[nt][u] = tp[(b + 0) * 64]; gf[nt][u] = tp[(b + 1) * 64];
+                gg[nt][u] = tp[(b + 2) * 64]; go[nt][u] = tp[(b + 3) * 64];
+                const f32x4 c1 = tq[(b + 4) * 64];
+                cp[nt][u] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dho[nt][u][e] = dhs[(size_t)roff[nt][e] * hpitch + 16 * u];
+            }
+    };
+    {
+        const f32x4* tp = tape_at(T - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                cc[nt][u] = tp[((nt * 2 + u) * 5 + 4) * 64];
+                dh[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dc[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    load_step(T - 1);
+    f32x4 w[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[0][j] = wbase[j * 64];
+
+    for (int fs = T - 1; fs >= 0; --fs) {
+        const long long trow = row0 + t_of(fs) * a.t_stride;
+        // ---- gate derivatives (torch.nn.LSTM backward), lane-local; da -> LDS image and HBM
+        float* const dgs = a.dG + trow * gpitch + dir * 4 * HD + ucol;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float i_ = gi[nt][u][e], f_ = gf[nt][u][e], g_ = gg[nt][u][e], o_ = go[nt][u][e];
+                    const float tc = tanh_f<false>(cc[nt][u][e]);
+                    const float dht = dho[nt][u][e] + dh[nt][u][e];
+                    const float dct = dc[nt][u][e] + dht * o_ * (1.f - tc * tc);
+                    const float da_o = dht * tc * o_ * (1.f - o_);
+                    const float da_i = dct * g_ * i_ * (1.f - i_);
+                    const float da_f = dct * cp[nt][u][e] * f_ * (1.f - f_);
+                    const float da_g = dct * i_ * (1.f - g_ * g_);
+                    dc[nt][u][e] = dct * f_;
+                    float* d = DA + (16 * nt + 4 * q + e) * GS + ucol + 16 * u;
+                    d[0] = da_i; d[HD] = da_f; d[2 * HD] = da_g; d[3 * HD] = da_o;
+                    if (val[nt][e]) {
+                        float* g = dgs + (size_t)roff[nt][e] * gpitch + 16 * u;
+                        g[0] = da_i; g[HD] = da_f; g[2 * HD] = da_g; g[3 * HD] = da_o;
+                    }
+                }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) cc[nt][u] = cp[nt][u];
+        if (fs > 0) load_step(fs - 1);          // in flight during the GEMM below
+        __syncthreads();
+
+        // ---- [dx | dh] = da @ [W_ih | W_hh]: 32 k-groups, weights of group g+1 in flight while group g computes
+        f32x4 acc[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* const Ac = DA + r * GS + 16 * q;
+#pragma unroll 1
+        for (int gp = 0; gp < NGB / 2; ++gp) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int grp = 2 * gp + half;
+                const gw_ptr wn = wbase + (((grp + 1) & (NGB - 1)) * 4) * 64;     // wraps to group 0 of the next step
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[half ^ 1][j] = wn[j * 64];
+                const float* src = Ac + 64 * (grp >> 2) + 4 * (grp & 3);
+                float av[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[nt][i] = src[nt * 16 * GS + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[nt][j] = mfma16(av[nt][i], w[half][j][i], acc[nt][j]);
+            }
+        }
+        __syncthreads();                        // every wave is done reading the image
+
+        float* const dxs = a.dX + ((long long)dir * a.rows_total + trow) * F + ucol;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dh[nt][u] = acc[nt][2 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (val[nt][e]) dxs[(size_t)roff[nt][e] * F + 16 * u] = acc[nt][u][e];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dprnn_lstm_pack_bwd(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                                   float* packedT, void* stream) {
+    if (!w_ih || !w_hh || !packedT) { dprnn_set_error("dprnn_lstm_pack_bwd: null pointer"); return -1; }
+    const int ndir = w_ih_r ? 2 : 1;
+    if (ndir == 2 && !w_hh_r) { dprnn_set_error("dprnn_lstm_pack_bwd: incomplete reverse direction"); return -1; }
+    const int n = ndir * PACKT_PER_DIR;
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w_ih, w_hh, w_ih_r, w_hh_r, packedT, ndir);
+    return dprnn_check_launch("lstm_pack_bwd_kernel");
+}
+
+extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                              int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                              int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_lstm_bwd: null pointer"); return -1; }
+    if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2) || rows_total < (int64_t)nseq * T) {
+        dprnn_set_error("dprnn_lstm_bwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d rows_total=%lld", nseq, T, inner_n, ndir,
+                        (long long)rows_total);
+        return -1;
+    }
+    BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
+              (long long)outer_stride, (long long)inner_stride, (long long)t_stride};
+    constexpr int NT = 2;
+    const size_t lds = (size_t)16 * NT * GS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lstm_bwd): %s", hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_kernel<NT>), dim3((nseq + 16 * NT - 1) / (16 * NT), ndir), dim3(256), lds,
+                       (hipStream_t)stream, a);
+    return dprnn_check_launch("lstm_bwd_kernel");
+}
