@@ -57,6 +57,75 @@ int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n
 int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
                 float* dA, int nd, int64_t rows, void* stream);
 
+/* ---- training variants of the mask-head forward (dprnn_mi355x.h) that keep what the backward needs:
+ * TG [rows][256] = [tanh(out conv) | sigmoid(gate conv)] (dprnn.py:157-158), mask [B*L*2][N] rows (b,l,spk) (:161-164) */
+int dprnn_head_gate_fwd_train(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
+                              float* V, float* TG, int64_t rows, void* stream);
+int dprnn_head_mask_decode_fwd_train(const float* V, const float* Wend, const float* wav, const float* enc_w,
+                                     const float* dec_w, float* taps, float* mask, int relu_act,
+                                     int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* Small reductions (per-utterance sums, per-channel parameter gradients, scalar PReLU slope) are accumulated with fp64
+ * atomics into caller-zeroed fp64 scratch; dprnn_scratch_to_grad converts n of them to the fp32 gradient
+ * (accumulate: 0 overwrite, 1 add). */
+int dprnn_scratch_to_grad(const double* scratch, float* grad, int n, int accumulate, void* stream);
+
+/* ---- decoder + masking + mask activation backward (encoder_decoder.py:40-42, dprnn.py:277, :161-164):
+ * dOut [B][2][T_out] -> dE [B*L*2][N] (gradient of the end_conv1x1 output, rows (b,l,spk)),
+ * dEnc [B*L][N] (gradient reaching the encoder output through the masking), dWd[N*ks] fp64 scratch (decoder.weight). */
+int dprnn_mask_decode_bwd(const float* dOut, const float* wav, const float* enc_w, const float* dec_w,
+                          const float* mask, int relu_act, float* dE, float* dEnc, double* dWd,
+                          int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- tanh * sigmoid gate backward (dprnn.py:180): dAG [rows][256] = [d out-conv pre-activation | d gate-conv ...] */
+int dprnn_gate_bwd(const float* dV, const float* TG, float* dAG, int64_t rows, void* stream);
+
+/* ---- Q operand of the conv2d weight gradient: out[(b,l)] = sum over chunks covering l of prelu(X[b][s][k])
+ * (dprnn.py:173,203-217), and the conv2d bias gradient dbias[256] += cnt(l) * dU[(b,l)] (fp64 scratch) */
+int dprnn_ola_prelu_sum(const float* X, const float* prelu_w, float* out, const float* dU, double* dbias,
+                        int B, int L, int K, int P, int S, void* stream);
+
+/* ---- conv2d + PReLU backward w.r.t. the slab (dprnn.py:173-178):
+ * dX[(b,s,k)] = (dU[(b, s*P+k-K)] @ W2d) * (x > 0 ? 1 : alpha) (zero outside [0,L)); dalpha (fp64 scratch scalar) */
+int dprnn_head_conv_bwd(const float* dU, const float* W2d, const float* X, const float* prelu_w, float* dX,
+                        double* dalpha, int B, int L, int K, int P, int S, void* stream);
+
+/* ---- GroupNorm(1,128)/GlobLN + residual backward on the slab (dprnn.py:90-92,98-99), two passes.
+ * Pass 1: dy = dXn (+ dXa + dXb when given -- the two per-direction dX slabs of the later recurrence -- written to dXo,
+ * which may alias dXn); red[b] += (sum gamma*dy, sum gamma*dy*xh), dgb[0:128] += dgamma, dgb[128:256] += dbeta (fp64
+ * scratch).  Z == NULL: only the sum.  Pass 2: dZ = rstd_b*(gamma*dy - red0_b/n - xh*red1_b/n). */
+int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
+                       const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
+                       double* red, double* dgb, void* stream);
+int dprnn_gn_bwd_dz(const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
+                    float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
+
+/* ---- DPRNN._segmentation backward (dprnn.py:189-201): dY[(b,l)] = sum over chunks covering l of (dXn + dXa + dXb) */
+int dprnn_segment_bwd(const float* dXn, const float* dXa, const float* dXb, float* dY,
+                      int B, int L, int K, int P, int S, void* stream);
+
+/* ---- encoder + bottleneck norm (encoder_decoder.py:25-33, dprnn.py:131-134); the encoder output is recomputed from
+ * the waveform, never stored.  norm_rows: A[(b,l)][n] = enc*sc + sh (Q operand of the bottleneck conv weight gradient).
+ * norm_bwd_stats: red[b], dgb[0:64 | 64:128] of the bottleneck norm for dy = dA.  encoder_bwd: gradient of the
+ * encoder output (norm backward + dEnc from the masking), ReLU, and dWe[N*ks] += d_pre * wav (fp64 scratch). */
+int dprnn_encoder_norm_rows(const float* wav, const float* enc_w, const float* sc, const float* sh, float* A,
+                            int B, int T, int L, int N, int ks, int stride, void* stream);
+int dprnn_encoder_norm_bwd_stats(const float* wav, const float* enc_w, const float* dA, const double* stats,
+                                 const float* gamma, float eps, double* red, double* dgb,
+                                 int B, int T, int L, int N, int ks, int stride, void* stream);
+int dprnn_encoder_bwd(const float* wav, const float* enc_w, const float* dA, const double* stats,
+                      const float* gamma, float eps, const double* red, const float* dEnc, double* dWe,
+                      int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- PIT SI-SDR loss = PITLossWrapper(pairwise_neg_sisdr, pit_from='pw_mtx') of asteroid==0.7.0 as called at
+ * src/trainers/trainer.py:39,104.  fwd: moments [B][n][n][5], pw [B][n][n] (SI-SDR dB, estimate i vs target j),
+ * loss_b [B] = -max over permutations of mean_i pw[i][perm[i]], perm [B][n] int32, coef [B][n][4] (all fp64 but perm);
+ * n <= 3.  bwd: dEst = upstream * d(mean_b loss_b)/d est  (upstream: device float scalar or NULL = 1). */
+int dprnn_pit_sisdr_fwd(const float* est, const float* tgt, double* moments, double* pw, double* loss_b,
+                        int* perm, double* coef, int B, int n, int T, void* stream);
+int dprnn_pit_sisdr_bwd(const float* est, const float* tgt, const int* perm, const double* coef,
+                        const float* upstream, float* dEst, int B, int n, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,12 @@ def dprnn_process(sd, cfg, x, L, taps: Optional[dict] = None):    # dprnn.py:171
     return h.reshape(B, 2, N, L)
 
 
+def tasnet_forward_autograd(sd, cfg, wav: torch.Tensor) -> torch.Tensor:
+    """tasnet_forward with autograd enabled: sd values that require grad receive .grad from a backward() through the
+    stock ATen operators -- the CPU restatement of the reference's training step (trainer.py:102-106)."""
+    return tasnet_forward.__wrapped__(sd, cfg, wav)
+
+
 @torch.no_grad()
 def tasnet_forward(sd, cfg, wav: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
     """dprnn.py:271-283: [B,T] -> [B,2,T]."""

@@ -40,3 +40,25 @@ def pit_si_sdr(est: np.ndarray, tgt: np.ndarray):
     scores = np.stack([np.mean([pw[:, i, p[i]] for i in range(n)], axis=0) for p in perms], axis=1)
     best = scores.argmax(1)
     return scores[np.arange(B), best], np.array([perms[b] for b in best])
+
+
+def pit_neg_sisdr_torch(est, tgt):
+    """The training loss of the reference (trainer.py:39,104) as differentiable torch ops on CPU:
+    asteroid PairwiseNegSDR('sisdr') + PITLossWrapper(pit_from='pw_mtx'), published algorithm restated --
+    mean over the batch of min over permutations of mean_i -SI-SDR(est_i, tgt_perm(i)).  fp32 like the reference."""
+    import torch
+    e = est - est.mean(-1, keepdim=True)
+    t = tgt - tgt.mean(-1, keepdim=True)
+    s_t = t.unsqueeze(1)                     # [B, 1, n, T]
+    s_e = e.unsqueeze(2)                     # [B, n, 1, T]
+    dot = (s_e * s_t).sum(-1, keepdim=True)
+    energy = (s_t ** 2).sum(-1, keepdim=True) + EPS
+    proj = dot * s_t / energy
+    noise = s_e - proj
+    sdr = (proj ** 2).sum(-1) / ((noise ** 2).sum(-1) + EPS)
+    pw = -10 * torch.log10(sdr + EPS)        # [B, est, tgt]
+    n = est.shape[1]
+    perms = list(itertools.permutations(range(n)))
+    losses = torch.stack([torch.stack([pw[:, i, p[i]] for i in range(n)], 1).mean(1) for p in perms], 1)   # [B, n!]
+    best, idx = losses.min(1)
+    return best.mean(), idx

@@ -92,9 +92,65 @@ def load_recipe(model, kind, cfg, seed):
     return sd
 
 
+GRAD_CASES = [
+    # name, cfg overrides, batch, samples, seed
+    ("grad_bss_wide_small", dict(WIDE), 2, 300, 60),
+    ("grad_bss_wide_gln_relu_unidir", dict(WIDE, norm_type="gLN", activation_type="relu", bidirectional=False, hop_length=5,
+                                           n_repeats=1), 3, 211, 68),
+    ("grad_bss_wide_k4", dict(WIDE, kernel_size=4, n_repeats=1), 2, 302, 62),
+    ("grad_bss_full_b2", dict(), 2, 24000, 63),
+    ("grad_bss_wide_gln", dict(WIDE, norm_type="gLN", n_repeats=1), 2, 211, 64),
+    ("grad_bss_wide_relu", dict(WIDE, activation_type="relu", n_repeats=1), 2, 211, 65),
+    ("grad_bss_wide_unidir", dict(WIDE, bidirectional=False, n_repeats=1), 2, 211, 66),
+    ("grad_bss_wide_hop5", dict(WIDE, hop_length=5, n_repeats=1), 3, 211, 67),
+]
+N_PROJ = 8
+FULL_MAX = 40000          # gradients up to this many elements are stored whole, larger ones as projections
+
+
+def grad_projection(name, shape):
+    """Fixed random directions for a parameter (shared with tests/test_gpu_train.py)."""
+    import zlib
+    g = np.random.default_rng([zlib.crc32(name.encode()), int(np.prod(shape))])
+    return g.standard_normal((N_PROJ, int(np.prod(shape)))).astype(np.float32)
+
+
+def make_grad_cases(only):
+    """Training step of the reference (trainer.py:98-106): out = model(mix); loss = PIT(-SI-SDR)(out, target);
+    loss.backward().  asteroid is not installed: the loss is oracle.sisdr.pit_neg_sisdr_torch (published algorithm)."""
+    from oracle.sisdr import pit_neg_sisdr_torch
+    from oracle.weights import make_sources
+    for name, over, B, T, seed in GRAD_CASES:
+        if only and name not in only:
+            continue
+        cfg = full_cfg(**over)
+        model = build("bss", cfg)
+        load_recipe(model, "bss", cfg, seed)
+        model.train()
+        src, mix = make_sources(B, T, seed=3000 + seed)
+        out = model(torch.from_numpy(mix))
+        tgt = torch.from_numpy(src[:, :, :out.shape[-1]].copy())
+        loss, idx = pit_neg_sisdr_torch(out, tgt)
+        loss.backward()
+        save = dict(mix=mix, tgt=tgt.numpy(), out=out.detach().numpy(), loss=np.float64(loss.item()), perm_index=idx.numpy())
+        for k, prm in model.named_parameters():
+            g = prm.grad.numpy()
+            save["norm_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            if g.size <= FULL_MAX:
+                save["grad_" + k] = g
+            else:
+                save["proj_" + k] = (grad_projection(k, g.shape).astype(np.float64) @ g.reshape(-1).astype(np.float64))
+        meta = dict(name=name, kind="bss", cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
+                    torch=torch.__version__)
+        save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
+        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}")
+
+
 def main():
     contract = {}
-    only = set(sys.argv[1:])          # optional: regenerate just the named cases (keeps the other files byte-identical)
+    only = set(sys.argv[1:])
+    make_grad_cases(only)          # optional: regenerate just the named cases (keeps the other files byte-identical)
     for name, kind, over, B, T, seed, want_taps, bn_train in CASES:
         if only and name not in only:
             continue

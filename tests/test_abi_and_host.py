@@ -107,10 +107,21 @@ def test_unsupported_config_fails_loudly():
         pkg.DPRNNTasNet(64, rnn_type="QRNN")                                       # getattr(nn, rnn_type) in the reference
 
 
-def test_training_mode_is_refused_until_backward_exists():
+def test_training_path_has_no_cpu_fallback_and_refuses_other_cells():
     m = pkg.DPRNNTasNet(64, n_repeats=1).train()
-    with pytest.raises(NotImplementedError, match="backward"):
+    with pytest.raises(pkg._lib.DprnnError, match="no CPU fallback"):     # differentiable forward: HIP device only
         m(torch.zeros(1, 300))
+    g = pkg.DPRNNTasNet(64, n_repeats=1, rnn_type="GRU").train()
+    with pytest.raises(NotImplementedError, match="training path"):       # backward kernels exist for the LSTM only
+        g(torch.zeros(1, 300))
+
+
+def test_saved_activation_estimate():
+    from tss_with_dprnn_amd import training
+    geo = engine.make_geometry(1, 24000, 64, 250, 125, 2, 1)
+    per_utt = training.saved_bytes_per_utt(geo, 12, [2] * 12)
+    assert 3.5e9 < per_utt < 5e9                       # ~4.2 GB per 3 s utterance: 64 do not fit in 288 GB
+    assert training.SAVE_BUDGET_BYTES // per_utt >= 32
 
 
 def test_geometry_matches_reference_shapes():

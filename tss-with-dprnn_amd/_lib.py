@@ -60,6 +60,21 @@ SIGNATURES = {
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
                     c_fp, c_fp, c_i, c_fp, c_fp],
     "dprnn_dgrad": [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i64, c_fp],
+    "dprnn_head_gate_fwd_train": [c_fp] * 7 + [c_i64, c_fp],
+    "dprnn_head_mask_decode_fwd_train": [c_fp] * 7 + [c_i] * 7 + [c_fp],
+    "dprnn_head_conv_bwd": [c_fp] * 6 + [c_i] * 5 + [c_fp],
+    "dprnn_gn_bwd_stats": [c_fp] * 7 + [c_f, c_i, c_i64, c_fp, c_fp, c_fp],
+    "dprnn_gn_bwd_dz": [c_fp] * 5 + [c_f, c_i, c_i64, c_fp, c_fp],
+    "dprnn_gate_bwd": [c_fp, c_fp, c_fp, c_i64, c_fp],
+    "dprnn_mask_decode_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
+    "dprnn_ola_prelu_sum": [c_fp] * 5 + [c_i] * 5 + [c_fp],
+    "dprnn_segment_bwd": [c_fp] * 4 + [c_i] * 5 + [c_fp],
+    "dprnn_encoder_norm_rows": [c_fp] * 5 + [c_i] * 6 + [c_fp],
+    "dprnn_encoder_norm_bwd_stats": [c_fp] * 5 + [c_f, c_fp, c_fp] + [c_i] * 6 + [c_fp],
+    "dprnn_encoder_bwd": [c_fp] * 5 + [c_f, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
+    "dprnn_scratch_to_grad": [c_fp, c_fp, c_i, c_i, c_fp],
+    "dprnn_pit_sisdr_fwd": [c_fp] * 7 + [c_i, c_i, c_i, c_fp],
+    "dprnn_pit_sisdr_bwd": [c_fp] * 6 + [c_i, c_i, c_i, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],

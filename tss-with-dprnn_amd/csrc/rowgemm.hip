@@ -85,22 +85,50 @@ extern "C" int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, cons
     return head_conv_ola(X, Z, stats, gamma, beta, eps, prelu_w, W2d, b2d, U, B, L, K, P, S, stream);
 }
 
-extern "C" int dprnn_head_gate_fwd(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
-                                   float* V, int64_t rows, void* stream) {
+static int head_gate(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
+                     float* V, float* TG, int64_t rows, void* stream) {
     if (!U || !Wo || !bo || !Wg || !bg || !V || rows <= 0) { dprnn_set_error("dprnn_head_gate_fwd: null pointer / rows"); return -1; }
     constexpr int RT = 2;
     PlainRows<RT> al{U, 128};
     if (g_fast_head) {
-        EpGate<RT, true> ep{V, bo, bg};
+        EpGate<RT, true> ep{V, bo, bg, TG};
         return launch_rowgemm<128, 256, RT>("head_gate", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
     }
-    EpGate<RT, false> ep{V, bo, bg};
+    EpGate<RT, false> ep{V, bo, bg, TG};
     return launch_rowgemm<128, 256, RT>("head_gate", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
 }
+
+extern "C" int dprnn_head_gate_fwd(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
+                                   float* V, int64_t rows, void* stream) {
+    return head_gate(U, Wo, bo, Wg, bg, V, nullptr, rows, stream);
+}
+
+extern "C" int dprnn_head_gate_fwd_train(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
+                                         float* V, float* TG, int64_t rows, void* stream) {
+    if (!TG) { dprnn_set_error("dprnn_head_gate_fwd_train: TG is null"); return -1; }
+    return head_gate(U, Wo, bo, Wg, bg, V, TG, rows, stream);
+}
+
+static int head_mask_decode(const float* V, const float* Wend, const float* wav, const float* enc_w,
+                            const float* dec_w, float* taps, float* masked_out, float* mask_all, int relu_act,
+                            int B, int T, int L, int N, int ks, int stride, void* stream);
 
 extern "C" int dprnn_head_mask_decode_fwd(const float* V, const float* Wend, const float* wav, const float* enc_w,
                                           const float* dec_w, float* taps, float* masked_out, int relu_act,
                                           int B, int T, int L, int N, int ks, int stride, void* stream) {
+    return head_mask_decode(V, Wend, wav, enc_w, dec_w, taps, masked_out, nullptr, relu_act, B, T, L, N, ks, stride, stream);
+}
+
+extern "C" int dprnn_head_mask_decode_fwd_train(const float* V, const float* Wend, const float* wav, const float* enc_w,
+                                                const float* dec_w, float* taps, float* mask, int relu_act,
+                                                int B, int T, int L, int N, int ks, int stride, void* stream) {
+    if (!mask) { dprnn_set_error("dprnn_head_mask_decode_fwd_train: mask is null"); return -1; }
+    return head_mask_decode(V, Wend, wav, enc_w, dec_w, taps, nullptr, mask, relu_act, B, T, L, N, ks, stride, stream);
+}
+
+static int head_mask_decode(const float* V, const float* Wend, const float* wav, const float* enc_w,
+                            const float* dec_w, float* taps, float* masked_out, float* mask_all, int relu_act,
+                            int B, int T, int L, int N, int ks, int stride, void* stream) {
     if (!V || !Wend || !wav || !enc_w || !dec_w || !taps) { dprnn_set_error("dprnn_head_mask_decode_fwd: null pointer"); return -1; }
     if (N != 64 || ks < 1 || ks > KSMAX || L != (T - ks) / stride + 1) {
         dprnn_set_error("dprnn_head_mask_decode_fwd: unsupported N=%d ks=%d (built for input_size 64, ks<=8)", N, ks);
@@ -110,9 +138,9 @@ extern "C" int dprnn_head_mask_decode_fwd(const float* V, const float* Wend, con
     PlainRows<RT> al{V, 128};
     const Geo geo{B, T, L, N, ks, stride};
     if (g_fast_head) {
-        EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+        EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
         return launch_rowgemm<128, 64, RT>("head_mask_decode", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
     }
-    EpMaskDecode<RT, 4, false> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+    EpMaskDecode<RT, 4, false> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
     return launch_rowgemm<128, 64, RT>("head_mask_decode", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
 }

@@ -258,6 +258,7 @@ struct EpHeadConv {             // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 c
 template <int RT, bool FAST>
 struct EpGate {                 // V[row][col] = tanh(acc[col]+bo[col]) * sigmoid(acc[128+col]+bg[col])
     float* V; const float* bo; const float* bg;
+    float* TG = nullptr;        // training forward: also keeps [tanh | sigmoid] as [row][256]
     __device__ void begin() {}
     __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int r, int q, int lane, long long M) {
@@ -269,8 +270,11 @@ struct EpGate {                 // V[row][col] = tanh(acc[col]+bo[col]) * sigmoi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long row = row0 + 16 * rt + 4 * q + e;
-                    if (row < M)
-                        V[row * F + 16 * ct + r] = tanh_f<FAST>(acc[rt][ct][e] + b1) * sigmoid_f<FAST>(acc[rt][ct + 8][e] + b2);
+                    if (row < M) {
+                        const float ta = tanh_f<FAST>(acc[rt][ct][e] + b1), sg = sigmoid_f<FAST>(acc[rt][ct + 8][e] + b2);
+                        V[row * F + 16 * ct + r] = ta * sg;
+                        if (TG) { TG[row * 256 + 16 * ct + r] = ta; TG[row * 256 + 128 + 16 * ct + r] = sg; }
+                    }
                 }
         }
     }
@@ -280,6 +284,7 @@ struct EpGate {                 // V[row][col] = tanh(acc[col]+bo[col]) * sigmoi
 template <int RT, int NCT, bool FAST>
 struct EpMaskDecode {
     const float* wav; const float* We; const float* Wd; float* taps; float* masked; int relu_act; Geo geo;
+    float* mask_all = nullptr;  // training forward: also keeps the mask as [row][N]
     __device__ void begin() {}
     __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
@@ -313,6 +318,7 @@ struct EpMaskDecode {
                     const float m = relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a);
                     const float me = m * en;
                     if (masked && ok && spk == 0) masked[bl * geo.N + n] = me;
+                    if (mask_all && ok) mask_all[row * geo.N + n] = m;
 #pragma unroll
                     for (int j = 0; j < KSMAX; ++j)
                         if (j < ks) tp[j] = fmaf(Wd[n * ks + j], me, tp[j]);

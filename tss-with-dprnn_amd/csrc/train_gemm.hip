@@ -234,3 +234,68 @@ extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0,
     dprnn_set_error("dprnn_dgrad: unsupported (kd, nd) = (%d, %d)", kd, nd);
     return -1;
 }
+
+// ------------------------------------------------------------------------------------------------ mask head: conv2d + PReLU backward
+// Gradient of  U[(b,l)] = sum_{(s,k) -> l} (W2d prelu(X[b][s][k]) + b2d)  (dprnn.py:173-178,203-217) wrt X:
+//   dX[(b,s,k)][c] = (dU[(b, l = s*P + k - K)][0:256] @ W2d)[c] * (x > 0 ? 1 : alpha),   zero where l is outside [0, L)
+// and dalpha += sum (dU @ W2d) * x * [x <= 0]  (fp64 atomics into a scratch scalar).
+namespace {
+template <int RT>
+struct SegGatherRows {         // A row (b,s,k) = dU row (b, s*P + k - K) or zeros
+    const float* dU; int L, K, P, S;
+    const float* p[RT];
+    __device__ void init(long long row0, int r, int q, long long M) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            long long row = row0 + 16 * rt + r;
+            if (row >= M) row = M - 1;
+            const int k = (int)(row % K);
+            const long long bs = row / K;
+            const int s = (int)(bs % S), b = (int)(bs / S);
+            const int l = s * P + k - K;
+            p[rt] = (l >= 0 && l < L) ? dU + ((long long)b * L + l) * 256 + 4 * q : nullptr;
+        }
+    }
+    __device__ f32x4 load(int rt, int g) const {
+        return p[rt] ? *reinterpret_cast<const f32x4*>(p[rt] + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+template <int RT>
+struct EpPreluBwd {
+    const float* X; const float* alpha_p; float* dX; double* dalpha;
+    float part;
+    __device__ void begin() { part = 0.f; }
+    __device__ void end(int lane) {
+        const double s = wave_sum((double)part);
+        if (lane == 0) atomicAdd(dalpha, s);
+    }
+    __device__ void operator()(f32x4 (&acc)[RT][8], long long row0, int r, int q, int lane, long long M) {
+        const float alpha = *alpha_p;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long row = row0 + 16 * rt + 4 * q + e;
+                if (row < M) {
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) {
+                        const float x = X[row * 128 + 16 * ct + r], g = acc[rt][ct][e];
+                        dX[row * 128 + 16 * ct + r] = x > 0.f ? g : alpha * g;
+                        if (!(x > 0.f)) part = fmaf(g, x, part);
+                    }
+                }
+            }
+    }
+};
+}  // namespace
+
+extern "C" int dprnn_head_conv_bwd(const float* dU, const float* W2d, const float* X, const float* prelu_w, float* dX,
+                                   double* dalpha, int B, int L, int K, int P, int S, void* stream) {
+    if (!dU || !W2d || !X || !prelu_w || !dX || !dalpha) { dprnn_set_error("dprnn_head_conv_bwd: null pointer"); return -1; }
+    if (K < 1 || P < 1 || P > K || S != (L + K) / P + 1) { dprnn_set_error("dprnn_head_conv_bwd: bad geometry"); return -1; }
+    constexpr int RT = 2;
+    SegGatherRows<RT> al{dU, L, K, P, S};
+    EpPreluBwd<RT> ep{X, prelu_w, dX, dalpha, 0.f};
+    return launch_rowgemm<256, 128, RT, true>("head_conv_bwd", W2d, 128, 256, nullptr, 0, (long long)B * S * K, al, ep, (hipStream_t)stream);
+}

@@ -145,8 +145,7 @@ class DPRNNTasNet(nn.Module):
                         norm_type=norm_type, activation_type=activation_type, dropout=dropout, stride=self.stride)
 
     def forward(self, input, debug=None):
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "DPRNNTasNet (MI355X): backward kernels are not built yet; run the forward under "
-                "torch.no_grad() or model.eval() (training step: SURVEY.md section 8f, rank 2)")
+        if debug is None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from . import training          # differentiable forward: autograd.Function over the HIP kernels
+            return training.tasnet_forward_autograd(self, input)
         return engine.tasnet_forward(self, input, debug)

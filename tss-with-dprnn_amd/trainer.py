@@ -1,0 +1,198 @@
+"""Data-parallel training step loop for the MI355X path (SURVEY.md section 8e "Training (config 4)", 8f rank 2).
+
+Mirror of the reference's ``Trainer`` step loop (src/trainers/trainer.py:86-133 train, :135-178 eval, :180-226 run,
+:294-306 checkpoints) with the one addition BASELINE.json's north_star asks for: gradients are averaged over the ranks
+with ONE all-reduce of a flat fp32 buffer (3 651 073 elements = 14.6 MB for the shipped model) between ``backward()``
+and ``clip_grad_norm_``.  One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI) in production,
+"gloo" in the CPU tests; no other collective is on the path (the logged loss is all-reduced once per epoch).
+
+The model forward/backward and the loss are the HIP kernels of training.py; optimizer, LR scheduler and gradient
+clipping are the stock torch objects the reference configures (scripts/train/config_bss.yaml:30-38), so checkpoints
+keep the reference format ``{'epoch', 'optimizer', 'model'}`` and load in either code base.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import deque
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .training import PITSiSdrLoss
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class FlatGradAllReducer:
+    """Average ``param.grad`` over the ranks with a single all-reduce.
+
+    The reference's loop calls ``optimizer.zero_grad()`` every step, which drops the grad tensors (set_to_none), so the
+    flat bucket is refilled from whatever grads exist after ``backward()``: one gather copy, one collective, one
+    scatter copy of 14.6 MB -- against ~0.5 s of backward kernels."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat: Optional[torch.Tensor] = None
+
+    def average(self) -> None:
+        world = _world()
+        if world == 1:
+            return
+        p0 = self.params[0]
+        if self.flat is None or self.flat.device != p0.device:
+            self.flat = torch.empty(self.numel, device=p0.device, dtype=torch.float32)
+        views, off = [], 0
+        for p in self.params:
+            views.append(self.flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / world)
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0) -> None:
+    """Every rank starts from rank `src`'s weights and buffers (the reference builds the model from the hydra config on
+    one process; replicas must agree before the first averaged step)."""
+    if _world() == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def train_step(model, loss_module, optimizer, mix, target, clip_norm: float = 0.0,
+               reducer: Optional[FlatGradAllReducer] = None):
+    """One iteration of Trainer.train (trainer.py:98-118).  Returns (loss tensor, reordered estimates)."""
+    optimizer.zero_grad()
+    out = model(mix)
+    loss, est = loss_module(out, target, return_est=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.average()
+    if clip_norm:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+    optimizer.step()
+    return loss.detach(), est.detach()
+
+
+class DistributedTrainer:
+    """Step loop with the reference Trainer's semantics; ``logger`` / ``reporter`` are optional duck-typed objects
+    (``logger.info(str)``, ``reporter.add_and_report(logs=dict, mode=str)``) so neither hydra nor wandb is needed."""
+
+    def __init__(self, model, optimizer, lr_scheduler=None, clip_norm: float = 0.0, device=None, logger=None,
+                 reporter=None, new_checkpoints_path: Optional[str] = None, n_checkpoints: int = 5, print_freq: int = 100,
+                 cur_epoch: int = 0, checkpoint_path: Optional[str] = None, scheduler_on_eval_loss: bool = True):
+        self.device = device if device is not None else next(model.parameters()).device
+        self.model = model
+        self.optimizer = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.scheduler_on_eval_loss = scheduler_on_eval_loss          # ReduceLROnPlateau (trainer.py:197-198) vs ExponentialLR
+        self.clip_norm = clip_norm or 0
+        self.logger, self.reporter = logger, reporter
+        self.loss_module = PITSiSdrLoss()
+        self.cur_epoch = cur_epoch
+        self.print_freq = print_freq
+        self.rank = dist.get_rank() if _world() > 1 else 0
+        self.new_checkpoints_path = new_checkpoints_path
+        self.checkpoint_queue = deque(maxlen=n_checkpoints)
+        if checkpoint_path is not None:                               # trainer.py:66-77
+            cpt = torch.load(checkpoint_path, map_location="cpu")
+            self.model.load_state_dict(cpt["model"])
+            if "optimizer" in cpt:
+                self.optimizer.load_state_dict(cpt["optimizer"])
+            self.cur_epoch = cpt.get("epoch", cur_epoch)
+        broadcast_parameters(self.model)
+        self.reducer = FlatGradAllReducer(self.model.parameters())
+
+    def _info(self, msg):
+        if self.logger is not None and self.rank == 0:
+            self.logger.info(msg)
+
+    def _mean_over_ranks(self, total: float, count: int) -> float:
+        t = torch.tensor([total, float(count)], dtype=torch.float64, device=self.device)
+        if _world() > 1:
+            dist.all_reduce(t)
+        return float(t[0] / max(t[1], 1.0))
+
+    def train(self, dataloader) -> float:
+        self.model.train()
+        total, steps = 0.0, 0
+        start = time.time()
+        for step, (mix, target) in enumerate(dataloader):
+            loss, _ = train_step(self.model, self.loss_module, self.optimizer, mix.to(self.device), target.to(self.device),
+                                 self.clip_norm, self.reducer)
+            total += loss.item()
+            steps += 1
+            if step % self.print_freq == 0:
+                self._info("<epoch:{:d}, iter:{:d}, lr:{:.3e}, loss:{:.3f}>.".format(
+                    self.cur_epoch, step, self.optimizer.param_groups[0]["lr"], -total / (step + 1)))
+        return self._log_epoch(total, steps, start, "train")
+
+    def eval(self, dataloader) -> float:
+        self.model.eval()
+        total, steps = 0.0, 0
+        start = time.time()
+        with torch.no_grad():
+            for mix, target in dataloader:
+                out = self.model(mix.to(self.device))
+                loss, _ = self.loss_module(out, target.to(self.device), return_est=True)
+                total += loss.item()
+                steps += 1
+        return self._log_epoch(total, steps, start, "eval")
+
+    def _log_epoch(self, total, steps, start, mode) -> float:
+        mean = self._mean_over_ranks(total, steps)                    # the all-reduced mean the scheduler must see
+        if self.reporter is not None and self.rank == 0:
+            self.reporter.add_and_report(logs={"step": self.cur_epoch, "loss": -mean, "metrics": None}, mode=mode)
+        self._info("Finished *** <epoch:{:d}, iter:{:d}, lr:{:.3e}, loss:{:.3f}, Total time:{:.3f} min>.".format(
+            self.cur_epoch, steps, self.optimizer.param_groups[0]["lr"], -mean, (time.time() - start) / 60))
+        return mean
+
+    def run(self, train_loader, eval_loader, n_epochs: int, early_stop: int):
+        best_loss, no_improve = 100500, 0                             # trainer.py:181
+        history = []
+        while self.cur_epoch < n_epochs:
+            self.cur_epoch += 1
+            train_loss = self.train(train_loader)
+            eval_loss = self.eval(eval_loader)
+            history.append((train_loss, eval_loss))
+            if self.lr_scheduler is not None:
+                if self.scheduler_on_eval_loss:
+                    self.lr_scheduler.step(eval_loss)
+                else:
+                    self.lr_scheduler.step()
+            if eval_loss >= best_loss:
+                no_improve += 1
+            else:
+                best_loss, no_improve = eval_loss, 0
+                self._save_checkpoint(best=True)
+            if no_improve == early_stop:
+                break
+        self._save_checkpoint(best=False)
+        return history
+
+    def _save_checkpoint(self, best: bool = False) -> Optional[str]:
+        if self.new_checkpoints_path is None or self.rank != 0:
+            return None
+        cpt = {"epoch": self.cur_epoch, "optimizer": self.optimizer.state_dict(), "model": self.model.state_dict()}
+        path = os.path.join(self.new_checkpoints_path, "{0}_{1}.pt".format(str(self.cur_epoch), "best" if best else "last"))
+        torch.save(cpt, path)
+        if len(self.checkpoint_queue) == self.checkpoint_queue.maxlen:
+            old = self.checkpoint_queue[0]
+            if os.path.exists(old) and old != path:
+                os.remove(old)
+        self.checkpoint_queue.append(path)
+        return path

@@ -1,0 +1,402 @@
+"""Training step of DPRNNTasNet on the MI355X path.
+
+The reference trains with stock autograd (src/trainers/trainer.py:98-118): ``out = model(mix)``,
+``loss = PITLossWrapper(pairwise_neg_sisdr)(out, target)``, ``loss.backward()``, ``clip_grad_norm_``,
+``optimizer.step()``.  Here the model forward under autograd is one ``torch.autograd.Function`` whose forward enqueues
+the training variants of the forward kernels (they keep what the backward needs: the slab after every path, the Linear
+outputs, the recurrence outputs and the LSTM gate tape) and whose backward enqueues the hand-written gradient kernels of
+include/dprnn_mi355x_train.h.  autograd only routes the resulting tensors into ``param.grad``: the reference's
+``Trainer`` loop, torch optimizers and ``clip_grad_norm_`` run unchanged on top.  There is no PyTorch fallback for
+any of the arithmetic.
+
+Memory (MI355X, 288 GB): the tape is 5 fp32 values per (row, direction, hidden unit) and path -- 3.0 GB per 3 s utterance
+for the shipped 6-block model, 4.2 GB with the other saved slabs -- so a whole 64-utterance batch does not fit.
+``SAVE_BUDGET_BYTES`` bounds what one pass keeps; a larger batch is cut into micro-batches that are re-run in the
+backward (forward recomputation, +1 forward per step), smaller batches keep everything from the first forward.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import engine
+from ._lib import DprnnError
+from .engine import F_BUILT, Stage, _norm_params, _p, _param, _rnn_tensors
+
+SAVE_BUDGET_BYTES = 160 << 30        # activations one forward may keep for its backward
+PACKT_PER_DIR = 512 * 256
+
+
+def check_supported_train(cfg: dict) -> None:
+    engine.check_supported(cfg)
+    if cfg["rnn_type"] != "LSTM":
+        raise NotImplementedError(f"DPRNN MI355X training path: rnn_type {cfg['rnn_type']!r} has inference kernels only "
+                                  "(the backward is built for the LSTM the shipped configs use)")
+
+
+def saved_bytes_per_utt(geo: engine.Geometry, n_paths: int, ndirs: List[int]) -> int:
+    rows = geo.S * geo.K
+    tape = sum(5 * nd for nd in ndirs) * rows * F_BUILT * 4
+    slabs = (n_paths + 1) * rows * F_BUILT * 4 + n_paths * rows * F_BUILT * 4 + sum(ndirs) * rows * F_BUILT * 4
+    head = geo.L * (2 * F_BUILT + 2 * F_BUILT + 2 * 2 * F_BUILT + 2 * geo.N) * 4
+    return tape + slabs + head
+
+
+def _paths(sep):
+    out = []
+    for blk in sep.dprnn_blocks:
+        out.append((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True))
+        out.append((blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))
+    return out
+
+
+def _addr(geo, intra):
+    B, S, K = geo.B, geo.S, geo.K
+    return (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
+
+
+def forward_train(model, wav: torch.Tensor, keep: bool = True):
+    """DPRNNTasNet.forward (dprnn.py:271-283) keeping the activations the backward needs.  Returns (out, saved)."""
+    cfg = model.cfg
+    dev = wav.device
+    st = Stage(dev)
+    lib = st.lib
+    geo = engine.make_geometry(wav.shape[0], wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                               cfg["kernel_size"], cfg["stride"])
+    if geo.T_out < 2:
+        raise DprnnError("utterance too short")
+    sep = model.separation
+    paths = _paths(sep)
+    npth = len(paths)
+    B, L, K, P, S, rows = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows
+    enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+    dec_w = _param(model.decoder.weight, "decoder.weight", dev)
+    f32 = dict(device=dev, dtype=torch.float32)
+    stats = torch.zeros(1 + npth, B, 2, device=dev, dtype=torch.float64)
+    lib.dprnn_set_gemm_mode(0)
+    sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0])
+    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo)
+    X = [torch.empty(rows, F_BUILT, **f32)]
+    Z, H, tapes = [], [], []
+    st.call("dprnn_segment_fwd", _p(Y), _p(X[0]), B, L, K, P, S)
+    del Y
+    packed = torch.empty(2 * engine.PACK_PER_DIR, **f32)
+    bsum = torch.empty(2 * 4 * F_BUILT, **f32)
+    for p, (rnn, lin, norm, intra) in enumerate(paths):
+        ndir, fw, bw = _rnn_tensors(rnn, dev)
+        st.call("dprnn_rnn_pack", 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+        addr = _addr(geo, intra)
+        Hp = torch.empty(rows, ndir * F_BUILT, **f32)
+        tape = torch.empty(lib.dprnn_lstm_tape_floats(addr[0], addr[1], ndir), **f32)
+        st.call("dprnn_lstm_fwd_train", _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+        w = _param(lin.weight, "linear.weight", dev)
+        if w.shape != (F_BUILT, ndir * F_BUILT):
+            raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+        Zp = torch.empty(rows, F_BUILT, **f32)
+        st.call("dprnn_proj_stats_fwd", _p(Hp), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Zp), _p(stats[1 + p]),
+                rows, S * K, ndir * F_BUILT)
+        gamma, beta, eps = _norm_params(norm)
+        Xn = torch.empty(rows, F_BUILT, **f32)
+        st.call("dprnn_norm_residual_fwd", _p(X[p]), _p(Zp), _p(stats[1 + p]), _p(_param(gamma, "norm.weight", dev)),
+                _p(_param(beta, "norm.bias", dev)), eps, _p(Xn), B, S * K)
+        X.append(Xn)
+        Z.append(Zp); H.append(Hp); tapes.append(tape)
+        if not keep:
+            X[p] = None; Z[p] = None; H[p] = None; tapes[p] = None
+    R = B * L * 2
+    U = torch.empty(B * L, 2 * F_BUILT, **f32)
+    V = torch.empty(R, F_BUILT, **f32)
+    TG = torch.empty(R, 2 * F_BUILT, **f32)
+    mask = torch.empty(R, geo.N, **f32)
+    taps = torch.empty(B, 2, L, geo.ks, **f32)
+    st.call("dprnn_head_conv_ola_fwd", _p(X[npth]), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
+            _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
+            _p(U), B, L, K, P, S)
+    st.call("dprnn_head_gate_fwd_train", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+            _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
+            _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), _p(TG), R)
+    st.call("dprnn_head_mask_decode_fwd_train", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(mask), 1 if cfg["activation_type"] == "relu" else 0,
+            B, geo.T, L, geo.N, geo.ks, geo.stride)
+    out = engine.decode(st, taps, geo, 2)
+    if not keep:
+        return out, None
+    saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask)
+    return out, saved
+
+
+def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter for the upstream gradient d_out [B, 2, T_out]; keys are state_dict names."""
+    cfg = model.cfg
+    geo: engine.Geometry = saved["geo"]
+    wav = saved["wav"]
+    dev = wav.device
+    st = Stage(dev)
+    lib = st.lib
+    sep = model.separation
+    paths = _paths(sep)
+    npth = len(paths)
+    B, L, K, P, S, rows, N, ks = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows, geo.N, geo.ks
+    R = B * L * 2
+    f32 = dict(device=dev, dtype=torch.float32)
+    d_out = d_out.contiguous().float()
+    if d_out.shape != (B, 2, geo.T_out):
+        raise DprnnError(f"upstream gradient has shape {tuple(d_out.shape)}, expected {(B, 2, geo.T_out)}")
+    enc_w = model.encoder.conv1d.weight
+    dec_w = model.decoder.weight
+    stats, X, Z, H, tapes = saved["stats"], saved["X"], saved["Z"], saved["H"], saved["tapes"]
+    grads: Dict[str, torch.Tensor] = {}
+
+    # fp64 scratch for the small reductions: [dWd | dWe | dalpha | db2d | bottleneck (red B*2, dgb 2*64) | per path (red B*2, dgb 2*128)]
+    o_wd, o_we, o_al, o_b2 = 0, N * ks, 2 * N * ks, 2 * N * ks + 1
+    o_bn = o_b2 + 2 * F_BUILT
+    o_path = o_bn + 2 * B + 2 * N
+    per_path = 2 * B + 2 * F_BUILT
+    scratch = torch.zeros(o_path + npth * per_path, device=dev, dtype=torch.float64)
+    sp = scratch.data_ptr()
+
+    def dptr(off):
+        return sp + 8 * off
+
+    def to_grad(off, like, n=None):
+        g = torch.empty_like(like)
+        st.call("dprnn_scratch_to_grad", dptr(off), _p(g), g.numel() if n is None else n, 0)
+        return g
+
+    ws_floats = max(lib.dprnn_wgrad_workspace_floats(512, 256, rows), lib.dprnn_wgrad_workspace_floats(256, 128, R))
+    ws = torch.empty(ws_floats, **f32)
+
+    def wgrad(Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, dW, ldm, ldn, db0, db1):
+        st.call("dprnn_wgrad", Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, _p(dW), ldm, ldn,
+                _p(db0), _p(db1), 0, _p(ws))
+
+    # ---- decoder, masking, mask activation (encoder_decoder.py:40-42, dprnn.py:277, :161-164)
+    dE = torch.empty(R, N, **f32)
+    dEnc = torch.empty(B * L, N, **f32)
+    st.call("dprnn_mask_decode_bwd", _p(d_out), _p(wav), _p(enc_w), _p(dec_w), _p(saved["mask"]),
+            1 if cfg["activation_type"] == "relu" else 0, _p(dE), _p(dEnc), dptr(o_wd), B, geo.T, L, N, ks, geo.stride)
+    grads["decoder.weight"] = to_grad(o_wd, dec_w)
+    # ---- end_conv1x1 (dprnn.py:160,181)
+    w_end = sep.end_conv1x1.weight
+    dV = torch.empty(R, F_BUILT, **f32)
+    st.call("dprnn_dgrad", _p(dE), N, _p(w_end), F_BUILT, N, 0, 0, _p(dV), F_BUILT, R)
+    g = torch.empty_like(w_end)
+    wgrad(_p(dE), N, N, _p(saved["V"]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, R, 1, 1, g, F_BUILT, 1, None, None)
+    grads["separation.end_conv1x1.weight"] = g
+    del dE
+    # ---- tanh(out) * sigmoid(gate) (dprnn.py:157-158,180)
+    dAG = torch.empty(R, 2 * F_BUILT, **f32)
+    st.call("dprnn_gate_bwd", _p(dV), _p(saved["TG"]), _p(dAG), R)
+    del dV
+    dU = torch.empty(B * L, 2 * F_BUILT, **f32)          # rows (b,l,spk) of 128 == rows (b,l) of 256
+    st.call("dprnn_dgrad", _p(dAG), 2 * F_BUILT, _p(sep.out[0].weight), F_BUILT, F_BUILT, _p(sep.gate[0].weight), F_BUILT,
+            _p(dU), F_BUILT, R)
+    gw = torch.empty(2 * F_BUILT, F_BUILT, **f32)
+    gb = torch.empty(2 * F_BUILT, **f32)
+    wgrad(_p(dAG), 2 * F_BUILT, 2 * F_BUILT, _p(saved["U"]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, R, 1, 1, gw, F_BUILT, 1, gb, None)
+    grads["separation.out.0.weight"] = gw[:F_BUILT].reshape(sep.out[0].weight.shape).clone()
+    grads["separation.gate.0.weight"] = gw[F_BUILT:].reshape(sep.gate[0].weight.shape).clone()
+    grads["separation.out.0.bias"] = gb[:F_BUILT].clone()
+    grads["separation.gate.0.bias"] = gb[F_BUILT:].clone()
+    del dAG
+    # ---- PReLU -> conv2d -> overlap-add (dprnn.py:173-178,203-217)
+    Xlast = X[npth]
+    pq = torch.empty(B * L, F_BUILT, **f32)
+    st.call("dprnn_ola_prelu_sum", _p(Xlast), _p(sep.prelu.weight), _p(pq), _p(dU), dptr(o_b2), B, L, K, P, S)
+    g = torch.empty_like(sep.conv2d.weight)
+    wgrad(_p(dU), 2 * F_BUILT, 2 * F_BUILT, _p(pq), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, B * L, 1, 1, g, F_BUILT, 1, None, None)
+    grads["separation.conv2d.weight"] = g
+    grads["separation.conv2d.bias"] = to_grad(o_b2, sep.conv2d.bias)
+    del pq
+    dX = torch.empty(rows, F_BUILT, **f32)
+    st.call("dprnn_head_conv_bwd", _p(dU), _p(sep.conv2d.weight), _p(Xlast), _p(sep.prelu.weight), _p(dX), dptr(o_al),
+            B, L, K, P, S)
+    grads["separation.prelu.weight"] = to_grad(o_al, sep.prelu.weight)
+    del dU
+
+    # ---- DPRNN blocks in reverse (dprnn.py:79-99)
+    dXd = torch.zeros(2, rows, F_BUILT, **f32)
+    dZ = torch.empty(rows, F_BUILT, **f32)
+    packedT = torch.empty(2 * PACKT_PER_DIR, **f32)
+    have_dx = False
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    for p in range(npth - 1, -1, -1):
+        rnn, lin, norm, intra = paths[p]
+        blk = f"separation.dprnn_blocks.{p // 2}." + ("intra" if intra else "inter")
+        ndir, fw, bw = _rnn_tensors(rnn, dev)
+        gamma, beta, eps = _norm_params(norm)
+        o_red = o_path + p * per_path
+        o_dgb = o_red + 2 * B
+        st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
+                _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, dptr(o_red), dptr(o_dgb))
+        st.call("dprnn_gn_bwd_dz", _p(dX), _p(Z[p]), _p(stats[1 + p]), dptr(o_red), _p(gamma), eps, B, S * K, _p(dZ))
+        gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
+        grads[f"{blk}_norm.{gname}"] = to_grad(o_dgb, gamma)
+        grads[f"{blk}_norm.{bname}"] = to_grad(o_dgb + F_BUILT, beta)
+        # Linear (dprnn.py:88,96)
+        hp = ndir * F_BUILT
+        dH = torch.empty(rows, hp, **f32)
+        st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, rows)
+        gw = torch.empty_like(lin.weight)
+        gb = torch.empty_like(lin.bias)
+        Hp = H[p]
+        wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
+              F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None)
+        grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
+        # recurrence (dprnn.py:86,95)
+        addr = _addr(geo, intra)
+        st.call("dprnn_lstm_pack_bwd", _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
+        dG = torch.empty(rows, ndir * 4 * F_BUILT, **f32)
+        st.call("dprnn_lstm_bwd", _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
+        del dH
+        for d in range(ndir):
+            suf = "_reverse" if d == 1 else ""
+            gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
+            gbias = torch.empty(4 * F_BUILT, **f32)
+            wgrad(dG.data_ptr() + 4 * 4 * F_BUILT * d, ndir * 4 * F_BUILT, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0,
+                  Hp.data_ptr() + 4 * F_BUILT * d, hp, F_BUILT, 1 if d == 0 else -1, rows, addr[5], addr[1],
+                  gcat, 2 * F_BUILT, 1, gbias, None)
+            pre = f"{blk}_rnn.rnn."
+            grads[pre + names[0] + suf] = gcat[:, :F_BUILT].contiguous()
+            grads[pre + names[1] + suf] = gcat[:, F_BUILT:].contiguous()
+            grads[pre + names[2] + suf] = gbias
+            grads[pre + names[3] + suf] = gbias.clone()
+        del dG
+        if ndir == 1:
+            dXd[1].zero_()
+        have_dx = True
+        # the saved activations of this path are no longer needed
+        Z[p] = None; H[p] = None; tapes[p] = None; X[p + 1] = None
+
+    # ---- segmentation (dprnn.py:189-201) and bottleneck (dprnn.py:131-136,169)
+    dY = torch.empty(B * L, F_BUILT, **f32)
+    st.call("dprnn_segment_bwd", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0, _p(dY), B, L, K, P, S)
+    del dX, dXd, dZ
+    bconv = sep.bottleneck[1]
+    wb = bconv.weight
+    if wb.shape[1] != N:
+        raise DprnnError("training path: the bottleneck conv must take the encoder channels only (DPRNNTasNet)")
+    A = torch.empty(B * L, N, **f32)
+    st.call("dprnn_encoder_norm_rows", _p(wav), _p(enc_w), _p(saved["sc"]), _p(saved["sh"]), _p(A), B, geo.T, L, N, ks, geo.stride)
+    gw = torch.empty_like(wb)
+    gb = torch.empty_like(bconv.bias)
+    wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, N, 1, gb, None)
+    grads["separation.bottleneck.1.weight"], grads["separation.bottleneck.1.bias"] = gw, gb
+    dA = A          # reuse
+    st.call("dprnn_dgrad", _p(dY), F_BUILT, _p(wb), N, F_BUILT, 0, 0, _p(dA), N, B * L)
+    gamma, beta, eps = _norm_params(sep.bottleneck[0])
+    st.call("dprnn_encoder_norm_bwd_stats", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, dptr(o_bn),
+            dptr(o_bn + 2 * B), B, geo.T, L, N, ks, geo.stride)
+    gname, bname = ("gamma", "beta") if hasattr(sep.bottleneck[0], "gamma") else ("weight", "bias")
+    grads[f"separation.bottleneck.0.{gname}"] = to_grad(o_bn + 2 * B, gamma)
+    grads[f"separation.bottleneck.0.{bname}"] = to_grad(o_bn + 2 * B + N, beta)
+    st.call("dprnn_encoder_bwd", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, dptr(o_bn), _p(dEnc), dptr(o_we),
+            B, geo.T, L, N, ks, geo.stride)
+    grads["encoder.conv1d.weight"] = to_grad(o_we, enc_w)
+    return grads
+
+
+class _TasNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, wav, names, *params):
+        ctx.model, ctx.names = model, names
+        B = wav.shape[0]
+        cfg = model.cfg
+        geo = engine.make_geometry(1, wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                                   cfg["kernel_size"], cfg["stride"])
+        ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in _paths(model.separation)]
+        per_utt = saved_bytes_per_utt(geo, len(ndirs), ndirs)
+        mb = max(1, min(B, SAVE_BUDGET_BYTES // per_utt))
+        if mb >= B:
+            out, saved = forward_train(model, wav, keep=True)
+            ctx.saved, ctx.wav, ctx.mb = saved, None, B
+        else:       # too large to keep: plain forward now, micro-batches are re-run in the backward
+            out = torch.cat([forward_train(model, wav[b0:b0 + mb].contiguous(), keep=False)[0] for b0 in range(0, B, mb)])
+            ctx.saved, ctx.wav, ctx.mb = None, wav, mb
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model, names = ctx.model, ctx.names
+        if ctx.saved is not None:
+            grads = backward(model, ctx.saved, d_out)
+            ctx.saved = None
+        else:
+            grads = None
+            wav, mb = ctx.wav, ctx.mb
+            d_out = d_out.contiguous()
+            for b0 in range(0, wav.shape[0], mb):
+                _, saved = forward_train(model, wav[b0:b0 + mb].contiguous(), keep=True)
+                g = backward(model, saved, d_out[b0:b0 + mb])
+                del saved
+                if grads is None:
+                    grads = g
+                else:
+                    for k in g:
+                        grads[k] += g[k]
+        return (None, None, None) + tuple(grads[n] for n in names)
+
+
+def tasnet_forward_autograd(model, wav: torch.Tensor) -> torch.Tensor:
+    """model(wav) under autograd: differentiable w.r.t. every parameter (not w.r.t. the waveform)."""
+    check_supported_train(model.cfg)
+    wav = engine.check_input(wav)
+    if wav.requires_grad:
+        raise NotImplementedError("DPRNN MI355X training path: gradients w.r.t. the input waveform are not computed")
+    named = [(n, p) for n, p in model.named_parameters()]
+    for n, p in named:
+        _param(p, n, wav.device)
+    with torch.cuda.device(wav.device):
+        return _TasNetFunction.apply(model, wav, tuple(n for n, _ in named), *[p for _, p in named])
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _PitSiSdrFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, tgt):
+        if not (est.is_cuda and tgt.is_cuda):
+            raise DprnnError("PITSiSdrLoss runs on the HIP device only")
+        est = est.contiguous().float()
+        tgt = tgt.contiguous().float()
+        B, n, T = est.shape
+        if tgt.shape != est.shape:
+            raise DprnnError(f"estimate {tuple(est.shape)} / target {tuple(tgt.shape)} shapes differ")
+        dev = est.device
+        with torch.cuda.device(dev):
+            st = Stage(dev)
+            mom = torch.empty(B, n, n, 5, device=dev, dtype=torch.float64)
+            pw = torch.empty(B, n, n, device=dev, dtype=torch.float64)
+            loss_b = torch.empty(B, device=dev, dtype=torch.float64)
+            perm = torch.empty(B, n, device=dev, dtype=torch.int32)
+            coef = torch.empty(B, n, 4, device=dev, dtype=torch.float64)
+            st.call("dprnn_pit_sisdr_fwd", _p(est), _p(tgt), _p(mom), _p(pw), _p(loss_b), _p(perm), _p(coef), B, n, T)
+        ctx.save_for_backward(est, tgt, perm, coef)
+        ctx.mark_non_differentiable(perm, pw)
+        return loss_b.mean().float(), perm, pw
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_perm, _g_pw):
+        est, tgt, perm, coef = ctx.saved_tensors
+        B, n, T = est.shape
+        d_est = torch.empty_like(est)
+        with torch.cuda.device(est.device):
+            st = Stage(est.device)
+            up = g_loss.detach().float().contiguous()
+            st.call("dprnn_pit_sisdr_bwd", _p(est), _p(tgt), _p(perm), _p(coef), _p(up), _p(d_est), B, n, T)
+        return d_est, None
+
+
+class PITSiSdrLoss(torch.nn.Module):
+    """``PITLossWrapper(pairwise_neg_sisdr, pit_from='pw_mtx')`` of asteroid==0.7.0 as the reference uses it
+    (src/trainers/trainer.py:39,104): mean over the batch of the minimum over source permutations of the mean negative
+    SI-SDR; ``return_est=True`` also returns the estimates reordered to the targets.  Forward and backward are HIP kernels
+    (fp64 moments, dprnn_pit_sisdr_fwd / _bwd)."""
+
+    def forward(self, est_targets, targets, return_est: bool = False):
+        loss, perm, _ = _PitSiSdrFunction.apply(est_targets, targets)
+        if not return_est:
+            return loss
+        inv = torch.argsort(perm.long(), dim=1)
+        reordered = torch.gather(est_targets, 1, inv.unsqueeze(-1).expand(-1, -1, est_targets.shape[-1]))
+        return loss, reordered
