@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Training-step timing on one MI355X: forward (with tape) + PIT SI-SDR loss + backward (+ Adam), shipped config,
+3 s utterances.  Prints utt/s and the per-entry-point time of one profiled step (HIP events around every C-ABI call).
+
+    python tools/bench_train.py --batch 16 --steps 3
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import engine, training
+from tss_with_dprnn_amd.training import PITSiSdrLoss
+
+
+class _All:
+    def __contains__(self, k):
+        return True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=24000)
+    ap.add_argument("--budget-gb", type=float, default=None)
+    a = ap.parse_args()
+    if a.budget_gb is not None:
+        training.SAVE_BUDGET_BYTES = int(a.budget_gb * (1 << 30))
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    lossm = PITSiSdrLoss()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    src = 0.07 * torch.randn(a.batch, 2, a.samples, generator=g)
+    mix = src.sum(1).to(dev)
+    tgt = src.to(dev)
+
+    def step():
+        opt.zero_grad()
+        out = model(mix)
+        loss = lossm(out, tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
+        opt.step()
+        return loss
+
+    l0 = step().item()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"batch {a.batch}: {dt * 1e3:.1f} ms/step, {a.batch / dt:.1f} utt/s, loss {l0:.4f} -> {loss.item():.4f}, "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    # forward alone (inference path, for the ratio)
+    model.eval()
+    with torch.no_grad():
+        model(mix); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            model(mix)
+        torch.cuda.synchronize()
+    fdt = (time.perf_counter() - t0) / a.steps
+    print(f"inference forward: {fdt * 1e3:.1f} ms ({a.batch / fdt:.1f} utt/s); training step = {dt / fdt:.2f} x forward")
+    model.train()
+    engine.PROFILE = {"names": _All(), "events": {}}
+    step()
+    torch.cuda.synchronize()
+    prof, engine.PROFILE = engine.PROFILE, None
+    rows = sorted(((sum(e0.elapsed_time(e1) for e0, e1 in ev), len(ev), n) for n, ev in prof["events"].items()), reverse=True)
+    tot = sum(r[0] for r in rows)
+    print(f"profiled step: {tot:.1f} ms inside C-ABI calls")
+    for ms, cnt, n in rows[:16]:
+        print(f"  {n:34s} {cnt:4d} calls {ms:9.2f} ms {100 * ms / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()

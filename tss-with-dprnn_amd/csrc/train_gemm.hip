@@ -218,18 +218,18 @@ extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0,
                            float* dA, int nd, int64_t rows, void* stream) {
     if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1)) { dprnn_set_error("dprnn_dgrad: null pointer / rows"); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    constexpr int RT = 4;
-    PlainRows<RT> al{dOut, kd};
-#define DG_CASE(KD, ND)                                                                                              \
+    // row tiles per wave: 4 x 16 rows while the accumulators fit (ND <= 128), 2 x 16 for the 256-wide outputs
+#define DG_CASE(KD, ND, RT)                                                                                          \
     if (kd == KD && nd == ND) {                                                                                      \
+        PlainRows<RT> al{dOut, kd};                                                                                  \
         EpBiasStore<RT, ND / 16> ep{dA, nullptr, nullptr, 1, nullptr};                                               \
         return launch_rowgemm<KD, ND, RT, true>("dgrad" #KD "x" #ND, W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st); \
     }
-    DG_CASE(128, 256)
-    DG_CASE(128, 128)
-    DG_CASE(64, 128)
-    DG_CASE(256, 128)
-    DG_CASE(128, 64)
+    DG_CASE(128, 256, 2)
+    DG_CASE(128, 128, 4)
+    DG_CASE(64, 128, 4)
+    DG_CASE(256, 128, 4)
+    DG_CASE(128, 64, 4)
 #undef DG_CASE
     dprnn_set_error("dprnn_dgrad: unsupported (kd, nd) = (%d, %d)", kd, nd);
     return -1;
