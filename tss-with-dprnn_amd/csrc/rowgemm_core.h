@@ -169,6 +169,27 @@ struct EpBiasStore {            // out[row][col] = acc*row_scale[row] + bias[col
 };
 
 template <int RT, int NCT>
+struct EpStore {                // out[row][col] = acc: plain store, one base pointer per row on full tiles
+    float* out;
+    __device__ void begin() {}
+    __device__ void end(int lane) {}
+    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
+        const bool full = row0 + 16 * RT <= M;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long row = row0 + 16 * rt + 4 * q + e;
+                if (full || row < M) {
+                    float* o = out + row * (16 * NCT) + r;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) o[16 * ct] = acc[rt][ct][e];
+                }
+            }
+    }
+};
+
+template <int RT, int NCT>
 struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in double
     float* Z; const float* bias; double* stats; long long rows_per_b;
     double d1, d2; long long cur_b;

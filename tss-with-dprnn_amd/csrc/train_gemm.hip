@@ -222,7 +222,7 @@ extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0,
 #define DG_CASE(KD, ND, RT)                                                                                          \
     if (kd == KD && nd == ND) {                                                                                      \
         PlainRows<RT> al{dOut, kd};                                                                                  \
-        EpBiasStore<RT, ND / 16> ep{dA, nullptr, nullptr, 1, nullptr};                                               \
+        EpStore<RT, ND / 16> ep{dA};                                                                                 \
         return launch_rowgemm<KD, ND, RT, true>("dgrad" #KD "x" #ND, W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st); \
     }
     DG_CASE(128, 256, 2)

@@ -83,13 +83,23 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True):
     del Y
     packed = torch.empty(2 * engine.PACK_PER_DIR, **f32)
     bsum = torch.empty(2 * 4 * F_BUILT, **f32)
-    for p, (rnn, lin, norm, intra) in enumerate(paths):
+    pending = None            # (Z, stats, gamma, beta, eps) of the previous path: its norm + residual is applied by the
+    for p, (rnn, lin, norm, intra) in enumerate(paths):     # next recurrence's loader, which also writes X[p]
         ndir, fw, bw = _rnn_tensors(rnn, dev)
         st.call("dprnn_rnn_pack", 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
         addr = _addr(geo, intra)
         Hp = torch.empty(rows, ndir * F_BUILT, **f32)
         tape = torch.empty(lib.dprnn_lstm_tape_floats(addr[0], addr[1], ndir), **f32)
-        st.call("dprnn_lstm_fwd_train", _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+        if pending is None:
+            st.call("dprnn_lstm_fwd_train", _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+        else:
+            pz, pstats, pg, pb, peps = pending
+            Xn = torch.empty(rows, F_BUILT, **f32)
+            st.call("dprnn_lstm_fwd_train", _p(X[p - 1]), _p(pz), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
+                    _p(Xn), _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+            X.append(Xn)
+            if not keep:
+                X[p - 1] = None
         w = _param(lin.weight, "linear.weight", dev)
         if w.shape != (F_BUILT, ndir * F_BUILT):
             raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
@@ -97,13 +107,16 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True):
         st.call("dprnn_proj_stats_fwd", _p(Hp), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Zp), _p(stats[1 + p]),
                 rows, S * K, ndir * F_BUILT)
         gamma, beta, eps = _norm_params(norm)
-        Xn = torch.empty(rows, F_BUILT, **f32)
-        st.call("dprnn_norm_residual_fwd", _p(X[p]), _p(Zp), _p(stats[1 + p]), _p(_param(gamma, "norm.weight", dev)),
-                _p(_param(beta, "norm.bias", dev)), eps, _p(Xn), B, S * K)
-        X.append(Xn)
-        Z.append(Zp); H.append(Hp); tapes.append(tape)
-        if not keep:
-            X[p] = None; Z[p] = None; H[p] = None; tapes[p] = None
+        pending = (Zp, stats[1 + p], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
+        if keep:
+            Z.append(Zp); H.append(Hp); tapes.append(tape)
+    # the last norm + residual is materialised: the PReLU backward and the conv2d weight gradient read X[npth]
+    pz, pstats, pg, pb, peps = pending
+    Xn = torch.empty(rows, F_BUILT, **f32)
+    st.call("dprnn_norm_residual_fwd", _p(X[npth - 1]), _p(pz), _p(pstats), _p(pg), _p(pb), peps, _p(Xn), B, S * K)
+    X.append(Xn)
+    if not keep:
+        X[npth - 1] = None
     R = B * L * 2
     U = torch.empty(B * L, 2 * F_BUILT, **f32)
     V = torch.empty(R, F_BUILT, **f32)
@@ -318,6 +331,11 @@ class _TasNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        with torch.cuda.device(d_out.device):
+            return _TasNetFunction._backward(ctx, d_out)
+
+    @staticmethod
+    def _backward(ctx, d_out):
         model, names = ctx.model, ctx.names
         if ctx.saved is not None:
             grads = backward(model, ctx.saved, d_out)
