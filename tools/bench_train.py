@@ -81,6 +81,15 @@ def main():
     print(f"profiled step: {tot:.1f} ms inside C-ABI calls")
     for ms, cnt, n in rows[:16]:
         print(f"  {n:34s} {cnt:4d} calls {ms:9.2f} ms {100 * ms / tot:5.1f} %")
+    # fp32-MFMA roofline of the three dominant kernels (peak 157.3 TFLOP/s): algorithmic FLOPs, DESIGN.md section 8
+    geo = engine.make_geometry(a.batch, a.samples, 64, 250, 125, 2, 1)
+    rws = geo.rows
+    lstm = 12 * rws * 2 * (2 * 256 * 512)                  # 12 paths x 2 directions, [x|h] (256) x 4 gates (512) per row
+    wg = 12 * (2 * rws * 2 * 512 * 256 + rws * 2 * 128 * 256)     # LSTM dW (both directions) + Linear dW per path
+    byname = {n: ms for ms, _, n in rows}
+    for n, fl in (("dprnn_lstm_fwd_train", lstm), ("dprnn_lstm_bwd", lstm), ("dprnn_wgrad", wg)):
+        tf = fl / (byname[n] * 1e-3) / 1e12
+        print(f"roofline {n:22s} {fl / 1e12:6.2f} TFLOP in {byname[n]:7.2f} ms = {tf:6.1f} TFLOP/s = {tf / 157.3:.2f} of the fp32 MFMA peak")
 
 
 if __name__ == "__main__":

@@ -456,6 +456,7 @@ static int g_pipelined64 = 0;
 extern "C" void dprnn_set_recur_pipelined(int on) { g_pipelined64 = on; }
 static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L2 end to end, same as the libm forms
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
+int dprnn_fast_activations_enabled(void) { return g_fast_act; }      // train_recur.hip
 
 static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
     if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_bilstm_fwd: null pointer"); return -1; }

@@ -53,7 +53,7 @@ struct BwdArgs {
     long long outer_stride, inner_stride, t_stride;
 };
 
-template <int NT>
+template <int NT, bool FAST>
 __global__ __launch_bounds__(256, 2)
 void lstm_bwd_kernel(BwdArgs a) {
     constexpr int NS = 16 * NT;
@@ -71,17 +71,22 @@ void lstm_bwd_kernel(BwdArgs a) {
     const int hpitch = a.ndir * HD, gpitch = a.ndir * 4 * HD;
     // rows of the accumulator tile this lane owns: seq 16*nt + 4*q + e; rows past nseq alias the tile's first row for
     // loads and are never stored
-    unsigned roff[NT][4];                  // row offset from row0 (rows)
+    // Every address is (uniform base of the step: SGPRs) + (32-bit per-lane byte offset, fixed for the whole kernel) +
+    // (immediate): no vector ALU work for addressing inside the step loop -- fp32 VALU instructions cost matrix time.
+    unsigned hoff[NT][4], goff[NT][4], xoff[NT][4];      // byte offsets into dH / dG / dX rows of this lane's sequences
     bool val[NT][4];
+    const int ucol = 32 * wave + r;        // + 16*u
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
             val[nt][e] = seq < a.nseq;
-            roff[nt][e] = (unsigned)(rowbase(val[nt][e] ? seq : seq0) - row0);
+            const unsigned ro = (unsigned)(rowbase(val[nt][e] ? seq : seq0) - row0);
+            hoff[nt][e] = (ro * hpitch + dir * HD + ucol) * 4u;
+            goff[nt][e] = (ro * gpitch + dir * 4 * HD + ucol) * 4u;
+            xoff[nt][e] = (ro * F + ucol) * 4u;
         }
-    const int ucol = 32 * wave + r;        // + 16*u
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const gw_ptr wbase = (gw_ptr)(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * NGB * 4 * 64) + lane;
     const f32x4* const tape0 = reinterpret_cast<const f32x4*>(a.tape) +
@@ -94,7 +99,7 @@ void lstm_bwd_kernel(BwdArgs a) {
     auto load_step = [&](int fs) __attribute__((always_inline)) {     // gates of step fs, c of step fs-1, dH of step fs
         const f32x4* tp = tape_at(fs);
         const f32x4* tq = tape_at(fs > 0 ? fs - 1 : 0);
-        const float* dhs = a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch + dir * HD + ucol;
+        const char* dhs = reinterpret_cast<const char*>(a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -105,7 +110,7 @@ void lstm_bwd_kernel(BwdArgs a) {
                 const f32x4 c1 = tq[(b + 4) * 64];
                 cp[nt][u] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dho[nt][u][e] = dhs[(size_t)roff[nt][e] * hpitch + 16 * u];
+                for (int e = 0; e < 4; ++e) dho[nt][u][e] = *reinterpret_cast<const float*>(dhs + hoff[nt][e] + 64 * u);
             }
     };
     {
@@ -127,7 +132,7 @@ void lstm_bwd_kernel(BwdArgs a) {
     for (int fs = T - 1; fs >= 0; --fs) {
         const long long trow = row0 + t_of(fs) * a.t_stride;
         // ---- gate derivatives (torch.nn.LSTM backward), lane-local; da -> LDS image and HBM
-        float* const dgs = a.dG + trow * gpitch + dir * 4 * HD + ucol;
+        char* const dgs = reinterpret_cast<char*>(a.dG + trow * gpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -135,7 +140,7 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float i_ = gi[nt][u][e], f_ = gf[nt][u][e], g_ = gg[nt][u][e], o_ = go[nt][u][e];
-                    const float tc = tanh_f<false>(cc[nt][u][e]);
+                    const float tc = tanh_f<FAST>(cc[nt][u][e]);
                     const float dht = dho[nt][u][e] + dh[nt][u][e];
                     const float dct = dc[nt][u][e] + dht * o_ * (1.f - tc * tc);
                     const float da_o = dht * tc * o_ * (1.f - o_);
@@ -146,7 +151,7 @@ void lstm_bwd_kernel(BwdArgs a) {
                     float* d = DA + (16 * nt + 4 * q + e) * GS + ucol + 16 * u;
                     d[0] = da_i; d[HD] = da_f; d[2 * HD] = da_g; d[3 * HD] = da_o;
                     if (val[nt][e]) {
-                        float* g = dgs + (size_t)roff[nt][e] * gpitch + 16 * u;
+                        float* g = reinterpret_cast<float*>(dgs + goff[nt][e] + 64 * u);
                         g[0] = da_i; g[HD] = da_f; g[2 * HD] = da_g; g[3 * HD] = da_o;
                     }
                 }
@@ -188,7 +193,7 @@ void lstm_bwd_kernel(BwdArgs a) {
         }
         __syncthreads();                        // every wave is done reading the image
 
-        float* const dxs = a.dX + ((long long)dir * a.rows_total + trow) * F + ucol;
+        char* const dxs = reinterpret_cast<char*>(a.dX + ((long long)dir * a.rows_total + trow) * F);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -196,7 +201,7 @@ void lstm_bwd_kernel(BwdArgs a) {
                 dh[nt][u] = acc[nt][2 + u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (val[nt][e]) dxs[(size_t)roff[nt][e] * F + 16 * u] = acc[nt][u][e];
+                    if (val[nt][e]) *reinterpret_cast<float*>(dxs + xoff[nt][e] + 64 * u) = acc[nt][u][e];
             }
         }
     }
@@ -215,6 +220,8 @@ extern "C" int dprnn_lstm_pack_bwd(const float* w_ih, const float* w_hh, const f
     return dprnn_check_launch("lstm_pack_bwd_kernel");
 }
 
+extern int dprnn_fast_activations_enabled(void);
+
 extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
                               int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                               int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
@@ -228,14 +235,15 @@ extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* p
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride};
     constexpr int NT = 2;
     const size_t lds = (size_t)16 * NT * GS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // tanh(c_t) is recomputed from the tape with the same form (v_exp_f32 / libm) the forward used
+    const bool fast = dprnn_fast_activations_enabled() != 0;
+    auto kern = fast ? &lstm_bwd_kernel<NT, true> : &lstm_bwd_kernel<NT, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fast]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lstm_bwd): %s", hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        attr_set[fast] = true;
     }
-    hipLaunchKernelGGL((lstm_bwd_kernel<NT>), dim3((nseq + 16 * NT - 1) / (16 * NT), ndir), dim3(256), lds,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((nseq + 16 * NT - 1) / (16 * NT), ndir), dim3(256), lds, (hipStream_t)stream, a);
     return dprnn_check_launch("lstm_bwd_kernel");
 }
