@@ -200,6 +200,10 @@ int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk, int T, int
  * target j; est [B][n_est][T], tgt [B][n_tgt][T], out [B][n_est][n_tgt] double. */
 int dprnn_pairwise_sisdr(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
                          void* stream);
+/* the evaluation-metric form asteroid.metrics.get_metrics(['si_sdr']) reports (src/inferencers/inferencer.py:64-70,
+ * delegating to pb_bss_eval.evaluation.si_sdr): no mean removal, no eps */
+int dprnn_pairwise_sisdr_metric(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
+                                void* stream);
 
 /* =====================  DPRNN-Spe / DPRNN-Spe-IRA speaker branch (src/models/dprnn_spe.py)  ===================== */
 

@@ -62,3 +62,15 @@ def pit_neg_sisdr_torch(est, tgt):
     losses = torch.stack([torch.stack([pw[:, i, p[i]] for i in range(n)], 1).mean(1) for p in perms], 1)   # [B, n!]
     best, idx = losses.min(1)
     return best.mean(), idx
+
+
+def si_sdr_eval_metric(est: np.ndarray, tgt: np.ndarray) -> np.ndarray:
+    """The 'si_sdr' that asteroid.metrics.get_metrics reports (inferencer.py:64-70): it delegates to
+    pb_bss_eval.evaluation.si_sdr(reference, estimation) -- neither package is installed here, published formula
+    restated (PARITY UNPINNED): no mean removal, no eps; 10 log10(|a t|^2 / |e - a t|^2), a = <e,t> / |t|^2."""
+    e = est.astype(np.float64)
+    t = tgt.astype(np.float64)
+    a = (e * t).sum(-1, keepdims=True) / (t * t).sum(-1, keepdims=True)
+    proj = a * t
+    noise = e - proj
+    return 10 * np.log10((proj * proj).sum(-1) / (noise * noise).sum(-1))

@@ -46,6 +46,7 @@ SIGNATURES = {
     "dprnn_head_mask_decode_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_decoder_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_pairwise_sisdr": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_pairwise_sisdr_metric": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_pointwise_fwd": [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i64, c_fp],
     "dprnn_bn_prep": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp, c_fp, c_i, c_fp],
     "dprnn_resblock_pool_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],

@@ -172,8 +172,11 @@ extern "C" int dprnn_decoder_fwd(const float* taps, float* out, int B, int nspk,
 // out[b][i][j] = 10 log10( |s|^2 / (|e - s|^2 + eps) + eps ),  e = est[b][i] - mean, t = tgt[b][j] - mean,
 // s = <e,t> t / (|t|^2 + eps), eps = 1e-8.  One workgroup per (b, i, j).
 namespace {
+// variant 0: the loss form above.  variant 1: the evaluation metric asteroid.metrics.get_metrics(['si_sdr']) reports
+// (src/inferencers/inferencer.py:64; it delegates to pb_bss_eval.evaluation.si_sdr): no mean removal, no eps --
+// 10 log10(|a t|^2 / |e - a t|^2), a = <e,t>/|t|^2.
 __global__ __launch_bounds__(256) void pairwise_sisdr_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
-                                                             double* __restrict__ out, int n_est, int n_tgt, int T) {
+                                                             double* __restrict__ out, int n_est, int n_tgt, int T, int variant) {
     const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x;
     const float* e = est + ((long long)b * n_est + i) * T;
     const float* t = tgt + ((long long)b * n_tgt + j) * T;
@@ -190,7 +193,8 @@ __global__ __launch_bounds__(256) void pairwise_sisdr_kernel(const float* __rest
     if (threadIdx.x == 0) {
         double v[5];
         for (int k = 0; k < 5; ++k) v[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-        const double n = (double)T, eps = 1e-8;
+        const double n = (double)T, eps = variant == 0 ? 1e-8 : 0.0;
+        if (variant != 0) { v[0] = 0.0; v[1] = 0.0; }
         const double ee = v[2] - v[0] * v[0] / n, tt = v[3] - v[1] * v[1] / n, et = v[4] - v[0] * v[1] / n;   // zero-mean moments
         const double alpha = et / (tt + eps);
         const double s2 = alpha * alpha * tt;                       // |s|^2
@@ -200,10 +204,20 @@ __global__ __launch_bounds__(256) void pairwise_sisdr_kernel(const float* __rest
 }
 }  // namespace
 
+static int pairwise_sisdr(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T, int variant,
+                          void* stream) {
+    if (!est || !tgt || !out) { dprnn_set_error("dprnn_pairwise_sisdr: null pointer"); return -1; }
+    if (B < 1 || n_est < 1 || n_tgt < 1 || T < 2 || variant < 0 || variant > 1) { dprnn_set_error("dprnn_pairwise_sisdr: bad sizes"); return -1; }
+    hipLaunchKernelGGL(pairwise_sisdr_kernel, dim3(n_tgt, n_est, B), dim3(256), 0, (hipStream_t)stream, est, tgt, out, n_est, n_tgt, T, variant);
+    return dprnn_check_launch("pairwise_sisdr_kernel");
+}
+
 extern "C" int dprnn_pairwise_sisdr(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
                                     void* stream) {
-    if (!est || !tgt || !out) { dprnn_set_error("dprnn_pairwise_sisdr: null pointer"); return -1; }
-    if (B < 1 || n_est < 1 || n_tgt < 1 || T < 2) { dprnn_set_error("dprnn_pairwise_sisdr: bad sizes"); return -1; }
-    hipLaunchKernelGGL(pairwise_sisdr_kernel, dim3(n_tgt, n_est, B), dim3(256), 0, (hipStream_t)stream, est, tgt, out, n_est, n_tgt, T);
-    return dprnn_check_launch("pairwise_sisdr_kernel");
+    return pairwise_sisdr(est, tgt, out, B, n_est, n_tgt, T, 0, stream);
+}
+
+extern "C" int dprnn_pairwise_sisdr_metric(const float* est, const float* tgt, double* out, int B, int n_est, int n_tgt, int T,
+                                           void* stream) {
+    return pairwise_sisdr(est, tgt, out, B, n_est, n_tgt, T, 1, stream);
 }
