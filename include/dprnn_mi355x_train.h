@@ -126,6 +126,17 @@ int dprnn_pit_sisdr_fwd(const float* est, const float* tgt, double* moments, dou
 int dprnn_pit_sisdr_bwd(const float* est, const float* tgt, const int* perm, const double* coef,
                         const float* upstream, float* dEst, int B, int n, int T, void* stream);
 
+/* ---- torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over ALL parameters in two launches
+ * (src/trainers/trainer.py:115-118; scripts/train/config_bss.yaml:30-33).  table: n_tensors device records
+ * {float* p; const float* g; float* m; float* v; int64 numel} (40 bytes each).  dprnn_multi_sumsq adds the sum of squares
+ * of every g to out[0] (fp64, zeroed by the caller).  dprnn_adam_multi applies, with the clip coefficient
+ * c = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping): g' = c*g + weight_decay*p;
+ * m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps) -- the update of
+ * torch.optim.Adam (amsgrad off); .grad is not modified. */
+int dprnn_multi_sumsq(const void* table, int n_tensors, double* out, void* stream);
+int dprnn_adam_multi(const void* table, int n_tensors, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float max_norm, const double* sumsq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

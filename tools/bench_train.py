@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--budget-gb", type=float, default=None)
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of training.FusedAdam")
     a = ap.parse_args()
     if a.budget_gb is not None:
         training.SAVE_BUDGET_BYTES = int(a.budget_gb * (1 << 30))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if a.torch_adam else training.FusedAdam(model.parameters(), lr=1e-3)
     lossm = PITSiSdrLoss()
     g = torch.Generator(device="cpu").manual_seed(1)
     src = 0.07 * torch.randn(a.batch, 2, a.samples, generator=g)
@@ -48,8 +49,11 @@ def main():
         out = model(mix)
         loss = lossm(out, tgt)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
-        opt.step()
+        if a.torch_adam:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
+            opt.step()
+        else:
+            opt.step(clip_norm=5)
         return loss
 
     l0 = step().item()

@@ -76,6 +76,8 @@ SIGNATURES = {
     "dprnn_scratch_to_grad": [c_fp, c_fp, c_i, c_i, c_fp],
     "dprnn_pit_sisdr_fwd": [c_fp] * 7 + [c_i, c_i, c_i, c_fp],
     "dprnn_pit_sisdr_bwd": [c_fp] * 6 + [c_i, c_i, c_i, c_fp],
+    "dprnn_multi_sumsq": [c_fp, c_i, c_fp, c_fp],
+    "dprnn_adam_multi": [c_fp, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_fp, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],

@@ -556,3 +556,65 @@ extern "C" int dprnn_pit_sisdr_bwd(const float* est, const float* tgt, const int
     hipLaunchKernelGGL(pit_bwd_kernel, dim3(gx, B * n), dim3(256), 0, (hipStream_t)stream, est, tgt, perm, coef, upstream, B, n, T, dEst);
     return dprnn_check_launch("pit_bwd_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------ clip + Adam over all parameters
+// torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (src/trainers/trainer.py:115-118; optimizer configured in
+// scripts/train/config_bss.yaml:30-33) as two launches over a device table of tensors instead of ~10 small launches per
+// parameter: (1) sum of squares of every gradient in fp64, (2) the Adam update with the clip coefficient
+// min(1, max_norm / (norm + 1e-6)) applied to the gradient on the fly (the update is identical to clipping .grad first;
+// .grad itself is left untouched).  weight_decay is the L2 form of torch.optim.Adam (g += wd * p).
+namespace {
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; };
+
+__global__ __launch_bounds__(256)
+void multi_sumsq_kernel(const AdamEntry* __restrict__ tab, double* __restrict__ out) {
+    const AdamEntry e = tab[blockIdx.y];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) {
+        const double x = e.g[i];
+        s += x * x;
+    }
+    s = wave_sum(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256)
+void adam_multi_kernel(const AdamEntry* __restrict__ tab, float lr, float b1, float b2, float eps, float wd,
+                       float bc1, float bc2_sqrt, float max_norm, const double* __restrict__ sumsq) {
+    const AdamEntry e = tab[blockIdx.y];
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float nrm = (float)sqrt(*sumsq);
+        coef = fminf(1.f, max_norm / (nrm + 1e-6f));
+    }
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) {
+        float g = e.g[i] * coef;
+        const float p = e.p[i];
+        if (wd != 0.f) g = fmaf(wd, p, g);
+        const float m = b1 * e.m[i] + (1.f - b1) * g;
+        const float v = b2 * e.v[i] + (1.f - b2) * g * g;
+        e.m[i] = m; e.v[i] = v;
+        e.p[i] = p - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    }
+}
+}  // namespace
+
+extern "C" int dprnn_multi_sumsq(const void* table, int n_tensors, double* out, void* stream) {
+    if (!table || !out || n_tensors < 1) { dprnn_set_error("dprnn_multi_sumsq: null pointer / count"); return -1; }
+    hipLaunchKernelGGL(multi_sumsq_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const AdamEntry*>(table), out);
+    return dprnn_check_launch("multi_sumsq_kernel");
+}
+
+extern "C" int dprnn_adam_multi(const void* table, int n_tensors, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, float max_norm, const double* sumsq, void* stream) {
+    if (!table || n_tensors < 1 || step < 1 || (max_norm > 0.f && !sumsq)) { dprnn_set_error("dprnn_adam_multi: bad arguments"); return -1; }
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const AdamEntry*>(table), lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), max_norm, sumsq);
+    return dprnn_check_launch("adam_multi_kernel");
+}

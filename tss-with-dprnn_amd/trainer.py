@@ -20,7 +20,7 @@ from typing import Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from .training import PITSiSdrLoss
+from .training import FusedAdam, PITSiSdrLoss
 
 
 def _world():
@@ -82,9 +82,12 @@ def train_step(model, loss_module, optimizer, mix, target, clip_norm: float = 0.
     loss.backward()
     if reducer is not None:
         reducer.average()
-    if clip_norm:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
-    optimizer.step()
+    if isinstance(optimizer, FusedAdam):
+        optimizer.step(clip_norm=clip_norm)              # clip + Adam in two launches
+    else:
+        if clip_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+        optimizer.step()
     return loss.detach(), est.detach()
 
 
