@@ -30,10 +30,16 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--budget-gb", type=float, default=None)
+    ap.add_argument("--groups", type=int, default=None, help="training.TRAIN_STREAM_GROUPS")
+    ap.add_argument("--min-group", type=int, default=None, help="training.MIN_TRAIN_GROUP")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of training.FusedAdam")
     a = ap.parse_args()
     if a.budget_gb is not None:
         training.SAVE_BUDGET_BYTES = int(a.budget_gb * (1 << 30))
+    if a.groups is not None:
+        training.TRAIN_STREAM_GROUPS = a.groups
+    if a.min_group is not None:
+        training.MIN_TRAIN_GROUP = a.min_group
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0).to(dev).train()

@@ -26,6 +26,12 @@ from .engine import F_BUILT, Stage, _norm_params, _p, _param, _rnn_tensors
 
 SAVE_BUDGET_BYTES = 160 << 30        # activations one forward may keep for its backward
 PACKT_PER_DIR = 512 * 256
+# Utterances are independent, so a (micro-)batch is processed as TRAIN_STREAM_GROUPS complete forward / backward
+# pipelines on their own HIP streams (as the inference path does): one group's weight-gradient GEMMs and streaming
+# passes fill the CUs another group's serial recurrence launches leave idle.
+TRAIN_STREAM_GROUPS = 2
+MIN_TRAIN_GROUP = 8                  # utterances per group at least
+_SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
 def check_supported_train(cfg: dict) -> None:
@@ -301,6 +307,62 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     return grads
 
 
+def _group_parts(n: int):
+    g = max(1, min(TRAIN_STREAM_GROUPS, n // MIN_TRAIN_GROUP))
+    cuts = [round(i * n / g) for i in range(g + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(g)]
+
+
+def _run_groups(dev, parts, fn):
+    """fn(b0, b1) for every part, each on its own persistent side stream (the same stream in forward and backward, so
+    the saved activations never cross streams); the caller's stream waits for all of them."""
+    if len(parts) == 1:
+        return [fn(*parts[0])]
+    pool = _SIDE_STREAMS.setdefault(dev, [])
+    while len(pool) < len(parts):
+        pool.append(torch.cuda.Stream(device=dev))
+    main = torch.cuda.current_stream(dev)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    results = []
+    for (b0, b1), side in zip(parts, pool):
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            results.append(fn(b0, b1))
+    for side in pool[: len(parts)]:
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+    return results
+
+
+def _to_main(t: torch.Tensor, dev):
+    t.record_stream(torch.cuda.current_stream(dev))       # produced on a side stream, consumed (and freed) on the caller's
+    return t
+
+
+def _forward_groups(model, wav):
+    dev = wav.device
+    parts = _group_parts(wav.shape[0])
+    res = _run_groups(dev, parts, lambda b0, b1: forward_train(model, wav[b0:b1].contiguous(), keep=True))
+    outs = [_to_main(r[0], dev) for r in res]
+    return (outs[0] if len(outs) == 1 else torch.cat(outs)), (parts, [r[1] for r in res])
+
+
+def _backward_groups(model, saved, d_out):
+    dev = d_out.device
+    parts, saved_list = saved
+    res = _run_groups(dev, parts, lambda b0, b1: backward(model, saved_list[parts.index((b0, b1))], d_out[b0:b1]))
+    saved_list.clear()
+    grads = res[0]
+    for k in grads:
+        _to_main(grads[k], dev)
+    for other in res[1:]:
+        for k in grads:
+            grads[k] += _to_main(other[k], dev)
+    return grads
+
+
 class _TasNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, wav, names, *params):
@@ -313,7 +375,7 @@ class _TasNetFunction(torch.autograd.Function):
         per_utt = saved_bytes_per_utt(geo, len(ndirs), ndirs)
         mb_max = max(1, SAVE_BUDGET_BYTES // per_utt)
         if mb_max >= B:
-            out, saved = forward_train(model, wav, keep=True)
+            out, saved = _forward_groups(model, wav)
             ctx.saved, ctx.wav, ctx.mb = saved, None, B
         else:
             # too large to keep: balanced micro-batches.  The first one runs the training forward and keeps its
@@ -321,7 +383,7 @@ class _TasNetFunction(torch.autograd.Function):
             # tape inside the backward, one micro-batch at a time.
             n_mb = -(-B // mb_max)
             mb = -(-B // n_mb)
-            out0, saved = forward_train(model, wav[:mb].contiguous(), keep=True)
+            out0, saved = _forward_groups(model, wav[:mb])
             with torch.no_grad():
                 out = torch.cat([out0, engine.tasnet_forward(model, wav[mb:].contiguous())])
             ctx.saved, ctx.wav, ctx.mb = saved, wav, mb
@@ -337,13 +399,13 @@ class _TasNetFunction(torch.autograd.Function):
         model, names = ctx.model, ctx.names
         d_out = d_out.contiguous()
         mb = ctx.mb
-        grads = backward(model, ctx.saved, d_out[:mb])
+        grads = _backward_groups(model, ctx.saved, d_out[:mb])
         ctx.saved = None
         if ctx.wav is not None:
             wav = ctx.wav
             for b0 in range(mb, wav.shape[0], mb):
-                _, saved = forward_train(model, wav[b0:b0 + mb].contiguous(), keep=True)
-                g = backward(model, saved, d_out[b0:b0 + mb])
+                _, saved = _forward_groups(model, wav[b0:b0 + mb])
+                g = _backward_groups(model, saved, d_out[b0:b0 + mb])
                 del saved
                 for k in g:
                     grads[k] += g[k]
