@@ -174,8 +174,10 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
         st.call("dprnn_scratch_to_grad", dptr(off), _p(g), g.numel() if n is None else n, 0)
         return g
 
-    ws_floats = max(lib.dprnn_wgrad_workspace_floats(512, 256, rows), lib.dprnn_wgrad_workspace_floats(256, 128, R))
-    ws = torch.empty(ws_floats, **f32)
+    # one workspace for every weight-gradient GEMM of this pass: (M, N, rows) of all dprnn_wgrad calls below
+    shapes = [(N, F_BUILT, R), (2 * F_BUILT, F_BUILT, R), (2 * F_BUILT, F_BUILT, B * L), (F_BUILT, 2 * F_BUILT, rows),
+              (4 * F_BUILT, 2 * F_BUILT, rows), (F_BUILT, N, B * L)]
+    ws = torch.empty(max(lib.dprnn_wgrad_workspace_floats(m_, n_, r_) for m_, n_, r_ in shapes), **f32)
 
     def wgrad(Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, dW, ldm, ldn, db0, db1):
         st.call("dprnn_wgrad", Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, _p(dW), ldm, ldn,
