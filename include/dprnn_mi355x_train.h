@@ -51,11 +51,13 @@ int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n
                 float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
                 float* workspace, void* stream);
 
-/* ---- data gradient of a Linear / 1x1 conv: dA[row][0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1 (kd-k0 rows)]
+/* ---- data gradient of a Linear / 1x1 conv: dA[row*lda + 0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1 (kd-k0 rows)]
  * row-major torch weights [kd][ldw] read transposed; (kd, nd) in {(128,256), (128,128), (64,128), (256,128), (128,64)}:
- * intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out + gate convs (:157-158), bottleneck conv (:135). */
+ * intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out + gate convs (:157-158), bottleneck conv (:135), speaker
+ * encoder convs (dprnn_spe.py:18-19,27,117-122; a 256 -> 256 conv is two calls on 128-column halves: W0 and dA offset by
+ * the column, lda = 256). */
 int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
-                float* dA, int nd, int64_t rows, void* stream);
+                float* dA, int lda, int nd, int64_t rows, void* stream);
 
 /* ---- training variants of the mask-head forward (dprnn_mi355x.h) that keep what the backward needs:
  * TG [rows][256] = [tanh(out conv) | sigmoid(gate conv)] (dprnn.py:157-158), mask [B*L*2][N] rows (b,l,spk) (:161-164) */
@@ -107,7 +109,7 @@ int dprnn_segment_bwd(const float* dXn, const float* dXa, const float* dXb, floa
 /* ---- encoder + bottleneck norm (encoder_decoder.py:25-33, dprnn.py:131-134); the encoder output is recomputed from
  * the waveform, never stored.  norm_rows: A[(b,l)][n] = enc*sc + sh (Q operand of the bottleneck conv weight gradient).
  * norm_bwd_stats: red[b], dgb[0:64 | 64:128] of the bottleneck norm for dy = dA.  encoder_bwd: gradient of the
- * encoder output (norm backward + dEnc from the masking), ReLU, and dWe[N*ks] += d_pre * wav (fp64 scratch). */
+ * encoder output (norm backward + dEnc from the masking; dEnc may be NULL), ReLU, and dWe[N*ks] += d_pre * wav (fp64 scratch). */
 int dprnn_encoder_norm_rows(const float* wav, const float* enc_w, const float* sc, const float* sh, float* A,
                             int B, int T, int L, int N, int ks, int stride, void* stream);
 int dprnn_encoder_norm_bwd_stats(const float* wav, const float* enc_w, const float* dA, const double* stats,
@@ -125,6 +127,55 @@ int dprnn_pit_sisdr_fwd(const float* est, const float* tgt, double* moments, dou
                         int* perm, double* coef, int B, int n, int T, void* stream);
 int dprnn_pit_sisdr_bwd(const float* est, const float* tgt, const int* perm, const double* coef,
                         const float* upstream, float* dEst, int B, int n, int T, void* stream);
+
+/* =====================  DPRNN-Spe speaker branch and fusions (src/models/dprnn_spe.py), backward  ===================== */
+
+/* ---- time mean (dprnn_spe.py:159-162): dE[b][t][c] = d_emb[b][c] / aux_T_b */
+int dprnn_time_mean_bwd(const float* d_emb, const float* aux_len, int n_len, float* dE, int B, int T3, int C, int ks,
+                        void* stream);
+
+/* ---- tail of ResBlock.forward backward (dprnn_spe.py:36-42; MaxPool1d(3) + PReLU + residual add): given dOut [B][T_in/3][C]
+ * writes dU [B][T_in][C], the gradient of u = Y2*scale + shift + res (it is the gradient of the BatchNorm2 output AND of
+ * the residual branch), and adds the PReLU slope gradient to the fp64 scratch scalar dalpha */
+int dprnn_resblock_pool_bwd(const float* dOut, const float* Y2, const float* scale, const float* shift, const float* res,
+                            const float* prelu_w, float* dU, double* dalpha, int B, int T_in, int C, void* stream);
+
+/* ---- nn.BatchNorm1d backward (dprnn_spe.py:20-21,32,35).  dprnn_bn_moments: per-channel mean / rstd the forward used
+ * (col_stats != NULL: batch statistics of train mode; NULL: running statistics of eval mode).  dprnn_bn_bwd: red[0:C] +=
+ * sum dY (= dbeta), red[C:2C] += sum dY*xh (= dgamma) in fp64 scratch, then dX = gamma*rstd*(dY - red0/M - xh*red1/M)
+ * (train) or dY*gamma*rstd (eval).  C = 128 or 256. */
+int dprnn_bn_moments(const double* col_stats, const float* running_mean, const float* running_var, int64_t count,
+                     float eps, float* mean, float* rstd, int C, void* stream);
+int dprnn_bn_bwd(const float* dY, const float* Y, const float* mean, const float* rstd, const float* gamma,
+                 int train, double* red, float* dX, int64_t M, int C, void* stream);
+
+/* ---- PReLU(BatchNorm1(conv1)) between the two convs of a ResBlock (dprnn_spe.py:33-34): rows = prelu(Y*scale + shift)
+ * (the Q operand of conv2's weight gradient) and its backward dB = dA*prelu'(b), dalpha (fp64 scratch scalar) */
+int dprnn_affine_prelu_rows(const float* Y, const float* scale, const float* shift, const float* prelu_w, float* out,
+                            int64_t M, int C, void* stream);
+int dprnn_affine_prelu_bwd(const float* dA, const float* Y, const float* scale, const float* shift, const float* prelu_w,
+                           float* dB, double* dalpha, int64_t M, int C, void* stream);
+
+/* out = a + b (n floats, multiple of 4): the two branches of a ResBlock meeting at its input */
+int dprnn_add_rows(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* out[b][c] += sum_l A[(b,l)][c] (fp64 scratch [B][C]): gradient of the per-utterance bias row of the 'cat' fusion */
+int dprnn_utt_colsum(const float* A, double* out, int B, int L, int C, void* stream);
+
+/* ---- gradients of dprnn_linear_small_fwd (pred_linear, fusion_linear*, aux_linear, the 'cat' half of bottleneck.1):
+ * d_in[b][k] (+)= sum_o d_out[b][o]*W[o*ldw + k0 + k] (d_in may be NULL); dW[o*ldw + k0 + k] = sum_b d_out[b][o]*in[b][k],
+ * db[o] = sum_b d_out[b][o] (dW / db may be NULL) */
+int dprnn_linear_small_bwd(const float* d_out, int do_pitch, const float* in, int in_pitch, const float* W, int ldw,
+                           int k0, int K, float* d_in, int di_pitch, int accumulate_in, float* dW, float* db,
+                           int B, int O, void* stream);
+
+/* ---- per-channel fusion operands (dprnn_spe.py:194-229: 'add', 'mul', 'film'; also the 'att' channel factor):
+ * a' = an*mul + add with an = enc*sc0 + sh0 the plain bottleneck-norm output (sc0/sh0 from dprnn_bottleneck_prep without
+ * mul/add).  Given dAp = gradient of a': dAn = dAp*mul (mul NULL: copy), dmul[b][c] += sum_l dAp*an, dadd[b][c] += sum_l dAp
+ * (fp64 scratch [B][N], either may be NULL). */
+int dprnn_fusion_bwd(const float* wav, const float* enc_w, const float* sc0, const float* sh0, const float* dAp,
+                     const float* mul, float* dAn, double* dmul, double* dadd,
+                     int B, int T, int L, int N, int ks, int stride, void* stream);
 
 /* ---- torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over ALL parameters in two launches
  * (src/trainers/trainer.py:115-118; scripts/train/config_bss.yaml:30-33).  table: n_tensors device records

@@ -147,10 +147,67 @@ def make_grad_cases(only):
         print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}")
 
 
+GRAD_SPE_CASES = [
+    # name, cfg overrides, batch, samples, reference samples, seed, BatchNorm in train mode
+    ("grad_spe_wide_cat", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 3, 300, 520, 80, True),
+    ("grad_spe_wide_cat_bneval", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 2, 300, 411, 81, False),
+    ("grad_spe_wide_add", dict(WIDE, fusion_type="add", norm_type="gLN", n_repeats=1, num_spks=11), 2, 211, 300, 82, True),
+    ("grad_spe_wide_mul", dict(WIDE, fusion_type="mul", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 83, True),
+    ("grad_spe_wide_film", dict(WIDE, fusion_type="film", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 84, True),
+]
+
+
+def make_grad_spe_cases(only):
+    """Training step of the reference for DPRNN-Spe (trainer_spe.py:25-46): est, aux = model(mix, reference, ref_len);
+    loss = PIT(-SI-SDR)(est[:, None], target[:, None]) + ce_gamma * CrossEntropy(aux, spk_idx); loss.backward()."""
+    from oracle.sisdr import pit_neg_sisdr_torch
+    from oracle.weights import make_sources
+    for name, over, B, T, Ta, seed, bn_train in GRAD_SPE_CASES:
+        if only and name not in only:
+            continue
+        cfg = full_cfg(**over)
+        model = build("spe", cfg)
+        load_recipe(model, "spe", cfg, seed)
+        model.train()
+        if not bn_train:
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.BatchNorm1d):
+                    mod.eval()
+        src, mix = make_sources(B, T, seed=3000 + seed)
+        aux = make_mixture(B, Ta, seed=4000 + seed)
+        spk_idx = np.random.default_rng(seed).integers(0, cfg["num_spks"], size=B)
+        est, logits = model(torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(float(Ta)))
+        tgt = torch.from_numpy(src[:, 0, :est.shape[-1]].copy())
+        l, _ = pit_neg_sisdr_torch(est.unsqueeze(1), tgt.unsqueeze(1))
+        ce = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(spk_idx))
+        loss = l + 0.5 * ce
+        loss.backward()
+        save = dict(mix=mix, aux=aux, aux_len=np.float32(Ta), tgt=tgt.numpy(), spk_idx=spk_idx, out=est.detach().numpy(),
+                    logits=logits.detach().numpy(), loss=np.float64(loss.item()))
+        for k, prm in model.named_parameters():
+            if prm.grad is None:
+                continue
+            g = prm.grad.numpy()
+            save["norm_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            if g.size <= 17000:              # smaller cut than the BSS cases: five more files
+                save["grad_" + k] = g
+            else:
+                save["proj_" + k] = (grad_projection(k, g.shape).astype(np.float64) @ g.reshape(-1).astype(np.float64))
+        for k, v in model.state_dict().items():
+            if "running_" in k:
+                save["buf_" + k] = v.numpy()
+        meta = dict(name=name, kind="spe", cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
+                    bn_training=bn_train, torch=torch.__version__)
+        save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
+        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}")
+
+
 def main():
     contract = {}
     only = set(sys.argv[1:])
-    make_grad_cases(only)          # optional: regenerate just the named cases (keeps the other files byte-identical)
+    make_grad_cases(only)
+    make_grad_spe_cases(only)          # optional: regenerate just the named cases (keeps the other files byte-identical)
     for name, kind, over, B, T, seed, want_taps, bn_train in CASES:
         if only and name not in only:
             continue

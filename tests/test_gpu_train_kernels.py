@@ -119,7 +119,7 @@ def test_dgrad_matches_matmul(kd, nd):
     want = dOut.astype(np.float64) @ W.astype(np.float64)
     st = _st()
     dA = torch.full((rows, nd), float("nan"), device=DEV)
-    st.call("dprnn_dgrad", _p(_t(dOut)), kd, _p(_t(W0)), nd, k0, _p(_t(W1)) if W1 is not None else 0, nd, _p(dA), nd, rows)
+    st.call("dprnn_dgrad", _p(_t(dOut)), kd, _p(_t(W0)), nd, k0, _p(_t(W1)) if W1 is not None else 0, nd, _p(dA), nd, nd, rows)
     torch.cuda.synchronize()
     assert rel_l2(dA.cpu().numpy(), want) < 1e-6
 

@@ -60,7 +60,7 @@ SIGNATURES = {
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
                     c_fp, c_fp, c_i, c_fp, c_fp],
-    "dprnn_dgrad": [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i64, c_fp],
+    "dprnn_dgrad": [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i64, c_fp],
     "dprnn_head_gate_fwd_train": [c_fp] * 7 + [c_i64, c_fp],
     "dprnn_head_mask_decode_fwd_train": [c_fp] * 7 + [c_i] * 7 + [c_fp],
     "dprnn_head_conv_bwd": [c_fp] * 6 + [c_i] * 5 + [c_fp],
@@ -77,6 +77,16 @@ SIGNATURES = {
     "dprnn_pit_sisdr_fwd": [c_fp] * 7 + [c_i, c_i, c_i, c_fp],
     "dprnn_pit_sisdr_bwd": [c_fp] * 6 + [c_i, c_i, c_i, c_fp],
     "dprnn_multi_sumsq": [c_fp, c_i, c_fp, c_fp],
+    "dprnn_time_mean_bwd": [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_resblock_pool_bwd": [c_fp] * 8 + [c_i, c_i, c_i, c_fp],
+    "dprnn_bn_moments": [c_fp, c_fp, c_fp, c_i64, c_f, c_fp, c_fp, c_i, c_fp],
+    "dprnn_bn_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_i64, c_i, c_fp],
+    "dprnn_affine_prelu_rows": [c_fp] * 5 + [c_i64, c_i, c_fp],
+    "dprnn_affine_prelu_bwd": [c_fp] * 7 + [c_i64, c_i, c_fp],
+    "dprnn_add_rows": [c_fp, c_fp, c_fp, c_i64, c_fp],
+    "dprnn_utt_colsum": [c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_linear_small_bwd": [c_fp, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp],
+    "dprnn_fusion_bwd": [c_fp] * 9 + [c_i] * 6 + [c_fp],
     "dprnn_adam_multi": [c_fp, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_fp, c_fp],
 }
 _VOID = {

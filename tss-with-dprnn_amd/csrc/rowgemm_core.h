@@ -169,8 +169,8 @@ struct EpBiasStore {            // out[row][col] = acc*row_scale[row] + bias[col
 };
 
 template <int RT, int NCT>
-struct EpStore {                // out[row][col] = acc: plain store, one base pointer per row on full tiles
-    float* out;
+struct EpStore {                // out[row*pitch + col] = acc: plain store, one base pointer per row on full tiles
+    float* out; long long pitch;
     __device__ void begin() {}
     __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
@@ -181,7 +181,7 @@ struct EpStore {                // out[row][col] = acc: plain store, one base po
             for (int e = 0; e < 4; ++e) {
                 const long long row = row0 + 16 * rt + 4 * q + e;
                 if (full || row < M) {
-                    float* o = out + row * (16 * NCT) + r;
+                    float* o = out + row * pitch + r;
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) o[16 * ct] = acc[rt][ct][e];
                 }

@@ -290,7 +290,7 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
                 dgam = fmaf(dy, xh, dgam); dbet += dy;
                 s1 = fmaf(g, dy, s1); s2 = fmaf(g * dy, xh, s2);
             } else {
-                const float denc = rs * (g * dy - m1 - xh * m2) + dEnc[row * 64 + n];
+                const float denc = rs * (g * dy - m1 - xh * m2) + (dEnc ? dEnc[row * 64 + n] : 0.f);
                 const float dpre = en > 0.f ? denc : 0.f;
 #pragma unroll
                 for (int j = 0; j < KSMAX; ++j)
@@ -522,7 +522,7 @@ extern "C" int dprnn_encoder_norm_bwd_stats(const float* wav, const float* enc_w
 extern "C" int dprnn_encoder_bwd(const float* wav, const float* enc_w, const float* dA, const double* stats,
                                  const float* gamma, float eps, const double* red, const float* dEnc, double* dWe,
                                  int B, int T, int L, int N, int ks, int stride, void* stream) {
-    if (!wav || !enc_w || !dA || !stats || !gamma || !red || !dEnc || !dWe) { dprnn_set_error("dprnn_encoder_bwd: null pointer"); return -1; }
+    if (!wav || !enc_w || !dA || !stats || !gamma || !red || !dWe) { dprnn_set_error("dprnn_encoder_bwd: null pointer"); return -1; }
     if (N != 64 || ks < 1 || ks > KSMAX || L != (T - ks) / stride + 1) { dprnn_set_error("dprnn_encoder_bwd: unsupported N=%d ks=%d", N, ks); return -1; }
     const Geo geo{B, T, L, N, ks, stride};
     const int ch = enc_chunks(B, L);

@@ -211,18 +211,19 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
 }
 
 // ------------------------------------------------------------------------------------------------ data gradients
-// dA[row][0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1] row-major [kd][ldw]: (kd, nd) in {(128,256), (128,128),
+// dA[row*lda + 0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1] row-major [kd][ldw]: (kd, nd) in {(128,256), (128,128),
 // (64,128), (256,128), (128,64)} -- intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out+gate convs (:157-158),
-// bottleneck conv (:135).
+// bottleneck conv (:135), speaker-encoder convs (dprnn_spe.py:18-19,27,117-122; 256 -> 256 as two 128-column halves:
+// offset W0 and dA by the column, lda = 256).
 extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
-                           float* dA, int nd, int64_t rows, void* stream) {
-    if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1)) { dprnn_set_error("dprnn_dgrad: null pointer / rows"); return -1; }
+                           float* dA, int lda, int nd, int64_t rows, void* stream) {
+    if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1) || lda < nd) { dprnn_set_error("dprnn_dgrad: null pointer / rows / lda"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     // row tiles per wave: 4 x 16 rows while the accumulators fit (ND <= 128), 2 x 16 for the 256-wide outputs
 #define DG_CASE(KD, ND, RT)                                                                                          \
     if (kd == KD && nd == ND) {                                                                                      \
         PlainRows<RT> al{dOut, kd};                                                                                  \
-        EpStore<RT, ND / 16> ep{dA};                                                                                 \
+        EpStore<RT, ND / 16> ep{dA, lda};                                                                               \
         return launch_rowgemm<KD, ND, RT, true>("dgrad" #KD "x" #ND, W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st); \
     }
     DG_CASE(128, 256, 2)

@@ -83,11 +83,8 @@ class DPRNNSpe(DPRNN):
         raise DprnnError("DPRNNSpe consumes raw waveforms on the MI355X path; call DPRNNSpeTasNet / DPRNNSpeIRATasNet")
 
 
-def _refuse_training(module, name):
-    if torch.is_grad_enabled() and module.training and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            f"{name} (MI355X): backward kernels are not built yet; run the forward under torch.no_grad() "
-            "(BatchNorm train-mode statistics are honoured under no_grad)")
+def _wants_grad(module):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
 class DPRNNSpeTasNet(nn.Module):
@@ -116,5 +113,11 @@ class DPRNNSpeTasNet(nn.Module):
     _ira = False
 
     def forward(self, input, aux, aux_len, debug=None):
-        _refuse_training(self, type(self).__name__)
+        if debug is None and _wants_grad(self):
+            if self._ira:
+                raise NotImplementedError(
+                    f"{type(self).__name__} (MI355X): the two-pass IRA wrapper has inference kernels only; run the forward "
+                    "under torch.no_grad() (training path: DPRNNTasNet and DPRNNSpeTasNet)")
+            from . import training_spe              # differentiable forward: autograd.Function over the HIP kernels
+            return training_spe.spe_forward_autograd(self, input, aux, aux_len)
         return engine.spe_forward(self, input, aux, aux_len, ira=self._ira, debug=debug)

@@ -62,8 +62,10 @@ def _addr(geo, intra):
     return (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
 
 
-def forward_train(model, wav: torch.Tensor, keep: bool = True):
-    """DPRNNTasNet.forward (dprnn.py:271-283) keeping the activations the backward needs.  Returns (out, saved)."""
+def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[dict] = None):
+    """DPRNNTasNet.forward (dprnn.py:271-283) keeping the activations the backward needs.  Returns (out, saved).
+    fusion (DPRNN-Spe, dprnn_spe.py:165-229): dict(mul, add, row_bias) entering the bottleneck; the output is then the
+    [B, 2, T_out] decode of both mask channels, of which DPRNN-Spe uses speaker 0."""
     cfg = model.cfg
     dev = wav.device
     st = Stage(dev)
@@ -81,8 +83,9 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True):
     f32 = dict(device=dev, dtype=torch.float32)
     stats = torch.zeros(1 + npth, B, 2, device=dev, dtype=torch.float64)
     lib.dprnn_set_gemm_mode(0)
-    sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0])
-    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo)
+    fusion = fusion or {}
+    sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], fusion.get("mul"), fusion.get("add"))
+    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"))
     X = [torch.empty(rows, F_BUILT, **f32)]
     Z, H, tapes = [], [], []
     st.call("dprnn_segment_fwd", _p(Y), _p(X[0]), B, L, K, P, S)
@@ -132,12 +135,35 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True):
     out = engine.decode(st, taps, geo, 2)
     if not keep:
         return out, None
-    saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask)
+    saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask,
+                 fusion=fusion)
     return out, saved
 
 
-def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Gradients of every parameter for the upstream gradient d_out [B, 2, T_out]; keys are state_dict names."""
+class _Scratch:
+    """Zeroed fp64 scratch for the small reductions of one backward pass, handed out in named slots."""
+
+    def __init__(self, dev, n: int = 1 << 16):
+        self.buf = torch.zeros(n, device=dev, dtype=torch.float64)
+        self.off: Dict[str, int] = {}
+        self.top = 0
+
+    def slot(self, name: str, n: int) -> int:
+        """Device address of slot `name` (created on first use)."""
+        if name not in self.off:
+            if self.top + n > self.buf.numel():
+                raise DprnnError("training scratch exhausted")
+            self.off[name] = self.top
+            self.top += n
+        return self.buf.data_ptr() + 8 * self.off[name]
+
+
+def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch] = None, extras: Optional[dict] = None
+             ) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter of the separator path for the upstream gradient d_out [B, 2, T_out]; keys are
+    state_dict names.  With `extras` (DPRNN-Spe) the gradients of the fusion operands are returned in it (d_mul, d_add,
+    d_row_bias: float32 [B, N|F]) and the encoder-weight gradient stays in scratch slot 'dWe' for the caller to finish
+    after the reference-utterance branch has added its share."""
     cfg = model.cfg
     geo: engine.Geometry = saved["geo"]
     wav = saved["wav"]
@@ -158,20 +184,14 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     stats, X, Z, H, tapes = saved["stats"], saved["X"], saved["Z"], saved["H"], saved["tapes"]
     grads: Dict[str, torch.Tensor] = {}
 
-    # fp64 scratch for the small reductions: [dWd | dWe | dalpha | db2d | bottleneck (red B*2, dgb 2*64) | per path (red B*2, dgb 2*128)]
-    o_wd, o_we, o_al, o_b2 = 0, N * ks, 2 * N * ks, 2 * N * ks + 1
-    o_bn = o_b2 + 2 * F_BUILT
-    o_path = o_bn + 2 * B + 2 * N
-    per_path = 2 * B + 2 * F_BUILT
-    scratch = torch.zeros(o_path + npth * per_path, device=dev, dtype=torch.float64)
-    sp = scratch.data_ptr()
+    scr = scratch if scratch is not None else _Scratch(dev)
+    fusion = saved.get("fusion") or {}
+    if (fusion and extras is None) or fusion.get("row_scale") is not None:
+        raise DprnnError("training path: this fusion has no backward here")
 
-    def dptr(off):
-        return sp + 8 * off
-
-    def to_grad(off, like, n=None):
+    def to_grad(addr, like):
         g = torch.empty_like(like)
-        st.call("dprnn_scratch_to_grad", dptr(off), _p(g), g.numel() if n is None else n, 0)
+        st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
         return g
 
     # one workspace for every weight-gradient GEMM of this pass: (M, N, rows) of all dprnn_wgrad calls below
@@ -187,12 +207,12 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     dE = torch.empty(R, N, **f32)
     dEnc = torch.empty(B * L, N, **f32)
     st.call("dprnn_mask_decode_bwd", _p(d_out), _p(wav), _p(enc_w), _p(dec_w), _p(saved["mask"]),
-            1 if cfg["activation_type"] == "relu" else 0, _p(dE), _p(dEnc), dptr(o_wd), B, geo.T, L, N, ks, geo.stride)
-    grads["decoder.weight"] = to_grad(o_wd, dec_w)
+            1 if cfg["activation_type"] == "relu" else 0, _p(dE), _p(dEnc), scr.slot("dWd", N * ks), B, geo.T, L, N, ks, geo.stride)
+    grads["decoder.weight"] = to_grad(scr.slot("dWd", N * ks), dec_w)
     # ---- end_conv1x1 (dprnn.py:160,181)
     w_end = sep.end_conv1x1.weight
     dV = torch.empty(R, F_BUILT, **f32)
-    st.call("dprnn_dgrad", _p(dE), N, _p(w_end), F_BUILT, N, 0, 0, _p(dV), F_BUILT, R)
+    st.call("dprnn_dgrad", _p(dE), N, _p(w_end), F_BUILT, N, 0, 0, _p(dV), F_BUILT, F_BUILT, R)
     g = torch.empty_like(w_end)
     wgrad(_p(dE), N, N, _p(saved["V"]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, R, 1, 1, g, F_BUILT, 1, None, None)
     grads["separation.end_conv1x1.weight"] = g
@@ -203,7 +223,7 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     del dV
     dU = torch.empty(B * L, 2 * F_BUILT, **f32)          # rows (b,l,spk) of 128 == rows (b,l) of 256
     st.call("dprnn_dgrad", _p(dAG), 2 * F_BUILT, _p(sep.out[0].weight), F_BUILT, F_BUILT, _p(sep.gate[0].weight), F_BUILT,
-            _p(dU), F_BUILT, R)
+            _p(dU), F_BUILT, F_BUILT, R)
     gw = torch.empty(2 * F_BUILT, F_BUILT, **f32)
     gb = torch.empty(2 * F_BUILT, **f32)
     wgrad(_p(dAG), 2 * F_BUILT, 2 * F_BUILT, _p(saved["U"]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, R, 1, 1, gw, F_BUILT, 1, gb, None)
@@ -215,16 +235,16 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     # ---- PReLU -> conv2d -> overlap-add (dprnn.py:173-178,203-217)
     Xlast = X[npth]
     pq = torch.empty(B * L, F_BUILT, **f32)
-    st.call("dprnn_ola_prelu_sum", _p(Xlast), _p(sep.prelu.weight), _p(pq), _p(dU), dptr(o_b2), B, L, K, P, S)
+    st.call("dprnn_ola_prelu_sum", _p(Xlast), _p(sep.prelu.weight), _p(pq), _p(dU), scr.slot("db2d", 2 * F_BUILT), B, L, K, P, S)
     g = torch.empty_like(sep.conv2d.weight)
     wgrad(_p(dU), 2 * F_BUILT, 2 * F_BUILT, _p(pq), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, B * L, 1, 1, g, F_BUILT, 1, None, None)
     grads["separation.conv2d.weight"] = g
-    grads["separation.conv2d.bias"] = to_grad(o_b2, sep.conv2d.bias)
+    grads["separation.conv2d.bias"] = to_grad(scr.slot("db2d", 2 * F_BUILT), sep.conv2d.bias)
     del pq
     dX = torch.empty(rows, F_BUILT, **f32)
-    st.call("dprnn_head_conv_bwd", _p(dU), _p(sep.conv2d.weight), _p(Xlast), _p(sep.prelu.weight), _p(dX), dptr(o_al),
+    st.call("dprnn_head_conv_bwd", _p(dU), _p(sep.conv2d.weight), _p(Xlast), _p(sep.prelu.weight), _p(dX), scr.slot("dalpha", 1),
             B, L, K, P, S)
-    grads["separation.prelu.weight"] = to_grad(o_al, sep.prelu.weight)
+    grads["separation.prelu.weight"] = to_grad(scr.slot("dalpha", 1), sep.prelu.weight)
     del dU
 
     # ---- DPRNN blocks in reverse (dprnn.py:79-99)
@@ -238,18 +258,17 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
         blk = f"separation.dprnn_blocks.{p // 2}." + ("intra" if intra else "inter")
         ndir, fw, bw = _rnn_tensors(rnn, dev)
         gamma, beta, eps = _norm_params(norm)
-        o_red = o_path + p * per_path
-        o_dgb = o_red + 2 * B
+        a_red, a_dgb = scr.slot(f"red{p}", 2 * B), scr.slot(f"dgb{p}", 2 * F_BUILT)
         st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
-                _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, dptr(o_red), dptr(o_dgb))
-        st.call("dprnn_gn_bwd_dz", _p(dX), _p(Z[p]), _p(stats[1 + p]), dptr(o_red), _p(gamma), eps, B, S * K, _p(dZ))
+                _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
+        st.call("dprnn_gn_bwd_dz", _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
         gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
-        grads[f"{blk}_norm.{gname}"] = to_grad(o_dgb, gamma)
-        grads[f"{blk}_norm.{bname}"] = to_grad(o_dgb + F_BUILT, beta)
+        grads[f"{blk}_norm.{gname}"] = to_grad(a_dgb, gamma)
+        grads[f"{blk}_norm.{bname}"] = to_grad(a_dgb + 8 * F_BUILT, beta)
         # Linear (dprnn.py:88,96)
         hp = ndir * F_BUILT
         dH = torch.empty(rows, hp, **f32)
-        st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, rows)
+        st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
         Hp = H[p]
@@ -287,25 +306,46 @@ def backward(model, saved: dict, d_out: torch.Tensor) -> Dict[str, torch.Tensor]
     del dX, dXd, dZ
     bconv = sep.bottleneck[1]
     wb = bconv.weight
-    if wb.shape[1] != N:
-        raise DprnnError("training path: the bottleneck conv must take the encoder channels only (DPRNNTasNet)")
+    ldb = wb.shape[1]                      # N, or N + embeddings_size for the 'cat' fusion (dprnn_spe.py:88-89)
+    if ldb != N and "row_bias" not in fusion:
+        raise DprnnError("training path: bottleneck conv wider than the encoder output without a 'cat' fusion")
     A = torch.empty(B * L, N, **f32)
     st.call("dprnn_encoder_norm_rows", _p(wav), _p(enc_w), _p(saved["sc"]), _p(saved["sh"]), _p(A), B, geo.T, L, N, ks, geo.stride)
     gw = torch.empty_like(wb)
     gb = torch.empty_like(bconv.bias)
-    wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, N, 1, gb, None)
+    wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, ldb, 1, gb, None)     # columns [0, N) of the weight
     grads["separation.bottleneck.1.weight"], grads["separation.bottleneck.1.bias"] = gw, gb
     dA = A          # reuse
-    st.call("dprnn_dgrad", _p(dY), F_BUILT, _p(wb), N, F_BUILT, 0, 0, _p(dA), N, B * L)
+    st.call("dprnn_dgrad", _p(dY), F_BUILT, _p(wb), ldb, F_BUILT, 0, 0, _p(dA), N, N, B * L)
     gamma, beta, eps = _norm_params(sep.bottleneck[0])
-    st.call("dprnn_encoder_norm_bwd_stats", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, dptr(o_bn),
-            dptr(o_bn + 2 * B), B, geo.T, L, N, ks, geo.stride)
-    gname, bname = ("gamma", "beta") if hasattr(sep.bottleneck[0], "gamma") else ("weight", "bias")
-    grads[f"separation.bottleneck.0.{gname}"] = to_grad(o_bn + 2 * B, gamma)
-    grads[f"separation.bottleneck.0.{bname}"] = to_grad(o_bn + 2 * B + N, beta)
-    st.call("dprnn_encoder_bwd", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, dptr(o_bn), _p(dEnc), dptr(o_we),
+    if extras is not None:
+        if fusion.get("row_bias") is not None:           # 'cat': per-utterance bias row W[:, N:] @ emb
+            st.call("dprnn_utt_colsum", _p(dY), scr.slot("d_row_bias", B * F_BUILT), B, L, F_BUILT)
+            extras["d_row_bias"] = to_grad(scr.slot("d_row_bias", B * F_BUILT), torch.empty(B, F_BUILT, **f32))
+        mul, add = fusion.get("mul"), fusion.get("add")
+        if mul is not None or add is not None:           # 'add' / 'mul' / 'film': a' = an*mul + add
+            sc0 = torch.empty(B, N, **f32)
+            sh0 = torch.empty_like(sc0)
+            st.call("dprnn_bottleneck_prep", _p(stats[0]), _p(gamma), _p(beta), eps, 0, 0, _p(sc0), _p(sh0), B, L, N)
+            dAn = torch.empty(B * L, N, **f32)
+            st.call("dprnn_fusion_bwd", _p(wav), _p(enc_w), _p(sc0), _p(sh0), _p(dA), _p(mul), _p(dAn),
+                    scr.slot("d_mul", B * N) if mul is not None else 0, scr.slot("d_add", B * N) if add is not None else 0,
+                    B, geo.T, L, N, ks, geo.stride)
+            if mul is not None:
+                extras["d_mul"] = to_grad(scr.slot("d_mul", B * N), torch.empty(B, N, **f32))
+            if add is not None:
+                extras["d_add"] = to_grad(scr.slot("d_add", B * N), torch.empty(B, N, **f32))
+            dA = dAn
+    a_red0, a_dgb0 = scr.slot("red_bn", 2 * B), scr.slot("dgb_bn", 2 * N)
+    st.call("dprnn_encoder_norm_bwd_stats", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, a_red0, a_dgb0,
             B, geo.T, L, N, ks, geo.stride)
-    grads["encoder.conv1d.weight"] = to_grad(o_we, enc_w)
+    gname, bname = ("gamma", "beta") if hasattr(sep.bottleneck[0], "gamma") else ("weight", "bias")
+    grads[f"separation.bottleneck.0.{gname}"] = to_grad(a_dgb0, gamma)
+    grads[f"separation.bottleneck.0.{bname}"] = to_grad(a_dgb0 + 8 * N, beta)
+    st.call("dprnn_encoder_bwd", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, a_red0, _p(dEnc),
+            scr.slot("dWe", N * ks), B, geo.T, L, N, ks, geo.stride)
+    if extras is None:
+        grads["encoder.conv1d.weight"] = to_grad(scr.slot("dWe", N * ks), enc_w)
     return grads
 
 

@@ -1,0 +1,310 @@
+"""Training step of DPRNNSpeTasNet on the MI355X path (reference src/trainers/trainer_spe.py:25-46):
+
+    est, aux = model(mix, reference, ref_len)
+    loss = PIT-SI-SDR(est, target) + ce_gamma * CrossEntropy(aux, spk_idx);  loss.backward()
+
+``DPRNNSpeTasNet.forward`` under autograd is one ``torch.autograd.Function`` with two outputs (estimate, speaker logits).
+The separator path re-uses training.forward_train / training.backward (the fusion operands enter the bottleneck); this
+module adds the speaker branch: spk_encoder (GroupNorm -> conv -> 3 ResBlocks with BatchNorm1d/PReLU/MaxPool1d(3) -> conv
+-> time mean, dprnn_spe.py:115-123,156-163), pred_linear, and the fusion Linears, forward with saved intermediates and
+backward through the kernels of include/dprnn_mi355x_train.h (dprnn_resblock_pool_bwd, dprnn_bn_bwd, ...).
+
+Supported under autograd: fusion_type 'cat', 'add', 'mul', 'film' with the LSTM cell.  The 'att' fusion and the two-pass
+DPRNN-Spe-IRA wrapper refuse loudly (inference only).  BatchNorm1d follows the module's mode: batch statistics (and the
+running-buffer update) in train(), running statistics in eval().  The whole batch is one pass (BatchNorm couples the
+utterances), so the batch must fit the activation budget of training.py.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import engine, training
+from ._lib import DprnnError
+from .engine import F_BUILT, Stage, _norm_params, _p, _param
+from .training import _Scratch
+
+TRAIN_FUSIONS = ("cat", "add", "mul", "film")
+
+
+def check_supported_spe_train(cfg: dict) -> None:
+    engine.check_supported_spe(cfg)
+    training.check_supported_train(cfg)
+    if cfg["fusion_type"] not in TRAIN_FUSIONS:
+        raise NotImplementedError(f"DPRNN-Spe MI355X training path: fusion_type {cfg['fusion_type']!r} has inference kernels "
+                                  f"only (backward exists for {TRAIN_FUSIONS})")
+
+
+def _resblock_train(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
+    """engine._resblock keeping what the backward needs."""
+    dev = Xin.device
+    rows = B * T
+    f32 = dict(device=dev, dtype=torch.float32)
+    sv = dict(x=Xin, B=B, T=T, cin=cin, cout=cout, blk=blk)
+    ys, affs, moms = [], [], []
+    src, kin = Xin, cin
+    for i, (conv, bn) in enumerate(((blk.conv1, blk.batch_norm1), (blk.conv2, blk.batch_norm2))):
+        tr = bn.training
+        cs = torch.zeros(cout, 2, device=dev, dtype=torch.float64) if tr else None
+        if i == 0:
+            y = engine._pointwise(st, src, rows, kin, conv.weight, None, cout, col_stats=cs)
+        else:
+            y = engine._pointwise(st, src, rows, kin, conv.weight, None, cout, in_scale=affs[0][0], in_shift=affs[0][1],
+                                  in_prelu=_param(blk.prelu1.weight, "prelu1.weight", dev), col_stats=cs)
+        mean = torch.empty(cout, **f32)
+        rstd = torch.empty(cout, **f32)
+        st.call("dprnn_bn_moments", _p(cs), _p(bn.running_mean), _p(bn.running_var), rows, float(bn.eps), _p(mean), _p(rstd), cout)
+        affs.append(engine._bn_fold(st, bn, cs, rows, dev))
+        moms.append((mean, rstd, tr))
+        ys.append(y)
+        src, kin = y, cout
+    res = engine._pointwise(st, Xin, rows, cin, blk.conv_downsample.weight, None, cout) if blk.downsample else Xin
+    out = torch.empty(B, T // 3, cout, **f32)
+    st.call("dprnn_resblock_pool_fwd", _p(ys[1]), _p(affs[1][0]), _p(affs[1][1]), _p(res),
+            _p(_param(blk.prelu2.weight, "prelu2.weight", dev)), _p(out), B, T, cout)
+    sv.update(y1=ys[0], y2=ys[1], aff1=affs[0], aff2=affs[1], mom1=moms[0], mom2=moms[1], res=res)
+    return out, T // 3, sv
+
+
+def spe_forward_train(model, wav, aux, aux_len):
+    """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) keeping the activations: returns (est [B,T_out], logits, saved)."""
+    cfg = model.cfg
+    dev = wav.device
+    st = Stage(dev)
+    N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
+    geo_a = engine.make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+    B = wav.shape[0]
+    sep = model.separation
+    se = sep.spk_encoder
+    enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+    aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
+    stats_a = torch.zeros(B, 2, device=dev, dtype=torch.float64)
+    sc_a, sh_a = engine.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats_a)
+    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
+    h, t = A0, geo_a.L
+    blocks = []
+    for blk, cin, cout in ((se[2], 128, 128), (se[3], 128, 256), (se[4], 256, 256)):
+        h, t, sv = _resblock_train(st, blk, h.view(B * t, cin), B, t, cin, cout)
+        blocks.append(sv)
+    if t < 1:
+        raise DprnnError("reference utterance too short for three MaxPool1d(3) stages")
+    h3 = h.view(B * t, 256)
+    E = engine._pointwise(st, h3, B * t, 256, se[5].weight, se[5].bias, 128)
+    emb = torch.empty(B, 128, device=dev, dtype=torch.float32)
+    st.call("dprnn_time_mean_fwd", _p(E), _p(aux_len_dev), aux_len_dev.numel(), _p(emb), B, t, 128, ks)
+    logits = engine._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, emb)
+    mul, add, row_bias = engine._fusion_operands(st, sep, cfg, emb)
+    fusion = dict(mul=mul, add=add, row_bias=row_bias)
+    out, saved = training.forward_train(model, wav, keep=True, fusion={k: v for k, v in fusion.items() if v is not None})
+    saved["spk"] = dict(aux=aux, aux_len=aux_len_dev, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, blocks=blocks,
+                        h3=h3, t3=t, emb=emb)
+    return out[:, 0, :], logits, saved
+
+
+def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows, need_dx=True):
+    """1x1 conv y = x @ W^T (W [cout][cin]): returns (dW, dx)."""
+    dev = dOut.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    gw = torch.empty_like(weight)
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(cout, cin, rows), **f32)
+    q1 = (x.data_ptr() + 4 * 128) if cin == 256 else 0
+    st.call("dprnn_wgrad", _p(dOut), cout, cout, _p(x), cin, min(cin, 128), 0, q1, cin, 128 if cin == 256 else 0, 0,
+            rows, 1, 1, _p(gw), cin, 1, 0, 0, 0, _p(ws))
+    dx = None
+    if need_dx:
+        dx = torch.empty(rows, cin, **f32)
+        if cin == 256:                      # two 128-column halves
+            for c0 in (0, 128):
+                st.call("dprnn_dgrad", _p(dOut), cout, weight.data_ptr() + 4 * c0, cin, cout, 0, 0, dx.data_ptr() + 4 * c0, cin, 128, rows)
+        else:
+            st.call("dprnn_dgrad", _p(dOut), cout, _p(weight), cin, cout, 0, 0, _p(dx), cin, cin, rows)
+    return gw, dx
+
+
+def _resblock_bwd(st, lib, scr: _Scratch, sv: dict, dOut, prefix: str, grads: Dict[str, torch.Tensor]):
+    """Backward of one ResBlock (dprnn_spe.py:31-42): returns the gradient of its input rows [B*T][cin]."""
+    blk, B, T, cin, cout = sv["blk"], sv["B"], sv["T"], sv["cin"], sv["cout"]
+    dev = dOut.device
+    rows = B * T
+    f32 = dict(device=dev, dtype=torch.float32)
+
+    def to_grad(addr, like):
+        g = torch.empty_like(like)
+        st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
+        return g
+
+    (s1, t1), (s2, t2) = sv["aff1"], sv["aff2"]
+    (m1, r1, tr1), (m2, r2, tr2) = sv["mom1"], sv["mom2"]
+    # MaxPool1d(3) + PReLU2 + residual add
+    dU = torch.empty(rows, cout, **f32)
+    a_al2 = scr.slot(prefix + "alpha2", 1)
+    st.call("dprnn_resblock_pool_bwd", _p(dOut), _p(sv["y2"]), _p(s2), _p(t2), _p(sv["res"]), _p(blk.prelu2.weight), _p(dU), a_al2,
+            B, T, cout)
+    grads[prefix + "prelu2.weight"] = to_grad(a_al2, blk.prelu2.weight)
+    # BatchNorm2
+    a_red2 = scr.slot(prefix + "bn2", 2 * cout)
+    dY2 = torch.empty(rows, cout, **f32)
+    st.call("dprnn_bn_bwd", _p(dU), _p(sv["y2"]), _p(m2), _p(r2), _p(blk.batch_norm2.weight), 1 if tr2 else 0, a_red2, _p(dY2), rows, cout)
+    grads[prefix + "batch_norm2.bias"] = to_grad(a_red2, blk.batch_norm2.bias)
+    grads[prefix + "batch_norm2.weight"] = to_grad(a_red2 + 8 * cout, blk.batch_norm2.weight)
+    # conv2 on a1 = prelu1(bn1(y1))
+    a1 = torch.empty(rows, cout, **f32)
+    st.call("dprnn_affine_prelu_rows", _p(sv["y1"]), _p(s1), _p(t1), _p(blk.prelu1.weight), _p(a1), rows, cout)
+    grads[prefix + "conv2.weight"], da1 = _conv_bwd(st, lib, dY2, cout, a1, cout, blk.conv2.weight, rows)
+    del a1, dY2
+    # PReLU1 + BatchNorm1
+    a_al1 = scr.slot(prefix + "alpha1", 1)
+    dB1 = torch.empty(rows, cout, **f32)
+    st.call("dprnn_affine_prelu_bwd", _p(da1), _p(sv["y1"]), _p(s1), _p(t1), _p(blk.prelu1.weight), _p(dB1), a_al1, rows, cout)
+    grads[prefix + "prelu1.weight"] = to_grad(a_al1, blk.prelu1.weight)
+    a_red1 = scr.slot(prefix + "bn1", 2 * cout)
+    dY1 = da1                                       # reuse
+    st.call("dprnn_bn_bwd", _p(dB1), _p(sv["y1"]), _p(m1), _p(r1), _p(blk.batch_norm1.weight), 1 if tr1 else 0, a_red1, _p(dY1), rows, cout)
+    grads[prefix + "batch_norm1.bias"] = to_grad(a_red1, blk.batch_norm1.bias)
+    grads[prefix + "batch_norm1.weight"] = to_grad(a_red1 + 8 * cout, blk.batch_norm1.weight)
+    del dB1
+    # conv1 and the residual branch meet at the block input
+    x = sv["x"]
+    grads[prefix + "conv1.weight"], dx = _conv_bwd(st, lib, dY1, cout, x, cin, blk.conv1.weight, rows)
+    if blk.downsample:
+        grads[prefix + "conv_downsample.weight"], dxr = _conv_bwd(st, lib, dU, cout, x, cin, blk.conv_downsample.weight, rows)
+    else:
+        dxr = dU
+    st.call("dprnn_add_rows", _p(dx), _p(dxr), _p(dx), rows * cin)
+    return dx
+
+
+def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    cfg = model.cfg
+    geo: engine.Geometry = saved["geo"]
+    dev = d_est.device
+    st = Stage(dev)
+    lib = st.lib
+    sep = model.separation
+    se = sep.spk_encoder
+    spk = saved["spk"]
+    B, N, ks = geo.B, geo.N, geo.ks
+    f32 = dict(device=dev, dtype=torch.float32)
+    enc_w = model.encoder.conv1d.weight
+    scr = _Scratch(dev)
+
+    def to_grad(addr, like):
+        g = torch.empty_like(like)
+        st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
+        return g
+
+    # separator: the estimate is speaker 0 of the two decoded channels (dprnn_spe.py:325)
+    d_out = torch.zeros(B, 2, geo.T_out, **f32)
+    d_out[:, 0, :] = d_est
+    extras: dict = {}
+    fusion = saved["fusion"]
+    grads = training.backward(model, saved, d_out, scratch=scr, extras=extras)
+
+    # gradient of the speaker embedding: pred_linear + fusion operands
+    emb = spk["emb"]
+    E_ = emb.shape[1]
+    d_emb = torch.zeros(B, E_, **f32)
+
+    def lin_bwd(d_o, lin_w, lin_b, wname, bname, k0=0, dW=None):
+        gw = dW if dW is not None else torch.empty_like(lin_w)
+        gb = torch.empty_like(lin_b) if lin_b is not None else None
+        st.call("dprnn_linear_small_bwd", _p(d_o), d_o.shape[1], _p(emb), E_, _p(lin_w), lin_w.shape[1], k0, E_, _p(d_emb), E_, 1,
+                _p(gw), _p(gb), B, d_o.shape[1])
+        grads[wname] = gw
+        if gb is not None:
+            grads[bname] = gb
+
+    if d_logits is not None:
+        lin_bwd(d_logits.contiguous().float(), sep.pred_linear.weight, sep.pred_linear.bias,
+                "separation.pred_linear.weight", "separation.pred_linear.bias")
+    else:
+        grads["separation.pred_linear.weight"] = torch.zeros_like(sep.pred_linear.weight)
+        grads["separation.pred_linear.bias"] = torch.zeros_like(sep.pred_linear.bias)
+    ft = cfg["fusion_type"]
+    if ft == "cat":
+        lin_bwd(extras["d_row_bias"], sep.bottleneck[1].weight, None, "separation.bottleneck.1.weight", None, k0=N,
+                dW=grads["separation.bottleneck.1.weight"])
+    elif ft == "add":
+        lin_bwd(extras["d_add"], sep.fusion_linear.weight, sep.fusion_linear.bias,
+                "separation.fusion_linear.weight", "separation.fusion_linear.bias")
+    elif ft == "mul":
+        lin_bwd(extras["d_mul"], sep.fusion_linear.weight, sep.fusion_linear.bias,
+                "separation.fusion_linear.weight", "separation.fusion_linear.bias")
+    elif ft == "film":
+        lin_bwd(extras["d_mul"], sep.fusion_linear_1.weight, sep.fusion_linear_1.bias,
+                "separation.fusion_linear_1.weight", "separation.fusion_linear_1.bias")
+        lin_bwd(extras["d_add"], sep.fusion_linear_2.weight, sep.fusion_linear_2.bias,
+                "separation.fusion_linear_2.weight", "separation.fusion_linear_2.bias")
+
+    # spk_encoder in reverse: time mean, conv P -> E, three ResBlocks, conv N -> O, GroupNorm, encoder
+    t3, h3 = spk["t3"], spk["h3"]
+    dE = torch.empty(B * t3, F_BUILT, **f32)
+    st.call("dprnn_time_mean_bwd", _p(d_emb), _p(spk["aux_len"]), spk["aux_len"].numel(), _p(dE), B, t3, F_BUILT, ks)
+    w5 = se[5].weight
+    gw5 = torch.empty_like(w5)
+    gb5 = torch.empty_like(se[5].bias)
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(128, 256, B * t3), **f32)
+    st.call("dprnn_wgrad", _p(dE), 128, 128, _p(h3), 256, 128, 0, h3.data_ptr() + 4 * 128, 256, 128, 0, B * t3, 1, 1,
+            _p(gw5), 256, 1, _p(gb5), 0, 0, _p(ws))
+    grads["separation.spk_encoder.5.weight"], grads["separation.spk_encoder.5.bias"] = gw5, gb5
+    dh = torch.empty(B * t3, 256, **f32)
+    st.call("dprnn_dgrad", _p(dE), 128, _p(w5), 256, 128, 0, 0, _p(dh), 256, 256, B * t3)
+    for i in (4, 3, 2):
+        sv = spk["blocks"][i - 2]
+        dh = _resblock_bwd(st, lib, scr, sv, dh.view(B, sv["T"] // 3, sv["cout"]), f"separation.spk_encoder.{i}.", grads)
+    # first conv (N -> O, with bias) on the normalised encoder output of the reference utterance
+    geo_a = spk["geo_a"]
+    rows_a = B * geo_a.L
+    aux = spk["aux"]
+    An = torch.empty(rows_a, N, **f32)
+    st.call("dprnn_encoder_norm_rows", _p(aux), _p(enc_w), _p(spk["sc_a"]), _p(spk["sh_a"]), _p(An), B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
+    w1 = se[1].weight
+    gw1 = torch.empty_like(w1)
+    gb1 = torch.empty_like(se[1].bias)
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(128, N, rows_a), **f32)
+    st.call("dprnn_wgrad", _p(dh), 128, 128, _p(An), N, N, 0, 0, 0, 0, 0, rows_a, 1, 1, _p(gw1), N, 1, _p(gb1), 0, 0, _p(ws))
+    grads["separation.spk_encoder.1.weight"], grads["separation.spk_encoder.1.bias"] = gw1, gb1
+    dAn = An
+    st.call("dprnn_dgrad", _p(dh), 128, _p(w1), N, 128, 0, 0, _p(dAn), N, N, rows_a)
+    g0, b0, eps0 = _norm_params(se[0])
+    a_red, a_dgb = scr.slot("red_spk", 2 * B), scr.slot("dgb_spk", 2 * N)
+    st.call("dprnn_encoder_norm_bwd_stats", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, a_dgb,
+            B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
+    grads["separation.spk_encoder.0.weight"] = to_grad(a_dgb, g0)
+    grads["separation.spk_encoder.0.bias"] = to_grad(a_dgb + 8 * N, b0)
+    st.call("dprnn_encoder_bwd", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, 0,
+            scr.slot("dWe", N * ks), B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
+    grads["encoder.conv1d.weight"] = to_grad(scr.slot("dWe", N * ks), enc_w)
+    return grads
+
+
+class _SpeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, wav, aux, aux_len, names, *params):
+        ctx.model, ctx.names = model, names
+        est, logits, saved = spe_forward_train(model, wav, aux, aux_len)
+        ctx.saved = saved
+        return est, logits
+
+    @staticmethod
+    def backward(ctx, d_est, d_logits):
+        with torch.cuda.device(d_est.device):
+            grads = spe_backward(ctx.model, ctx.saved, d_est.contiguous().float(), d_logits)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+def spe_forward_autograd(model, wav, aux, aux_len):
+    """model(mix, reference, ref_len) under autograd: differentiable w.r.t. every parameter."""
+    check_supported_spe_train(model.cfg)
+    wav, aux = engine.check_input(wav), engine.check_input(aux, "aux")
+    if aux.shape[0] != wav.shape[0]:
+        raise DprnnError("mixture and reference batch sizes differ")
+    if wav.requires_grad or aux.requires_grad:
+        raise NotImplementedError("DPRNN MI355X training path: gradients w.r.t. the waveforms are not computed")
+    named = [(n, p) for n, p in model.named_parameters()]
+    for n, p in named:
+        _param(p, n, wav.device)
+    with torch.cuda.device(wav.device):
+        return _SpeFunction.apply(model, wav, aux, aux_len, tuple(n for n, _ in named), *[p for _, p in named])
