@@ -146,6 +146,12 @@ def fusion_cat(emb, x):                         # dprnn_spe.py:186-192
     return torch.cat([x, emb.unsqueeze(-1).repeat(1, 1, x.shape[-1])], 1)
 
 
+def spe_forward_autograd(sd, cfg, wav, aux_wav, aux_len, training_bn=False):
+    """spe_forward ('cat' fusion) with autograd enabled: CPU restatement of the reference's DPRNN-Spe training step
+    (trainer_spe.py:36-45)."""
+    return spe_forward.__wrapped__(sd, cfg, wav, aux_wav, aux_len, training_bn)
+
+
 @torch.no_grad()
 def spe_forward(sd, cfg, wav, aux_wav, aux_len, training_bn=False):
     """dprnn_spe.py:314-327, 'cat' fusion only (other fusions: oracle.dprnn_numpy)."""

@@ -117,7 +117,7 @@ def test_segmentation_overlap_add_identity():
         assert np.array_equal(onp.overlap_add(seg, 101, K, P), 2 * x)
 
 
-GRAD_SMALL = [n for n in golden_names("grad_") if "full" not in n]
+GRAD_SMALL = [n for n in golden_names("grad_bss") if "full" not in n]
 
 
 @pytest.mark.parametrize("name", GRAD_SMALL)
@@ -144,3 +144,36 @@ def test_oracle_training_step_matches_reference_autograd(name):
             pr = rng.standard_normal((8, got.size)).astype(np.float32).astype(np.float64) @ got.reshape(-1).astype(np.float64)
             err = np.abs(pr - g["proj_" + k]).max() / nrm
         assert err < 5e-6, (k, err)
+
+
+@pytest.mark.parametrize("name", ["grad_spe_wide_cat", "grad_spe_wide_cat_bneval"])
+def test_oracle_spe_training_step_matches_reference_autograd(name):
+    """The same for DPRNN-Spe ('cat' fusion; BatchNorm in train and eval mode): trainer_spe.py:36-45."""
+    import zlib
+    from oracle.sisdr import pit_neg_sisdr_torch
+    g = load_golden(name)
+    m = g["meta"]
+    sd = {}
+    for k, v in make_state("spe", m["cfg"], m["seed"]).items():
+        t = torch.from_numpy(np.asarray(v))
+        sd[k] = t.requires_grad_(True) if t.is_floating_point() and "running_" not in k else t
+    est, logits = otc.spe_forward_autograd(sd, m["cfg"], torch.from_numpy(g["mix"]), torch.from_numpy(g["aux"]),
+                                           torch.tensor(float(g["aux_len"])), m["bn_training"])
+    l, _ = pit_neg_sisdr_torch(est.unsqueeze(1), torch.from_numpy(g["tgt"]).unsqueeze(1))
+    loss = l + 0.5 * torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(g["spk_idx"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    checked = 0
+    for k, v in sd.items():
+        if "norm_" + k not in g:
+            continue
+        got, nrm = v.grad.numpy(), float(g["norm_" + k])
+        if "grad_" + k in g:
+            err = np.linalg.norm(got.astype(np.float64) - g["grad_" + k]) / nrm
+        else:
+            rng = np.random.default_rng([zlib.crc32(k.encode()), got.size])
+            pr = rng.standard_normal((8, got.size)).astype(np.float32).astype(np.float64) @ got.reshape(-1).astype(np.float64)
+            err = np.abs(pr - g["proj_" + k]).max() / nrm
+        assert err < 5e-6, (k, err)
+        checked += 1
+    assert checked > 60
