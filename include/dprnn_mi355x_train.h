@@ -172,10 +172,23 @@ int dprnn_linear_small_bwd(const float* d_out, int do_pitch, const float* in, in
 /* ---- per-channel fusion operands (dprnn_spe.py:194-229: 'add', 'mul', 'film'; also the 'att' channel factor):
  * a' = an*mul + add with an = enc*sc0 + sh0 the plain bottleneck-norm output (sc0/sh0 from dprnn_bottleneck_prep without
  * mul/add).  Given dAp = gradient of a': dAn = dAp*mul (mul NULL: copy), dmul[b][c] += sum_l dAp*an, dadd[b][c] += sum_l dAp
- * (fp64 scratch [B][N], either may be NULL). */
+ * (fp64 scratch [B][N], either may be NULL).
+ * 'att' fusion (dprnn_spe.py:178-183,214-222; mul = a = fusion_linear(emb)): with d_scores [B][La] (dprnn_att_softmax_bwd)
+ * and the averaging conv (avg_w [N][ks_a], avg_b [N], stride ks_a) the attention-score path is added:
+ * dAn[b][l][c] += dS[b][t]*a[b][c]*avg_w[c][j], dmul[b][c] += dS[b][t]*(avg_w[c][j]*an + [j==0]*avg_b[c]), l = t*ks_a + j.
+ * d_scores NULL: no attention path. */
 int dprnn_fusion_bwd(const float* wav, const float* enc_w, const float* sc0, const float* sh0, const float* dAp,
                      const float* mul, float* dAn, double* dmul, double* dadd,
+                     const float* d_scores, const float* avg_w, const float* avg_b, int ks_a,
                      int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* ---- 'att' fusion, per-frame factor (dprnn_bottleneck_att_fwd: Y = rs[b][l]*(W a') + bias, rs = upsampled softmax + 1):
+ * dG = dY*rs (gradient of W a'), d_rs[(b,l)] = sum_f dY*(Y - bias)/rs, dbias[f] += sum dY (fp64 scratch [128]).
+ * dprnn_att_softmax_bwd: nearest-upsampling + softmax backward of dprnn_att_row_scale:
+ * d_scores[b][t] = att*(d_att - sum_t att*d_att), att = softmax_t(scores), d_att[t] = sum of d_rs over the frames reading t. */
+int dprnn_att_scale_bwd(const float* dY, const float* Y, const float* bias, const float* row_scale, float* dG,
+                        float* d_rs, double* dbias, int64_t rows, void* stream);
+int dprnn_att_softmax_bwd(const float* d_rs, const float* scores, float* d_scores, int B, int L, int ks_a, void* stream);
 
 /* ---- torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over ALL parameters in two launches
  * (src/trainers/trainer.py:115-118; scripts/train/config_bss.yaml:30-33).  table: n_tensors device records

@@ -154,6 +154,8 @@ GRAD_SPE_CASES = [
     ("grad_spe_wide_add", dict(WIDE, fusion_type="add", norm_type="gLN", n_repeats=1, num_spks=11), 2, 211, 300, 82, True),
     ("grad_spe_wide_mul", dict(WIDE, fusion_type="mul", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 83, True),
     ("grad_spe_wide_film", dict(WIDE, fusion_type="film", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 84, True),
+    ("grad_spe_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 301, 411, 85, True),
+    ("grad_spe_wide_att_k4", dict(WIDE, fusion_type="att", norm_type="gLN", kernel_size=4, n_repeats=1, num_spks=11), 2, 302, 411, 86, True),
 ]
 
 

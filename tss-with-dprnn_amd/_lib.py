@@ -86,7 +86,9 @@ SIGNATURES = {
     "dprnn_add_rows": [c_fp, c_fp, c_fp, c_i64, c_fp],
     "dprnn_utt_colsum": [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_linear_small_bwd": [c_fp, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp],
-    "dprnn_fusion_bwd": [c_fp] * 9 + [c_i] * 6 + [c_fp],
+    "dprnn_fusion_bwd": [c_fp] * 12 + [c_i] * 7 + [c_fp],
+    "dprnn_att_scale_bwd": [c_fp] * 7 + [c_i64, c_fp],
+    "dprnn_att_softmax_bwd": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_adam_multi": [c_fp, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_fp, c_fp],
 }
 _VOID = {

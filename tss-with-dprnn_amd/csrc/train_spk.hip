@@ -254,10 +254,16 @@ __global__ void linear_small_bwd_w_kernel(const float* __restrict__ d_out, int d
 
 // per-channel fusion operands (dprnn_spe.py:194-229): a' = an*mul + add with an = enc*sc0 + sh0 the plain norm output.
 // d_an = da'*mul;  dmul[b][c] += sum_l da'*an;  dadd[b][c] += sum_l da'   (fp64 scratch; mul == null: d_an = da')
+// 'att' fusion (dprnn_spe.py:178-183,214-222; mul = a = fusion_linear(emb)): the attention scores
+// scores[b][t] = sum_c a[b][c]*avg[b][c][t], avg = depth-wise conv (avg_w [N][ks_a], avg_b, stride ks_a) of an, add
+// d_an[b][l][c] += dS[b][t]*a[b][c]*avg_w[c][j] and dmul[b][c] += dS[b][t]*(avg_w[c][j]*an + [j == 0]*avg_b[c]),
+// l = t*ks_a + j, for the score gradient dS (dprnn_att_softmax_bwd).
 __global__ __launch_bounds__(256)
 void fusion_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ We, Geo geo, const float* __restrict__ sc0,
                        const float* __restrict__ sh0, const float* __restrict__ dAp, const float* __restrict__ mul,
-                       float* __restrict__ dAn, double* __restrict__ dmul, double* __restrict__ dadd, int chunks) {
+                       float* __restrict__ dAn, double* __restrict__ dmul, double* __restrict__ dadd, int chunks,
+                       const float* __restrict__ dS, const float* __restrict__ avg_w, const float* __restrict__ avg_b,
+                       int ks_a, int La) {
     const int n = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int ks = geo.ks;
     const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -278,9 +284,19 @@ void fusion_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ 
         en = fmaxf(en, 0.f);
         const long long row = (long long)b * geo.L + l;
         const float g = dAp[row * 64 + n];
-        am = fmaf(g, fmaf(en, s0, t0), am);
+        const float an = fmaf(en, s0, t0);
+        am = fmaf(g, an, am);
         aa += g;
-        dAn[row * 64 + n] = g * m;
+        float dan = g * m;
+        if (dS) {
+            const int t = l / ks_a, j = l - t * ks_a;
+            if (t < La) {
+                const float ds = dS[(long long)b * La + t], w = avg_w[n * ks_a + j];
+                dan = fmaf(ds * m, w, dan);
+                am = fmaf(ds, fmaf(w, an, j == 0 ? avg_b[n] : 0.f), am);
+            }
+        }
+        dAn[row * 64 + n] = dan;
     }
     __shared__ float red[4][2][64];
     red[slot][0][n] = am; red[slot][1][n] = aa;
@@ -403,15 +419,123 @@ extern "C" int dprnn_linear_small_bwd(const float* d_out, int do_pitch, const fl
 
 extern "C" int dprnn_fusion_bwd(const float* wav, const float* enc_w, const float* sc0, const float* sh0, const float* dAp,
                                 const float* mul, float* dAn, double* dmul, double* dadd,
+                                const float* d_scores, const float* avg_w, const float* avg_b, int ks_a,
                                 int B, int T, int L, int N, int ks, int stride, void* stream) {
     if (!wav || !enc_w || !sc0 || !sh0 || !dAp || !dAn) { dprnn_set_error("dprnn_fusion_bwd: null pointer"); return -1; }
+    if (d_scores && (!mul || !avg_w || !avg_b || ks_a < 1 || L < ks_a)) { dprnn_set_error("dprnn_fusion_bwd: incomplete 'att' operands"); return -1; }
     if (N != 64 || ks < 1 || ks > KSMAX || L != (T - ks) / stride + 1) { dprnn_set_error("dprnn_fusion_bwd: unsupported N=%d ks=%d", N, ks); return -1; }
     const Geo geo{B, T, L, N, ks, stride};
     int chunks = (4 * num_cus() + B - 1) / B;
     const int maxc = (L + 63) / 64;
     if (chunks > maxc) chunks = maxc;
     if (chunks < 1) chunks = 1;
+    const int La = d_scores ? (L - ks_a) / ks_a + 1 : 0;
     hipLaunchKernelGGL(fusion_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, wav, enc_w, geo, sc0, sh0, dAp, mul,
-                       dAn, dmul, dadd, chunks);
+                       dAn, dmul, dadd, chunks, d_scores, avg_w, avg_b, ks_a, La);
     return dprnn_check_launch("fusion_bwd_kernel");
+}
+
+// ---- 'att' fusion, frame factor: Y = rs[b][l]*G + bias with G = W a' (dprnn_bottleneck_att_fwd).  Given dY:
+// dG = dY*rs, d_rs[(b,l)] = sum_f dY*(Y - bias)/rs (rs = softmax + 1 >= 1), dbias[f] += sum dY (fp64 scratch)
+namespace {
+__global__ __launch_bounds__(256)
+void att_scale_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ bias,
+                          const float* __restrict__ rs, float* __restrict__ dG, float* __restrict__ d_rs,
+                          double* __restrict__ dbias, long long rows) {
+    const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    for (long long row = (long long)blockIdx.x * 8 + rr; row < rows; row += (long long)gridDim.x * 8) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dY + row * 128 + 4 * c4);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * 128 + 4 * c4);
+        const float r = rs[row], ir = 1.f / r;
+        float dot = 0.f;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dot = fmaf(d[e], (y[e] - bv[e]) * ir, dot); o[e] = d[e] * r; bs[e] += d[e]; }
+        *reinterpret_cast<f32x4*>(dG + row * 128 + 4 * c4) = o;
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) dot += __shfl_xor(dot, m, 64);       // the 32 lanes of a row are one half-wave
+        if (c4 == 0) d_rs[row] = dot;
+    }
+    __shared__ float red[8][128];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rr][4 * c4 + e] = bs[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)red[k][threadIdx.x];
+        atomicAdd(&dbias[threadIdx.x], s);
+    }
+}
+
+// softmax over time + nearest upsampling backward (dprnn_att_row_scale): att = softmax(scores),
+// d_att[t] = sum over the frames l that read att[t] of d_rs[l], dS = att*(d_att - sum_t att*d_att); one workgroup per utterance
+__global__ __launch_bounds__(256)
+void att_softmax_bwd_kernel(const float* __restrict__ d_rs, const float* __restrict__ scores, float* __restrict__ dS, int La, int L) {
+    const int b = blockIdx.x;
+    const float* s = scores + (long long)b * La;
+    const float* g = d_rs + (long long)b * L;
+    float* o = dS + (long long)b * La;
+    __shared__ float red[4];
+    __shared__ float stat[3];
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < La; t += 256) m = fmaxf(m, s[t]);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = stat[0];
+    float z = 0.f;
+    for (int t = threadIdx.x; t < La; t += 256) z += expf(s[t] - m);
+    z = wave_sum(z);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = z;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[1] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float inv = 1.f / stat[1];
+    const float scale = (float)La / (float)L;
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < La; t += 256) {
+        // frames l with min(floor(l*scale), La-1) == t: search a window around t/scale (same float arithmetic as the forward)
+        int lo = (int)floorf((float)t / scale) - 2, hi = (int)ceilf((float)(t + 1) / scale) + 2;
+        if (lo < 0) lo = 0;
+        if (t == La - 1 || hi > L) hi = L;
+        float da = 0.f;
+        for (int l = lo; l < hi; ++l) {
+            int src = (int)floorf((float)l * scale);
+            if (src > La - 1) src = La - 1;
+            if (src == t) da += g[l];
+        }
+        o[t] = da;
+        dot = fmaf(expf(s[t] - m) * inv, da, dot);
+    }
+    dot = wave_sum(dot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[2] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    dot = stat[2];
+    for (int t = threadIdx.x; t < La; t += 256) o[t] = expf(s[t] - m) * inv * (o[t] - dot);
+}
+}  // namespace
+
+extern "C" int dprnn_att_scale_bwd(const float* dY, const float* Y, const float* bias, const float* row_scale, float* dG,
+                                   float* d_rs, double* dbias, int64_t rows, void* stream) {
+    if (!dY || !Y || !bias || !row_scale || !dG || !d_rs || !dbias || rows < 1) { dprnn_set_error("dprnn_att_scale_bwd: null pointer / rows"); return -1; }
+    hipLaunchKernelGGL(att_scale_bwd_kernel, dim3(grid_rows((rows + 7) / 8, 1)), dim3(256), 0, (hipStream_t)stream,
+                       dY, Y, bias, row_scale, dG, d_rs, dbias, (long long)rows);
+    return dprnn_check_launch("att_scale_bwd_kernel");
+}
+
+extern "C" int dprnn_att_softmax_bwd(const float* d_rs, const float* scores, float* d_scores, int B, int L, int ks_a, void* stream) {
+    if (!d_rs || !scores || !d_scores || B < 1 || ks_a < 1 || L < ks_a) { dprnn_set_error("dprnn_att_softmax_bwd: null pointer / sizes"); return -1; }
+    const int La = (L - ks_a) / ks_a + 1;
+    hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_rs, scores, d_scores, La, L);
+    return dprnn_check_launch("att_softmax_bwd_kernel");
 }

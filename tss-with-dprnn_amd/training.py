@@ -85,7 +85,8 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     lib.dprnn_set_gemm_mode(0)
     fusion = fusion or {}
     sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], fusion.get("mul"), fusion.get("add"))
-    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"))
+    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"), fusion.get("row_scale"))
+    Y_keep = Y if (keep and fusion.get("row_scale") is not None) else None        # 'att': the backward needs W a' = (Y - b) / rs
     X = [torch.empty(rows, F_BUILT, **f32)]
     Z, H, tapes = [], [], []
     st.call("dprnn_segment_fwd", _p(Y), _p(X[0]), B, L, K, P, S)
@@ -136,7 +137,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     if not keep:
         return out, None
     saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask,
-                 fusion=fusion)
+                 fusion=fusion, Y=Y_keep)
     return out, saved
 
 
@@ -186,8 +187,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
 
     scr = scratch if scratch is not None else _Scratch(dev)
     fusion = saved.get("fusion") or {}
-    if (fusion and extras is None) or fusion.get("row_scale") is not None:
-        raise DprnnError("training path: this fusion has no backward here")
+    if fusion and extras is None:
+        raise DprnnError("training path: fusion operands need the DPRNN-Spe backward (training_spe.py)")
 
     def to_grad(addr, like):
         g = torch.empty_like(like)
@@ -312,8 +313,17 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     A = torch.empty(B * L, N, **f32)
     st.call("dprnn_encoder_norm_rows", _p(wav), _p(enc_w), _p(saved["sc"]), _p(saved["sh"]), _p(A), B, geo.T, L, N, ks, geo.stride)
     gw = torch.empty_like(wb)
-    gb = torch.empty_like(bconv.bias)
-    wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, ldb, 1, gb, None)     # columns [0, N) of the weight
+    row_scale = fusion.get("row_scale")
+    d_rs = None
+    if row_scale is None:
+        gb = torch.empty_like(bconv.bias)
+        wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, ldb, 1, gb, None)     # columns [0, N) of the weight
+    else:            # 'att': Y = rs*(W a') + b  ->  the conv sees dG = dY*rs, the bias sees dY
+        d_rs = torch.empty(B * L, **f32)
+        st.call("dprnn_att_scale_bwd", _p(dY), _p(saved["Y"]), _p(bconv.bias), _p(row_scale), _p(dY), _p(d_rs),
+                scr.slot("dbb", F_BUILT), B * L)
+        gb = to_grad(scr.slot("dbb", F_BUILT), bconv.bias)
+        wgrad(_p(dY), F_BUILT, F_BUILT, _p(A), N, N, 0, 0, 0, 0, 0, B * L, 1, 1, gw, ldb, 1, None, None)
     grads["separation.bottleneck.1.weight"], grads["separation.bottleneck.1.bias"] = gw, gb
     dA = A          # reuse
     st.call("dprnn_dgrad", _p(dY), F_BUILT, _p(wb), ldb, F_BUILT, 0, 0, _p(dA), N, N, B * L)
@@ -328,9 +338,14 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
             sh0 = torch.empty_like(sc0)
             st.call("dprnn_bottleneck_prep", _p(stats[0]), _p(gamma), _p(beta), eps, 0, 0, _p(sc0), _p(sh0), B, L, N)
             dAn = torch.empty(B * L, N, **f32)
+            d_scores, avg_w, avg_b, ks_a = None, None, None, 0
+            if d_rs is not None:             # 'att': back through the nearest upsampling and the softmax over time
+                avg_w, avg_b, ks_a = fusion["avg_w"], fusion["avg_b"], fusion["ks_a"]
+                d_scores = torch.empty_like(fusion["scores"])
+                st.call("dprnn_att_softmax_bwd", _p(d_rs), _p(fusion["scores"]), _p(d_scores), B, L, ks_a)
             st.call("dprnn_fusion_bwd", _p(wav), _p(enc_w), _p(sc0), _p(sh0), _p(dA), _p(mul), _p(dAn),
                     scr.slot("d_mul", B * N) if mul is not None else 0, scr.slot("d_add", B * N) if add is not None else 0,
-                    B, geo.T, L, N, ks, geo.stride)
+                    _p(d_scores), _p(avg_w), _p(avg_b), ks_a, B, geo.T, L, N, ks, geo.stride)
             if mul is not None:
                 extras["d_mul"] = to_grad(scr.slot("d_mul", B * N), torch.empty(B, N, **f32))
             if add is not None:

@@ -9,8 +9,8 @@ module adds the speaker branch: spk_encoder (GroupNorm -> conv -> 3 ResBlocks wi
 -> time mean, dprnn_spe.py:115-123,156-163), pred_linear, and the fusion Linears, forward with saved intermediates and
 backward through the kernels of include/dprnn_mi355x_train.h (dprnn_resblock_pool_bwd, dprnn_bn_bwd, ...).
 
-Supported under autograd: fusion_type 'cat', 'add', 'mul', 'film' with the LSTM cell.  The 'att' fusion and the two-pass
-DPRNN-Spe-IRA wrapper refuse loudly (inference only).  BatchNorm1d follows the module's mode: batch statistics (and the
+Supported under autograd: every fusion_type ('cat', 'add', 'mul', 'film', 'att') with the LSTM cell.  The two-pass
+DPRNN-Spe-IRA wrapper refuses loudly (inference only).  BatchNorm1d follows the module's mode: batch statistics (and the
 running-buffer update) in train(), running statistics in eval().  The whole batch is one pass (BatchNorm couples the
 utterances), so the batch must fit the activation budget of training.py.
 """
@@ -25,7 +25,7 @@ from ._lib import DprnnError
 from .engine import F_BUILT, Stage, _norm_params, _p, _param
 from .training import _Scratch
 
-TRAIN_FUSIONS = ("cat", "add", "mul", "film")
+TRAIN_FUSIONS = ("cat", "add", "mul", "film", "att")
 
 
 def check_supported_spe_train(cfg: dict) -> None:
@@ -96,6 +96,27 @@ def spe_forward_train(model, wav, aux, aux_len):
     logits = engine._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, emb)
     mul, add, row_bias = engine._fusion_operands(st, sep, cfg, emb)
     fusion = dict(mul=mul, add=add, row_bias=row_bias)
+    if cfg["fusion_type"] == "att":        # per-frame factor: softmax attention over the averaged norm output (dprnn_spe.py:178-183)
+        for prm in sep.average.parameters():
+            if prm.requires_grad:
+                raise NotImplementedError("DPRNN-Spe MI355X training path: the 'att' averaging conv is frozen in the reference "
+                                          "(dprnn_spe.py:102-103); its gradient is not computed")
+        geo = engine.make_geometry(B, wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+        stats_m = torch.zeros(B, 2, device=dev, dtype=torch.float64)
+        st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_m), B, geo.T, geo.L, N, ks, stride)
+        g_, b_, eps_ = _norm_params(sep.bottleneck[0])
+        sc0 = torch.empty(B, N, device=dev, dtype=torch.float32)
+        sh0 = torch.empty_like(sc0)
+        st.call("dprnn_bottleneck_prep", _p(stats_m), _p(g_), _p(b_), eps_, 0, 0, _p(sc0), _p(sh0), B, geo.L, N)
+        ks_a = sep.average.kernel_size[0]
+        if sep.average.stride[0] != ks_a or sep.average.groups != N:
+            raise DprnnError("unexpected averaging conv geometry in the 'att' fusion")
+        La = (geo.L - ks_a) // ks_a + 1
+        scores = torch.empty(B, La, device=dev, dtype=torch.float32)
+        row_scale = torch.empty(B, geo.L, device=dev, dtype=torch.float32)
+        st.call("dprnn_att_row_scale", _p(wav), _p(enc_w), _p(sc0), _p(sh0), _p(sep.average.weight), _p(sep.average.bias), _p(mul),
+                _p(scores), _p(row_scale), B, geo.T, geo.L, N, ks, stride, ks_a)
+        fusion.update(row_scale=row_scale, scores=scores, avg_w=sep.average.weight, avg_b=sep.average.bias, ks_a=ks_a)
     out, saved = training.forward_train(model, wav, keep=True, fusion={k: v for k, v in fusion.items() if v is not None})
     saved["spk"] = dict(aux=aux, aux_len=aux_len_dev, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, blocks=blocks,
                         h3=h3, t3=t, emb=emb)
@@ -228,7 +249,7 @@ def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[tor
     elif ft == "add":
         lin_bwd(extras["d_add"], sep.fusion_linear.weight, sep.fusion_linear.bias,
                 "separation.fusion_linear.weight", "separation.fusion_linear.bias")
-    elif ft == "mul":
+    elif ft in ("mul", "att"):
         lin_bwd(extras["d_mul"], sep.fusion_linear.weight, sep.fusion_linear.bias,
                 "separation.fusion_linear.weight", "separation.fusion_linear.bias")
     elif ft == "film":
