@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--budget-gb", type=float, default=None)
+    ap.add_argument("--model", default="bss", choices=["bss", "spe"], help="DPRNNTasNet, or DPRNNSpeTasNet ('att' fusion, config_tss.yaml)")
     ap.add_argument("--groups", type=int, default=None, help="training.TRAIN_STREAM_GROUPS")
     ap.add_argument("--min-group", type=int, default=None, help="training.MIN_TRAIN_GROUP")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of training.FusedAdam")
@@ -42,18 +43,29 @@ def main():
         training.MIN_TRAIN_GROUP = a.min_group
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0).to(dev).train()
+    if a.model == "bss":
+        model = pkg.DPRNNTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0).to(dev).train()
+    else:
+        model = pkg.DPRNNSpeTasNet(64, 128, 128, 250, 2, 125, 6, True, "LSTM", "ln", "sigmoid", 0, None, 128, 256, 128, 251,
+                                   "att").to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if a.torch_adam else training.FusedAdam(model.parameters(), lr=1e-3)
     lossm = PITSiSdrLoss()
     g = torch.Generator(device="cpu").manual_seed(1)
     src = 0.07 * torch.randn(a.batch, 2, a.samples, generator=g)
     mix = src.sum(1).to(dev)
     tgt = src.to(dev)
+    aux = (0.07 * torch.randn(a.batch, a.samples, generator=g)).to(dev)
+    spk = torch.randint(0, 251, (a.batch,), generator=g).to(dev)
+    ref_len = torch.tensor(float(a.samples), device=dev)
 
     def step():
         opt.zero_grad()
-        out = model(mix)
-        loss = lossm(out, tgt)
+        if a.model == "bss":
+            out = model(mix)
+            loss = lossm(out, tgt)
+        else:                                   # trainer_spe.py:36-45
+            est, logits = model(mix, aux, ref_len)
+            loss = lossm(est.unsqueeze(1), tgt[:, :1, : est.shape[-1]]) + 0.5 * torch.nn.functional.cross_entropy(logits, spk)
         loss.backward()
         if a.torch_adam:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
@@ -73,11 +85,12 @@ def main():
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # forward alone (inference path, for the ratio)
     model.eval()
+    fwd = (lambda: model(mix)) if a.model == "bss" else (lambda: model(mix, aux, ref_len))
     with torch.no_grad():
-        model(mix); torch.cuda.synchronize()
+        fwd(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            model(mix)
+            fwd()
         torch.cuda.synchronize()
     fdt = (time.perf_counter() - t0) / a.steps
     print(f"inference forward: {fdt * 1e3:.1f} ms ({a.batch / fdt:.1f} utt/s); training step = {dt / fdt:.2f} x forward")
