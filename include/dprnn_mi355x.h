@@ -209,26 +209,28 @@ int dprnn_pairwise_sisdr_metric(const float* est, const float* tgt, double* out,
 
 /* ---- generic 1x1 conv on channels-last rows (spk_encoder convs, ResBlock convs: dprnn_spe.py:18-19,27,115-122):
  * out[m][col0 + o] = sum_k W[(col0+o)*ldw + k] * a(m,k) + bias[col0+o],  o < 128, k < kdim (64|128|256)
- * a(m,k) = prelu(A[m*a_pitch + k] * in_scale[u*aff_stride + k] + in_shift[..]),  u = m / rows_per_utt
- * (in_scale/in_shift NULL: no affine; aff_stride 0: shared over utterances; in_prelu NULL: no PReLU) --
+ * a(m,k) = prelu((A[m*a_pitch + k] - in_mean[..]) * in_scale[u*aff_stride + k] + in_shift[..]),  u = m / rows_per_utt
+ * (in_scale/in_shift NULL: no affine; in_mean NULL: 0; aff_stride 0: shared over utterances; in_prelu NULL: no PReLU) --
  * this is how BatchNorm1d+PReLU of the previous conv (dprnn_spe.py:33-34) and GroupNorm of d0 are folded in.
  * col_stats (optional, [channels][2] fp64, zeroed by caller) += per-channel (sum, sumsq) of the outputs:
  * the batch statistics nn.BatchNorm1d needs in train mode. */
 int dprnn_pointwise_fwd(const float* A, int a_pitch, int kdim, const float* in_scale, const float* in_shift,
-                        int aff_stride, int64_t rows_per_utt, const float* in_prelu, const float* W, int ldw,
+                        const float* in_mean, int aff_stride, int64_t rows_per_utt, const float* in_prelu, const float* W, int ldw,
                         const float* bias, float* out, int out_pitch, int col0, double* col_stats, int64_t M,
                         void* stream);
 
-/* ---- nn.BatchNorm1d (dprnn_spe.py:20-21) folded to y*scale[c] + shift[c], eps 1e-5.
+/* ---- nn.BatchNorm1d (dprnn_spe.py:20-21) as (y - mean[c])*scale[c] + shift[c] with scale = gamma/sqrt(var + eps),
+ * shift = beta, eps 1e-5 (the mean is subtracted before the scale, as torch does: folding it into the shift loses
+ * channels whose mean dwarfs their spread to cancellation).
  * col_stats NULL: eval mode (running statistics).  Otherwise train mode: batch statistics over `count`
  * elements per channel, and running_mean / running_var / num_batches_tracked are updated in place as torch does. */
 int dprnn_bn_prep(const float* gamma, const float* beta, float* running_mean, float* running_var,
                   int64_t* num_batches_tracked, const double* col_stats, int64_t count, float momentum,
-                  float eps, float* scale, float* shift, int C, void* stream);
+                  float eps, float* scale, float* shift, float* mean, int C, void* stream);
 
-/* ---- tail of ResBlock.forward (dprnn_spe.py:35-42): out[b][t][c] = max_{j<3} prelu2(Y2*scale+shift + res)[b][3t+j][c]
+/* ---- tail of ResBlock.forward (dprnn_spe.py:35-42): out[b][t][c] = max_{j<3} prelu2((Y2-mean)*scale+shift + res)[b][3t+j][c]
  * (BatchNorm2 + residual/downsample add + PReLU + MaxPool1d(3)); out is [B][T_in/3][C]. */
-int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, const float* shift, const float* res,
+int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, const float* shift, const float* mean, const float* res,
                             const float* prelu_w, float* out, int B, int T_in, int C, void* stream);
 
 /* ---- DPRNNSpe._auxiliary tail (dprnn_spe.py:159-162): emb[b][c] = sum_t E[b][t][c] / aux_T,

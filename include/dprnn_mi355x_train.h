@@ -60,11 +60,12 @@ int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, co
                 float* dA, int lda, int nd, int64_t rows, void* stream);
 
 /* ---- training variants of the mask-head forward (dprnn_mi355x.h) that keep what the backward needs:
- * TG [rows][256] = [tanh(out conv) | sigmoid(gate conv)] (dprnn.py:157-158), mask [B*L*2][N] rows (b,l,spk) (:161-164) */
+ * TG [rows][256] = [tanh(out conv) | sigmoid(gate conv)] (dprnn.py:157-158), mask [B*L*2][N] rows (b,l,spk) (:161-164);
+ * masked_out (optional, [B*L][N]) = mask_0*enc, the d0 of DPRNN-Spe-IRA (dprnn_spe_ira.py:79-80) */
 int dprnn_head_gate_fwd_train(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,
                               float* V, float* TG, int64_t rows, void* stream);
 int dprnn_head_mask_decode_fwd_train(const float* V, const float* Wend, const float* wav, const float* enc_w,
-                                     const float* dec_w, float* taps, float* mask, int relu_act,
+                                     const float* dec_w, float* taps, float* mask, float* masked_out, int relu_act,
                                      int B, int T, int L, int N, int ks, int stride, void* stream);
 
 /* Small reductions (per-utterance sums, per-channel parameter gradients, scalar PReLU slope) are accumulated with fp64
@@ -74,9 +75,11 @@ int dprnn_scratch_to_grad(const double* scratch, float* grad, int n, int accumul
 
 /* ---- decoder + masking + mask activation backward (encoder_decoder.py:40-42, dprnn.py:277, :161-164):
  * dOut [B][2][T_out] -> dE [B*L*2][N] (gradient of the end_conv1x1 output, rows (b,l,spk)),
- * dEnc [B*L][N] (gradient reaching the encoder output through the masking), dWd[N*ks] fp64 scratch (decoder.weight). */
+ * dEnc [B*L][N] (gradient reaching the encoder output through the masking), dWd[N*ks] fp64 scratch (decoder.weight).
+ * dM0 (optional, [B*L][N]): an encoder-domain gradient of d0 = mask_0*enc added for speaker 0 (DPRNN-Spe-IRA feeds d0
+ * to the speaker encoder, dprnn_spe_ira.py:79-84). */
 int dprnn_mask_decode_bwd(const float* dOut, const float* wav, const float* enc_w, const float* dec_w,
-                          const float* mask, int relu_act, float* dE, float* dEnc, double* dWd,
+                          const float* mask, int relu_act, float* dE, float* dEnc, double* dWd, const float* dM0,
                           int B, int T, int L, int N, int ks, int stride, void* stream);
 
 /* ---- tanh * sigmoid gate backward (dprnn.py:180): dAG [rows][256] = [d out-conv pre-activation | d gate-conv ...] */
@@ -119,6 +122,13 @@ int dprnn_encoder_bwd(const float* wav, const float* enc_w, const float* dA, con
                       const float* gamma, float eps, const double* red, const float* dEnc, double* dWe,
                       int B, int T, int L, int N, int ks, int stride, void* stream);
 
+/* ---- GroupNorm(1,64) of a materialised [B][L][64] tensor (d0 in DPRNN-Spe-IRA, dprnn_spe_ira.py:84 -> dprnn_spe.py:116):
+ * rows64_affine: A = X*sc[b] + sh[b] (the normalised rows, Q operand of the following conv's weight gradient);
+ * rows64_norm_bwd: red[b] / dgb (dgamma | dbeta) as dprnn_encoder_norm_bwd_stats, then dX = gradient of the rows. */
+int dprnn_rows64_affine(const float* X, const float* sc, const float* sh, float* A, int B, int L, void* stream);
+int dprnn_rows64_norm_bwd(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
+                          double* red, double* dgb, float* dX, int B, int L, void* stream);
+
 /* ---- PIT SI-SDR loss = PITLossWrapper(pairwise_neg_sisdr, pit_from='pw_mtx') of asteroid==0.7.0 as called at
  * src/trainers/trainer.py:39,104.  fwd: moments [B][n][n][5], pw [B][n][n] (SI-SDR dB, estimate i vs target j),
  * loss_b [B] = -max over permutations of mean_i pw[i][perm[i]], perm [B][n] int32, coef [B][n][4] (all fp64 but perm);
@@ -135,10 +145,11 @@ int dprnn_time_mean_bwd(const float* d_emb, const float* aux_len, int n_len, flo
                         void* stream);
 
 /* ---- tail of ResBlock.forward backward (dprnn_spe.py:36-42; MaxPool1d(3) + PReLU + residual add): given dOut [B][T_in/3][C]
- * writes dU [B][T_in][C], the gradient of u = Y2*scale + shift + res (it is the gradient of the BatchNorm2 output AND of
+ * writes dU [B][T_in][C], the gradient of u = (Y2 - mean)*scale + shift + res (it is the gradient of the BatchNorm2 output AND of
  * the residual branch), and adds the PReLU slope gradient to the fp64 scratch scalar dalpha */
-int dprnn_resblock_pool_bwd(const float* dOut, const float* Y2, const float* scale, const float* shift, const float* res,
-                            const float* prelu_w, float* dU, double* dalpha, int B, int T_in, int C, void* stream);
+int dprnn_resblock_pool_bwd(const float* dOut, const float* Y2, const float* scale, const float* shift, const float* mean,
+                            const float* res, const float* prelu_w, float* dU, double* dalpha, int B, int T_in, int C,
+                            void* stream);
 
 /* ---- nn.BatchNorm1d backward (dprnn_spe.py:20-21,32,35).  dprnn_bn_moments: per-channel mean / rstd the forward used
  * (col_stats != NULL: batch statistics of train mode; NULL: running statistics of eval mode).  dprnn_bn_bwd: red[0:C] +=
@@ -149,12 +160,12 @@ int dprnn_bn_moments(const double* col_stats, const float* running_mean, const f
 int dprnn_bn_bwd(const float* dY, const float* Y, const float* mean, const float* rstd, const float* gamma,
                  int train, double* red, float* dX, int64_t M, int C, void* stream);
 
-/* ---- PReLU(BatchNorm1(conv1)) between the two convs of a ResBlock (dprnn_spe.py:33-34): rows = prelu(Y*scale + shift)
+/* ---- PReLU(BatchNorm1(conv1)) between the two convs of a ResBlock (dprnn_spe.py:33-34): rows = prelu((Y-mean)*scale + shift)
  * (the Q operand of conv2's weight gradient) and its backward dB = dA*prelu'(b), dalpha (fp64 scratch scalar) */
-int dprnn_affine_prelu_rows(const float* Y, const float* scale, const float* shift, const float* prelu_w, float* out,
-                            int64_t M, int C, void* stream);
-int dprnn_affine_prelu_bwd(const float* dA, const float* Y, const float* scale, const float* shift, const float* prelu_w,
-                           float* dB, double* dalpha, int64_t M, int C, void* stream);
+int dprnn_affine_prelu_rows(const float* Y, const float* scale, const float* shift, const float* mean, const float* prelu_w,
+                            float* out, int64_t M, int C, void* stream);
+int dprnn_affine_prelu_bwd(const float* dA, const float* Y, const float* scale, const float* shift, const float* mean,
+                           const float* prelu_w, float* dB, double* dalpha, int64_t M, int C, void* stream);
 
 /* out = a + b (n floats, multiple of 4): the two branches of a ResBlock meeting at its input */
 int dprnn_add_rows(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -156,6 +156,9 @@ GRAD_SPE_CASES = [
     ("grad_spe_wide_film", dict(WIDE, fusion_type="film", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 84, True),
     ("grad_spe_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 301, 411, 85, True),
     ("grad_spe_wide_att_k4", dict(WIDE, fusion_type="att", norm_type="gLN", kernel_size=4, n_repeats=1, num_spks=11), 2, 302, 411, 86, True),
+    ("grad_ira_wide_cat", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 2, 300, 411, 87, True),
+    ("grad_ira_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 211, 300, 88, True),
+    ("grad_ira_wide_film_bneval", dict(WIDE, fusion_type="film", norm_type="gLN", n_repeats=1, num_spks=11), 2, 211, 300, 89, False),
 ]
 
 
@@ -168,8 +171,9 @@ def make_grad_spe_cases(only):
         if only and name not in only:
             continue
         cfg = full_cfg(**over)
-        model = build("spe", cfg)
-        load_recipe(model, "spe", cfg, seed)
+        kind = "ira" if name.startswith("grad_ira") else "spe"
+        model = build(kind, cfg)
+        load_recipe(model, kind, cfg, seed)
         model.train()
         if not bn_train:
             for mod in model.modules():
@@ -198,7 +202,7 @@ def make_grad_spe_cases(only):
         for k, v in model.state_dict().items():
             if "running_" in k:
                 save["buf_" + k] = v.numpy()
-        meta = dict(name=name, kind="spe", cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
+        meta = dict(name=name, kind=kind, cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
                     bn_training=bn_train, torch=torch.__version__)
         save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)

@@ -61,11 +61,11 @@ def test_bn_train_running_stats_follow_torch():
     ref.train()
     want = ref(y.t().unsqueeze(0)).squeeze(0).t()
     cs = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)], dim=1).contiguous()
-    scale = torch.empty(C, device=DEV); shift = torch.empty(C, device=DEV)
+    scale = torch.empty(C, device=DEV); shift = torch.empty(C, device=DEV); mean = torch.empty(C, device=DEV)
     st.call("dprnn_bn_prep", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-            bn.num_batches_tracked.data_ptr(), cs.data_ptr(), n, 0.1, 1e-5, scale.data_ptr(), shift.data_ptr(), C)
+            bn.num_batches_tracked.data_ptr(), cs.data_ptr(), n, 0.1, 1e-5, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), C)
     torch.cuda.synchronize()
-    got = y * scale + shift
+    got = (y - mean) * scale + shift
     assert rel_l2(got.detach().cpu().numpy(), want.detach().cpu().numpy()) < 1e-6
     assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-6, atol=1e-7)
     assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-6, atol=1e-7)

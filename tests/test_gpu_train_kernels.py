@@ -107,10 +107,10 @@ def test_lstm_backward_matches_autograd(path, B, S, K):
         assert max(e1, e2, e3, e4) < 1e-5
 
 
+@pytest.mark.parametrize("rows", [1256, 198, 22, 1])
 @pytest.mark.parametrize("kd,nd", [(128, 256), (128, 128), (64, 128), (256, 128), (128, 64)])
-def test_dgrad_matches_matmul(kd, nd):
+def test_dgrad_matches_matmul(kd, nd, rows):
     rng = np.random.default_rng(kd + nd)
-    rows = 1000 + kd
     dOut = rng.standard_normal((rows, kd)).astype(np.float32)
     k0 = kd if kd != 256 else 128
     W0 = rng.standard_normal((k0, nd)).astype(np.float32)
@@ -148,3 +148,64 @@ def test_wgrad_matches_matmul(M, N, rows, acc):
     gb = db.cpu().numpy().astype(np.float64) - (1 if acc else 0)
     assert rel_l2(got, want) < 2e-6
     assert rel_l2(gb, wb) < 2e-6
+
+
+def test_rows64_groupnorm_backward_matches_autograd():
+    """dprnn_rows64_affine / dprnn_rows64_norm_bwd (GroupNorm(1,64) of the materialised d0 in DPRNN-Spe-IRA) vs F.group_norm."""
+    rng = np.random.default_rng(11)
+    B, L, N = 3, 77, 64
+    x = torch.from_numpy(rng.standard_normal((B, L, N)).astype(np.float32) * 1.5 + 0.2)
+    x[:, ::3, ::2] = 0.0                                            # d0 = mask*relu(...) holds exact zeros
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy(rng.uniform(-0.3, 0.3, N).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rng.standard_normal((B, L, N)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.functional.group_norm(xr.transpose(1, 2), 1, gamma, beta, 1e-5).transpose(1, 2)
+    y.backward(dy)
+    st = _st()
+    xd, dyd, g, b = _t(x), _t(dy), _t(gamma.detach()), _t(beta.detach())
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_rows_stats", _p(xd), _p(stats), B, L, N)
+    sc = torch.empty(B, N, device=DEV); sh = torch.empty(B, N, device=DEV)
+    st.call("dprnn_bottleneck_prep", _p(stats), _p(g), _p(b), 1e-5, 0, 0, _p(sc), _p(sh), B, L, N)
+    A = torch.empty(B * L, N, device=DEV)
+    st.call("dprnn_rows64_affine", _p(xd), _p(sc), _p(sh), _p(A), B, L)
+    red = torch.zeros(2 * B, device=DEV, dtype=torch.float64)
+    dgb = torch.zeros(2 * N, device=DEV, dtype=torch.float64)
+    dX = torch.full((B * L, N), float("nan"), device=DEV)
+    st.call("dprnn_rows64_norm_bwd", _p(xd), _p(dyd), _p(stats), _p(g), 1e-5, _p(red), _p(dgb), _p(dX), B, L)
+    torch.cuda.synchronize()
+    assert rel_l2(A.cpu().numpy().reshape(B, L, N), y.detach().numpy()) < 1e-6
+    assert rel_l2(dX.cpu().numpy().reshape(B, L, N), xr.grad.numpy()) < 2e-6
+    assert rel_l2(dgb[:N].cpu().numpy(), gamma.grad.numpy()) < 2e-6
+    assert rel_l2(dgb[N:].cpu().numpy(), beta.grad.numpy()) < 2e-6
+
+
+def test_mask_decode_backward_with_encoder_domain_gradient():
+    """dprnn_mask_decode_bwd incl. dM0 (gradient of d0 = mask_0*enc, DPRNN-Spe-IRA) vs autograd of the stock operators."""
+    rng = np.random.default_rng(12)
+    B, T, N, ks, stride = 2, 203, 64, 4, 2
+    L = (T - ks) // stride + 1
+    wav = torch.from_numpy(rng.standard_normal((B, T)).astype(np.float32))
+    We = torch.from_numpy((rng.standard_normal((N, 1, ks)) * 0.5).astype(np.float32)).requires_grad_(True)
+    Wd = torch.from_numpy((rng.standard_normal((N, 1, ks)) * 0.5).astype(np.float32)).requires_grad_(True)
+    E = torch.from_numpy(rng.standard_normal((B, 2, N, L)).astype(np.float32)).requires_grad_(True)      # end_conv1x1 output
+    d_out = torch.from_numpy(rng.standard_normal((B, 2, (L - 1) * stride + ks)).astype(np.float32))
+    d_d0 = torch.from_numpy(rng.standard_normal((B, N, L)).astype(np.float32))
+    enc = torch.relu(torch.nn.functional.conv1d(wav[:, None], We, stride=stride))                         # [B,N,L]
+    M = torch.sigmoid(E)
+    masked = M * enc[:, None]
+    out = torch.stack([torch.nn.functional.conv_transpose1d(masked[:, i], Wd, stride=stride)[:, 0] for i in range(2)], 1)
+    ((out * d_out).sum() + (masked[:, 0] * d_d0).sum()).backward()
+    st = _st()
+    mask_rows = M.detach().permute(0, 3, 1, 2).reshape(B * L * 2, N)                                      # rows (b,l,spk)
+    dE = torch.full((B * L * 2, N), float("nan"), device=DEV)
+    dEnc = torch.full((B * L, N), float("nan"), device=DEV)
+    dWd = torch.zeros(N * ks, device=DEV, dtype=torch.float64)
+    dM0 = d_d0.permute(0, 2, 1).reshape(B * L, N)
+    st.call("dprnn_mask_decode_bwd", _p(_t(d_out)), _p(_t(wav)), _p(_t(We.detach())), _p(_t(Wd.detach())), _p(_t(mask_rows)), 0,
+            _p(dE), _p(dEnc), _p(dWd), _p(_t(dM0)), B, T, L, N, ks, stride)
+    torch.cuda.synchronize()
+    want_dE = E.grad.permute(0, 3, 1, 2).reshape(B * L * 2, N).numpy()
+    assert rel_l2(dE.cpu().numpy(), want_dE) < 2e-6
+    assert rel_l2(dWd.cpu().numpy().reshape(N, ks), Wd.grad.numpy()[:, 0]) < 2e-6

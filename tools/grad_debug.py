@@ -10,13 +10,24 @@ from tss_with_dprnn_amd.training import PITSiSdrLoss
 
 name = sys.argv[1]
 g = load_golden(name); m = g["meta"]
-model, _, _ = build_model("bss", m["cfg"], m["seed"], "cuda:0")
+model, _, _ = build_model(m["kind"], m["cfg"], m["seed"], "cuda:0")
 model.train()
-out = model(torch.from_numpy(g["mix"]).cuda())
-loss = PITSiSdrLoss()(out, torch.from_numpy(g["tgt"]).cuda())
+if m["kind"] == "bss":
+    out = model(torch.from_numpy(g["mix"]).cuda())
+    loss = PITSiSdrLoss()(out, torch.from_numpy(g["tgt"]).cuda())
+else:
+    if not m.get("bn_training", True):
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.eval()
+    est, logits = model(torch.from_numpy(g["mix"]).cuda(), torch.from_numpy(g["aux"]).cuda(), torch.tensor(float(g["aux_len"])))
+    tgt = torch.from_numpy(g["tgt"]).cuda()
+    loss = PITSiSdrLoss()(est.unsqueeze(1), tgt.unsqueeze(1)) + 0.5 * torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["spk_idx"]).cuda())
 loss.backward()
 print("loss", loss.item(), float(g["loss"]))
 for k, p in model.named_parameters():
+    if "norm_" + k not in g:
+        continue
     got = p.grad.cpu().numpy(); nrm = float(g["norm_" + k])
     if "grad_" + k in g:
         err = np.linalg.norm(got.astype(np.float64) - g["grad_" + k]) / nrm

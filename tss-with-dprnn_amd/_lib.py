@@ -47,9 +47,9 @@ SIGNATURES = {
     "dprnn_decoder_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_pairwise_sisdr": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_pairwise_sisdr_metric": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
-    "dprnn_pointwise_fwd": [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i64, c_fp],
-    "dprnn_bn_prep": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp, c_fp, c_i, c_fp],
-    "dprnn_resblock_pool_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_pointwise_fwd": [c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i64, c_fp],
+    "dprnn_bn_prep": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_fp, c_fp, c_fp, c_i, c_fp],
+    "dprnn_resblock_pool_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_time_mean_fwd": [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_linear_small_fwd": [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_rows_stats": [c_fp, c_fp, c_i, c_i64, c_i, c_fp],
@@ -62,12 +62,14 @@ SIGNATURES = {
                     c_fp, c_fp, c_i, c_fp, c_fp],
     "dprnn_dgrad": [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i64, c_fp],
     "dprnn_head_gate_fwd_train": [c_fp] * 7 + [c_i64, c_fp],
-    "dprnn_head_mask_decode_fwd_train": [c_fp] * 7 + [c_i] * 7 + [c_fp],
+    "dprnn_head_mask_decode_fwd_train": [c_fp] * 8 + [c_i] * 7 + [c_fp],
     "dprnn_head_conv_bwd": [c_fp] * 6 + [c_i] * 5 + [c_fp],
     "dprnn_gn_bwd_stats": [c_fp] * 7 + [c_f, c_i, c_i64, c_fp, c_fp, c_fp],
     "dprnn_gn_bwd_dz": [c_fp] * 5 + [c_f, c_i, c_i64, c_fp, c_fp],
     "dprnn_gate_bwd": [c_fp, c_fp, c_fp, c_i64, c_fp],
-    "dprnn_mask_decode_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
+    "dprnn_mask_decode_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
+    "dprnn_rows64_affine": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp],
+    "dprnn_rows64_norm_bwd": [c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_i, c_fp],
     "dprnn_ola_prelu_sum": [c_fp] * 5 + [c_i] * 5 + [c_fp],
     "dprnn_segment_bwd": [c_fp] * 4 + [c_i] * 5 + [c_fp],
     "dprnn_encoder_norm_rows": [c_fp] * 5 + [c_i] * 6 + [c_fp],
@@ -78,11 +80,11 @@ SIGNATURES = {
     "dprnn_pit_sisdr_bwd": [c_fp] * 6 + [c_i, c_i, c_i, c_fp],
     "dprnn_multi_sumsq": [c_fp, c_i, c_fp, c_fp],
     "dprnn_time_mean_bwd": [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp],
-    "dprnn_resblock_pool_bwd": [c_fp] * 8 + [c_i, c_i, c_i, c_fp],
+    "dprnn_resblock_pool_bwd": [c_fp] * 9 + [c_i, c_i, c_i, c_fp],
     "dprnn_bn_moments": [c_fp, c_fp, c_fp, c_i64, c_f, c_fp, c_fp, c_i, c_fp],
     "dprnn_bn_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_i64, c_i, c_fp],
-    "dprnn_affine_prelu_rows": [c_fp] * 5 + [c_i64, c_i, c_fp],
-    "dprnn_affine_prelu_bwd": [c_fp] * 7 + [c_i64, c_i, c_fp],
+    "dprnn_affine_prelu_rows": [c_fp] * 6 + [c_i64, c_i, c_fp],
+    "dprnn_affine_prelu_bwd": [c_fp] * 8 + [c_i64, c_i, c_fp],
     "dprnn_add_rows": [c_fp, c_fp, c_fp, c_i64, c_fp],
     "dprnn_utt_colsum": [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_linear_small_bwd": [c_fp, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp],

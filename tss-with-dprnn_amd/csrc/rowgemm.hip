@@ -120,10 +120,10 @@ extern "C" int dprnn_head_mask_decode_fwd(const float* V, const float* Wend, con
 }
 
 extern "C" int dprnn_head_mask_decode_fwd_train(const float* V, const float* Wend, const float* wav, const float* enc_w,
-                                                const float* dec_w, float* taps, float* mask, int relu_act,
+                                                const float* dec_w, float* taps, float* mask, float* masked_out, int relu_act,
                                                 int B, int T, int L, int N, int ks, int stride, void* stream) {
     if (!mask) { dprnn_set_error("dprnn_head_mask_decode_fwd_train: mask is null"); return -1; }
-    return head_mask_decode(V, Wend, wav, enc_w, dec_w, taps, nullptr, mask, relu_act, B, T, L, N, ks, stride, stream);
+    return head_mask_decode(V, Wend, wav, enc_w, dec_w, taps, masked_out, mask, relu_act, B, T, L, N, ks, stride, stream);
 }
 
 static int head_mask_decode(const float* V, const float* Wend, const float* wav, const float* enc_w,

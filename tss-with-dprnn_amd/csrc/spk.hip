@@ -6,11 +6,13 @@ using namespace rg;
 
 namespace {
 
-// A[row][k] -> prelu(a * s[u*aff_stride + k] + t[...]), u = row / rows_per_utt; every piece optional.
+// A[row][k] -> prelu((a - m[k]) * s[u*aff_stride + k] + t[...]), u = row / rows_per_utt; every piece optional.
+// The mean is subtracted BEFORE the scale (as torch's batch_norm does): folding it into the shift (t - m*s) loses the
+// result to cancellation in channels whose mean dwarfs their spread.
 template <int RT>
 struct AffineRows {
     const float* A; int pitch;
-    const float* sc; const float* sh; int aff_stride; long long rows_per_utt;
+    const float* sc; const float* sh; const float* mn; int aff_stride; long long rows_per_utt;
     const float* prelu_p;
     const float* p[RT];
     const float* ps[RT];
@@ -33,6 +35,11 @@ struct AffineRows {
         if (sc) {
             const f32x4 s = *reinterpret_cast<const f32x4*>(ps[rt] + 16 * g);
             const f32x4 t = *reinterpret_cast<const f32x4*>(pt[rt] + 16 * g);
+            if (mn) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mn + (ps[rt] - sc) + 16 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] -= m[e];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], s[e], t[e]);
         }
@@ -71,7 +78,9 @@ struct EpStoreColStats {
         for (int ct = 0; ct < 8; ++ct) {
             const int col = col0 + 16 * ct + r;
             const float bv = bias ? bias[col] : 0.f;
-            float p1 = 0.f, p2 = 0.f;
+            // sums in fp64 element by element: the batch variance is E[y^2] - mean^2, and channels whose mean dwarfs their
+            // spread (after PReLU + MaxPool) lose it to fp32 rounding of the squares otherwise
+            double p1 = 0.0, p2 = 0.0;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -80,20 +89,22 @@ struct EpStoreColStats {
                     if (row < M) {
                         const float v = acc[rt][ct][e] + bv;
                         out[row * pitch + col] = v;
-                        p1 += v; p2 = fmaf(v, v, p2);
+                        p1 += (double)v; p2 = fma((double)v, (double)v, p2);
                     }
                 }
-            d1[ct] += (double)p1; d2[ct] += (double)p2;
+            d1[ct] += p1; d2[ct] += p2;
         }
     }
 };
 
-// BatchNorm1d folded to y*scale + shift (eps 1e-5).  col_stats == NULL: running statistics (eval).
+// BatchNorm1d as (y - mean)*scale + shift with scale = gamma/sqrt(var + eps), shift = beta (eps 1e-5).
+// col_stats == NULL: running statistics (eval).
 // Otherwise batch statistics (biased variance) and the running buffers are updated in place exactly as
 // nn.BatchNorm1d does in train mode (momentum, unbiased variance, num_batches_tracked += 1).
 __global__ void bn_prep_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                float* running_var, long long* nbt, const double* __restrict__ col_stats, long long count,
-                               float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+                               float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                               float* __restrict__ mean_out, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean, var;
@@ -109,21 +120,22 @@ __global__ void bn_prep_kernel(const float* __restrict__ gamma, const float* __r
     } else {
         mean = running_mean[c]; var = running_var[c];
     }
-    const float s = gamma[c] / sqrtf(var + eps);
-    scale[c] = s;
-    shift[c] = beta[c] - mean * s;
+    scale[c] = gamma[c] / sqrtf(var + eps);
+    shift[c] = beta[c];
+    mean_out[c] = mean;
 }
 
-// out[b][t3][c] = max_{j<3} prelu(y[b][3*t3+j][c]*scale[c] + shift[c] + res[b][3*t3+j][c])   (dprnn_spe.py:35-42)
+// out[b][t3][c] = max_{j<3} prelu((y[b][3*t3+j][c] - mean[c])*scale[c] + shift[c] + res[b][3*t3+j][c])   (dprnn_spe.py:35-42)
 __global__ __launch_bounds__(256) void resblock_pool_kernel(const f32x4* __restrict__ Y, const f32x4* __restrict__ scale,
-                                                            const f32x4* __restrict__ shift, const f32x4* __restrict__ res,
+                                                            const f32x4* __restrict__ shift, const f32x4* __restrict__ mean,
+                                                            const f32x4* __restrict__ res,
                                                             const float* __restrict__ prelu_w, f32x4* __restrict__ out,
                                                             long long total4, int T_in, int T_out, int C4) {
     const float alpha = *prelu_w;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c4 = (int)(i % C4); const long long bt = i / C4;
         const int t3 = (int)(bt % T_out); const long long b = bt / T_out;
-        const f32x4 s = scale[c4], t = shift[c4];
+        const f32x4 s = scale[c4], t = shift[c4], mu = mean[c4];
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void resblock_pool_kernel(const f32x4* __restr
             const f32x4 y = Y[src], rr = res[src];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = fmaf(y[e], s[e], t[e]) + rr[e];
+                float v = fmaf(y[e] - mu[e], s[e], t[e]) + rr[e];
                 v = v >= 0.f ? v : alpha * v;
                 m[e] = fmaxf(m[e], v);
             }
@@ -254,16 +266,17 @@ int launch_pointwise(const AffineRows<4>& al, const EpStoreColStats<4>& ep, cons
 }  // namespace
 
 extern "C" int dprnn_pointwise_fwd(const float* A, int a_pitch, int kdim, const float* in_scale, const float* in_shift,
-                                   int aff_stride, int64_t rows_per_utt, const float* in_prelu, const float* W, int ldw,
+                                   const float* in_mean, int aff_stride, int64_t rows_per_utt, const float* in_prelu, const float* W, int ldw,
                                    const float* bias, float* out, int out_pitch, int col0, double* col_stats, int64_t M,
                                    void* stream) {
     if (!A || !W || !out || M <= 0) { dprnn_set_error("dprnn_pointwise_fwd: null pointer / M"); return -1; }
     if ((kdim != 64 && kdim != 128 && kdim != 256) || a_pitch < kdim || (a_pitch % 4) || ldw < kdim || (ldw % 4) ||
-        (col0 % 16) || out_pitch < col0 + 128 || (aff_stride && rows_per_utt <= 0) || ((in_scale == nullptr) != (in_shift == nullptr))) {
+        (col0 % 16) || out_pitch < col0 + 128 || (aff_stride && rows_per_utt <= 0) || ((in_scale == nullptr) != (in_shift == nullptr)) ||
+        (in_mean && !in_scale)) {
         dprnn_set_error("dprnn_pointwise_fwd: unsupported kdim=%d a_pitch=%d ldw=%d col0=%d out_pitch=%d", kdim, a_pitch, ldw, col0, out_pitch);
         return -1;
     }
-    AffineRows<4> al{A, a_pitch, in_scale, in_shift, aff_stride, (long long)(rows_per_utt > 0 ? rows_per_utt : 1), in_prelu};
+    AffineRows<4> al{A, a_pitch, in_scale, in_shift, in_mean, aff_stride, (long long)(rows_per_utt > 0 ? rows_per_utt : 1), in_prelu};
     EpStoreColStats<4> ep{out, out_pitch, col0, bias, col_stats};
     const float* Wc = W + (long long)col0 * ldw;
     // the epilogue indexes bias/out/stats with col0 + col, the weight rows are pre-offset
@@ -276,23 +289,24 @@ extern "C" int dprnn_pointwise_fwd(const float* A, int a_pitch, int kdim, const 
 
 extern "C" int dprnn_bn_prep(const float* gamma, const float* beta, float* running_mean, float* running_var,
                              int64_t* num_batches_tracked, const double* col_stats, int64_t count, float momentum,
-                             float eps, float* scale, float* shift, int C, void* stream) {
-    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) { dprnn_set_error("dprnn_bn_prep: null pointer"); return -1; }
+                             float eps, float* scale, float* shift, float* mean, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || !mean) { dprnn_set_error("dprnn_bn_prep: null pointer"); return -1; }
     hipLaunchKernelGGL(bn_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
-                       running_var, (long long*)num_batches_tracked, col_stats, (long long)count, momentum, eps, scale, shift, C);
+                       running_var, (long long*)num_batches_tracked, col_stats, (long long)count, momentum, eps, scale, shift, mean, C);
     return dprnn_check_launch("bn_prep_kernel");
 }
 
-extern "C" int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, const float* shift, const float* res,
+extern "C" int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, const float* shift, const float* mean, const float* res,
                                        const float* prelu_w, float* out, int B, int T_in, int C, void* stream) {
-    if (!Y2 || !scale || !shift || !res || !prelu_w || !out) { dprnn_set_error("dprnn_resblock_pool_fwd: null pointer"); return -1; }
+    if (!Y2 || !scale || !shift || !mean || !res || !prelu_w || !out) { dprnn_set_error("dprnn_resblock_pool_fwd: null pointer"); return -1; }
     if (C % 4 || T_in < 3) { dprnn_set_error("dprnn_resblock_pool_fwd: bad sizes T_in=%d C=%d", T_in, C); return -1; }
     const int T_out = T_in / 3;
     const long long total4 = (long long)B * T_out * (C / 4);
     long long g = (total4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
     hipLaunchKernelGGL(resblock_pool_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(Y2), reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       reinterpret_cast<const f32x4*>(res), prelu_w, reinterpret_cast<f32x4*>(out), total4, T_in, T_out, C / 4);
+                       reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(res), prelu_w, reinterpret_cast<f32x4*>(out),
+                       total4, T_in, T_out, C / 4);
     return dprnn_check_launch("resblock_pool_kernel");
 }
 

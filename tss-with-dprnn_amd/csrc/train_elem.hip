@@ -138,7 +138,8 @@ void gate_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ TG,
 __global__ __launch_bounds__(256)
 void mask_decode_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ wav, const float* __restrict__ We,
                             const float* __restrict__ Wd, const float* __restrict__ Mk, int relu_act, Geo geo, int T_out,
-                            float* __restrict__ dE, float* __restrict__ dEnc, double* __restrict__ dWd) {
+                            float* __restrict__ dE, float* __restrict__ dEnc, double* __restrict__ dWd,
+                            const float* __restrict__ dM0) {
     const int n = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int ks = geo.ks;
     float we[KSMAX], wd[KSMAX], acc[KSMAX];
@@ -166,6 +167,7 @@ void mask_decode_bwd_kernel(const float* __restrict__ dOut, const float* __restr
 #pragma unroll
             for (int j = 0; j < KSMAX; ++j)
                 if (j < ks) { dm = fmaf(wd[j], g[j], dm); acc[j] = fmaf(m * en, g[j], acc[j]); }
+            if (dM0 && spk == 0) dm += dM0[row * 64 + n];        // encoder-domain gradient of d0 = mask_0*enc (DPRNN-Spe-IRA)
             const float dact = relu_act ? (m > 0.f ? 1.f : 0.f) : m * (1.f - m);
             dE[(row * 2 + spk) * 64 + n] = dm * en * dact;
             denc = fmaf(dm, m, denc);
@@ -252,13 +254,17 @@ void segment_bwd_kernel(const float* __restrict__ dXn, const float* __restrict__
 // mode 0: A[(b,l)][n] = enc*sc[b][n] + sh[b][n]                         (the normalised encoder output, Q of the bottleneck wgrad)
 // mode 1: dy = dA[(b,l)][n]: red[b] += (sum g*dy, sum g*dy*xh), dgb[0][n] += dy*xh, dgb[1][n] += dy        (norm backward, pass 1)
 // mode 2: denc = rs*(g*dy - s1/n - xh*s2/n) + dEnc;  dpre = denc*[enc > 0];  dWe[n][j] += dpre*wav[b][l*stride+j]   (pass 2)
-template <int MODE>
+// MAT: the rows are a materialised [B*L][64] tensor Xmat instead of the encoder output recomputed from the waveform
+// (GroupNorm of d0 = mask_0*enc in DPRNN-Spe-IRA, dprnn_spe_ira.py:84 -> dprnn_spe.py:116): no ReLU, and mode 2 writes
+// the gradient of the rows to dXout instead of accumulating the encoder weight gradient.
+template <int MODE, bool MAT = false>
 __global__ __launch_bounds__(256)
 void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict__ We, Geo geo,
                          const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ A,
                          const float* __restrict__ dA, const double* __restrict__ stats, const float* __restrict__ gamma,
                          float eps, double* __restrict__ red, double* __restrict__ dgb,
-                         const float* __restrict__ dEnc, double* __restrict__ dWe, int chunks_per_utt) {
+                         const float* __restrict__ dEnc, double* __restrict__ dWe, int chunks_per_utt,
+                         const float* __restrict__ Xmat = nullptr, float* __restrict__ dXout = nullptr) {
     const int n = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int ks = geo.ks;
     const int b = blockIdx.x / chunks_per_utt, ch = blockIdx.x % chunks_per_utt;
@@ -266,7 +272,7 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
     const int l0 = per * ch, l1 = (l0 + per < geo.L) ? l0 + per : geo.L;
     float we[KSMAX], acc[KSMAX];
 #pragma unroll
-    for (int j = 0; j < KSMAX; ++j) { we[j] = j < ks ? We[n * ks + j] : 0.f; acc[j] = 0.f; }
+    for (int j = 0; j < KSMAX; ++j) { we[j] = (!MAT && j < ks) ? We[n * ks + j] : 0.f; acc[j] = 0.f; }
     float mu = 0.f, rs = 0.f, g = 0.f, m1 = 0.f, m2 = 0.f, scn = 0.f, shn = 0.f;
     const double cnt = (double)geo.L * (double)geo.N;
     if (MODE == 0) { scn = sc[b * geo.N + n]; shn = sh[b * geo.N + n]; }
@@ -274,13 +280,17 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
     if (MODE == 2) { m1 = (float)(red[2 * b] / cnt); m2 = (float)(red[2 * b + 1] / cnt); }
     float dgam = 0.f, dbet = 0.f, s1 = 0.f, s2 = 0.f;
     for (int l = l0 + slot; l < l1; l += 4) {
-        const float* x = wav + (long long)b * geo.T + (long long)l * geo.stride;
-        float en = 0.f;
-#pragma unroll
-        for (int j = 0; j < KSMAX; ++j)
-            if (j < ks) en = fmaf(we[j], x[j], en);
-        en = fmaxf(en, 0.f);
         const long long row = (long long)b * geo.L + l;
+        const float* x = MAT ? nullptr : wav + (long long)b * geo.T + (long long)l * geo.stride;
+        float en = 0.f;
+        if constexpr (MAT) {
+            en = Xmat[row * 64 + n];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KSMAX; ++j)
+                if (j < ks) en = fmaf(we[j], x[j], en);
+            en = fmaxf(en, 0.f);
+        }
         if (MODE == 0) {
             A[row * 64 + n] = fmaf(en, scn, shn);
         } else {
@@ -291,10 +301,14 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
                 s1 = fmaf(g, dy, s1); s2 = fmaf(g * dy, xh, s2);
             } else {
                 const float denc = rs * (g * dy - m1 - xh * m2) + (dEnc ? dEnc[row * 64 + n] : 0.f);
-                const float dpre = en > 0.f ? denc : 0.f;
+                if constexpr (MAT) {
+                    dXout[row * 64 + n] = denc;
+                } else {
+                    const float dpre = en > 0.f ? denc : 0.f;
 #pragma unroll
-                for (int j = 0; j < KSMAX; ++j)
-                    if (j < ks) acc[j] = fmaf(dpre, x[j], acc[j]);
+                    for (int j = 0; j < KSMAX; ++j)
+                        if (j < ks) acc[j] = fmaf(dpre, x[j], acc[j]);
+                }
             }
         }
     }
@@ -314,7 +328,7 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
             atomicAdd(&red[2 * b + 1], sred[1][0] + sred[1][1] + sred[1][2] + sred[1][3]);
         }
     }
-    if (MODE == 2) {
+    if (MODE == 2 && !MAT) {
         __shared__ float wred[4][64][KSMAX];
 #pragma unroll
         for (int j = 0; j < KSMAX; ++j) wred[slot][n][j] = acc[j];
@@ -460,14 +474,14 @@ extern "C" int dprnn_gate_bwd(const float* dV, const float* TG, float* dAG, int6
 }
 
 extern "C" int dprnn_mask_decode_bwd(const float* dOut, const float* wav, const float* enc_w, const float* dec_w,
-                                     const float* mask, int relu_act, float* dE, float* dEnc, double* dWd,
+                                     const float* mask, int relu_act, float* dE, float* dEnc, double* dWd, const float* dM0,
                                      int B, int T, int L, int N, int ks, int stride, void* stream) {
     if (!dOut || !wav || !enc_w || !dec_w || !mask || !dE || !dEnc || !dWd) { dprnn_set_error("dprnn_mask_decode_bwd: null pointer"); return -1; }
     if (N != 64 || ks < 1 || ks > KSMAX || L != (T - ks) / stride + 1) { dprnn_set_error("dprnn_mask_decode_bwd: unsupported N=%d ks=%d", N, ks); return -1; }
     const Geo geo{B, T, L, N, ks, stride};
     const int T_out = (L - 1) * stride + ks;
     hipLaunchKernelGGL(mask_decode_bwd_kernel, dim3(grid_for(((long long)B * L + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       dOut, wav, enc_w, dec_w, mask, relu_act, geo, T_out, dE, dEnc, dWd);
+                       dOut, wav, enc_w, dec_w, mask, relu_act, geo, T_out, dE, dEnc, dWd, dM0);
     return dprnn_check_launch("mask_decode_bwd_kernel");
 }
 
@@ -529,6 +543,30 @@ extern "C" int dprnn_encoder_bwd(const float* wav, const float* enc_w, const flo
     hipLaunchKernelGGL(encoder_rows_kernel<2>, dim3(B * ch), dim3(256), 0, (hipStream_t)stream, wav, enc_w, geo, nullptr, nullptr,
                        nullptr, dA, stats, gamma, eps, const_cast<double*>(red), nullptr, dEnc, dWe, ch);
     return dprnn_check_launch("encoder_rows_kernel<2>");
+}
+
+// ---- the same three passes on a materialised [B][L][64] tensor (GroupNorm(1,64) of d0 in DPRNN-Spe-IRA)
+extern "C" int dprnn_rows64_affine(const float* X, const float* sc, const float* sh, float* A, int B, int L, void* stream) {
+    if (!X || !sc || !sh || !A || B < 1 || L < 1) { dprnn_set_error("dprnn_rows64_affine: null pointer / sizes"); return -1; }
+    const Geo geo{B, 0, L, 64, 1, 1};
+    const int ch = enc_chunks(B, L);
+    hipLaunchKernelGGL((encoder_rows_kernel<0, true>), dim3(B * ch), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, geo, sc, sh, A,
+                       nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, ch, X, nullptr);
+    return dprnn_check_launch("encoder_rows_kernel<0,mat>");
+}
+
+extern "C" int dprnn_rows64_norm_bwd(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
+                                     double* red, double* dgb, float* dX, int B, int L, void* stream) {
+    if (!X || !dA || !stats || !gamma || !red || !dgb || !dX || B < 1 || L < 1) { dprnn_set_error("dprnn_rows64_norm_bwd: null pointer / sizes"); return -1; }
+    const Geo geo{B, 0, L, 64, 1, 1};
+    const int ch = enc_chunks(B, L);
+    hipLaunchKernelGGL((encoder_rows_kernel<1, true>), dim3(B * ch), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, geo, nullptr,
+                       nullptr, nullptr, dA, stats, gamma, eps, red, dgb, nullptr, nullptr, ch, X, nullptr);
+    int rc = dprnn_check_launch("encoder_rows_kernel<1,mat>");
+    if (rc) return rc;
+    hipLaunchKernelGGL((encoder_rows_kernel<2, true>), dim3(B * ch), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, geo, nullptr,
+                       nullptr, nullptr, dA, stats, gamma, eps, red, nullptr, nullptr, nullptr, ch, X, dX);
+    return dprnn_check_launch("encoder_rows_kernel<2,mat>");
 }
 
 extern "C" int dprnn_scratch_to_grad(const double* scratch, float* grad, int n, int accumulate, void* stream) {

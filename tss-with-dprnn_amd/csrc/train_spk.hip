@@ -38,21 +38,22 @@ void time_mean_bwd_kernel(const float* __restrict__ d_emb, const float* __restri
 // 0 elsewhere (and on the up to two tail rows the pooling drops); dalpha += dOut*u where u <= 0 at the argmax.
 __global__ __launch_bounds__(256)
 void resblock_pool_bwd_kernel(const f32x4* __restrict__ dOut, const f32x4* __restrict__ Y, const f32x4* __restrict__ scale,
-                              const f32x4* __restrict__ shift, const f32x4* __restrict__ res, const float* __restrict__ prelu_w,
+                              const f32x4* __restrict__ shift, const f32x4* __restrict__ mean, const f32x4* __restrict__ res,
+                              const float* __restrict__ prelu_w,
                               f32x4* __restrict__ dU, double* __restrict__ dalpha, long long total4, int T_in, int T_out, int C4) {
     const float alpha = *prelu_w;
     float part = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c4 = (int)(i % C4); const long long bt = i / C4;
         const int t3 = (int)(bt % T_out); const long long b = bt / T_out;
-        const f32x4 s = scale[c4], t = shift[c4], g = dOut[i];
+        const f32x4 s = scale[c4], t = shift[c4], mu = mean[c4], g = dOut[i];
         f32x4 u[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const long long src = (b * T_in + 3 * t3 + j) * C4 + c4;
             const f32x4 y = Y[src], rr = res[src];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u[j][e] = fmaf(y[e], s[e], t[e]) + rr[e];
+            for (int e = 0; e < 4; ++e) u[j][e] = fmaf(y[e] - mu[e], s[e], t[e]) + rr[e];
         }
         f32x4 o[3];
 #pragma unroll
@@ -163,7 +164,8 @@ void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__
 // out = prelu(Y*scale + shift): the input of the ResBlock's second conv (dprnn_spe.py:33-35), Q operand of its weight gradient
 __global__ __launch_bounds__(256)
 void affine_prelu_rows_kernel(const float* __restrict__ Y, const float* __restrict__ scale, const float* __restrict__ shift,
-                              const float* __restrict__ prelu_w, float* __restrict__ out, long long M, int C) {
+                              const float* __restrict__ mean, const float* __restrict__ prelu_w, float* __restrict__ out,
+                              long long M, int C) {
     const float alpha = *prelu_w;
     const int C4 = C / 4;
     const long long total4 = M * C4;
@@ -171,9 +173,10 @@ void affine_prelu_rows_kernel(const float* __restrict__ Y, const float* __restri
         const int c4 = (int)(i % C4);
         const f32x4 y = reinterpret_cast<const f32x4*>(Y)[i];
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + 4 * c4), t = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float b = fmaf(y[e], s[e], t[e]); o[e] = b >= 0.f ? b : alpha * b; }
+        for (int e = 0; e < 4; ++e) { const float b = fmaf(y[e] - mu[e], s[e], t[e]); o[e] = b >= 0.f ? b : alpha * b; }
         reinterpret_cast<f32x4*>(out)[i] = o;
     }
 }
@@ -181,7 +184,8 @@ void affine_prelu_rows_kernel(const float* __restrict__ Y, const float* __restri
 // dB = dA * prelu'(b), b = Y*scale + shift; dalpha += dA*b where b <= 0
 __global__ __launch_bounds__(256)
 void affine_prelu_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ Y, const float* __restrict__ scale,
-                             const float* __restrict__ shift, const float* __restrict__ prelu_w, float* __restrict__ dB,
+                             const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ prelu_w,
+                             float* __restrict__ dB,
                              double* __restrict__ dalpha, long long M, int C) {
     const float alpha = *prelu_w;
     const int C4 = C / 4;
@@ -191,10 +195,11 @@ void affine_prelu_bwd_kernel(const float* __restrict__ dA, const float* __restri
         const int c4 = (int)(i % C4);
         const f32x4 y = reinterpret_cast<const f32x4*>(Y)[i], g = reinterpret_cast<const f32x4*>(dA)[i];
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + 4 * c4), t = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float b = fmaf(y[e], s[e], t[e]);
+            const float b = fmaf(y[e] - mu[e], s[e], t[e]);
             o[e] = b > 0.f ? g[e] : alpha * g[e];
             if (!(b > 0.f)) part = fmaf(g[e], b, part);
         }
@@ -322,16 +327,17 @@ extern "C" int dprnn_time_mean_bwd(const float* d_emb, const float* aux_len, int
     return dprnn_check_launch("time_mean_bwd_kernel");
 }
 
-extern "C" int dprnn_resblock_pool_bwd(const float* dOut, const float* Y2, const float* scale, const float* shift, const float* res,
-                                       const float* prelu_w, float* dU, double* dalpha, int B, int T_in, int C, void* stream) {
-    if (!dOut || !Y2 || !scale || !shift || !res || !prelu_w || !dU || !dalpha) { dprnn_set_error("dprnn_resblock_pool_bwd: null pointer"); return -1; }
+extern "C" int dprnn_resblock_pool_bwd(const float* dOut, const float* Y2, const float* scale, const float* shift, const float* mean,
+                                       const float* res, const float* prelu_w, float* dU, double* dalpha, int B, int T_in, int C,
+                                       void* stream) {
+    if (!dOut || !Y2 || !scale || !shift || !mean || !res || !prelu_w || !dU || !dalpha) { dprnn_set_error("dprnn_resblock_pool_bwd: null pointer"); return -1; }
     if (C % 4 || T_in < 3) { dprnn_set_error("dprnn_resblock_pool_bwd: bad sizes T_in=%d C=%d", T_in, C); return -1; }
     const int T_out = T_in / 3;
     const long long total4 = (long long)B * T_out * (C / 4);
     hipLaunchKernelGGL(resblock_pool_bwd_kernel, dim3(grid_rows(total4, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(dOut), reinterpret_cast<const f32x4*>(Y2), reinterpret_cast<const f32x4*>(scale),
-                       reinterpret_cast<const f32x4*>(shift), reinterpret_cast<const f32x4*>(res), prelu_w,
-                       reinterpret_cast<f32x4*>(dU), dalpha, total4, T_in, T_out, C / 4);
+                       reinterpret_cast<const f32x4*>(shift), reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(res),
+                       prelu_w, reinterpret_cast<f32x4*>(dU), dalpha, total4, T_in, T_out, C / 4);
     return dprnn_check_launch("resblock_pool_bwd_kernel");
 }
 
@@ -365,19 +371,19 @@ extern "C" int dprnn_bn_bwd(const float* dY, const float* Y, const float* mean, 
     return dprnn_check_launch("bn_bwd_apply_kernel");
 }
 
-extern "C" int dprnn_affine_prelu_rows(const float* Y, const float* scale, const float* shift, const float* prelu_w, float* out,
-                                       int64_t M, int C, void* stream) {
-    if (!Y || !scale || !shift || !prelu_w || !out || M < 1 || (C % 4)) { dprnn_set_error("dprnn_affine_prelu_rows: null pointer / sizes"); return -1; }
+extern "C" int dprnn_affine_prelu_rows(const float* Y, const float* scale, const float* shift, const float* mean, const float* prelu_w,
+                                       float* out, int64_t M, int C, void* stream) {
+    if (!Y || !scale || !shift || !mean || !prelu_w || !out || M < 1 || (C % 4)) { dprnn_set_error("dprnn_affine_prelu_rows: null pointer / sizes"); return -1; }
     hipLaunchKernelGGL(affine_prelu_rows_kernel, dim3(grid_rows((long long)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       Y, scale, shift, prelu_w, out, (long long)M, C);
+                       Y, scale, shift, mean, prelu_w, out, (long long)M, C);
     return dprnn_check_launch("affine_prelu_rows_kernel");
 }
 
-extern "C" int dprnn_affine_prelu_bwd(const float* dA, const float* Y, const float* scale, const float* shift, const float* prelu_w,
-                                      float* dB, double* dalpha, int64_t M, int C, void* stream) {
-    if (!dA || !Y || !scale || !shift || !prelu_w || !dB || !dalpha || M < 1 || (C % 4)) { dprnn_set_error("dprnn_affine_prelu_bwd: null pointer / sizes"); return -1; }
+extern "C" int dprnn_affine_prelu_bwd(const float* dA, const float* Y, const float* scale, const float* shift, const float* mean,
+                                      const float* prelu_w, float* dB, double* dalpha, int64_t M, int C, void* stream) {
+    if (!dA || !Y || !scale || !shift || !mean || !prelu_w || !dB || !dalpha || M < 1 || (C % 4)) { dprnn_set_error("dprnn_affine_prelu_bwd: null pointer / sizes"); return -1; }
     hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3(grid_rows((long long)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       dA, Y, scale, shift, prelu_w, dB, dalpha, (long long)M, C);
+                       dA, Y, scale, shift, mean, prelu_w, dB, dalpha, (long long)M, C);
     return dprnn_check_launch("affine_prelu_bwd_kernel");
 }
 

@@ -114,10 +114,6 @@ class DPRNNSpeTasNet(nn.Module):
 
     def forward(self, input, aux, aux_len, debug=None):
         if debug is None and _wants_grad(self):
-            if self._ira:
-                raise NotImplementedError(
-                    f"{type(self).__name__} (MI355X): the two-pass IRA wrapper has inference kernels only; run the forward "
-                    "under torch.no_grad() (training path: DPRNNTasNet and DPRNNSpeTasNet)")
             from . import training_spe              # differentiable forward: autograd.Function over the HIP kernels
             return training_spe.spe_forward_autograd(self, input, aux, aux_len)
         return engine.spe_forward(self, input, aux, aux_len, ira=self._ira, debug=debug)

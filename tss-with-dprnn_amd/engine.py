@@ -418,12 +418,12 @@ def _linear_small(st: Stage, lin_w, lin_b, x, k0: int = 0, K: Optional[int] = No
 
 
 def _pointwise(st: Stage, A, rows, kdim, conv_w, conv_b, cout, in_scale=None, in_shift=None, aff_stride=0,
-               rows_per_utt=0, in_prelu=None, col_stats=None):
+               rows_per_utt=0, in_prelu=None, col_stats=None, in_mean=None):
     dev = A.device
     w = _param(conv_w, "conv.weight", dev)
     out = torch.empty(rows, cout, device=dev, dtype=torch.float32)
     for col0 in range(0, cout, 128):
-        st.call("dprnn_pointwise_fwd", _p(A), kdim, kdim, _p(in_scale), _p(in_shift), aff_stride, rows_per_utt,
+        st.call("dprnn_pointwise_fwd", _p(A), kdim, kdim, _p(in_scale), _p(in_shift), _p(in_mean), aff_stride, rows_per_utt,
                 _p(in_prelu), _p(w), kdim, _p(_param(conv_b, "conv.bias", dev)) if conv_b is not None else 0,
                 _p(out), cout, col0, _p(col_stats), rows)
     return out
@@ -435,10 +435,11 @@ def _bn_fold(st: Stage, bn, col_stats, count, dev):
     C = bn.num_features
     scale = torch.empty(C, device=dev, dtype=torch.float32)
     shift = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
     st.call("dprnn_bn_prep", _p(_param(bn.weight, "bn.weight", dev)), _p(_param(bn.bias, "bn.bias", dev)),
             _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(col_stats), count,
-            float(bn.momentum), float(bn.eps), _p(scale), _p(shift), C)
-    return scale, shift
+            float(bn.momentum), float(bn.eps), _p(scale), _p(shift), _p(mean), C)
+    return scale, shift, mean          # y -> (y - mean) * scale + shift
 
 
 def _resblock(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
@@ -448,14 +449,14 @@ def _resblock(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
     tr1, tr2 = blk.batch_norm1.training, blk.batch_norm2.training
     cs1 = torch.zeros(cout, 2, device=dev, dtype=torch.float64) if tr1 else None
     y1 = _pointwise(st, Xin, rows, cin, blk.conv1.weight, None, cout, col_stats=cs1)
-    s1, t1 = _bn_fold(st, blk.batch_norm1, cs1, rows, dev)
+    s1, t1, m1 = _bn_fold(st, blk.batch_norm1, cs1, rows, dev)
     cs2 = torch.zeros(cout, 2, device=dev, dtype=torch.float64) if tr2 else None
-    y2 = _pointwise(st, y1, rows, cout, blk.conv2.weight, None, cout, in_scale=s1, in_shift=t1,
+    y2 = _pointwise(st, y1, rows, cout, blk.conv2.weight, None, cout, in_scale=s1, in_shift=t1, in_mean=m1,
                     in_prelu=_param(blk.prelu1.weight, "prelu1.weight", dev), col_stats=cs2)
-    s2, t2 = _bn_fold(st, blk.batch_norm2, cs2, rows, dev)
+    s2, t2, m2 = _bn_fold(st, blk.batch_norm2, cs2, rows, dev)
     res = _pointwise(st, Xin, rows, cin, blk.conv_downsample.weight, None, cout) if blk.downsample else Xin
     out = torch.empty(B, T // 3, cout, device=dev, dtype=torch.float32)
-    st.call("dprnn_resblock_pool_fwd", _p(y2), _p(s2), _p(t2), _p(res), _p(_param(blk.prelu2.weight, "prelu2.weight", dev)),
+    st.call("dprnn_resblock_pool_fwd", _p(y2), _p(s2), _p(t2), _p(m2), _p(res), _p(_param(blk.prelu2.weight, "prelu2.weight", dev)),
             _p(out), B, T, cout)
     return out, T // 3
 

@@ -62,7 +62,7 @@ def _addr(geo, intra):
     return (B * S, K, B * S, 0, K, 1) if intra else (B * K, S, K, S * K, 1, K)
 
 
-def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[dict] = None):
+def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[dict] = None, want_d0: bool = False):
     """DPRNNTasNet.forward (dprnn.py:271-283) keeping the activations the backward needs.  Returns (out, saved).
     fusion (DPRNN-Spe, dprnn_spe.py:165-229): dict(mul, add, row_bias) entering the bottleneck; the output is then the
     [B, 2, T_out] decode of both mask channels, of which DPRNN-Spe uses speaker 0."""
@@ -124,6 +124,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     TG = torch.empty(R, 2 * F_BUILT, **f32)
     mask = torch.empty(R, geo.N, **f32)
     taps = torch.empty(B, 2, L, geo.ks, **f32)
+    d0 = torch.empty(B * L, geo.N, **f32) if want_d0 else None            # mask_0 * enc (DPRNN-Spe-IRA)
     st.call("dprnn_head_conv_ola_fwd", _p(X[npth]), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
             _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
             _p(U), B, L, K, P, S)
@@ -131,13 +132,13 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
             _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
             _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), _p(TG), R)
     st.call("dprnn_head_mask_decode_fwd_train", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
-            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(mask), 1 if cfg["activation_type"] == "relu" else 0,
+            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(mask), _p(d0), 1 if cfg["activation_type"] == "relu" else 0,
             B, geo.T, L, geo.N, geo.ks, geo.stride)
     out = engine.decode(st, taps, geo, 2)
     if not keep:
         return out, None
     saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask,
-                 fusion=fusion, Y=Y_keep)
+                 fusion=fusion, Y=Y_keep, d0=d0)
     return out, saved
 
 
@@ -208,7 +209,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     dE = torch.empty(R, N, **f32)
     dEnc = torch.empty(B * L, N, **f32)
     st.call("dprnn_mask_decode_bwd", _p(d_out), _p(wav), _p(enc_w), _p(dec_w), _p(saved["mask"]),
-            1 if cfg["activation_type"] == "relu" else 0, _p(dE), _p(dEnc), scr.slot("dWd", N * ks), B, geo.T, L, N, ks, geo.stride)
+            1 if cfg["activation_type"] == "relu" else 0, _p(dE), _p(dEnc), scr.slot("dWd", N * ks),
+            _p(extras.get("dM0")) if extras else 0, B, geo.T, L, N, ks, geo.stride)
     grads["decoder.weight"] = to_grad(scr.slot("dWd", N * ks), dec_w)
     # ---- end_conv1x1 (dprnn.py:160,181)
     w_end = sep.end_conv1x1.weight

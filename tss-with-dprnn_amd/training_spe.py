@@ -9,10 +9,12 @@ module adds the speaker branch: spk_encoder (GroupNorm -> conv -> 3 ResBlocks wi
 -> time mean, dprnn_spe.py:115-123,156-163), pred_linear, and the fusion Linears, forward with saved intermediates and
 backward through the kernels of include/dprnn_mi355x_train.h (dprnn_resblock_pool_bwd, dprnn_bn_bwd, ...).
 
-Supported under autograd: every fusion_type ('cat', 'add', 'mul', 'film', 'att') with the LSTM cell.  The two-pass
-DPRNN-Spe-IRA wrapper refuses loudly (inference only).  BatchNorm1d follows the module's mode: batch statistics (and the
-running-buffer update) in train(), running statistics in eval().  The whole batch is one pass (BatchNorm couples the
-utterances), so the batch must fit the activation budget of training.py.
+Supported under autograd: every fusion_type ('cat', 'add', 'mul', 'film', 'att') with the LSTM cell, for DPRNNSpeTasNet and
+for the two-pass DPRNNSpeIRATasNet (dprnn_spe_ira.py:53-115: the first pass's d0 = mask_0*enc feeds the speaker encoder a
+second time, aux_linear merges the two embeddings, the second separator pass re-uses the weights; its backward chains the
+two separator passes through d0 and sums the shared parameters' gradients).  BatchNorm1d follows the module's mode: batch
+statistics (and the running-buffer update) in train(), running statistics in eval().  The whole batch is one pass
+(BatchNorm couples the utterances), so the batch must fit the activation budget of training.py.
 """
 from __future__ import annotations
 
@@ -51,7 +53,7 @@ def _resblock_train(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
             y = engine._pointwise(st, src, rows, kin, conv.weight, None, cout, col_stats=cs)
         else:
             y = engine._pointwise(st, src, rows, kin, conv.weight, None, cout, in_scale=affs[0][0], in_shift=affs[0][1],
-                                  in_prelu=_param(blk.prelu1.weight, "prelu1.weight", dev), col_stats=cs)
+                                  in_mean=affs[0][2], in_prelu=_param(blk.prelu1.weight, "prelu1.weight", dev), col_stats=cs)
         mean = torch.empty(cout, **f32)
         rstd = torch.empty(cout, **f32)
         st.call("dprnn_bn_moments", _p(cs), _p(bn.running_mean), _p(bn.running_var), rows, float(bn.eps), _p(mean), _p(rstd), cout)
@@ -61,28 +63,24 @@ def _resblock_train(st: Stage, blk, Xin, B: int, T: int, cin: int, cout: int):
         src, kin = y, cout
     res = engine._pointwise(st, Xin, rows, cin, blk.conv_downsample.weight, None, cout) if blk.downsample else Xin
     out = torch.empty(B, T // 3, cout, **f32)
-    st.call("dprnn_resblock_pool_fwd", _p(ys[1]), _p(affs[1][0]), _p(affs[1][1]), _p(res),
+    st.call("dprnn_resblock_pool_fwd", _p(ys[1]), _p(affs[1][0]), _p(affs[1][1]), _p(affs[1][2]), _p(res),
             _p(_param(blk.prelu2.weight, "prelu2.weight", dev)), _p(out), B, T, cout)
     sv.update(y1=ys[0], y2=ys[1], aff1=affs[0], aff2=affs[1], mom1=moms[0], mom2=moms[1], res=res)
     return out, T // 3, sv
 
 
-def spe_forward_train(model, wav, aux, aux_len):
-    """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) keeping the activations: returns (est [B,T_out], logits, saved)."""
-    cfg = model.cfg
-    dev = wav.device
-    st = Stage(dev)
-    N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
-    geo_a = engine.make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
-    B = wav.shape[0]
-    sep = model.separation
+def _acc(grads: Dict[str, torch.Tensor], name: str, t: torch.Tensor) -> None:
+    """Shared parameters collect one gradient per use (two speaker-encoder runs, two separator passes in IRA)."""
+    if name in grads:
+        grads[name] = grads[name] + t
+    else:
+        grads[name] = t
+
+
+def _spk_tail_forward(st: Stage, sep, A0, B: int, T: int, aux_len_dev, ks: int):
+    """spk_encoder[2:] + time mean (dprnn_spe.py:117-122,156-163) from the first conv's output A0 [B*T][128]."""
     se = sep.spk_encoder
-    enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
-    aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
-    stats_a = torch.zeros(B, 2, device=dev, dtype=torch.float64)
-    sc_a, sh_a = engine.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats_a)
-    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
-    h, t = A0, geo_a.L
+    h, t = A0, T
     blocks = []
     for blk, cin, cout in ((se[2], 128, 128), (se[3], 128, 256), (se[4], 256, 256)):
         h, t, sv = _resblock_train(st, blk, h.view(B * t, cin), B, t, cin, cout)
@@ -91,9 +89,19 @@ def spe_forward_train(model, wav, aux, aux_len):
         raise DprnnError("reference utterance too short for three MaxPool1d(3) stages")
     h3 = h.view(B * t, 256)
     E = engine._pointwise(st, h3, B * t, 256, se[5].weight, se[5].bias, 128)
-    emb = torch.empty(B, 128, device=dev, dtype=torch.float32)
+    emb = torch.empty(B, 128, device=A0.device, dtype=torch.float32)
     st.call("dprnn_time_mean_fwd", _p(E), _p(aux_len_dev), aux_len_dev.numel(), _p(emb), B, t, 128, ks)
-    logits = engine._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, emb)
+    return emb, dict(blocks=blocks, h3=h3, t3=t, aux_len=aux_len_dev)
+
+
+def _fusion_for(st: Stage, model, wav, emb, geo):
+    """Fusion operands of one separator pass for the embedding `emb` (dprnn_spe.py:165-229)."""
+    cfg = model.cfg
+    sep = model.separation
+    dev = wav.device
+    N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
+    B = wav.shape[0]
+    enc_w = model.encoder.conv1d.weight
     mul, add, row_bias = engine._fusion_operands(st, sep, cfg, emb)
     fusion = dict(mul=mul, add=add, row_bias=row_bias)
     if cfg["fusion_type"] == "att":        # per-frame factor: softmax attention over the averaged norm output (dprnn_spe.py:178-183)
@@ -101,7 +109,6 @@ def spe_forward_train(model, wav, aux, aux_len):
             if prm.requires_grad:
                 raise NotImplementedError("DPRNN-Spe MI355X training path: the 'att' averaging conv is frozen in the reference "
                                           "(dprnn_spe.py:102-103); its gradient is not computed")
-        geo = engine.make_geometry(B, wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
         stats_m = torch.zeros(B, 2, device=dev, dtype=torch.float64)
         st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_m), B, geo.T, geo.L, N, ks, stride)
         g_, b_, eps_ = _norm_params(sep.bottleneck[0])
@@ -117,10 +124,50 @@ def spe_forward_train(model, wav, aux, aux_len):
         st.call("dprnn_att_row_scale", _p(wav), _p(enc_w), _p(sc0), _p(sh0), _p(sep.average.weight), _p(sep.average.bias), _p(mul),
                 _p(scores), _p(row_scale), B, geo.T, geo.L, N, ks, stride, ks_a)
         fusion.update(row_scale=row_scale, scores=scores, avg_w=sep.average.weight, avg_b=sep.average.bias, ks_a=ks_a)
-    out, saved = training.forward_train(model, wav, keep=True, fusion={k: v for k, v in fusion.items() if v is not None})
-    saved["spk"] = dict(aux=aux, aux_len=aux_len_dev, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, blocks=blocks,
-                        h3=h3, t3=t, emb=emb)
-    return out[:, 0, :], logits, saved
+    return {k: v for k, v in fusion.items() if v is not None}
+
+
+def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
+    """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) / DPRNNSpeIRATasNet.forward (dprnn_spe_ira.py:53-115,179-190) keeping
+    the activations: returns (est [B,T_out], logits, saved)."""
+    cfg = model.cfg
+    dev = wav.device
+    st = Stage(dev)
+    N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
+    geo = engine.make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+    geo_a = engine.make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+    B = wav.shape[0]
+    sep = model.separation
+    se = sep.spk_encoder
+    enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+    aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
+    stats_a = torch.zeros(B, 2, device=dev, dtype=torch.float64)
+    sc_a, sh_a = engine.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats_a)
+    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
+    v0, tail0 = _spk_tail_forward(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
+    spk0 = dict(aux=aux, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, tail=tail0, emb=v0)
+    out, saved = training.forward_train(model, wav, keep=True, fusion=_fusion_for(st, model, wav, v0, geo), want_d0=ira)
+    saved["spk"] = spk0
+    if not ira:
+        logits = engine._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v0)
+        return out[:, 0, :], logits, saved
+    # second embedding from the first estimate d0 = mask_0 * enc (dprnn_spe_ira.py:79-92), GroupNorm folded into the conv loader
+    d0 = saved["d0"]
+    stats_d = torch.zeros(B, 2, device=dev, dtype=torch.float64)
+    st.call("dprnn_rows_stats", _p(d0), _p(stats_d), B, geo.L, N)
+    g0, b0, eps0 = _norm_params(se[0])
+    sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
+    sh_d = torch.empty_like(sc_d)
+    st.call("dprnn_bottleneck_prep", _p(stats_d), _p(g0), _p(b0), eps0, 0, 0, _p(sc_d), _p(sh_d), B, geo.L, N)
+    A0d = engine._pointwise(st, d0, B * geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d, aff_stride=N,
+                            rows_per_utt=geo.L)
+    v1p, tail1 = _spk_tail_forward(st, sep, A0d, B, geo.L, aux_len_dev, ks)
+    vcat = torch.cat((v0, v1p), dim=1).contiguous()
+    v1 = engine._linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, vcat)
+    out2, saved2 = training.forward_train(model, wav, keep=True, fusion=_fusion_for(st, model, wav, v1, geo))
+    logits = engine._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v1)
+    ira_saved = dict(pass1=saved, pass2=saved2, d0=d0, stats_d=stats_d, sc_d=sc_d, sh_d=sh_d, tail1=tail1, vcat=vcat, v1=v1, geo=geo)
+    return out2[:, 0, :], logits, ira_saved
 
 
 def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows, need_dx=True):
@@ -143,7 +190,7 @@ def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows, need_dx=True):
     return gw, dx
 
 
-def _resblock_bwd(st, lib, scr: _Scratch, sv: dict, dOut, prefix: str, grads: Dict[str, torch.Tensor]):
+def _resblock_bwd(st, lib, scr: _Scratch, sv: dict, dOut, prefix: str, grads: Dict[str, torch.Tensor], tag: str = ""):
     """Backward of one ResBlock (dprnn_spe.py:31-42): returns the gradient of its input rows [B*T][cin]."""
     blk, B, T, cin, cout = sv["blk"], sv["B"], sv["T"], sv["cin"], sv["cout"]
     dev = dOut.device
@@ -155,31 +202,31 @@ def _resblock_bwd(st, lib, scr: _Scratch, sv: dict, dOut, prefix: str, grads: Di
         st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
         return g
 
-    (s1, t1), (s2, t2) = sv["aff1"], sv["aff2"]
+    (s1, t1, mu1), (s2, t2, mu2) = sv["aff1"], sv["aff2"]
     (m1, r1, tr1), (m2, r2, tr2) = sv["mom1"], sv["mom2"]
     # MaxPool1d(3) + PReLU2 + residual add
     dU = torch.empty(rows, cout, **f32)
-    a_al2 = scr.slot(prefix + "alpha2", 1)
-    st.call("dprnn_resblock_pool_bwd", _p(dOut), _p(sv["y2"]), _p(s2), _p(t2), _p(sv["res"]), _p(blk.prelu2.weight), _p(dU), a_al2,
+    a_al2 = scr.slot(tag + prefix + "alpha2", 1)
+    st.call("dprnn_resblock_pool_bwd", _p(dOut), _p(sv["y2"]), _p(s2), _p(t2), _p(mu2), _p(sv["res"]), _p(blk.prelu2.weight), _p(dU), a_al2,
             B, T, cout)
     grads[prefix + "prelu2.weight"] = to_grad(a_al2, blk.prelu2.weight)
     # BatchNorm2
-    a_red2 = scr.slot(prefix + "bn2", 2 * cout)
+    a_red2 = scr.slot(tag + prefix + "bn2", 2 * cout)
     dY2 = torch.empty(rows, cout, **f32)
     st.call("dprnn_bn_bwd", _p(dU), _p(sv["y2"]), _p(m2), _p(r2), _p(blk.batch_norm2.weight), 1 if tr2 else 0, a_red2, _p(dY2), rows, cout)
     grads[prefix + "batch_norm2.bias"] = to_grad(a_red2, blk.batch_norm2.bias)
     grads[prefix + "batch_norm2.weight"] = to_grad(a_red2 + 8 * cout, blk.batch_norm2.weight)
     # conv2 on a1 = prelu1(bn1(y1))
     a1 = torch.empty(rows, cout, **f32)
-    st.call("dprnn_affine_prelu_rows", _p(sv["y1"]), _p(s1), _p(t1), _p(blk.prelu1.weight), _p(a1), rows, cout)
+    st.call("dprnn_affine_prelu_rows", _p(sv["y1"]), _p(s1), _p(t1), _p(mu1), _p(blk.prelu1.weight), _p(a1), rows, cout)
     grads[prefix + "conv2.weight"], da1 = _conv_bwd(st, lib, dY2, cout, a1, cout, blk.conv2.weight, rows)
     del a1, dY2
     # PReLU1 + BatchNorm1
-    a_al1 = scr.slot(prefix + "alpha1", 1)
+    a_al1 = scr.slot(tag + prefix + "alpha1", 1)
     dB1 = torch.empty(rows, cout, **f32)
-    st.call("dprnn_affine_prelu_bwd", _p(da1), _p(sv["y1"]), _p(s1), _p(t1), _p(blk.prelu1.weight), _p(dB1), a_al1, rows, cout)
+    st.call("dprnn_affine_prelu_bwd", _p(da1), _p(sv["y1"]), _p(s1), _p(t1), _p(mu1), _p(blk.prelu1.weight), _p(dB1), a_al1, rows, cout)
     grads[prefix + "prelu1.weight"] = to_grad(a_al1, blk.prelu1.weight)
-    a_red1 = scr.slot(prefix + "bn1", 2 * cout)
+    a_red1 = scr.slot(tag + prefix + "bn1", 2 * cout)
     dY1 = da1                                       # reuse
     st.call("dprnn_bn_bwd", _p(dB1), _p(sv["y1"]), _p(m1), _p(r1), _p(blk.batch_norm1.weight), 1 if tr1 else 0, a_red1, _p(dY1), rows, cout)
     grads[prefix + "batch_norm1.bias"] = to_grad(a_red1, blk.batch_norm1.bias)
@@ -196,85 +243,158 @@ def _resblock_bwd(st, lib, scr: _Scratch, sv: dict, dOut, prefix: str, grads: Di
     return dx
 
 
-def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
-    cfg = model.cfg
-    geo: engine.Geometry = saved["geo"]
-    dev = d_est.device
-    st = Stage(dev)
-    lib = st.lib
+def _to_grad(st, addr, like):
+    g = torch.empty_like(like)
+    st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
+    return g
+
+
+def _lin_bwd(st, grads, d_o, x, lin_w, lin_b, wname, bname, d_in, k0=0, dW=None, accumulate=True):
+    """Gradients of out = W[:, k0:k0+K] x + b for one small per-utterance Linear; d_in (+)= d_o @ W."""
+    B, K = x.shape
+    gw = dW if dW is not None else torch.empty_like(lin_w)
+    gb = torch.empty_like(lin_b) if lin_b is not None else None
+    st.call("dprnn_linear_small_bwd", _p(d_o), d_o.shape[1], _p(x), K, _p(lin_w), lin_w.shape[1], k0, K, _p(d_in), d_in.shape[1], 1,
+            _p(gw), _p(gb), B, d_o.shape[1])
+    if dW is None:
+        _acc(grads, wname, gw)
+    if gb is not None:
+        _acc(grads, bname, gb)
+
+
+def _fusion_linears_bwd(st, model, grads, extras, gsep, emb, d_emb):
+    """d_emb += gradient through the fusion operands of one separator pass; gsep: that pass's gradient dict (the 'cat'
+    half of the bottleneck weight is written into its tensor in place)."""
     sep = model.separation
-    se = sep.spk_encoder
-    spk = saved["spk"]
-    B, N, ks = geo.B, geo.N, geo.ks
-    f32 = dict(device=dev, dtype=torch.float32)
-    enc_w = model.encoder.conv1d.weight
-    scr = _Scratch(dev)
-
-    def to_grad(addr, like):
-        g = torch.empty_like(like)
-        st.call("dprnn_scratch_to_grad", addr, _p(g), g.numel(), 0)
-        return g
-
-    # separator: the estimate is speaker 0 of the two decoded channels (dprnn_spe.py:325)
-    d_out = torch.zeros(B, 2, geo.T_out, **f32)
-    d_out[:, 0, :] = d_est
-    extras: dict = {}
-    fusion = saved["fusion"]
-    grads = training.backward(model, saved, d_out, scratch=scr, extras=extras)
-
-    # gradient of the speaker embedding: pred_linear + fusion operands
-    emb = spk["emb"]
-    E_ = emb.shape[1]
-    d_emb = torch.zeros(B, E_, **f32)
-
-    def lin_bwd(d_o, lin_w, lin_b, wname, bname, k0=0, dW=None):
-        gw = dW if dW is not None else torch.empty_like(lin_w)
-        gb = torch.empty_like(lin_b) if lin_b is not None else None
-        st.call("dprnn_linear_small_bwd", _p(d_o), d_o.shape[1], _p(emb), E_, _p(lin_w), lin_w.shape[1], k0, E_, _p(d_emb), E_, 1,
-                _p(gw), _p(gb), B, d_o.shape[1])
-        grads[wname] = gw
-        if gb is not None:
-            grads[bname] = gb
-
-    if d_logits is not None:
-        lin_bwd(d_logits.contiguous().float(), sep.pred_linear.weight, sep.pred_linear.bias,
-                "separation.pred_linear.weight", "separation.pred_linear.bias")
-    else:
-        grads["separation.pred_linear.weight"] = torch.zeros_like(sep.pred_linear.weight)
-        grads["separation.pred_linear.bias"] = torch.zeros_like(sep.pred_linear.bias)
-    ft = cfg["fusion_type"]
+    ft = model.cfg["fusion_type"]
+    N = model.cfg["input_size"]
     if ft == "cat":
-        lin_bwd(extras["d_row_bias"], sep.bottleneck[1].weight, None, "separation.bottleneck.1.weight", None, k0=N,
-                dW=grads["separation.bottleneck.1.weight"])
+        _lin_bwd(st, grads, extras["d_row_bias"], emb, sep.bottleneck[1].weight, None, None, None, d_emb, k0=N,
+                 dW=gsep["separation.bottleneck.1.weight"])
     elif ft == "add":
-        lin_bwd(extras["d_add"], sep.fusion_linear.weight, sep.fusion_linear.bias,
-                "separation.fusion_linear.weight", "separation.fusion_linear.bias")
+        _lin_bwd(st, grads, extras["d_add"], emb, sep.fusion_linear.weight, sep.fusion_linear.bias,
+                 "separation.fusion_linear.weight", "separation.fusion_linear.bias", d_emb)
     elif ft in ("mul", "att"):
-        lin_bwd(extras["d_mul"], sep.fusion_linear.weight, sep.fusion_linear.bias,
-                "separation.fusion_linear.weight", "separation.fusion_linear.bias")
+        _lin_bwd(st, grads, extras["d_mul"], emb, sep.fusion_linear.weight, sep.fusion_linear.bias,
+                 "separation.fusion_linear.weight", "separation.fusion_linear.bias", d_emb)
     elif ft == "film":
-        lin_bwd(extras["d_mul"], sep.fusion_linear_1.weight, sep.fusion_linear_1.bias,
-                "separation.fusion_linear_1.weight", "separation.fusion_linear_1.bias")
-        lin_bwd(extras["d_add"], sep.fusion_linear_2.weight, sep.fusion_linear_2.bias,
-                "separation.fusion_linear_2.weight", "separation.fusion_linear_2.bias")
+        _lin_bwd(st, grads, extras["d_mul"], emb, sep.fusion_linear_1.weight, sep.fusion_linear_1.bias,
+                 "separation.fusion_linear_1.weight", "separation.fusion_linear_1.bias", d_emb)
+        _lin_bwd(st, grads, extras["d_add"], emb, sep.fusion_linear_2.weight, sep.fusion_linear_2.bias,
+                 "separation.fusion_linear_2.weight", "separation.fusion_linear_2.bias", d_emb)
 
-    # spk_encoder in reverse: time mean, conv P -> E, three ResBlocks, conv N -> O, GroupNorm, encoder
-    t3, h3 = spk["t3"], spk["h3"]
+
+def _spk_tail_backward(st, lib, scr: _Scratch, tag: str, sep, tail: dict, d_emb, B: int, ks: int, grads) -> torch.Tensor:
+    """Backward of _spk_tail_forward: returns the gradient of A0 [B*T][128]; parameter gradients are added into grads."""
+    se = sep.spk_encoder
+    dev = d_emb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    t3, h3 = tail["t3"], tail["h3"]
     dE = torch.empty(B * t3, F_BUILT, **f32)
-    st.call("dprnn_time_mean_bwd", _p(d_emb), _p(spk["aux_len"]), spk["aux_len"].numel(), _p(dE), B, t3, F_BUILT, ks)
+    st.call("dprnn_time_mean_bwd", _p(d_emb), _p(tail["aux_len"]), tail["aux_len"].numel(), _p(dE), B, t3, F_BUILT, ks)
     w5 = se[5].weight
     gw5 = torch.empty_like(w5)
     gb5 = torch.empty_like(se[5].bias)
     ws = torch.empty(lib.dprnn_wgrad_workspace_floats(128, 256, B * t3), **f32)
     st.call("dprnn_wgrad", _p(dE), 128, 128, _p(h3), 256, 128, 0, h3.data_ptr() + 4 * 128, 256, 128, 0, B * t3, 1, 1,
             _p(gw5), 256, 1, _p(gb5), 0, 0, _p(ws))
-    grads["separation.spk_encoder.5.weight"], grads["separation.spk_encoder.5.bias"] = gw5, gb5
+    _acc(grads, "separation.spk_encoder.5.weight", gw5)
+    _acc(grads, "separation.spk_encoder.5.bias", gb5)
     dh = torch.empty(B * t3, 256, **f32)
     st.call("dprnn_dgrad", _p(dE), 128, _p(w5), 256, 128, 0, 0, _p(dh), 256, 256, B * t3)
     for i in (4, 3, 2):
-        sv = spk["blocks"][i - 2]
-        dh = _resblock_bwd(st, lib, scr, sv, dh.view(B, sv["T"] // 3, sv["cout"]), f"separation.spk_encoder.{i}.", grads)
-    # first conv (N -> O, with bias) on the normalised encoder output of the reference utterance
+        sv = tail["blocks"][i - 2]
+        g_blk: Dict[str, torch.Tensor] = {}
+        dh = _resblock_bwd(st, lib, scr, sv, dh.view(B, sv["T"] // 3, sv["cout"]), f"separation.spk_encoder.{i}.", g_blk, tag)
+        for k, v in g_blk.items():
+            _acc(grads, k, v)
+    return dh
+
+
+def _pass_backward(model, saved, d_out, extras):
+    scr = _Scratch(d_out.device)
+    g = training.backward(model, saved, d_out, scratch=scr, extras=extras)
+    return g, scr
+
+
+def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[torch.Tensor], ira: bool = False
+                 ) -> Dict[str, torch.Tensor]:
+    cfg = model.cfg
+    dev = d_est.device
+    st = Stage(dev)
+    lib = st.lib
+    sep = model.separation
+    se = sep.spk_encoder
+    last = saved["pass2"] if ira else saved
+    first = saved["pass1"] if ira else saved
+    geo: engine.Geometry = last["geo"]
+    spk = first["spk"]
+    B, N, ks = geo.B, geo.N, geo.ks
+    f32 = dict(device=dev, dtype=torch.float32)
+    enc_w = model.encoder.conv1d.weight
+    scr = _Scratch(dev)
+    E_ = spk["emb"].shape[1]
+    grads: Dict[str, torch.Tensor] = {}
+
+    # the separator pass that produced the estimate: speaker 0 of the two decoded channels (dprnn_spe.py:325)
+    d_out = torch.zeros(B, 2, geo.T_out, **f32)
+    d_out[:, 0, :] = d_est
+    extras: dict = {}
+    g_last, scr_last = _pass_backward(model, last, d_out, extras)
+    emb_last = saved["v1"] if ira else spk["emb"]
+    d_emb_last = torch.zeros(B, E_, **f32)
+    if d_logits is not None:
+        _lin_bwd(st, grads, d_logits.contiguous().float(), emb_last, sep.pred_linear.weight, sep.pred_linear.bias,
+                 "separation.pred_linear.weight", "separation.pred_linear.bias", d_emb_last)
+    else:
+        grads["separation.pred_linear.weight"] = torch.zeros_like(sep.pred_linear.weight)
+        grads["separation.pred_linear.bias"] = torch.zeros_like(sep.pred_linear.bias)
+    _fusion_linears_bwd(st, model, grads, extras, g_last, emb_last, d_emb_last)
+    for k, v in g_last.items():
+        _acc(grads, k, v)
+    dWe = _to_grad(st, scr_last.slot("dWe", N * ks), enc_w)
+
+    if ira:
+        # aux_linear merges (v0, v1') (dprnn_spe_ira.py:86-92)
+        d_vcat = torch.zeros(B, 2 * E_, **f32)
+        _lin_bwd(st, grads, d_emb_last, saved["vcat"], sep.aux_linear.weight, sep.aux_linear.bias,
+                 "separation.aux_linear.weight", "separation.aux_linear.bias", d_vcat)
+        d_v0 = d_vcat[:, :E_].contiguous()
+        d_v1p = d_vcat[:, E_:].contiguous()
+        # speaker encoder on d0: tail, first conv with the GroupNorm of d0 folded in, GroupNorm backward -> gradient of d0
+        dA0d = _spk_tail_backward(st, lib, scr, "d0.", sep, saved["tail1"], d_v1p, B, ks, grads)
+        rows_m = B * geo.L
+        d0 = saved["d0"]
+        An = torch.empty(rows_m, N, **f32)
+        st.call("dprnn_rows64_affine", _p(d0), _p(saved["sc_d"]), _p(saved["sh_d"]), _p(An), B, geo.L)
+        w1 = se[1].weight
+        gw1 = torch.empty_like(w1)
+        gb1 = torch.empty_like(se[1].bias)
+        ws = torch.empty(lib.dprnn_wgrad_workspace_floats(128, N, rows_m), **f32)
+        st.call("dprnn_wgrad", _p(dA0d), 128, 128, _p(An), N, N, 0, 0, 0, 0, 0, rows_m, 1, 1, _p(gw1), N, 1, _p(gb1), 0, 0, _p(ws))
+        _acc(grads, "separation.spk_encoder.1.weight", gw1)
+        _acc(grads, "separation.spk_encoder.1.bias", gb1)
+        dAn = An
+        st.call("dprnn_dgrad", _p(dA0d), 128, _p(w1), N, 128, 0, 0, _p(dAn), N, N, rows_m)
+        g0, b0, eps0 = _norm_params(se[0])
+        a_red, a_dgb = scr.slot("red_d0", 2 * B), scr.slot("dgb_d0", 2 * N)
+        dD0 = torch.empty(rows_m, N, **f32)
+        st.call("dprnn_rows64_norm_bwd", _p(d0), _p(dAn), _p(saved["stats_d"]), _p(g0), eps0, a_red, a_dgb, _p(dD0), B, geo.L)
+        _acc(grads, "separation.spk_encoder.0.weight", _to_grad(st, a_dgb, g0))
+        _acc(grads, "separation.spk_encoder.0.bias", _to_grad(st, a_dgb + 8 * N, b0))
+        # first separator pass: its decoded output is unused; the gradient enters through d0 (dprnn_spe_ira.py:79-80)
+        extras1: dict = {"dM0": dD0}
+        g1, scr1 = _pass_backward(model, first, torch.zeros(B, 2, geo.T_out, **f32), extras1)
+        _fusion_linears_bwd(st, model, grads, extras1, g1, spk["emb"], d_v0)
+        for k, v in g1.items():
+            _acc(grads, k, v)
+        dWe = dWe + _to_grad(st, scr1.slot("dWe", N * ks), enc_w)
+        d_emb0 = d_v0
+    else:
+        d_emb0 = d_emb_last
+
+    # speaker encoder on the reference utterance: tail, conv N -> O, GroupNorm, encoder (dprnn_spe.py:115-122,156-163)
+    dA0 = _spk_tail_backward(st, lib, scr, "aux.", sep, spk["tail"], d_emb0, B, ks, grads)
     geo_a = spk["geo_a"]
     rows_a = B * geo_a.L
     aux = spk["aux"]
@@ -284,19 +404,20 @@ def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[tor
     gw1 = torch.empty_like(w1)
     gb1 = torch.empty_like(se[1].bias)
     ws = torch.empty(lib.dprnn_wgrad_workspace_floats(128, N, rows_a), **f32)
-    st.call("dprnn_wgrad", _p(dh), 128, 128, _p(An), N, N, 0, 0, 0, 0, 0, rows_a, 1, 1, _p(gw1), N, 1, _p(gb1), 0, 0, _p(ws))
-    grads["separation.spk_encoder.1.weight"], grads["separation.spk_encoder.1.bias"] = gw1, gb1
+    st.call("dprnn_wgrad", _p(dA0), 128, 128, _p(An), N, N, 0, 0, 0, 0, 0, rows_a, 1, 1, _p(gw1), N, 1, _p(gb1), 0, 0, _p(ws))
+    _acc(grads, "separation.spk_encoder.1.weight", gw1)
+    _acc(grads, "separation.spk_encoder.1.bias", gb1)
     dAn = An
-    st.call("dprnn_dgrad", _p(dh), 128, _p(w1), N, 128, 0, 0, _p(dAn), N, N, rows_a)
+    st.call("dprnn_dgrad", _p(dA0), 128, _p(w1), N, 128, 0, 0, _p(dAn), N, N, rows_a)
     g0, b0, eps0 = _norm_params(se[0])
     a_red, a_dgb = scr.slot("red_spk", 2 * B), scr.slot("dgb_spk", 2 * N)
     st.call("dprnn_encoder_norm_bwd_stats", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, a_dgb,
             B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
-    grads["separation.spk_encoder.0.weight"] = to_grad(a_dgb, g0)
-    grads["separation.spk_encoder.0.bias"] = to_grad(a_dgb + 8 * N, b0)
+    _acc(grads, "separation.spk_encoder.0.weight", _to_grad(st, a_dgb, g0))
+    _acc(grads, "separation.spk_encoder.0.bias", _to_grad(st, a_dgb + 8 * N, b0))
     st.call("dprnn_encoder_bwd", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, 0,
             scr.slot("dWe", N * ks), B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
-    grads["encoder.conv1d.weight"] = to_grad(scr.slot("dWe", N * ks), enc_w)
+    grads["encoder.conv1d.weight"] = dWe + _to_grad(st, scr.slot("dWe", N * ks), enc_w)
     return grads
 
 
@@ -304,14 +425,15 @@ class _SpeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, wav, aux, aux_len, names, *params):
         ctx.model, ctx.names = model, names
-        est, logits, saved = spe_forward_train(model, wav, aux, aux_len)
+        ctx.ira = bool(getattr(model, "_ira", False))
+        est, logits, saved = spe_forward_train(model, wav, aux, aux_len, ctx.ira)
         ctx.saved = saved
         return est, logits
 
     @staticmethod
     def backward(ctx, d_est, d_logits):
         with torch.cuda.device(d_est.device):
-            grads = spe_backward(ctx.model, ctx.saved, d_est.contiguous().float(), d_logits)
+            grads = spe_backward(ctx.model, ctx.saved, d_est.contiguous().float(), d_logits, ctx.ira)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
