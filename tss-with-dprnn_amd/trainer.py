@@ -91,6 +91,27 @@ def train_step(model, loss_module, optimizer, mix, target, clip_norm: float = 0.
     return loss.detach(), est.detach()
 
 
+def train_step_spe(model, loss_module, optimizer, mix, target, reference, spk_idx, ce_gamma: float, clip_norm: float = 0.0,
+                   reducer: Optional[FlatGradAllReducer] = None):
+    """One iteration of TrainerSpe.train (trainer_spe.py:25-56): SI-SDR of the extracted speaker + ce_gamma * speaker CE."""
+    optimizer.zero_grad()
+    ref_len = torch.tensor(reference.shape[1], dtype=torch.float32, device=reference.device)
+    est, logits = model(mix, reference, ref_len)
+    l = loss_module(est.unsqueeze(1), target.unsqueeze(1))
+    ce = torch.nn.functional.cross_entropy(logits, spk_idx)        # the caller-side loss of the reference, on [B, num_spks] logits
+    loss = l + ce_gamma * ce
+    loss.backward()
+    if reducer is not None:
+        reducer.average()
+    if isinstance(optimizer, FusedAdam):
+        optimizer.step(clip_norm=clip_norm)
+    else:
+        if clip_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+        optimizer.step()
+    return loss.detach(), l.detach(), ce.detach()
+
+
 class DistributedTrainer:
     """Step loop with the reference Trainer's semantics; ``logger`` / ``reporter`` are optional duck-typed objects
     (``logger.info(str)``, ``reporter.add_and_report(logs=dict, mode=str)``) so neither hydra nor wandb is needed."""
@@ -119,6 +140,7 @@ class DistributedTrainer:
             self.cur_epoch = cpt.get("epoch", cur_epoch)
         broadcast_parameters(self.model)
         self.reducer = FlatGradAllReducer(self.model.parameters())
+        self.ce_gamma: Optional[float] = None       # set (TrainerSpe: config['ce_gamma']) to train DPRNN-Spe / IRA models
 
     def _info(self, msg):
         if self.logger is not None and self.rank == 0:
@@ -134,9 +156,16 @@ class DistributedTrainer:
         self.model.train()
         total, steps = 0.0, 0
         start = time.time()
-        for step, (mix, target) in enumerate(dataloader):
-            loss, _ = train_step(self.model, self.loss_module, self.optimizer, mix.to(self.device), target.to(self.device),
-                                 self.clip_norm, self.reducer)
+        for step, batch in enumerate(dataloader):
+            if self.ce_gamma is None:                                 # Trainer.train: (mix, target)
+                mix, target = batch
+                loss, _ = train_step(self.model, self.loss_module, self.optimizer, mix.to(self.device), target.to(self.device),
+                                     self.clip_norm, self.reducer)
+            else:                                                     # TrainerSpe.train: (mix, target, reference, spk_idx)
+                mix, target, reference, spk_idx = batch
+                loss, _, _ = train_step_spe(self.model, self.loss_module, self.optimizer, mix.to(self.device),
+                                            target.to(self.device), reference.to(self.device), spk_idx.to(self.device),
+                                            self.ce_gamma, self.clip_norm, self.reducer)
             total += loss.item()
             steps += 1
             if step % self.print_freq == 0:
@@ -149,9 +178,16 @@ class DistributedTrainer:
         total, steps = 0.0, 0
         start = time.time()
         with torch.no_grad():
-            for mix, target in dataloader:
-                out = self.model(mix.to(self.device))
-                loss, _ = self.loss_module(out, target.to(self.device), return_est=True)
+            for batch in dataloader:
+                if self.ce_gamma is None:
+                    mix, target = batch
+                    out = self.model(mix.to(self.device))
+                    loss = self.loss_module(out, target.to(self.device))
+                else:                                                 # trainer_spe.py:88-97: SI-SDR only
+                    mix, target, reference = batch[0].to(self.device), batch[1].to(self.device), batch[2].to(self.device)
+                    ref_len = torch.tensor(reference.shape[1], dtype=torch.float32, device=self.device)
+                    est, _ = self.model(mix, reference, ref_len)
+                    loss = self.loss_module(est.unsqueeze(1), target.unsqueeze(1))
                 total += loss.item()
                 steps += 1
         return self._log_epoch(total, steps, start, "eval")

@@ -138,6 +138,14 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     geo_a = engine.make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
     B = wav.shape[0]
     sep = model.separation
+    ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in training._paths(sep)]
+    need = (2 if ira else 1) * B * training.saved_bytes_per_utt(engine.make_geometry(1, wav.shape[1], N, cfg["chunk_length"],
+                                                                                      cfg["hop_length"], ks, stride), len(ndirs), ndirs)
+    if need > training.SAVE_BUDGET_BYTES:
+        raise DprnnError(f"DPRNN-Spe training step: batch {B} needs {need / 2**30:.0f} GiB of saved activations, above "
+                         f"training.SAVE_BUDGET_BYTES ({training.SAVE_BUDGET_BYTES / 2**30:.0f} GiB); BatchNorm couples the "
+                         "utterances of the speaker branch, so this path does not cut the batch into micro-batches -- lower the "
+                         "batch size (config_tss.yaml ships batch_size 5)")
     se = sep.spk_encoder
     enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
     aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
