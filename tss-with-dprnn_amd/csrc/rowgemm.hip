@@ -34,6 +34,10 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
     return bottleneck(wav, enc_w, sc, sh, Wb, ldw, bb, nullptr, row_scale, Y, B, T, L, N, ks, stride, stream);
 }
 
+#ifndef PROJ_NW
+#define PROJ_NW 8
+#endif
+
 extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
                                     int64_t M, int64_t rows_per_utt, int kdim, void* stream) {
     if (!H || !W || !bias || !Z || !stats) { dprnn_set_error("dprnn_proj_stats_fwd: null pointer"); return -1; }
@@ -44,8 +48,8 @@ extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float*
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
     EpProjStats<RT, 8> ep{Z, bias, stats, (long long)rows_per_utt};
-    if (kdim == 256) return launch_rowgemm<256, 128, RT>("proj_stats256", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
-    return launch_rowgemm<128, 128, RT>("proj_stats128", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+    if (kdim == 256) return launch_rowgemm<256, 128, RT, false, PROJ_NW>("proj_stats256", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+    return launch_rowgemm<128, 128, RT, false, PROJ_NW>("proj_stats128", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
 }
 
 // The PReLU slope is a device scalar (nn.PReLU weight): the loader reads it through its pointer.

@@ -360,8 +360,10 @@ struct EpMaskDecode {
 // WT = false: out = A @ W^T with W [ND][ldw] row-major (W0: columns < nd0, W1: the rest) -- the forward products.
 // WT = true (backward, data gradients): out = A @ W with W [KD][ldw] row-major (W0: k < nd0, W1: the rest), i.e. the
 // same torch parameter read transposed while it is staged.
-template <int KD, int ND, int RT, class AL, class EP, bool WT = false>
-__global__ __launch_bounds__(256, 1)
+// NW: waves per workgroup (4 or 8).  The workgroup count is one per CU (the weights fill most of the LDS), so NW = 8 puts
+// two waves on every SIMD: one wave's HBM row loads and epilogue stores overlap the other's MFMAs.
+template <int KD, int ND, int RT, class AL, class EP, bool WT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1)
 void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
                     long long M, AL al, EP ep) {
     constexpr int NCT = ND / 16, NG = KD / 16, K4 = KD / 4;
@@ -370,14 +372,14 @@ void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float
     const int r = lane & 15, q = lane >> 4;
 
     if constexpr (!WT) {
-        for (int idx = tid; idx < ND * K4; idx += 256) {
+        for (int idx = tid; idx < ND * K4; idx += 64 * NW) {
             const int col = idx / K4, k4 = idx % K4;
             const float* src = col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1;
             const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * k4);
             wl[((k4 >> 2) * NCT + (col >> 4)) * 64 + (k4 & 3) * 16 + (col & 15)] = v;
         }
     } else {
-        for (int idx = tid; idx < ND * K4; idx += 256) {
+        for (int idx = tid; idx < ND * K4; idx += 64 * NW) {
             const int col = idx % ND, k4 = idx / ND;            // consecutive threads read consecutive columns
             f32x4 v;
 #pragma unroll
@@ -390,7 +392,7 @@ void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float
     }
     __syncthreads();
 
-    constexpr int ROWS_IT = 4 * RT * 16;
+    constexpr int ROWS_IT = NW * RT * 16;
     const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
     const long long per = (nchunk + gridDim.x - 1) / gridDim.x;
     long long c0 = per * blockIdx.x, c1 = c0 + per;
@@ -444,22 +446,22 @@ inline int num_cus() {
     return g_num_cus;
 }
 
-template <int KD, int ND, int RT, bool WT = false, class AL, class EP>
+template <int KD, int ND, int RT, bool WT = false, int NW = 4, class AL, class EP>
 int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
                    const AL& al, const EP& ep, hipStream_t st) {
     const size_t lds = (size_t)KD * ND * sizeof(float);
-    auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP, WT>;
+    auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP, WT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
-    constexpr int ROWS_IT = 4 * RT * 16;
+    constexpr int ROWS_IT = NW * RT * 16;
     long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
     long long grid = nchunk < num_cus() ? nchunk : num_cus();
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
     return dprnn_check_launch(what);
 }
 
