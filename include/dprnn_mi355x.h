@@ -44,22 +44,13 @@ void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
  * recurrence entry points, so set it before packing): 0 = exact fp32 operands on the fp32 MFMA (default, what every
  * parity claim and the bench headline refer to); 1 = operands split into three bf16 pieces, the six cross products of
  * order <= 2^-16 on the bf16 MFMA with fp32 accumulation (product error ~2^-24: end-to-end deviation identical to the
- * fp32 path's own rounding noise); 2 = two pieces / three products (product error ~2^-16) -- recur_split.hip;
- * 3 / 4 = the same two arithmetics in a GEMM-like kernel (waves split the sequences, weights shared through an LDS
- * ring filled by LDS-DMA: half the L2 weight bytes per FLOP) -- recur_split3.hip. */
+ * fp32 path's own rounding noise); 2 = two pieces / three products (product error ~2^-16) -- recur_split.hip. */
 void dprnn_set_gemm_mode(int mode);
 int dprnn_get_gemm_mode(void);
-/* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order);
- * dprnn_lstm_pack_split3 is the layout of modes 3 / 4 ([slab][gate][unit tile][piece]) */
-int dprnn_lstm_pack_split3(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                           const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
-                           void* packed, float* bsum, void* stream);
+/* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order) */
 int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                           const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                           void* packed, float* bsum, void* stream);
-/* seq_tile 64 of dprnn_bilstm_fwd: 1 = software-pipelined kernel (cell update hidden under the other half's
- * gate GEMM, recur64.hip), 0 = plain 64-sequence tile */
-void dprnn_set_recur_pipelined(int on);
 
 /* ---- encoder statistics: Encoder.forward (src/models/encoder_decoder.py:25-33) feeding the
  * bottleneck norm (src/models/dprnn.py:131-136).  enc[b,n,l] = relu(sum_j We[n][j]*wav[b][l*stride+j])

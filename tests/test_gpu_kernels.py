@@ -71,41 +71,6 @@ def test_bilstm_matches_oracle(seq_tile, mode):
     assert rel_l2(got, want) < 2e-6
 
 
-@pytest.mark.parametrize("mode,B,S,K", [("intra", 3, 29, 7), ("inter", 2, 5, 77), ("intra", 1, 64, 1), ("inter", 1, 3, 130)])
-def test_bilstm_pipelined64_matches_oracle(mode, B, S, K):
-    """Software-pipelined 64-sequence kernel (recur64.hip): ragged tails, T = 1, several workgroups."""
-    rng = np.random.default_rng(B * 100 + S)
-    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
-    sd, p = _lstm_sd(43)
-    if mode == "intra":
-        want = onp.single_rnn(sd, p, X.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
-    else:
-        want = onp.single_rnn(sd, p, X.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
-        want = want.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
-    st = _st()
-    packed = torch.empty(2 * engine.PACK_PER_DIR, device=DEV)
-    bsum = torch.empty(2 * 512, device=DEV)
-    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
-    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
-    st.call("dprnn_lstm_pack", *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
-    Xd = _t(X)
-    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
-    st.lib.dprnn_set_recur_pipelined(1)
-    try:
-        if mode == "intra":
-            st.call("dprnn_bilstm_fwd", Xd.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
-                    B * S, K, B * S, 0, K, 1, 2, 64)
-        else:
-            st.call("dprnn_bilstm_fwd", Xd.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
-                    B * K, S, K, S * K, 1, K, 2, 64)
-        torch.cuda.synchronize()
-    finally:
-        st.lib.dprnn_set_recur_pipelined(0)
-    got = H.cpu().numpy()
-    assert np.isfinite(got).all()
-    assert rel_l2(got, want) < 2e-6
-
-
 @pytest.mark.parametrize("mode,seq_tile", [("intra", 32), ("inter", 16), ("inter", 64)])
 def test_bilstm_with_pending_norm(mode, seq_tile):
     """dprnn_bilstm_norm_fwd: x' = X + norm(Z) applied in the loader, x' written once, H computed from x'."""
@@ -144,7 +109,7 @@ def test_bilstm_with_pending_norm(mode, seq_tile):
     assert rel_l2(H.cpu().numpy(), want) < 2e-6
 
 
-@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5), (3, 2e-6), (4, 3e-5)])
+@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
 @pytest.mark.parametrize("path", ["intra", "inter"])
 def test_bilstm_split_gemm_modes(mode, tol, path):
     """Optional bf16-split gate GEMM (recur_split.hip): 6 products ~ fp32 accuracy, 3 products ~ 2^-16."""

@@ -82,12 +82,10 @@ def main():
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3")
-    ap.add_argument("--pipelined", type=int, default=0, help="seq_tile 64 uses the software-pipelined kernel")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
     lib.dprnn_set_fast_activations(a.fast)
-    lib.dprnn_set_recur_pipelined(a.pipelined)
     lib.dprnn_set_gemm_mode(a.gemm_mode)
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()

@@ -36,7 +36,6 @@ SIGNATURES = {
     "dprnn_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
                       c_i64, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
-    "dprnn_lstm_pack_split3": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
@@ -96,7 +95,6 @@ SIGNATURES = {
 _VOID = {
     "dprnn_set_fast_activations": [c_i],
     "dprnn_set_fast_head_activations": [c_i],
-    "dprnn_set_recur_pipelined": [c_i],
     "dprnn_set_gemm_mode": [c_i],
 }
 _SPECIAL = {

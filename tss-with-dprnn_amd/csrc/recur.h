@@ -1,4 +1,4 @@
-// Shared declarations of the recurrence kernels (recur.hip, recur64.hip).
+// Shared declarations of the recurrence kernels (recur.hip, recur_split.hip, train_recur.hip).
 #pragma once
 #include "common.h"
 
@@ -17,7 +17,6 @@ struct RecurArgs {
     int nseq, T, inner_n, ndir;
     long long outer_stride, inner_stride, t_stride;   // in rows
     unsigned long long* stamps;                       // diagnostic build only: [wg][8] counters
-    float* dump;                                      // recur64: landing zone for rows past nseq
     // optional fused "pending norm + residual" of the previous path (dprnn.py:90-92,98-99): when Z != nullptr the
     // kernel reads x' = X + (Z - mean_b)*rstd_b*gamma + beta, and direction 0 also writes x' to Xout (!= X)
     const float* Z;
@@ -32,10 +31,6 @@ struct RecurArgs {
     float* tape;                                      // training forward only: activated gates + cell state per step
 };
 
-// software-pipelined 64-sequence variant (recur64.hip)
-int launch_bilstm64(const RecurArgs& a, bool fast, hipStream_t st);
 // optional bf16-split gate GEMM (recur_split.hip): products = 6 or 3
 int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
-// same arithmetic, GEMM-like structure: waves split the sequences, weights shared through an LDS ring (recur_split3.hip)
-int launch_bilstm_split3(const RecurArgs& a, int products, bool fast, hipStream_t st);
 }  // namespace recur

@@ -419,24 +419,19 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// 0 exact fp32 MFMA (default); bf16-split: 1 = 6 products, 2 = 3 products (per-wave weight stream, recur_split.hip);
-// 3 = 6 products, 4 = 3 products (weights shared through an LDS ring, recur_split3.hip)
+// 0 exact fp32 MFMA (default); bf16-split: 1 = 6 products, 2 = 3 products (recur_split.hip)
 static int g_gemm_mode = 0;
-extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode >= 1 && mode <= 4) ? mode : 0; }
+extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
 extern "C" int dprnn_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" int dprnn_lstm_pack_split(const float*, const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, void*, float*, void*);
-extern "C" int dprnn_lstm_pack_split3(const float*, const float*, const float*, const float*, const float*, const float*,
-                                      const float*, const float*, void*, float*, void*);
 
 extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                               const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                               float* packed, float* bsum, void* stream) {
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_rnn_pack: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (cell == 0 && g_gemm_mode >= 3)      // optional split modes: bf16 piece planes instead of fp32 fragments
-        return dprnn_lstm_pack_split3(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
-    if (cell == 0 && g_gemm_mode != 0)
+    if (cell == 0 && g_gemm_mode != 0)       // optional split modes: bf16 piece planes instead of fp32 fragments
         return dprnn_lstm_pack_split(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_rnn_pack: incomplete reverse direction"); return -1; }
@@ -452,8 +447,6 @@ extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float
     return dprnn_rnn_pack(0, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
 }
 
-static int g_pipelined64 = 0;
-extern "C" void dprnn_set_recur_pipelined(int on) { g_pipelined64 = on; }
 static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L2 end to end, same as the libm forms
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
 int dprnn_fast_activations_enabled(void) { return g_fast_act; }      // train_recur.hip
@@ -480,14 +473,12 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
     }
     if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (g_gemm_mode >= 3) return launch_bilstm_split3(a, g_gemm_mode == 3 ? 6 : 3, fast, st);
     if (g_gemm_mode != 0) return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, seq_tile, fast, st);
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
         case 32: return fast ? launch_bilstm<2, true>(a, st) : launch_bilstm<2, false>(a, st);
         case 48: return fast ? launch_bilstm<3, true>(a, st) : launch_bilstm<3, false>(a, st);
         case 64:
-            if (g_pipelined64 && !a.Z) return launch_bilstm64(a, fast, st);
             return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
         default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,32,48,64 (got %d)", seq_tile); return -1;
     }

@@ -26,7 +26,6 @@ typedef const u32x4 __attribute__((address_space(1)))* gfrag_ptr;
 
 constexpr int NSLAB = 8;                       // k-slabs of 32 over [x | h]
 constexpr int PITCH = 528;                     // bytes per LDS row (256 bf16 + 16 B pad)
-constexpr int SPLIT_PACK_PER_DIR = 4 * NSLAB * 8 * 3 * 64 * 4;     // u32 per direction
 
 __device__ __forceinline__ unsigned bf16_bits(float v) {            // round-to-nearest-even bf16 of v, in the low 16 bits
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
