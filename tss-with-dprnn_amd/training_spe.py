@@ -18,7 +18,7 @@ statistics (and the running-buffer update) in train(), running statistics in eva
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -178,7 +178,7 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     return out2[:, 0, :], logits, ira_saved
 
 
-def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows, need_dx=True):
+def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows):
     """1x1 conv y = x @ W^T (W [cout][cin]): returns (dW, dx)."""
     dev = dOut.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -187,14 +187,12 @@ def _conv_bwd(st, lib, dOut, cout, x, cin, weight, rows, need_dx=True):
     q1 = (x.data_ptr() + 4 * 128) if cin == 256 else 0
     st.call("dprnn_wgrad", _p(dOut), cout, cout, _p(x), cin, min(cin, 128), 0, q1, cin, 128 if cin == 256 else 0, 0,
             rows, 1, 1, _p(gw), cin, 1, 0, 0, 0, _p(ws))
-    dx = None
-    if need_dx:
-        dx = torch.empty(rows, cin, **f32)
-        if cin == 256:                      # two 128-column halves
-            for c0 in (0, 128):
-                st.call("dprnn_dgrad", _p(dOut), cout, weight.data_ptr() + 4 * c0, cin, cout, 0, 0, dx.data_ptr() + 4 * c0, cin, 128, rows)
-        else:
-            st.call("dprnn_dgrad", _p(dOut), cout, _p(weight), cin, cout, 0, 0, _p(dx), cin, cin, rows)
+    dx = torch.empty(rows, cin, **f32)
+    if cin == 256:                          # two 128-column halves
+        for c0 in (0, 128):
+            st.call("dprnn_dgrad", _p(dOut), cout, weight.data_ptr() + 4 * c0, cin, cout, 0, 0, dx.data_ptr() + 4 * c0, cin, 128, rows)
+    else:
+        st.call("dprnn_dgrad", _p(dOut), cout, _p(weight), cin, cout, 0, 0, _p(dx), cin, cin, rows)
     return gw, dx
 
 
@@ -257,7 +255,7 @@ def _to_grad(st, addr, like):
     return g
 
 
-def _lin_bwd(st, grads, d_o, x, lin_w, lin_b, wname, bname, d_in, k0=0, dW=None, accumulate=True):
+def _lin_bwd(st, grads, d_o, x, lin_w, lin_b, wname, bname, d_in, k0=0, dW=None):
     """Gradients of out = W[:, k0:k0+K] x + b for one small per-utterance Linear; d_in (+)= d_o @ W."""
     B, K = x.shape
     gw = dW if dW is not None else torch.empty_like(lin_w)
