@@ -38,6 +38,22 @@ int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, flo
                    int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                    int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
 
+/* ---- the same three entry points for every rnn_type the reference accepts (getattr(nn, rnn_type), dprnn.py:23):
+ * cell 0 = LSTM, 1 = GRU, 2 = RNN (tanh), packing as dprnn_rnn_pack.  dG per row and direction: LSTM [i,f,g,o] (512),
+ * GRU [r, z, n_x, n_h] (512: dW_ih rows (r,z,n) pair with (r,z,n_x), dW_hh rows with (r,z,n_h); b_ih / b_hh likewise),
+ * RNN [a] (128). */
+int64_t dprnn_rnn_tape_floats(int cell, int nseq, int T, int ndir);
+int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                        const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                        const float* packed, const float* bsum, float* H, float* tape,
+                        int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                        int64_t t_stride, int ndir, void* stream);
+int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                       float* packedT, void* stream);
+int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                  int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                  int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
+
 /* ---- weight gradient of every Linear / 1x1 conv / LSTM weight: dW[m*ldm + n*ldn] (+)= sum_rows P[row][m]*Q[row][n],
  * m < M (multiple of 4), n < n0 + n1; Q is given as up to two blocks of <= 128 columns (Q1 may be NULL; n0 must be
  * 128 when Q1 is used).  A block with dt != 0 reads Q row (row - dt*t_stride) and zero where t - dt leaves [0, T),

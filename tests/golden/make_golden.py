@@ -103,6 +103,9 @@ GRAD_CASES = [
     ("grad_bss_wide_relu", dict(WIDE, activation_type="relu", n_repeats=1), 2, 211, 65),
     ("grad_bss_wide_unidir", dict(WIDE, bidirectional=False, n_repeats=1), 2, 211, 66),
     ("grad_bss_wide_hop5", dict(WIDE, hop_length=5, n_repeats=1), 3, 211, 67),
+    ("grad_bss_wide_gru", dict(WIDE, rnn_type="GRU", n_repeats=1), 2, 211, 69),
+    ("grad_bss_wide_gru_unidir", dict(WIDE, rnn_type="GRU", bidirectional=False, norm_type="gLN", n_repeats=2), 3, 211, 70),
+    ("grad_bss_wide_rnn", dict(WIDE, rnn_type="RNN", n_repeats=1), 2, 211, 71),
 ]
 N_PROJ = 8
 FULL_MAX = 40000          # gradients up to this many elements are stored whole, larger ones as projections

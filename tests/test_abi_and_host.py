@@ -107,12 +107,12 @@ def test_unsupported_config_fails_loudly():
         pkg.DPRNNTasNet(64, rnn_type="QRNN")                                       # getattr(nn, rnn_type) in the reference
 
 
-def test_training_path_has_no_cpu_fallback_and_refuses_other_cells():
+def test_training_path_has_no_cpu_fallback():
     m = pkg.DPRNNTasNet(64, n_repeats=1).train()
     with pytest.raises(pkg._lib.DprnnError, match="no CPU fallback"):     # differentiable forward: HIP device only
         m(torch.zeros(1, 300))
-    g = pkg.DPRNNTasNet(64, n_repeats=1, rnn_type="GRU").train()
-    with pytest.raises(NotImplementedError, match="training path"):       # backward kernels exist for the LSTM only
+    g = pkg.DPRNNTasNet(64, n_repeats=1, rnn_type="GRU").train()        # GRU / RNN cells train too: same refusal of CPU tensors
+    with pytest.raises(pkg._lib.DprnnError, match="no CPU fallback"):
         g(torch.zeros(1, 300))
 
 

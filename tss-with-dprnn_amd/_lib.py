@@ -56,6 +56,10 @@ SIGNATURES = {
     "dprnn_lstm_fwd_train": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
                              c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_pack_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_rnn_fwd_train": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
+                            c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_rnn_pack_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_rnn_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
                     c_fp, c_fp, c_i, c_fp, c_fp],
@@ -103,6 +107,7 @@ _SPECIAL = {
     "dprnn_num_cus": ([], c_i),
     "dprnn_get_gemm_mode": ([], c_i),
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
+    "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))

@@ -77,14 +77,14 @@ __global__ void rnn_pack_kernel(const float* __restrict__ w_ih, const float* __r
 // DIAG (diagnostic builds only, wrong results on purpose): 1 = every k-group re-reads weight group 0 (L1-resident:
 // no L2 weight stream), 2 = A fragments read once per step instead of per k-group (no LDS operand traffic),
 // 3 = cell update skipped (h = gate pre-activation), 4 = no HBM store of h.
-// SAVE (training forward, LSTM only): every step also writes the activated gates and the new cell state to a.tape in
-// this kernel's own fragment order -- [dir][workgroup][step][wave][nt][u][i,f,g,o,c][lane] float4 over the lane's four
-// sequences -- which lstm_bwd_kernel (train_recur.hip) reads back with the same thread mapping: 16-byte coalesced
-// stores and loads, no transposition.
+// SAVE (training forward): every step also writes what the backward needs to a.tape in this kernel's own fragment order
+// -- [dir][workgroup][step][wave][nt][u][slot][lane] float4 over the lane's four sequences; slots: LSTM i,f,g,o,c;
+// GRU r,z,n,(W_hn h + b_hn),h; Elman RNN h -- which the backward kernels (train_recur.hip) read back with the same thread
+// mapping: 16-byte coalesced stores and loads, no transposition.
 template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0, bool SAVE = false>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
-    static_assert(!SAVE || CELL == 0, "the gate tape is defined for the LSTM cell");
+    constexpr int NTAPE = CELL == 2 ? 1 : 5;          // tape slots per (nt, u)
     constexpr int NS = 16 * NT;
     constexpr int NGA = CELL == 2 ? 1 : 4;            // accumulator slots in use (see rnn_pack_kernel)
     constexpr int NXV = NS / 8;                       // float4 x loads per thread per step
@@ -328,7 +328,7 @@ void bilstm_kernel(RecurArgs a) {
         f32x4* tp = nullptr;
         if constexpr (SAVE)
             tp = reinterpret_cast<f32x4*>(a.tape) +
-                 ((((size_t)dir * gridDim.x + blockIdx.x) * T + step) * 4 + wave) * (NT * 2 * 5 * 64) + lane;
+                 ((((size_t)dir * gridDim.x + blockIdx.x) * T + step) * 4 + wave) * (NT * 2 * NTAPE * 64) + lane;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -351,18 +351,21 @@ void bilstm_kernel(RecurArgs a) {
                     } else if constexpr (CELL == 1) {     // GRU: n = tanh(n_x + r*n_h), h' = (1-z)*n + z*h (c holds h)
                         const float rg = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
                         const float zg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
-                        const float ng = tanh_f<FAST>((acc[nt][2][u][e] + bias[2][u]) + rg * (acc[nt][3][u][e] + bias[3][u]));
+                        const float nh = acc[nt][3][u][e] + bias[3][u];
+                        const float ng = tanh_f<FAST>((acc[nt][2][u][e] + bias[2][u]) + rg * nh);
                         h = (1.f - zg) * ng + zg * c[nt][u][e];
                         c[nt][u][e] = h;
+                        if constexpr (SAVE) { sv[0][e] = rg; sv[1][e] = zg; sv[2][e] = ng; sv[3][e] = nh; sv[4][e] = h; }
                     } else {                              // Elman RNN, tanh
                         h = tanh_b<FAST>(acc[nt][0][u][e], bias[0][u]);
+                        if constexpr (SAVE) sv[0][e] = h;
                     }
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
                     if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
                 }
                 if constexpr (SAVE) {
 #pragma unroll
-                    for (int x = 0; x < 5; ++x) tp[((nt * 2 + u) * 5 + x) * 64] = sv[x];
+                    for (int x = 0; x < NTAPE; ++x) tp[((nt * 2 + u) * NTAPE + x) * 64] = sv[x];
                 }
             }
         if (more) {
@@ -521,20 +524,22 @@ extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const doubl
 }
 
 // ---- training forward: dprnn_rnn_fwd for the LSTM cell on 32-sequence tiles, plus the gate tape for dprnn_lstm_bwd
-extern "C" int64_t dprnn_lstm_tape_floats(int nseq, int T, int ndir) {
-    return (int64_t)ndir * ((nseq + 31) / 32) * T * (32 * HD * 5);
+extern "C" int64_t dprnn_rnn_tape_floats(int cell, int nseq, int T, int ndir) {
+    return (int64_t)ndir * ((nseq + 31) / 32) * T * (32 * HD * (cell == 2 ? 1 : 5));
 }
+extern "C" int64_t dprnn_lstm_tape_floats(int nseq, int T, int ndir) { return dprnn_rnn_tape_floats(0, nseq, T, ndir); }
 
-extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double* stats, const float* gamma,
-                                    const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
-                                    const float* packed, const float* bsum, float* H, float* tape,
-                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
-                                    int64_t t_stride, int ndir, void* stream) {
+extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                                   const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                   const float* packed, const float* bsum, float* H, float* tape,
+                                   int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                   int64_t t_stride, int ndir, void* stream) {
     if (!tape) { dprnn_set_error("dprnn_lstm_fwd_train: tape is null"); return -1; }
+    if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_fwd_train: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     if (g_gemm_mode != 0) { dprnn_set_error("dprnn_lstm_fwd_train: the training path uses the exact fp32 gate GEMM (gemm mode 0)"); return -1; }
     RecurArgs a{};
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
-    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = 0;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
     a.rows_per_utt = rows_per_utt; a.Xout = Xout; a.tape = tape;
     if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_lstm_fwd_train: null pointer"); return -1; }
@@ -546,8 +551,19 @@ extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double
         dprnn_set_error("dprnn_lstm_fwd_train: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
         return -1;
     }
-    return g_fast_act ? launch_bilstm<2, true, 0, true>(a, (hipStream_t)stream)
-                      : launch_bilstm<2, false, 0, true>(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (cell == 1) return g_fast_act ? launch_bilstm<2, true, 1, true>(a, st) : launch_bilstm<2, false, 1, true>(a, st);
+    if (cell == 2) return g_fast_act ? launch_bilstm<2, true, 2, true>(a, st) : launch_bilstm<2, false, 2, true>(a, st);
+    return g_fast_act ? launch_bilstm<2, true, 0, true>(a, st) : launch_bilstm<2, false, 0, true>(a, st);
+}
+
+extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double* stats, const float* gamma,
+                                    const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                    const float* packed, const float* bsum, float* H, float* tape,
+                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                    int64_t t_stride, int ndir, void* stream) {
+    return dprnn_rnn_fwd_train(0, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, tape,
+                               nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
 }
 
 // Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][8] u64

@@ -15,6 +15,11 @@
 // the weight gradients dW_ih = da^T x, dW_hh = da^T h_{t-1}, db = sum da are one large GEMM over all rows
 // (dprnn_wgrad, train_gemm.hip) outside the serial loop.  dx of the two directions goes to two slabs that the
 // consumer adds (no atomics: the result does not depend on scheduling).
+//
+// The same kernel serves the other cells torch.nn offers behind rnn_type (dprnn.py:23), selected by CELL:
+//   GRU  (1): tape r, z, n, nh = W_hn h + b_hn, h;  da slots (r, z, n_x, n_h) -- K = 512 like the LSTM, the transposed
+//             weight pack carries zero blocks where n_x has no h part and n_h no x part; dh_{t-1} also gets dh_t * z directly
+//   RNN  (2): tape h;  da = dh_t * (1 - h^2), K = 128.
 #include "recur.h"
 using namespace recur;
 
@@ -22,15 +27,14 @@ namespace {
 
 typedef const f32x4 __attribute__((address_space(1)))* gw_ptr;
 
-constexpr int GS = 513;                    // LDS row stride of the da image (floats): 512 + 1 pad
-constexpr int NGB = 32;                    // k-groups of 16 over the 512 gate rows
-constexpr int PACKT_PER_DIR = 4 * NGB * 4 * 256;   // floats: [wave][grp][col tile 4][lane][4]
+constexpr int kdim_of(int cell) { return cell == 2 ? 128 : 512; }          // rows of the da image: gate slots * 128
+constexpr int PACKT_PER_DIR = 4 * 32 * 4 * 256;   // floats: [wave][grp 32][col tile 4][lane][4] (RNN uses the first 8 groups)
 
 // packedT[dir][wave][grp][j][lane][i] = Wcat[k][col],  k = 64*(grp>>2) + 16*q + 4*(grp&3) + i (gate row, 0..511),
 // col: j < 2 -> input column 32*wave + 16*j + r (W_ih), j >= 2 -> hidden column 32*wave + 16*(j-2) + r (W_hh)
 __global__ void lstm_pack_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                      const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
-                                     float* __restrict__ packedT, int ndir) {
+                                     float* __restrict__ packedT, int ndir, int cell) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ndir * PACKT_PER_DIR) return;
     const int i = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 3, grp = (idx >> 10) & 31;
@@ -39,7 +43,18 @@ __global__ void lstm_pack_bwd_kernel(const float* __restrict__ w_ih, const float
     const int k = 64 * (grp >> 2) + 16 * q + 4 * (grp & 3) + i;
     const float* wi = dir ? w_ih_r : w_ih;
     const float* wh = dir ? w_hh_r : w_hh;
-    packedT[idx] = j < 2 ? wi[k * F + 32 * wave + 16 * j + r] : wh[k * HD + 32 * wave + 16 * (j - 2) + r];
+    const int xc = 32 * wave + 16 * j + r, hc = 32 * wave + 16 * (j - 2) + r;
+    float v = 0.f;
+    if (cell == 0) {
+        v = j < 2 ? wi[k * F + xc] : wh[k * HD + hc];
+    } else if (cell == 1) {            // da slots r, z, n_x, n_h; torch rows r, z, n
+        const int slot = k >> 7, unit = k & 127;
+        if (j < 2) { if (slot < 3) v = wi[(slot * HD + unit) * F + xc]; }
+        else { if (slot < 2) v = wh[(slot * HD + unit) * HD + hc]; else if (slot == 3) v = wh[(2 * HD + unit) * HD + hc]; }
+    } else if (k < HD) {
+        v = j < 2 ? wi[k * F + xc] : wh[k * HD + hc];
+    }
+    packedT[idx] = v;
 }
 
 struct BwdArgs {
@@ -53,10 +68,12 @@ struct BwdArgs {
     long long outer_stride, inner_stride, t_stride;
 };
 
-template <int NT, bool FAST>
+template <int NT, bool FAST, int CELL = 0>
 __global__ __launch_bounds__(256, 2)
 void lstm_bwd_kernel(BwdArgs a) {
     constexpr int NS = 16 * NT;
+    constexpr int KG = kdim_of(CELL), GS = KG + 1, NGB = KG / 16;     // da image: KG columns + 1 pad (odd stride), k-groups of 16
+    constexpr int NTAPE = CELL == 2 ? 1 : 5;
     extern __shared__ __attribute__((aligned(16))) float DA[];        // [NS][GS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -68,7 +85,7 @@ void lstm_bwd_kernel(BwdArgs a) {
         return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
     };
     const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);
-    const int hpitch = a.ndir * HD, gpitch = a.ndir * 4 * HD;
+    const int hpitch = a.ndir * HD, gpitch = a.ndir * KG;
     // rows of the accumulator tile this lane owns: seq 16*nt + 4*q + e; rows past nseq alias the tile's first row for
     // loads and are never stored
     // Every address is (uniform base of the step: SGPRs) + (32-bit per-lane byte offset, fixed for the whole kernel) +
@@ -84,14 +101,14 @@ void lstm_bwd_kernel(BwdArgs a) {
             val[nt][e] = seq < a.nseq;
             const unsigned ro = (unsigned)(rowbase(val[nt][e] ? seq : seq0) - row0);
             hoff[nt][e] = (ro * hpitch + dir * HD + ucol) * 4u;
-            goff[nt][e] = (ro * gpitch + dir * 4 * HD + ucol) * 4u;
+            goff[nt][e] = (ro * gpitch + dir * KG + ucol) * 4u;
             xoff[nt][e] = (ro * F + ucol) * 4u;
         }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const gw_ptr wbase = (gw_ptr)(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * NGB * 4 * 64) + lane;
+    const gw_ptr wbase = (gw_ptr)(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * 32 * 4 * 64) + lane;
     const f32x4* const tape0 = reinterpret_cast<const f32x4*>(a.tape) +
-                               (((size_t)dir * gridDim.x + blockIdx.x) * T * 4 + wave) * (NT * 2 * 5 * 64) + lane;
-    auto tape_at = [&](int fs) { return tape0 + (size_t)fs * 4 * (NT * 2 * 5 * 64); };
+                               (((size_t)dir * gridDim.x + blockIdx.x) * T * 4 + wave) * (NT * 2 * NTAPE * 64) + lane;
+    auto tape_at = [&](int fs) { return tape0 + (size_t)fs * 4 * (NT * 2 * NTAPE * 64); };
     auto t_of = [&](int fs) { return (long long)(dir ? (T - 1 - fs) : fs); };      // forward step -> time index
 
     f32x4 gi[NT][2], gf[NT][2], gg[NT][2], go[NT][2], cc[NT][2], cp[NT][2], dho[NT][2];
@@ -104,11 +121,15 @@ void lstm_bwd_kernel(BwdArgs a) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int b = (nt * 2 + u) * 5;
-                gi[nt][u] = tp[(b + 0) * 64]; gf[nt][u] = tp[(b + 1) * 64];
-                gg[nt][u] = tp[(b + 2) * 64]; go[nt][u] = tp[(b + 3) * 64];
-                const f32x4 c1 = tq[(b + 4) * 64];
-                cp[nt][u] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
+                const int b = (nt * 2 + u) * NTAPE;
+                // LSTM: i, f, g, o and c_{t-1};  GRU: r, z, n, nh and h_{t-1};  RNN: h_t
+                gi[nt][u] = tp[(b + 0) * 64];
+                if constexpr (CELL != 2) {
+                    gf[nt][u] = tp[(b + 1) * 64];
+                    gg[nt][u] = tp[(b + 2) * 64]; go[nt][u] = tp[(b + 3) * 64];
+                    const f32x4 c1 = tq[(b + 4) * 64];
+                    cp[nt][u] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dho[nt][u][e] = *reinterpret_cast<const float*>(dhs + hoff[nt][e] + 64 * u);
             }
@@ -119,7 +140,7 @@ void lstm_bwd_kernel(BwdArgs a) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                cc[nt][u] = tp[((nt * 2 + u) * 5 + 4) * 64];
+                cc[nt][u] = CELL == 0 ? tp[((nt * 2 + u) * NTAPE + 4) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
                 dh[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dc[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -139,26 +160,42 @@ void lstm_bwd_kernel(BwdArgs a) {
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float i_ = gi[nt][u][e], f_ = gf[nt][u][e], g_ = gg[nt][u][e], o_ = go[nt][u][e];
-                    const float tc = tanh_f<FAST>(cc[nt][u][e]);
                     const float dht = dho[nt][u][e] + dh[nt][u][e];
-                    const float dct = dc[nt][u][e] + dht * o_ * (1.f - tc * tc);
-                    const float da_o = dht * tc * o_ * (1.f - o_);
-                    const float da_i = dct * g_ * i_ * (1.f - i_);
-                    const float da_f = dct * cp[nt][u][e] * f_ * (1.f - f_);
-                    const float da_g = dct * i_ * (1.f - g_ * g_);
-                    dc[nt][u][e] = dct * f_;
                     float* d = DA + (16 * nt + 4 * q + e) * GS + ucol + 16 * u;
-                    d[0] = da_i; d[HD] = da_f; d[2 * HD] = da_g; d[3 * HD] = da_o;
-                    if (val[nt][e]) {
-                        float* g = reinterpret_cast<float*>(dgs + goff[nt][e] + 64 * u);
-                        g[0] = da_i; g[HD] = da_f; g[2 * HD] = da_g; g[3 * HD] = da_o;
+                    float* g = reinterpret_cast<float*>(dgs + goff[nt][e] + 64 * u);
+                    if constexpr (CELL == 0) {
+                        const float i_ = gi[nt][u][e], f_ = gf[nt][u][e], g_ = gg[nt][u][e], o_ = go[nt][u][e];
+                        const float tc = tanh_f<FAST>(cc[nt][u][e]);
+                        const float dct = dc[nt][u][e] + dht * o_ * (1.f - tc * tc);
+                        const float da_o = dht * tc * o_ * (1.f - o_);
+                        const float da_i = dct * g_ * i_ * (1.f - i_);
+                        const float da_f = dct * cp[nt][u][e] * f_ * (1.f - f_);
+                        const float da_g = dct * i_ * (1.f - g_ * g_);
+                        dc[nt][u][e] = dct * f_;
+                        d[0] = da_i; d[HD] = da_f; d[2 * HD] = da_g; d[3 * HD] = da_o;
+                        if (val[nt][e]) { g[0] = da_i; g[HD] = da_f; g[2 * HD] = da_g; g[3 * HD] = da_o; }
+                    } else if constexpr (CELL == 1) {     // h' = (1-z) n + z h,  n = tanh(n_x + r*n_h)
+                        const float r_ = gi[nt][u][e], z_ = gf[nt][u][e], n_ = gg[nt][u][e], nh = go[nt][u][e];
+                        const float dpn = dht * (1.f - z_) * (1.f - n_ * n_);
+                        const float da_z = dht * (cp[nt][u][e] - n_) * z_ * (1.f - z_);
+                        const float da_r = dpn * nh * r_ * (1.f - r_);
+                        const float da_nh = dpn * r_;
+                        dc[nt][u][e] = dht * z_;                 // the direct dh_{t-1} term, added after the GEMM
+                        d[0] = da_r; d[HD] = da_z; d[2 * HD] = dpn; d[3 * HD] = da_nh;
+                        if (val[nt][e]) { g[0] = da_r; g[HD] = da_z; g[2 * HD] = dpn; g[3 * HD] = da_nh; }
+                    } else {                              // h = tanh(a)
+                        const float h_ = gi[nt][u][e];
+                        const float da = dht * (1.f - h_ * h_);
+                        d[0] = da;
+                        if (val[nt][e]) g[0] = da;
                     }
                 }
+        if constexpr (CELL == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) cc[nt][u] = cp[nt][u];
+                for (int u = 0; u < 2; ++u) cc[nt][u] = cp[nt][u];
+        }
         if (fs > 0) load_step(fs - 1);          // in flight during the GEMM below
         __syncthreads();
 
@@ -199,6 +236,10 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 dh[nt][u] = acc[nt][2 + u];
+                if constexpr (CELL == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dh[nt][u][e] += dc[nt][u][e];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (val[nt][e]) *reinterpret_cast<float*>(dxs + xoff[nt][e] + 64 * u) = acc[nt][u][e];
@@ -209,41 +250,65 @@ void lstm_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
-extern "C" int dprnn_lstm_pack_bwd(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
-                                   float* packedT, void* stream) {
-    if (!w_ih || !w_hh || !packedT) { dprnn_set_error("dprnn_lstm_pack_bwd: null pointer"); return -1; }
+extern "C" int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                                  float* packedT, void* stream) {
+    if (!w_ih || !w_hh || !packedT) { dprnn_set_error("dprnn_rnn_pack_bwd: null pointer"); return -1; }
+    if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     const int ndir = w_ih_r ? 2 : 1;
-    if (ndir == 2 && !w_hh_r) { dprnn_set_error("dprnn_lstm_pack_bwd: incomplete reverse direction"); return -1; }
+    if (ndir == 2 && !w_hh_r) { dprnn_set_error("dprnn_rnn_pack_bwd: incomplete reverse direction"); return -1; }
     const int n = ndir * PACKT_PER_DIR;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       w_ih, w_hh, w_ih_r, w_hh_r, packedT, ndir);
+                       w_ih, w_hh, w_ih_r, w_hh_r, packedT, ndir, cell);
     return dprnn_check_launch("lstm_pack_bwd_kernel");
+}
+
+extern "C" int dprnn_lstm_pack_bwd(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                                   float* packedT, void* stream) {
+    return dprnn_rnn_pack_bwd(0, w_ih, w_hh, w_ih_r, w_hh_r, packedT, stream);
 }
 
 extern int dprnn_fast_activations_enabled(void);
 
-extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
-                              int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
-                              int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
-    if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_lstm_bwd: null pointer"); return -1; }
+namespace {
+template <int CELL>
+int launch_bwd(const BwdArgs& a, hipStream_t st) {
+    constexpr int NT = 2;
+    const size_t lds = (size_t)16 * NT * (kdim_of(CELL) + 1) * sizeof(float);
+    // the LSTM's tanh(c_t) is recomputed from the tape with the same form (v_exp_f32 / libm) the forward used
+    const bool fast = dprnn_fast_activations_enabled() != 0;
+    auto kern = fast ? &lstm_bwd_kernel<NT, true, CELL> : &lstm_bwd_kernel<NT, false, CELL>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fast]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(rnn_bwd): %s", hipGetErrorString(e)); return -2; }
+        attr_set[fast] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.nseq + 16 * NT - 1) / (16 * NT), a.ndir), dim3(256), lds, st, a);
+    return dprnn_check_launch("lstm_bwd_kernel");
+}
+}  // namespace
+
+extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                             int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                             int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_rnn_bwd: null pointer"); return -1; }
     if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2) || rows_total < (int64_t)nseq * T) {
-        dprnn_set_error("dprnn_lstm_bwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d rows_total=%lld", nseq, T, inner_n, ndir,
+        dprnn_set_error("dprnn_rnn_bwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d rows_total=%lld", nseq, T, inner_n, ndir,
                         (long long)rows_total);
         return -1;
     }
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride};
-    constexpr int NT = 2;
-    const size_t lds = (size_t)16 * NT * GS * sizeof(float);
-    // tanh(c_t) is recomputed from the tape with the same form (v_exp_f32 / libm) the forward used
-    const bool fast = dprnn_fast_activations_enabled() != 0;
-    auto kern = fast ? &lstm_bwd_kernel<NT, true> : &lstm_bwd_kernel<NT, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fast]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lstm_bwd): %s", hipGetErrorString(e)); return -2; }
-        attr_set[fast] = true;
+    switch (cell) {
+        case 0: return launch_bwd<0>(a, (hipStream_t)stream);
+        case 1: return launch_bwd<1>(a, (hipStream_t)stream);
+        case 2: return launch_bwd<2>(a, (hipStream_t)stream);
+        default: dprnn_set_error("dprnn_rnn_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1;
     }
-    hipLaunchKernelGGL(kern, dim3((nseq + 16 * NT - 1) / (16 * NT), ndir), dim3(256), lds, (hipStream_t)stream, a);
-    return dprnn_check_launch("lstm_bwd_kernel");
+}
+
+extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                              int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                              int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    return dprnn_rnn_bwd(0, dH, tape, packedT, dX, dG, rows_total, nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
 }

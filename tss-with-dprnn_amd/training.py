@@ -35,10 +35,7 @@ _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
 def check_supported_train(cfg: dict) -> None:
-    engine.check_supported(cfg)
-    if cfg["rnn_type"] != "LSTM":
-        raise NotImplementedError(f"DPRNN MI355X training path: rnn_type {cfg['rnn_type']!r} has inference kernels only "
-                                  "(the backward is built for the LSTM the shipped configs use)")
+    engine.check_supported(cfg)          # LSTM, GRU and RNN cells all have forward-with-tape and backward kernels
 
 
 def saved_bytes_per_utt(geo: engine.Geometry, n_paths: int, ndirs: List[int]) -> int:
@@ -98,11 +95,12 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     # stores are in the same kernel (measured at B = 32: 109.6 ms against 101.4 + 5.7 ms).
     for p, (rnn, lin, norm, intra) in enumerate(paths):
         ndir, fw, bw = _rnn_tensors(rnn, dev)
-        st.call("dprnn_rnn_pack", 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+        cell = engine.CELL_ID[rnn.rnn.mode]
+        st.call("dprnn_rnn_pack", cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
         addr = _addr(geo, intra)
         Hp = torch.empty(rows, ndir * F_BUILT, **f32)
-        tape = torch.empty(lib.dprnn_lstm_tape_floats(addr[0], addr[1], ndir), **f32)
-        st.call("dprnn_lstm_fwd_train", _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+        tape = torch.empty(lib.dprnn_rnn_tape_floats(cell, addr[0], addr[1], ndir), **f32)
+        st.call("dprnn_rnn_fwd_train", cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
         w = _param(lin.weight, "linear.weight", dev)
         if w.shape != (F_BUILT, ndir * F_BUILT):
             raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
@@ -280,22 +278,44 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
         # recurrence (dprnn.py:86,95)
         addr = _addr(geo, intra)
-        st.call("dprnn_lstm_pack_bwd", _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
-        dG = torch.empty(rows, ndir * 4 * F_BUILT, **f32)
-        st.call("dprnn_lstm_bwd", _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
+        cell = engine.CELL_ID[rnn.rnn.mode]
+        kg = F_BUILT if cell == 2 else 4 * F_BUILT          # gate-gradient columns per direction: LSTM i,f,g,o; GRU r,z,n_x,n_h; RNN a
+        st.call("dprnn_rnn_pack_bwd", cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
+        dG = torch.empty(rows, ndir * kg, **f32)
+        st.call("dprnn_rnn_bwd", cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
         del dH
+        pre = f"{blk}_rnn.rnn."
         for d in range(ndir):
             suf = "_reverse" if d == 1 else ""
-            gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
-            gbias = torch.empty(4 * F_BUILT, **f32)
-            wgrad(dG.data_ptr() + 4 * 4 * F_BUILT * d, ndir * 4 * F_BUILT, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0,
-                  Hp.data_ptr() + 4 * F_BUILT * d, hp, F_BUILT, 1 if d == 0 else -1, rows, addr[5], addr[1],
-                  gcat, 2 * F_BUILT, 1, gbias, None)
-            pre = f"{blk}_rnn.rnn."
-            grads[pre + names[0] + suf] = gcat[:, :F_BUILT].contiguous()
-            grads[pre + names[1] + suf] = gcat[:, F_BUILT:].contiguous()
-            grads[pre + names[2] + suf] = gbias
-            grads[pre + names[3] + suf] = gbias.clone()
+            gbase = dG.data_ptr() + 4 * kg * d
+            hprev = (Hp.data_ptr() + 4 * F_BUILT * d, hp, F_BUILT, 1 if d == 0 else -1)        # h_{t-1} of this direction
+            if cell == 0:         # one GEMM: dG^T [x | h_prev] -> [W_ih | W_hh] (torch rows i,f,g,o)
+                gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
+                gbias = torch.empty(4 * F_BUILT, **f32)
+                wgrad(gbase, ndir * kg, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, *hprev, rows, addr[5], addr[1],
+                      gcat, 2 * F_BUILT, 1, gbias, None)
+                g_ih, g_hh = gcat[:, :F_BUILT].contiguous(), gcat[:, F_BUILT:].contiguous()
+                b_ih, b_hh = gbias, gbias.clone()
+            elif cell == 1:       # torch rows r,z,n: W_ih pairs with (r, z, n_x), W_hh with (r, z, n_h)
+                g_ih = torch.empty(3 * F_BUILT, F_BUILT, **f32)
+                g_hh = torch.empty(3 * F_BUILT, F_BUILT, **f32)
+                b_ih = torch.empty(3 * F_BUILT, **f32)
+                b_hh = torch.empty(3 * F_BUILT, **f32)
+                wgrad(gbase, ndir * kg, 3 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, rows, 1, 1, g_ih, F_BUILT, 1, b_ih, None)
+                wgrad(gbase, ndir * kg, 2 * F_BUILT, hprev[0], hprev[1], F_BUILT, hprev[3], 0, 0, 0, 0, rows, addr[5], addr[1],
+                      g_hh, F_BUILT, 1, b_hh, None)
+                wgrad(gbase + 4 * 3 * F_BUILT, ndir * kg, F_BUILT, hprev[0], hprev[1], F_BUILT, hprev[3], 0, 0, 0, 0, rows, addr[5],
+                      addr[1], g_hh[2 * F_BUILT:], F_BUILT, 1, b_hh[2 * F_BUILT:], None)
+            else:
+                g_ih = torch.empty(F_BUILT, F_BUILT, **f32)
+                g_hh = torch.empty(F_BUILT, F_BUILT, **f32)
+                b_ih = torch.empty(F_BUILT, **f32)
+                wgrad(gbase, ndir * kg, F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, 0, 0, 0, 0, rows, 1, 1, g_ih, F_BUILT, 1, b_ih, None)
+                wgrad(gbase, ndir * kg, F_BUILT, hprev[0], hprev[1], F_BUILT, hprev[3], 0, 0, 0, 0, rows, addr[5], addr[1],
+                      g_hh, F_BUILT, 1, None, None)
+                b_hh = b_ih.clone()
+            grads[pre + names[0] + suf], grads[pre + names[1] + suf] = g_ih, g_hh
+            grads[pre + names[2] + suf], grads[pre + names[3] + suf] = b_ih, b_hh
         del dG
         if ndir == 1:
             dXd[1].zero_()
