@@ -41,6 +41,30 @@ template <bool FAST> __device__ __forceinline__ float tanh_b(float x, float bk) 
     else return tanh_acc(x + bk);
 }
 
+// Two-element forms: the regular arithmetic becomes packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32, two results per
+// issue slot); v_exp_f32 / v_rcp_f32 stay per element.  Same operations as the scalar forms above.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool FAST> __device__ __forceinline__ f32x2 sigmoid_b2(f32x2 x, float bk) {
+    if constexpr (FAST) {
+        const f32x2 a = x * f32x2{-1.4426950408889634f, -1.4426950408889634f} + f32x2{bk, bk};
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    } else {
+        return f32x2{sigmoid_acc(x[0] + bk), sigmoid_acc(x[1] + bk)};
+    }
+}
+template <bool FAST> __device__ __forceinline__ f32x2 tanh_b2(f32x2 x, float bk) {
+    if constexpr (FAST) {
+        const f32x2 a = x * f32x2{2.8853900817779268f, 2.8853900817779268f} + f32x2{bk, bk};
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return f32x2{1.f, 1.f} - f32x2{2.f, 2.f} * r;
+    } else {
+        return f32x2{tanh_acc(x[0] + bk), tanh_acc(x[1] + bk)};
+    }
+}
+template <bool FAST> __device__ __forceinline__ f32x2 tanh_f2(f32x2 x) { return tanh_b2<FAST>(x, 0.f); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -152,11 +152,9 @@ void bilstm_kernel(RecurArgs a) {
         }
     }
     // x' of one staged float4 (identity when nothing is pending)
-    auto fix = [&](f32x4 x, f32x4 z, int m) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = x[e] + ((z[e] - mu[m]) * rs[m] * gam[e] + bet[e]);
-        return o;
+    auto fix = [&](f32x4 x, f32x4 z, int m) {        // whole-vector arithmetic: packed fp32 instructions, two lanes each
+        const f32x4 mu4 = {mu[m], mu[m], mu[m], mu[m]}, rs4 = {rs[m], rs[m], rs[m], rs[m]};
+        return x + ((z - mu4) * rs4 * gam + bet);
     };
     // time index -> scalar bases
     auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
@@ -334,6 +332,26 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 f32x4 sv[5];
+                if constexpr (CELL == 0 && DIAG != 3) {
+                    // LSTM, gate order i,f,g,o (torch.nn.LSTM), two sequences per instruction where the arithmetic allows
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const f32x2 ig = sigmoid_b2<FAST>(f32x2{acc[nt][0][u][2 * p], acc[nt][0][u][2 * p + 1]}, bias[0][u]);
+                        const f32x2 fg = sigmoid_b2<FAST>(f32x2{acc[nt][1][u][2 * p], acc[nt][1][u][2 * p + 1]}, bias[1][u]);
+                        const f32x2 gg = tanh_b2<FAST>(f32x2{acc[nt][2][u][2 * p], acc[nt][2][u][2 * p + 1]}, bias[2][u]);
+                        const f32x2 og = sigmoid_b2<FAST>(f32x2{acc[nt][3][u][2 * p], acc[nt][3][u][2 * p + 1]}, bias[3][u]);
+                        const f32x2 cn = fg * f32x2{c[nt][u][2 * p], c[nt][u][2 * p + 1]} + ig * gg;
+                        const f32x2 h2 = og * tanh_f2<FAST>(cn);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int e = 2 * p + k;
+                            c[nt][u][e] = cn[k];
+                            if constexpr (SAVE) { sv[0][e] = ig[k]; sv[1][e] = fg[k]; sv[2][e] = gg[k]; sv[3][e] = og[k]; sv[4][e] = cn[k]; }
+                            Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h2[k];
+                            if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h2[k];
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float h;
@@ -362,6 +380,7 @@ void bilstm_kernel(RecurArgs a) {
                     }
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
                     if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
+                }
                 }
                 if constexpr (SAVE) {
 #pragma unroll

@@ -157,39 +157,43 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                // whole-vector arithmetic over the lane's four sequences: packed fp32 instructions (two results per issue slot)
+                const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                const f32x4 dht = dho[nt][u] + dh[nt][u];
+                f32x4 da0, da1, da2, da3;                  // gradient of the pre-activations, in the image's slot order
+                if constexpr (CELL == 0) {
+                    const f32x4 i_ = gi[nt][u], f_ = gf[nt][u], g_ = gg[nt][u], o_ = go[nt][u];
+                    const f32x2 t01 = tanh_f2<FAST>(f32x2{cc[nt][u][0], cc[nt][u][1]}), t23 = tanh_f2<FAST>(f32x2{cc[nt][u][2], cc[nt][u][3]});
+                    const f32x4 tc = {t01[0], t01[1], t23[0], t23[1]};
+                    const f32x4 dct = dc[nt][u] + dht * o_ * (one - tc * tc);
+                    da3 = dht * tc * o_ * (one - o_);
+                    da0 = dct * g_ * i_ * (one - i_);
+                    da1 = dct * cp[nt][u] * f_ * (one - f_);
+                    da2 = dct * i_ * (one - g_ * g_);
+                    dc[nt][u] = dct * f_;
+                } else if constexpr (CELL == 1) {     // h' = (1-z) n + z h,  n = tanh(n_x + r*n_h); slots r, z, n_x, n_h
+                    const f32x4 r_ = gi[nt][u], z_ = gf[nt][u], n_ = gg[nt][u], nh = go[nt][u];
+                    da2 = dht * (one - z_) * (one - n_ * n_);
+                    da1 = dht * (cp[nt][u] - n_) * z_ * (one - z_);
+                    da0 = da2 * nh * r_ * (one - r_);
+                    da3 = da2 * r_;
+                    dc[nt][u] = dht * z_;                 // the direct dh_{t-1} term, added after the GEMM
+                } else {                              // h = tanh(a)
+                    da0 = dht * (one - gi[nt][u] * gi[nt][u]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dht = dho[nt][u][e] + dh[nt][u][e];
                     float* d = DA + (16 * nt + 4 * q + e) * GS + ucol + 16 * u;
                     float* g = reinterpret_cast<float*>(dgs + goff[nt][e] + 64 * u);
-                    if constexpr (CELL == 0) {
-                        const float i_ = gi[nt][u][e], f_ = gf[nt][u][e], g_ = gg[nt][u][e], o_ = go[nt][u][e];
-                        const float tc = tanh_f<FAST>(cc[nt][u][e]);
-                        const float dct = dc[nt][u][e] + dht * o_ * (1.f - tc * tc);
-                        const float da_o = dht * tc * o_ * (1.f - o_);
-                        const float da_i = dct * g_ * i_ * (1.f - i_);
-                        const float da_f = dct * cp[nt][u][e] * f_ * (1.f - f_);
-                        const float da_g = dct * i_ * (1.f - g_ * g_);
-                        dc[nt][u][e] = dct * f_;
-                        d[0] = da_i; d[HD] = da_f; d[2 * HD] = da_g; d[3 * HD] = da_o;
-                        if (val[nt][e]) { g[0] = da_i; g[HD] = da_f; g[2 * HD] = da_g; g[3 * HD] = da_o; }
-                    } else if constexpr (CELL == 1) {     // h' = (1-z) n + z h,  n = tanh(n_x + r*n_h)
-                        const float r_ = gi[nt][u][e], z_ = gf[nt][u][e], n_ = gg[nt][u][e], nh = go[nt][u][e];
-                        const float dpn = dht * (1.f - z_) * (1.f - n_ * n_);
-                        const float da_z = dht * (cp[nt][u][e] - n_) * z_ * (1.f - z_);
-                        const float da_r = dpn * nh * r_ * (1.f - r_);
-                        const float da_nh = dpn * r_;
-                        dc[nt][u][e] = dht * z_;                 // the direct dh_{t-1} term, added after the GEMM
-                        d[0] = da_r; d[HD] = da_z; d[2 * HD] = dpn; d[3 * HD] = da_nh;
-                        if (val[nt][e]) { g[0] = da_r; g[HD] = da_z; g[2 * HD] = dpn; g[3 * HD] = da_nh; }
-                    } else {                              // h = tanh(a)
-                        const float h_ = gi[nt][u][e];
-                        const float da = dht * (1.f - h_ * h_);
-                        d[0] = da;
-                        if (val[nt][e]) g[0] = da;
+                    d[0] = da0[e];
+                    if constexpr (CELL != 2) { d[HD] = da1[e]; d[2 * HD] = da2[e]; d[3 * HD] = da3[e]; }
+                    if (val[nt][e]) {
+                        g[0] = da0[e];
+                        if constexpr (CELL != 2) { g[HD] = da1[e]; g[2 * HD] = da2[e]; g[3 * HD] = da3[e]; }
                     }
                 }
+            }
         if constexpr (CELL == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
