@@ -176,8 +176,18 @@ void bilstm_kernel(RecurArgs a) {
 
     // wave-uniform weight slice (SGPR base, global address space) + lane index: saddr-form loads, scalar address math
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const gw_ptr wsl = (gw_ptr)(reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NGRP * 8 * 64);
-    const gw_ptr wbase = wsl + lane;
+    // The wave's weight slice as a buffer resource (4 SGPRs): fragment x of k-group g is
+    // buffer_load_dwordx4 v, lane*16, rsrc, soffset = g*8 KB + x KB -- the group offset lives in an SGPR, so no vector ALU
+    // instruction computes a weight address inside the step loop (with 64-bit global addresses the compiler spent ~15 of them
+    // per pair of k-groups, and fp32 vector instructions cost matrix time here).
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NGRP * 8 * 64), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16u;
+    auto wfrag = [&](int grp, int x) __attribute__((always_inline)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(grp * 8 * 1024 + x * 1024), 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
 
     // ---- prologue: x_{t0} -> Xs[0], zeros -> Hs[0]
     {
@@ -208,7 +218,7 @@ void bilstm_kernel(RecurArgs a) {
 
     f32x4 w[2][8];
 #pragma unroll
-    for (int x = 0; x < 2 * NGA; ++x) w[0][x] = wbase[x * 64];
+    for (int x = 0; x < 2 * NGA; ++x) w[0][x] = wfrag(0, x);
     __syncthreads();
 
     unsigned long long st_t0 = 0, st_r0 = 0, st_mfma = 0, st_act = 0;
@@ -250,9 +260,9 @@ void bilstm_kernel(RecurArgs a) {
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
                 // weights of the next k-group (wraps to group 0 of the next step: same bytes every step)
-                const gw_ptr wn = wbase + (DIAG == 1 ? 0 : (((grp + 1) & 15) * 8) * 64);
+                const int gnext = DIAG == 1 ? 0 : ((grp + 1) & 15);
 #pragma unroll
-                for (int x = 0; x < 2 * NGA; ++x) w[half ^ 1][x] = wn[x * 64];
+                for (int x = 0; x < 2 * NGA; ++x) w[half ^ 1][x] = wfrag(gnext, x);
                 const float* src = Ac + (DIAG == 2 ? 0 : 64 * (grp >> 2) + 4 * (grp & 3));
                 float av[NT][4];
 #pragma unroll
@@ -291,9 +301,8 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
-                const gw_ptr wn = wbase + ((((grp + 1) & 15) * 8) * 64);
 #pragma unroll
-                for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wn[x * 64];
+                for (int x = 0; x < 8; ++x) w[half ^ 1][x] = wfrag((grp + 1) & 15, x);
                 const int gn = (grp + 1) & 15;             // group 15 prefetches group 0 of the old image: unused
                 const float* src = Ac + 64 * (gn >> 2) + 4 * (gn & 3);
 #pragma unroll
