@@ -105,6 +105,7 @@ void bilstm_kernel(RecurArgs a) {
         return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
     };
     const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);          // uniform
+    constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond every resource's range: stores dropped, loads return 0
     const int hpitch = a.ndir * HD;
     // ---- x staging descriptors: float4 f = tid + 256*m covers row f>>5, floats 4*(f&31)..+3
     unsigned xoff[NXV];                               // byte offset from X + row0*F
@@ -128,7 +129,7 @@ void bilstm_kernel(RecurArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
             hval[nt][e] = seq < a.nseq;
-            hoff[nt][e] = (unsigned)((rowbase(hval[nt][e] ? seq : seq0) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u;
+            hoff[nt][e] = hval[nt][e] ? (unsigned)((rowbase(seq) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u : OOB;
         }
     // ---- pending norm of the previous path, applied while x is staged
     const bool fuse = a.Z != nullptr;
@@ -183,10 +184,23 @@ void bilstm_kernel(RecurArgs a) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NGRP * 8 * 64), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16u;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto wfrag = [&](int grp, int x) __attribute__((always_inline)) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(grp * 8 * 1024 + x * 1024), 0);
         return __builtin_bit_cast(f32x4, v);
+    };
+    // The same for the activations: one buffer resource per tensor whose base is the row of the step (scalar), per-lane
+    // 32-bit offsets fixed for the whole kernel.  A lane whose sequence does not exist gets an offset beyond the range
+    // (OOB): the hardware drops its stores and returns zeros for its loads -- no exec-mask branches in the step loop.
+    constexpr unsigned RANGE = 0x7fffffffu;
+    auto rsrc_at = [&](const float* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, RANGE, 0x00020000);
+    };
+    auto bload4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    };
+    auto bstore4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
     };
 
     // ---- prologue: x_{t0} -> Xs[0], zeros -> Hs[0]
@@ -233,15 +247,15 @@ void bilstm_kernel(RecurArgs a) {
         f32x4 xr[NXV], zr[NXV];
         const long long tn = dir ? (t - 1) : (t + 1);
         if (more) {
-            const char* xs = reinterpret_cast<const char*>(a.X + tbase(tn) * F);
-            const char* zs = reinterpret_cast<const char*>(a.Z + tbase(tn) * F);
             // rows past nseq alias the tile's first row (xoff), so every lane loads unconditionally: no exec-mask
             // branches, no zero fills -- their h is never stored and a duplicated x' store carries identical bytes
+            const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(tn) * F);
 #pragma unroll
-            for (int m = 0; m < NXV; ++m) xr[m] = *reinterpret_cast<const f32x4*>(xs + xoff[m]);
+            for (int m = 0; m < NXV; ++m) xr[m] = bload4(xrs, xoff[m]);
             if (fuse) {
+                const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(tn) * F);
 #pragma unroll
-                for (int m = 0; m < NXV; ++m) zr[m] = *reinterpret_cast<const f32x4*>(zs + xoff[m]);
+                for (int m = 0; m < NXV; ++m) zr[m] = bload4(zrs, xoff[m]);
             }
         }
         f32x4 acc[NT][4][2];
@@ -331,7 +345,7 @@ void bilstm_kernel(RecurArgs a) {
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); st_mfma += st_b - st_a; }
         // ---- LSTM cell (gate order i,f,g,o), lane-local
         float* const Hn = XH + nxt * NS * XS + HD;
-        char* const hs = reinterpret_cast<char*>(a.H + tbase(t) * hpitch);
+        const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
         f32x4* tp = nullptr;
         if constexpr (SAVE)
             tp = reinterpret_cast<f32x4*>(a.tape) +
@@ -357,7 +371,7 @@ void bilstm_kernel(RecurArgs a) {
                             c[nt][u][e] = cn[k];
                             if constexpr (SAVE) { sv[0][e] = ig[k]; sv[1][e] = fg[k]; sv[2][e] = gg[k]; sv[3][e] = og[k]; sv[4][e] = cn[k]; }
                             Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h2[k];
-                            if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h2[k];
+                            if (DIAG != 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(float(h2[k])), hrs, hoff[nt][e] + 64 * u, 0, 0);
                         }
                     }
                 } else {
@@ -388,7 +402,7 @@ void bilstm_kernel(RecurArgs a) {
                         if constexpr (SAVE) sv[0][e] = h;
                     }
                     Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
-                    if (DIAG != 4 && hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
+                    if (DIAG != 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrs, hoff[nt][e] + 64 * u, 0, 0);
                 }
                 }
                 if constexpr (SAVE) {
@@ -398,13 +412,13 @@ void bilstm_kernel(RecurArgs a) {
             }
         if (more) {
             float* const Xn = XH + nxt * NS * XS;
-            char* os = reinterpret_cast<char*>(a.Xout + tbase(tn) * F);
+            const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(tn) * F);
 #pragma unroll
             for (int m = 0; m < NXV; ++m) {
                 f32x4 v = xr[m];
                 if (fuse) {
                     v = fix(v, zr[m], m);
-                    if (dir == 0) *reinterpret_cast<f32x4*>(os + xoff[m]) = v;
+                    if (dir == 0) bstore4(ors, xoff[m], v);
                 }
                 float* d = Xn + xlds[m];
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
