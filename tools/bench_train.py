@@ -110,7 +110,11 @@ def main():
     lstm = 12 * rws * 2 * (2 * 256 * 512)                  # 12 paths x 2 directions, [x|h] (256) x 4 gates (512) per row
     wg = 12 * (2 * rws * 2 * 512 * 256 + rws * 2 * 128 * 256)     # LSTM dW (both directions) + Linear dW per path
     byname = {n: ms for ms, _, n in rows}
-    for n, fl in (("dprnn_lstm_fwd_train", lstm), ("dprnn_lstm_bwd", lstm), ("dprnn_wgrad", wg)):
+    for names, fl in ((("dprnn_lstm_fwd_train", "dprnn_rnn_fwd_train"), lstm), (("dprnn_lstm_bwd", "dprnn_rnn_bwd"), lstm),
+                      (("dprnn_wgrad",), wg)):
+        n = next((x for x in names if x in byname), None)
+        if n is None:
+            continue
         tf = fl / (byname[n] * 1e-3) / 1e12
         print(f"roofline {n:22s} {fl / 1e12:6.2f} TFLOP in {byname[n]:7.2f} ms = {tf:6.1f} TFLOP/s = {tf / 157.3:.2f} of the fp32 MFMA peak")
 

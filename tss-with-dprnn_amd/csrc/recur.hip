@@ -243,6 +243,12 @@ void bilstm_kernel(RecurArgs a) {
         const int cur = step & 1, nxt = cur ^ 1;
         const long long t = dir ? (T - 1 - step) : step;
         const bool more = step + 1 < T;
+        // keep "offset + constant" inside the loop body so the constant lands in the instruction's immediate field
+        // instead of a second, hoisted copy of every offset register
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(hoff[nt][e]));
         // prefetch x_{t+1} into registers
         f32x4 xr[NXV], zr[NXV];
         const long long tn = dir ? (t - 1) : (t + 1);
@@ -346,10 +352,15 @@ void bilstm_kernel(RecurArgs a) {
         // ---- LSTM cell (gate order i,f,g,o), lane-local
         float* const Hn = XH + nxt * NS * XS + HD;
         const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
-        f32x4* tp = nullptr;
-        if constexpr (SAVE)
-            tp = reinterpret_cast<f32x4*>(a.tape) +
-                 ((((size_t)dir * gridDim.x + blockIdx.x) * T + step) * 4 + wave) * (NT * 2 * NTAPE * 64) + lane;
+        // tape: this workgroup's steps are contiguous; entry i of the step lives in 4 KiB window i>>2 (one resource per
+        // window, scalar base) at immediate offset (i&3) KiB.  The scalar-offset operand stays the constant 0 on purpose:
+        // a 128-bit buffer store whose data registers are rewritten by the next VALU instruction needs a wait state,
+        // and the compiler's hazard recognizer inserts it only for the immediate form -- with an SGPR offset the
+        // o-gate entry of one tile came back corrupted on gfx950 (profiles/r01_recur_microbench.txt).
+        constexpr unsigned TSTEP = 4u * (NT * 2 * NTAPE * 64) * 16u;
+        const float* const tstep = SAVE ? a.tape + (((size_t)dir * gridDim.x + blockIdx.x) * T + step) * (TSTEP / 4) : nullptr;
+        unsigned tlane = (unsigned)(wave * (NT * 2 * NTAPE * 64) + lane) * 16u;
+        if constexpr (SAVE) asm volatile("" : "+v"(tlane));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -407,7 +418,10 @@ void bilstm_kernel(RecurArgs a) {
                 }
                 if constexpr (SAVE) {
 #pragma unroll
-                    for (int x = 0; x < NTAPE; ++x) tp[((nt * 2 + u) * NTAPE + x) * 64] = sv[x];
+                    for (int x = 0; x < NTAPE; ++x) {
+                        const int i = (nt * 2 + u) * NTAPE + x;
+                        bstore4(rsrc_at(tstep + (i >> 2) * 1024), tlane + (unsigned)((i & 3) * 1024), sv[x]);
+                    }
                 }
             }
         if (more) {

@@ -86,61 +86,74 @@ void lstm_bwd_kernel(BwdArgs a) {
     };
     const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);
     const int hpitch = a.ndir * HD, gpitch = a.ndir * KG;
-    // rows of the accumulator tile this lane owns: seq 16*nt + 4*q + e; rows past nseq alias the tile's first row for
-    // loads and are never stored
-    // Every address is (uniform base of the step: SGPRs) + (32-bit per-lane byte offset, fixed for the whole kernel) +
-    // (immediate): no vector ALU work for addressing inside the step loop -- fp32 VALU instructions cost matrix time.
+    // rows of the accumulator tile this lane owns: seq 16*nt + 4*q + e.
+    // Every global access goes through a buffer resource whose base is the step's row (SGPRs) with a 32-bit per-lane
+    // byte offset fixed for the whole kernel (+ immediate): no vector ALU work for addressing inside the step loop --
+    // fp32 VALU instructions cost matrix time.  Rows past nseq carry an offset beyond the resource's range: the
+    // hardware returns zeros for their loads and drops their stores, so the loop has no exec-mask branches either.
+    constexpr unsigned OOB = 0x80000000u;
     unsigned hoff[NT][4], goff[NT][4], xoff[NT][4];      // byte offsets into dH / dG / dX rows of this lane's sequences
-    bool val[NT][4];
     const int ucol = 32 * wave + r;        // + 16*u
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
-            val[nt][e] = seq < a.nseq;
-            const unsigned ro = (unsigned)(rowbase(val[nt][e] ? seq : seq0) - row0);
-            hoff[nt][e] = (ro * hpitch + dir * HD + ucol) * 4u;
-            goff[nt][e] = (ro * gpitch + dir * KG + ucol) * 4u;
-            xoff[nt][e] = (ro * F + ucol) * 4u;
+            const bool val = seq < a.nseq;
+            const unsigned ro = (unsigned)(rowbase(val ? seq : seq0) - row0);
+            hoff[nt][e] = val ? (ro * hpitch + dir * HD + ucol) * 4u : OOB;
+            goff[nt][e] = val ? (ro * gpitch + dir * KG + ucol) * 4u : OOB;
+            xoff[nt][e] = val ? (ro * F + ucol) * 4u : OOB;
         }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const gw_ptr wbase = (gw_ptr)(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * 32 * 4 * 64) + lane;
-    const f32x4* const tape0 = reinterpret_cast<const f32x4*>(a.tape) +
-                               (((size_t)dir * gridDim.x + blockIdx.x) * T * 4 + wave) * (NT * 2 * NTAPE * 64) + lane;
-    auto tape_at = [&](int fs) { return tape0 + (size_t)fs * 4 * (NT * 2 * NTAPE * 64); };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto rsrc_at = [&](const void* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+    };
+    auto bload4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    const unsigned lane16 = lane * 16u;
+    // weights: fragment (k-group g, column tile j) of this wave at scalar offset (4 g + j) KiB
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_at(reinterpret_cast<const f32x4*>(a.WpT) + (size_t)(dir * 4 + wave_u) * 32 * 4 * 64);
+    auto wfrag = [&](int grp, int j) __attribute__((always_inline)) { return bload4(wrs, lane16, (unsigned)((grp * 4 + j) * 1024)); };
+    // tape: this workgroup's steps are contiguous; entry x of (step fs, wave) at scalar offset
+    constexpr unsigned TSTEP = 4u * (NT * 2 * NTAPE * 64) * 16u;      // bytes per step (4 waves)
+    const __amdgpu_buffer_rsrc_t trs = rsrc_at(reinterpret_cast<const f32x4*>(a.tape) +
+                                               ((size_t)dir * gridDim.x + blockIdx.x) * T * 4 * (NT * 2 * NTAPE * 64));
+    const unsigned tlane = (unsigned)(wave * (NT * 2 * NTAPE * 64) + lane) * 16u;
+    auto tape_ld = [&](int fs, int x) __attribute__((always_inline)) { return bload4(trs, tlane, (unsigned)fs * TSTEP + (unsigned)x * 1024u); };
     auto t_of = [&](int fs) { return (long long)(dir ? (T - 1 - fs) : fs); };      // forward step -> time index
 
     f32x4 gi[NT][2], gf[NT][2], gg[NT][2], go[NT][2], cc[NT][2], cp[NT][2], dho[NT][2];
     f32x4 dh[NT][2], dc[NT][2];
     auto load_step = [&](int fs) __attribute__((always_inline)) {     // gates of step fs, c of step fs-1, dH of step fs
-        const f32x4* tp = tape_at(fs);
-        const f32x4* tq = tape_at(fs > 0 ? fs - 1 : 0);
-        const char* dhs = reinterpret_cast<const char*>(a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch);
+        const int fq = fs > 0 ? fs - 1 : 0;
+        const __amdgpu_buffer_rsrc_t dhs = rsrc_at(a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int b = (nt * 2 + u) * NTAPE;
                 // LSTM: i, f, g, o and c_{t-1};  GRU: r, z, n, nh and h_{t-1};  RNN: h_t
-                gi[nt][u] = tp[(b + 0) * 64];
+                gi[nt][u] = tape_ld(fs, b + 0);
                 if constexpr (CELL != 2) {
-                    gf[nt][u] = tp[(b + 1) * 64];
-                    gg[nt][u] = tp[(b + 2) * 64]; go[nt][u] = tp[(b + 3) * 64];
-                    const f32x4 c1 = tq[(b + 4) * 64];
+                    gf[nt][u] = tape_ld(fs, b + 1);
+                    gg[nt][u] = tape_ld(fs, b + 2); go[nt][u] = tape_ld(fs, b + 3);
+                    const f32x4 c1 = tape_ld(fq, b + 4);
                     cp[nt][u] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dho[nt][u][e] = *reinterpret_cast<const float*>(dhs + hoff[nt][e] + 64 * u);
+                for (int e = 0; e < 4; ++e)
+                    dho[nt][u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dhs, hoff[nt][e] + 64 * u, 0, 0));
             }
     };
     {
-        const f32x4* tp = tape_at(T - 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                cc[nt][u] = CELL == 0 ? tp[((nt * 2 + u) * NTAPE + 4) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                cc[nt][u] = CELL == 0 ? tape_ld(T - 1, (nt * 2 + u) * NTAPE + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 dh[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dc[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -148,12 +161,18 @@ void lstm_bwd_kernel(BwdArgs a) {
     load_step(T - 1);
     f32x4 w[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[0][j] = wbase[j * 64];
+    for (int j = 0; j < 4; ++j) w[0][j] = wfrag(0, j);
 
     for (int fs = T - 1; fs >= 0; --fs) {
         const long long trow = row0 + t_of(fs) * a.t_stride;
+        // keep "offset + constant" inside the loop body so the constant lands in the instruction's immediate field
+        // instead of a second, hoisted copy of every offset register
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(hoff[nt][e]), "+v"(goff[nt][e]), "+v"(xoff[nt][e]));
         // ---- gate derivatives (torch.nn.LSTM backward), lane-local; da -> LDS image and HBM
-        char* const dgs = reinterpret_cast<char*>(a.dG + trow * gpitch);
+        const __amdgpu_buffer_rsrc_t dgs = rsrc_at(a.dG + trow * gpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -185,12 +204,16 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float* d = DA + (16 * nt + 4 * q + e) * GS + ucol + 16 * u;
-                    float* g = reinterpret_cast<float*>(dgs + goff[nt][e] + 64 * u);
-                    d[0] = da0[e];
-                    if constexpr (CELL != 2) { d[HD] = da1[e]; d[2 * HD] = da2[e]; d[3 * HD] = da3[e]; }
-                    if (val[nt][e]) {
-                        g[0] = da0[e];
-                        if constexpr (CELL != 2) { g[HD] = da1[e]; g[2 * HD] = da2[e]; g[3 * HD] = da3[e]; }
+                    const unsigned go_ = goff[nt][e] + 64 * u;
+                    const float v0 = da0[e];
+                    d[0] = v0;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), dgs, go_, 0, 0);
+                    if constexpr (CELL != 2) {
+                        const float v1 = da1[e], v2 = da2[e], v3 = da3[e];
+                        d[HD] = v1; d[2 * HD] = v2; d[3 * HD] = v3;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), dgs, go_ + 4 * HD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v2), dgs, go_ + 8 * HD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), dgs, go_ + 12 * HD, 0, 0);
                     }
                 }
             }
@@ -215,9 +238,9 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int grp = 2 * gp + half;
-                const gw_ptr wn = wbase + (((grp + 1) & (NGB - 1)) * 4) * 64;     // wraps to group 0 of the next step
+                const int gn = (grp + 1) & (NGB - 1);                            // wraps to group 0 of the next step
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[half ^ 1][j] = wn[j * 64];
+                for (int j = 0; j < 4; ++j) w[half ^ 1][j] = wfrag(gn, j);
                 const float* src = Ac + 64 * (grp >> 2) + 4 * (grp & 3);
                 float av[NT][4];
 #pragma unroll
@@ -234,7 +257,7 @@ void lstm_bwd_kernel(BwdArgs a) {
         }
         __syncthreads();                        // every wave is done reading the image
 
-        char* const dxs = reinterpret_cast<char*>(a.dX + ((long long)dir * a.rows_total + trow) * F);
+        const __amdgpu_buffer_rsrc_t dxs = rsrc_at(a.dX + ((long long)dir * a.rows_total + trow) * F);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -245,8 +268,10 @@ void lstm_bwd_kernel(BwdArgs a) {
                     for (int e = 0; e < 4; ++e) dh[nt][u][e] += dc[nt][u][e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (val[nt][e]) *reinterpret_cast<float*>(dxs + xoff[nt][e] + 64 * u) = acc[nt][u][e];
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[nt][u][e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dxs, xoff[nt][e] + 64 * u, 0, 0);
+                }
             }
         }
     }
