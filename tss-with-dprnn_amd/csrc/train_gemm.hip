@@ -47,28 +47,54 @@ void wgrad_kernel(WgradArgs a) {
     long long r1 = r0 + a.rows_per_split;
     if (r1 > a.rows) r1 = a.rows;
 
-    // staging assignment: P chunk = 16 rows x 64 float4 -> 2 per thread (fixed column chunk), Q chunk = 16 x 32 -> 1
+    // staging assignment: P chunk = 16 rows x 64 float4 -> 2 per thread (fixed column chunk), Q chunk = 16 x 32 -> 1.
+    // Loads go through buffer resources whose base is the chunk's first row (scalar, advanced per chunk) and whose
+    // range ends at row r1: the per-lane byte offsets are fixed for the whole kernel, rows past the range and masked
+    // lanes (offset OOB) read as zero -- no 64-bit vector address arithmetic and no division inside the chunk loop.
+    constexpr unsigned OOB = 0x80000000u;
     const int pc4 = tid & 63, prow = tid >> 6;          // rows prow, prow + 8
     const int qc4 = tid & 31, qrow = tid >> 5;
     const int pcol = mb * WG_MB + 4 * pc4;
     const bool pok = pcol < a.M;                         // M is a multiple of 4
     const bool qok = 4 * qc4 < qd.cols;
+    unsigned poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) poff[j] = pok ? (unsigned)(((prow + 8 * j) * a.ldp + pcol) * 4) : OOB;
+    const unsigned qoff = qok ? (unsigned)((qrow * qd.ld + 4 * qc4) * 4) : OOB;
+    // time index of this lane's Q row (shifted blocks only), advanced by 16 rows per chunk without dividing
+    const int ts = (int)a.t_stride;                      // t_stride and T fit 32 bits (checked by the launcher)
+    int tq = 0, remq = 0;
+    if (qd.dt != 0) {
+        const long long row = r0 + qrow;
+        tq = (int)((row / a.t_stride) % a.T);
+        remq = (int)(row % a.t_stride);
+    }
+    auto rsrc_rows = [&](const float* base, long long row, int ld) __attribute__((always_inline)) {
+        // rows [row, r1) of a [rows][ld] matrix; the shifted Q block may start before the matrix (those lanes are masked)
+        const long long left = (r1 - row) * (long long)ld * 4;
+        const unsigned range = left > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + row * ld), 0, range, 0x00020000);
+    };
     f32x4 pv[2], qv, psum = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](long long row0) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t prs = rsrc_rows(a.P, row0, a.ldp);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long row = row0 + prow + 8 * j;
-            pv[j] = (pok && row < r1) ? *reinterpret_cast<const f32x4*>(a.P + row * a.ldp + pcol) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        const long long row = row0 + qrow;
-        bool ok = qok && row < r1;
-        long long src = row;
+        for (int j = 0; j < 2; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, poff[j], 0, 0));
+        unsigned qo = qoff;
         if (qd.dt != 0) {
-            const long long t = (row / a.t_stride) % a.T - qd.dt;
-            ok = ok && t >= 0 && t < a.T;
-            src = row - (long long)qd.dt * a.t_stride;
+            const int t = tq - qd.dt;
+            if (t < 0 || t >= a.T) qo = OOB;
         }
-        qv = ok ? *reinterpret_cast<const f32x4*>(qd.p + src * qd.ld + 4 * qc4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // Q row = row - dt*t_stride: the shift moves the scalar base, the range still ends at (unshifted) row r1
+        const long long shift = (long long)qd.dt * a.t_stride;
+        const long long left = (r1 - row0) * (long long)qd.ld * 4;
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(qd.p + (row0 - shift) * qd.ld), 0, left > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left, 0x00020000);
+        qv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, qo, 0, 0));
+        if (qd.dt != 0) {                                // advance the time index to the next chunk's row
+            if (ts == 1) { tq += WG_R; while (tq >= a.T) tq -= a.T; }
+            else { remq += WG_R; while (remq >= ts) { remq -= ts; if (++tq == a.T) tq = 0; } }
+        }
     };
     auto store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -138,23 +164,53 @@ void wgrad_kernel(WgradArgs a) {
 }
 
 // dW[m*ldm + n*ldn] = (accumulate ? dW : 0) + sum_s part[s][m][n];  db likewise (two optional destinations: the
-// LSTM's b_ih and b_hh receive the same gradient)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int splits,
-                                    int Mpad, int Npad, int M, int N, float* __restrict__ dW, long long ldm,
-                                    long long ldn, float* __restrict__ db0, float* __restrict__ db1, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < M * N) {
-        const int m = idx / N, n = idx % N;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[((long long)k * Mpad + m) * Npad + n];
-        float* d = dW + m * ldm + n * ldn;
-        *d = accumulate ? *d + s : s;
+// LSTM's b_ih and b_hh receive the same gradient).  A workgroup of 4 waves sums 64 float4 column groups: wave w adds the
+// partials s = w, w+4, ... (eight independent loads in flight), the four wave sums are added in wave order -- a fixed
+// order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256)
+void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int splits,
+                         int Mpad, int Npad, int M, int N, float* __restrict__ dW, long long ldm,
+                         long long ldn, float* __restrict__ db0, float* __restrict__ db1, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n4 = N / 4;                                   // N is a multiple of 4
+    const int nmat = M * n4, nb4 = part_b ? M / 4 : 0;      // float4 items: the matrix, then the bias row
+    const int item = blockIdx.x * 64 + lane;
+    const bool mat = item < nmat, bias = !mat && item < nmat + nb4;
+    const float* src = nullptr;
+    long long stride = 0;
+    int m = 0, n = 0;
+    if (mat) { m = item / n4; n = 4 * (item % n4); src = part + (long long)m * Npad + n; stride = (long long)Mpad * Npad; }
+    else if (bias) { m = 4 * (item - nmat); src = part_b + m; stride = Mpad; }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (src) {
+        int k = w;
+        for (; k + 28 < splits; k += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (k + 4 * u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(src + k * stride);
     }
-    if (part_b && idx < M) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part_b[(long long)k * Mpad + idx];
-        if (db0) db0[idx] = accumulate ? db0[idx] + s : s;
-        if (db1) db1[idx] = accumulate ? db1[idx] + s : s;
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && src) {
+        s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (mat) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* d = dW + m * ldm + (n + e) * ldn;
+                *d = accumulate ? *d + s[e] : s[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (db0) db0[m + e] = accumulate ? db0[m + e] + s[e] : s[e];
+                if (db1) db1[m + e] = accumulate ? db1[m + e] + s[e] : s[e];
+            }
+        }
     }
 }
 
@@ -186,7 +242,8 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     if (!P || !Q0 || !dW || !workspace) { dprnn_set_error("dprnn_wgrad: null pointer"); return -1; }
     const int N = n0 + (Q1 ? n1 : 0);
     if (rows <= 0 || M <= 0 || (M % 4) || n0 <= 0 || n0 > WG_NB || (n0 % 4) || (Q1 && (n1 <= 0 || n1 > WG_NB || (n1 % 4) || n0 != WG_NB)) ||
-        (ldp % 4) || (ldq0 % 4) || (Q1 && (ldq1 % 4)) || ((dt0 || dt1) && (t_stride <= 0 || T <= 0))) {
+        (ldp % 4) || (ldq0 % 4) || (Q1 && (ldq1 % 4)) || ((dt0 || dt1) && (t_stride <= 0 || T <= 0)) || t_stride > 0x7fffffffLL ||
+        ldp > (1 << 20) || ldq0 > (1 << 20) || ldq1 > (1 << 20)) {
         dprnn_set_error("dprnn_wgrad: unsupported shapes M=%d n0=%d n1=%d ldp=%d ldq0=%d rows=%lld", M, n0, n1, ldp, ldq0, (long long)rows);
         return -1;
     }
@@ -204,8 +261,8 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     hipLaunchKernelGGL(wgrad_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
     int rc = dprnn_check_launch("wgrad_kernel");
     if (rc) return rc;
-    const int n = M * N > M ? M * N : M;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    const int items = M * (N / 4) + (a.part_b ? M / 4 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        a.part, a.part_b, (int)splits, a.Mpad, a.Npad, M, N, dW, (long long)ldm, (long long)ldn, db0, db1, accumulate);
     return dprnn_check_launch("wgrad_reduce_kernel");
 }

@@ -106,7 +106,6 @@ void lstm_bwd_kernel(BwdArgs a) {
             xoff[nt][e] = val ? (ro * F + ucol) * 4u : OOB;
         }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto rsrc_at = [&](const void* p) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
     };
