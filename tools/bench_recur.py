@@ -36,6 +36,44 @@ def run(st, seq_tile, nwg, T, ndir=2, iters=3):
     return ms, flops / ms / 1e9
 
 
+def run_train(st, nwg, T, ndir=2, iters=3):
+    """dprnn_rnn_fwd_train (forward + gate tape) and dprnn_rnn_bwd (BPTT) on a grid of nwg 32-sequence workgroups."""
+    lib = st.lib
+    nseq = nwg * 32 // ndir
+    rows = nseq * T
+    X = torch.randn(rows, 128, device="cuda") * 0.5
+    H = torch.empty(rows, ndir * 128, device="cuda")
+    dH = torch.randn(rows, ndir * 128, device="cuda") * 0.1
+    dX = torch.empty(ndir, rows, 128, device="cuda")
+    dG = torch.empty(rows, ndir * 512, device="cuda")
+    tape = torch.empty(lib.dprnn_rnn_tape_floats(0, nseq, T, ndir), device="cuda")
+    packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
+    packedT = torch.empty(ndir * 512 * 256, device="cuda")
+    bsum = torch.empty(ndir * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    p = lambda t: t.data_ptr()
+    st.call("dprnn_rnn_pack", 0, *[p(t) for t in w], *[p(t) for t in w], p(packed), p(bsum))
+    st.call("dprnn_rnn_pack_bwd", 0, p(w[0]), p(w[1]), p(w[0]), p(w[1]), p(packedT))
+    addr = (nseq, T, nseq, 0, T, 1, ndir)
+    calls = {"fwd_train": ("dprnn_rnn_fwd_train", (0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), p(tape), *addr)),
+             "bwd": ("dprnn_rnn_bwd", (0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr))}
+    flops = nseq * T * ndir * 2 * 256 * 512
+    out = {}
+    for k, (fn, args) in calls.items():
+        st.call(fn, *args)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            st.call(fn, *args)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        out[k] = (ms, flops / ms / 1e9)
+    return out
+
+
 def stamps(st, seq_tile, per_cu, T, ndir=2):
     ncu = st.lib.dprnn_num_cus()
     nwg = ncu * per_cu
@@ -82,6 +120,7 @@ def main():
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3")
+    ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
@@ -93,6 +132,10 @@ def main():
     if a.stamps:
         for seq_tile, per_cu in ((32, 1), (32, 2), (64, 1)):
             stamps(st, seq_tile, per_cu, a.T)
+        return
+    if a.train:
+        for k, (ms, tf) in run_train(st, ncu * 2, a.T, iters=5).items():
+            print(f"train {k}: {ms:.3f} ms {tf:.1f} TFLOP/s = {tf / 157.3:.2f} of the fp32 MFMA peak")
         return
     if a.only:
         seq_tile, per_cu = (int(v) for v in a.only.split(","))
