@@ -165,6 +165,17 @@ def test_bilstm_unidirectional():
     assert rel_l2(H.cpu().numpy(), want) < 2e-6
 
 
+def test_bilstm_rejects_tiles_wider_than_the_32_bit_offsets():
+    """The step loop addresses a tile with 32-bit per-lane byte offsets below 2^31: a geometry
+    whose tile would span more is refused by the launcher before anything is launched."""
+    st = _st()
+    buf = torch.zeros(1024, device=DEV)
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        st.call("dprnn_bilstm_fwd", buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(),
+                4 * 250, 3000, 250, 3000 * 250, 1, 250, 2, 0)      # inter path of 12-minute utterances: 3 GB per tile span
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("kdim", [256, 128])
 def test_proj_stats_and_norm_residual(kdim):
     B, rows_per = 3, 77                    # utterance boundaries fall inside 64-row tiles

@@ -31,6 +31,16 @@ struct RecurArgs {
     float* tape;                                      // training forward only: activated gates + cell state per step
 };
 
+// The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's
+// sequence inside its tile); offsets at or above 2^31 mean "no such sequence".  True when the widest tile (64 sequences)
+// stays below that for a row pitch of pitch_floats: a tile spans at most ceil(64 / inner_n) outer strides.
+inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inner_stride, long long t_stride, long long pitch_floats) {
+    if (outer_stride < 0 || inner_stride < 0 || t_stride < 0) return false;
+    const long long outer_steps = 63 / inner_n + 1, inner_steps = inner_n < 64 ? inner_n - 1 : 63;
+    const long long span_rows = outer_steps * outer_stride + inner_steps * inner_stride + 1;
+    return span_rows * pitch_floats * 4 < 0x7fffffffLL;
+}
+
 // optional bf16-split gate GEMM (recur_split.hip): products = 6 or 3
 int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
 }  // namespace recur

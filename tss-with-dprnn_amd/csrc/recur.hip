@@ -520,6 +520,11 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         dprnn_set_error("dprnn_bilstm_norm_fwd: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
         return -1;
     }
+    if (!tile_offsets_fit(a.inner_n, a.outer_stride, a.inner_stride, a.t_stride, a.ndir * HD)) {
+        dprnn_set_error("dprnn_bilstm_fwd: a sequence tile spans more than 2 GiB of H (outer_stride=%lld rows): split the batch",
+                        a.outer_stride);
+        return -1;
+    }
     if (seq_tile == 0) seq_tile = a.nseq <= 16 ? 16 : 32;
     const bool fast = g_fast_act != 0;
     if (a.cell == 1 || a.cell == 2) {       // GRU / Elman: 16- or 32-sequence tiles
@@ -605,6 +610,11 @@ extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, con
     }
     if (a.Z && (!a.stats || !a.gamma || !a.beta || !a.Xout || a.Xout == a.X || a.seqs_per_utt <= 0 || a.rows_per_utt <= 0)) {
         dprnn_set_error("dprnn_lstm_fwd_train: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
+        return -1;
+    }
+    if (!tile_offsets_fit(a.inner_n, a.outer_stride, a.inner_stride, a.t_stride, a.ndir * HD) ||
+        (long long)a.T * 4 * (2 * 2 * 5 * 64) * 16 >= 0x7fffffffLL) {
+        dprnn_set_error("dprnn_rnn_fwd_train: a sequence tile spans more than 2 GiB (outer_stride=%lld rows, T=%d)", a.outer_stride, a.T);
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -325,6 +325,12 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
                         (long long)rows_total);
         return -1;
     }
+    if (!recur::tile_offsets_fit(inner_n, outer_stride, inner_stride, t_stride, (long long)ndir * 512) ||
+        (long long)T * 4 * (2 * 2 * 5 * 64) * 16 >= 0x7fffffffLL) {
+        dprnn_set_error("dprnn_rnn_bwd: a sequence tile spans more than 2 GiB of dG (outer_stride=%lld rows, T=%d): split the batch",
+                        (long long)outer_stride, T);
+        return -1;
+    }
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride};
     switch (cell) {
