@@ -38,11 +38,11 @@ def _lstm_sd(seed, bidir=True):
     return sd, p
 
 
-@pytest.mark.parametrize("seq_tile", [16, 32, 48, 64])
+@pytest.mark.parametrize("seq_tile", [16, -16, 32, 48, 64])
 @pytest.mark.parametrize("mode", ["intra", "inter"])
 def test_bilstm_matches_oracle(seq_tile, mode):
     B, S, K = 2, 7, 11                     # 14 / 22 sequences: never a multiple of a tile
-    rng = np.random.default_rng(seq_tile + (0 if mode == "intra" else 1))
+    rng = np.random.default_rng(abs(seq_tile) + (0 if mode == "intra" else 1))
     X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
     sd, p = _lstm_sd(42)
     if mode == "intra":
@@ -71,11 +71,11 @@ def test_bilstm_matches_oracle(seq_tile, mode):
     assert rel_l2(got, want) < 2e-6
 
 
-@pytest.mark.parametrize("mode,seq_tile", [("intra", 32), ("inter", 16), ("inter", 64)])
+@pytest.mark.parametrize("mode,seq_tile", [("intra", 32), ("inter", 16), ("intra", -16), ("inter", 64)])
 def test_bilstm_with_pending_norm(mode, seq_tile):
     """dprnn_bilstm_norm_fwd: x' = X + norm(Z) applied in the loader, x' written once, H computed from x'."""
     B, S, K = 3, 6, 9
-    rng = np.random.default_rng(seq_tile)
+    rng = np.random.default_rng(abs(seq_tile))
     X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
     Zr = (rng.standard_normal((B, S, K, 128)) * 1.3 + 0.2).astype(np.float32)
     gamma = (1 + 0.1 * rng.standard_normal(128)).astype(np.float32)
@@ -167,12 +167,16 @@ def test_bilstm_unidirectional():
 
 def test_bilstm_rejects_tiles_wider_than_the_32_bit_offsets():
     """The step loop addresses a tile with 32-bit per-lane byte offsets below 2^31: a geometry
-    whose tile would span more is refused by the launcher before anything is launched."""
+    whose tile could span more is refused by the launcher before anything is launched.  The buffers are complete for
+    the single sequence described, so even a launcher that failed to refuse would stay in bounds."""
     st = _st()
-    buf = torch.zeros(1024, device=DEV)
+    X = torch.zeros(128, device=DEV)
+    H = torch.zeros(256, device=DEV)
+    packed = torch.zeros(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.zeros(2 * 512, device=DEV)
     with pytest.raises(RuntimeError, match="2 GiB"):
-        st.call("dprnn_bilstm_fwd", buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(),
-                4 * 250, 3000, 250, 3000 * 250, 1, 250, 2, 0)      # inter path of 12-minute utterances: 3 GB per tile span
+        st.call("dprnn_bilstm_fwd", X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+                1, 1, 1, 1 << 40, 1, 1, 2, 0)           # one sequence, one step; outer stride of 2^40 rows
     torch.cuda.synchronize()
 
 

@@ -16,7 +16,7 @@ model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()
 model = model.to("cuda:0")
 for B in (1, 2, 4, 8, 16):
     x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
-    for tile in (0, 16, 32):
+    for tile in (0, 16, -16, 32):
         engine.SEQ_TILE["intra"] = engine.SEQ_TILE["inter"] = tile
         with torch.no_grad():
             for _ in range(2):

@@ -81,18 +81,27 @@ __global__ void rnn_pack_kernel(const float* __restrict__ w_ih, const float* __r
 // -- [dir][workgroup][step][wave][nt][u][slot][lane] float4 over the lane's four sequences; slots: LSTM i,f,g,o,c;
 // GRU r,z,n,(W_hn h + b_hn),h; Elman RNN h -- which the backward kernels (train_recur.hip) read back with the same thread
 // mapping: 16-byte coalesced stores and loads, no transposition.
-template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0, bool SAVE = false>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1))
+// NW = 8 (16-sequence tile only): the low-latency form for small batches -- eight waves, each owning 16 hidden units
+// (NU = 1 column tile per gate instead of 2), so a step carries half the MFMAs per wave; same packed weights (wave w reads
+// the fragments of wave w/2, column tile w&1), same LDS image.
+template <int NT, bool FAST, bool STAMP = false, int DIAG = 0, int SCHED = 0, int CELL = 0, bool SAVE = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
+    static_assert(NW == 4 || (NW == 8 && NT == 1 && SCHED == 0 && !SAVE && !STAMP), "8 waves: 16-sequence inference tile only");
+    constexpr int NU = 8 / NW;                        // 16-unit column tiles per wave and gate
+    constexpr int THREADS = 64 * NW;
     constexpr int NTAPE = CELL == 2 ? 1 : 5;          // tape slots per (nt, u)
     constexpr int NS = 16 * NT;
     constexpr int NGA = CELL == 2 ? 1 : 4;            // accumulator slots in use (see rnn_pack_kernel)
-    constexpr int NXV = NS / 8;                       // float4 x loads per thread per step
+    constexpr int NXV = NS * 32 / THREADS;            // float4 x loads per thread per step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const XH = smem;                           // [2][NS][XS]: row = x_t (128) | h_{t-1} (128)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
+    const int wq = NW == 4 ? wave : (wave >> 1);      // quarter of the hidden units (the packed weights' wave index)
+    const int ub = NW == 4 ? 0 : (wave & 1);          // first column tile of this wave inside the quarter
+    const int ucol0 = 32 * wq + 16 * ub;              // first hidden unit of the wave
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * NS;
     const int T = a.T;
@@ -114,7 +123,7 @@ void bilstm_kernel(RecurArgs a) {
     const int c4 = tid & 31;
 #pragma unroll
     for (int m = 0; m < NXV; ++m) {
-        const int f = tid + 256 * m, row = f >> 5;
+        const int f = tid + THREADS * m, row = f >> 5;
         const int seq = seq0 + row;
         xval[m] = seq < a.nseq;
         xoff[m] = (unsigned)((rowbase(xval[m] ? seq : seq0) - row0) * F + c4 * 4) * 4u;
@@ -129,7 +138,7 @@ void bilstm_kernel(RecurArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
             hval[nt][e] = seq < a.nseq;
-            hoff[nt][e] = hval[nt][e] ? (unsigned)((rowbase(seq) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u : OOB;
+            hoff[nt][e] = hval[nt][e] ? (unsigned)((rowbase(seq) - row0) * hpitch + dir * HD + ucol0 + r) * 4u : OOB;
         }
     // ---- pending norm of the previous path, applied while x is staged
     const bool fuse = a.Z != nullptr;
@@ -142,7 +151,7 @@ void bilstm_kernel(RecurArgs a) {
         bet = *reinterpret_cast<const f32x4*>(a.beta + 4 * c4);
 #pragma unroll
         for (int m = 0; m < NXV; ++m) {
-            const int seq = seq0 + (tid >> 5) + 8 * m;
+            const int seq = seq0 + (tid >> 5) + (THREADS / 32) * m;
             const int b = (seq < a.nseq ? seq : seq0) / a.seqs_per_utt;
             const double cnt = (double)a.rows_per_utt * (double)F;
             const double mean = a.stats[2 * b] / cnt;
@@ -162,12 +171,12 @@ void bilstm_kernel(RecurArgs a) {
 
     // bias enters through the activation's own first instruction (x*k + b*k is one v_fma), so the accumulators
     // start from an inline-constant zero instead of 64 v_mov per step
-    float bias[4][2];
+    float bias[4][NU];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+        for (int u = 0; u < NU; ++u) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + ucol0 + 16 * u + r];
             // pre-scaled for the activation that consumes the slot directly (sigmoid: -log2e, tanh: 2*log2e);
             // the GRU candidate slots (2, 3) enter a product first and keep the plain bias
             const bool is_tanh = (CELL == 0 && g == 2) || CELL == 2;
@@ -176,7 +185,8 @@ void bilstm_kernel(RecurArgs a) {
         }
 
     // wave-uniform weight slice (SGPR base, global address space) + lane index: saddr-form loads, scalar address math
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wq);
+    const int ub_u = __builtin_amdgcn_readfirstlane(ub);
     // The wave's weight slice as a buffer resource (4 SGPRs): fragment x of k-group g is
     // buffer_load_dwordx4 v, lane*16, rsrc, soffset = g*8 KB + x KB -- the group offset lives in an SGPR, so no vector ALU
     // instruction computes a weight address inside the step loop (with 64-bit global addresses the compiler spent ~15 of them
@@ -185,10 +195,12 @@ void bilstm_kernel(RecurArgs a) {
         const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NGRP * 8 * 64), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16u;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    auto wfrag = [&](int grp, int x) __attribute__((always_inline)) {
+    auto wfrag = [&](int grp, int x) __attribute__((always_inline)) {     // x = 2*gate + column tile of the quarter
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(grp * 8 * 1024 + x * 1024), 0);
         return __builtin_bit_cast(f32x4, v);
     };
+    // this wave's fragment (gate gt, own column tile u) of k-group grp
+    auto wown = [&](int grp, int gt, int u) __attribute__((always_inline)) { return wfrag(grp, 2 * gt + ub_u + u); };
     // The same for the activations: one buffer resource per tensor whose base is the row of the step (scalar), per-lane
     // 32-bit offsets fixed for the whole kernel.  A lane whose sequence does not exist gets an offset beyond the range
     // (OOB): the hardware drops its stores and returns zeros for its loads -- no exec-mask branches in the step loop.
@@ -222,17 +234,19 @@ void bilstm_kernel(RecurArgs a) {
             float* d = XH + xlds[m];
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
-        for (int i = tid; i < NS * HD; i += 256) XH[(i >> 7) * XS + HD + (i & 127)] = 0.f;
+        for (int i = tid; i < NS * HD; i += THREADS) XH[(i >> 7) * XS + HD + (i & 127)] = 0.f;
     }
-    f32x4 c[NT][2];
+    f32x4 c[NT][NU];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) c[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NU; ++u) c[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 w[2][8];
+    f32x4 w[2][4 * NU];                               // [buffer][gate * NU + column tile]
 #pragma unroll
-    for (int x = 0; x < 2 * NGA; ++x) w[0][x] = wfrag(0, x);
+    for (int gt = 0; gt < NGA; ++gt)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w[0][gt * NU + u] = wown(0, gt, u);
     __syncthreads();
 
     unsigned long long st_t0 = 0, st_r0 = 0, st_mfma = 0, st_act = 0;
@@ -264,7 +278,7 @@ void bilstm_kernel(RecurArgs a) {
                 for (int m = 0; m < NXV; ++m) zr[m] = bload4(zrs, xoff[m]);
             }
         }
-        f32x4 acc[NT][4][2];
+        f32x4 acc[NT][4][NU];
         const float* const Ac = XH + cur * NS * XS + r * XS + 16 * q;
         if constexpr (SCHED == 0) {
         // 16 k-groups, two per trip; the weights of group g+1 are in flight while group g computes
@@ -273,7 +287,7 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NU; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int gp = 0; gp < NGRP / 2; ++gp) {
 #pragma unroll
@@ -282,7 +296,9 @@ void bilstm_kernel(RecurArgs a) {
                 // weights of the next k-group (wraps to group 0 of the next step: same bytes every step)
                 const int gnext = DIAG == 1 ? 0 : ((grp + 1) & 15);
 #pragma unroll
-                for (int x = 0; x < 2 * NGA; ++x) w[half ^ 1][x] = wfrag(gnext, x);
+                for (int gt = 0; gt < NGA; ++gt)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) w[half ^ 1][gt * NU + u] = wown(gnext, gt, u);
                 const float* src = Ac + (DIAG == 2 ? 0 : 64 * (grp >> 2) + 4 * (grp & 3));
                 float av[NT][4];
 #pragma unroll
@@ -296,11 +312,11 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
                         for (int gt = 0; gt < NGA; ++gt)
 #pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                acc[nt][gt][u] = mfma16(av[nt][i], w[half][gt * 2 + u][i], acc[nt][gt][u]);
+                            for (int u = 0; u < NU; ++u)
+                                acc[nt][gt][u] = mfma16(av[nt][i], w[half][gt * NU + u][i], acc[nt][gt][u]);
             }
         }
-        } else {
+        } else if constexpr (NU == 2) {
         static_assert(SCHED == 0 || CELL == 0, "the interleaved schedule is instantiated for the LSTM cell only");
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -364,7 +380,7 @@ void bilstm_kernel(RecurArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 f32x4 sv[5];
                 if constexpr (CELL == 0 && DIAG != 3) {
                     // LSTM, gate order i,f,g,o (torch.nn.LSTM), two sequences per instruction where the arithmetic allows
@@ -381,7 +397,7 @@ void bilstm_kernel(RecurArgs a) {
                             const int e = 2 * p + k;
                             c[nt][u][e] = cn[k];
                             if constexpr (SAVE) { sv[0][e] = ig[k]; sv[1][e] = fg[k]; sv[2][e] = gg[k]; sv[3][e] = og[k]; sv[4][e] = cn[k]; }
-                            Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h2[k];
+                            Hn[(16 * nt + 4 * q + e) * XS + ucol0 + 16 * u + r] = h2[k];
                             if (DIAG != 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(float(h2[k])), hrs, hoff[nt][e] + 64 * u, 0, 0);
                         }
                     }
@@ -412,7 +428,7 @@ void bilstm_kernel(RecurArgs a) {
                         h = tanh_b<FAST>(acc[nt][0][u][e], bias[0][u]);
                         if constexpr (SAVE) sv[0][e] = h;
                     }
-                    Hn[(16 * nt + 4 * q + e) * XS + 32 * wave + 16 * u + r] = h;
+                    Hn[(16 * nt + 4 * q + e) * XS + ucol0 + 16 * u + r] = h;
                     if (DIAG != 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrs, hoff[nt][e] + 64 * u, 0, 0);
                 }
                 }
@@ -457,7 +473,7 @@ void bilstm_kernel(RecurArgs a) {
     }
 }
 
-template <int NT, bool FAST, int CELL = 0, bool SAVE = false>
+template <int NT, bool FAST, int CELL = 0, bool SAVE = false, int NW = 4>
 int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     constexpr int NS = 16 * NT;
     // one workgroup per CU (NT >= 3): prefetch A fragments a k-group ahead and spread the memory instructions
@@ -466,13 +482,13 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NS * XS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
-    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE, NW>), grid, dim3(64 * NW), lds, st, a);
     return dprnn_check_launch("bilstm_kernel");
 }
 
@@ -527,24 +543,27 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
     }
     if (seq_tile == 0) seq_tile = a.nseq <= 16 ? 16 : 32;
     const bool fast = g_fast_act != 0;
+    // 16-sequence tiles run on eight waves (half the MFMA chain per wave and step: the small-batch latency form);
+    // -16 selects the four-wave form of the same tile (kept for A/B measurements: tools/latency.py)
     if (a.cell == 1 || a.cell == 2) {       // GRU / Elman: 16- or 32-sequence tiles
-        const bool small = seq_tile == 16;
+        const bool small = seq_tile == 16 || seq_tile == -16;
         if (a.cell == 1) {
-            if (small) return fast ? launch_bilstm<1, true, 1>(a, st) : launch_bilstm<1, false, 1>(a, st);
+            if (small) return fast ? launch_bilstm<1, true, 1, false, 8>(a, st) : launch_bilstm<1, false, 1, false, 8>(a, st);
             return fast ? launch_bilstm<2, true, 1>(a, st) : launch_bilstm<2, false, 1>(a, st);
         }
-        if (small) return fast ? launch_bilstm<1, true, 2>(a, st) : launch_bilstm<1, false, 2>(a, st);
+        if (small) return fast ? launch_bilstm<1, true, 2, false, 8>(a, st) : launch_bilstm<1, false, 2, false, 8>(a, st);
         return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
     }
     if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     if (g_gemm_mode != 0) return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, seq_tile, fast, st);
     switch (seq_tile) {
-        case 16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
+        case 16: return fast ? launch_bilstm<1, true, 0, false, 8>(a, st) : launch_bilstm<1, false, 0, false, 8>(a, st);
+        case -16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
         case 32: return fast ? launch_bilstm<2, true>(a, st) : launch_bilstm<2, false>(a, st);
         case 48: return fast ? launch_bilstm<3, true>(a, st) : launch_bilstm<3, false>(a, st);
         case 64:
             return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
-        default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,32,48,64 (got %d)", seq_tile); return -1;
+        default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,-16,32,48,64 (got %d)", seq_tile); return -1;
     }
 }
 
