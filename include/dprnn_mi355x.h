@@ -106,7 +106,8 @@ int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
  * reads X row(q,t) [F], writes H row(q,t) [ndir*Hd] (fwd | bwd).  Zero initial state (dprnn.py:36).
  * intra path (dprnn.py:84-86): nseq=B*S, T=K, inner_n=nseq, inner_stride=K, t_stride=1
  * inter path (dprnn.py:94-95): nseq=B*K, T=S, inner_n=K, outer_stride=S*K, inner_stride=1, t_stride=K
- * seq_tile: sequences per workgroup (16, 32, 48 or 64; 0 = choose). */
+ * seq_tile: sequences per workgroup (16, 32, 48 or 64; 0 = choose).  16 runs on eight waves of 16 hidden units each
+ * (the small-batch latency form); -16 selects the four-wave form of the same tile (for A/B measurements). */
 int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                      int64_t t_stride, int ndir, int seq_tile, void* stream);
