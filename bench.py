@@ -202,6 +202,9 @@ def main():
                          ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
                          "kernel_ms": kern_ms, "launches_timed": len(ev), "launches_per_step": launches_per_step,
                          "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
+                         # achieved = per_launch_tflops x mean_concurrency: the launches of the four pipelines overlap
+                         "per_launch_tflops": flop_per_launch / (kern_ms * 1e-3) / 1e12,
+                         "mean_concurrency": sum(e - s_ for s_, e in spans) / union_ms if union_ms > 0 else None,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
         if optional is not None:
