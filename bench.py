@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=0,
                     help="0 exact fp32 MFMA (headline); 1/2 = optional bf16-split gate GEMM with 6/3 products")
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
+    ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
     args = ap.parse_args()
@@ -102,6 +103,8 @@ def main():
     if args.min_group is not None:
         engine.MIN_GROUP_BATCH = args.min_group
     engine.GEMM_MODE = args.gemm_mode
+    if args.group_sizes:
+        engine.GROUP_SIZES = [int(v) for v in args.group_sizes.split(",")]
 
     B = args.batch
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing

@@ -258,7 +258,15 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         st.call("dprnn_norm_residual_fwd", _p(g.X), _p(Z), _p(stats_slot), _p(gamma), _p(beta), eps, _p(g.X), B, S * K)
 
 
+GROUP_SIZES = None        # experiment knob: explicit utterance-group sizes (must sum to the batch), else an even split
+
+
 def _split(B: int):
+    if GROUP_SIZES and sum(GROUP_SIZES) == B:
+        cuts = [0]
+        for n_ in GROUP_SIZES:
+            cuts.append(cuts[-1] + n_)
+        return [(cuts[i], cuts[i + 1]) for i in range(len(GROUP_SIZES))]
     n = max(1, min(STREAM_GROUPS, B // MIN_GROUP_BATCH))
     cuts = [round(i * B / n) for i in range(n + 1)]
     return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
