@@ -30,11 +30,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--budget-gb", type=float, default=None)
+    ap.add_argument("--keep-max-first", type=int, default=0)
     ap.add_argument("--model", default="bss", choices=["bss", "spe"], help="DPRNNTasNet, or DPRNNSpeTasNet ('att' fusion, config_tss.yaml)")
     ap.add_argument("--groups", type=int, default=None, help="training.TRAIN_STREAM_GROUPS")
     ap.add_argument("--min-group", type=int, default=None, help="training.MIN_TRAIN_GROUP")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of training.FusedAdam")
     a = ap.parse_args()
+    training.KEEP_MAX_FIRST = bool(a.keep_max_first)
     if a.budget_gb is not None:
         training.SAVE_BUDGET_BYTES = int(a.budget_gb * (1 << 30))
     if a.groups is not None:
