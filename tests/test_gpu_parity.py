@@ -197,10 +197,11 @@ def test_stream_groups_do_not_change_results():
     assert torch.equal(again, outs[2]), "multi-stream forward is not run-to-run deterministic"
 
 
-@pytest.mark.parametrize("B,T", [(1, 2), (2, 3), (1, 100), (3, 251), (2, 1000), (65, 600)])
+@pytest.mark.parametrize("B,T", [(1, 2), (2, 3), (1, 100), (3, 251), (2, 1000), (65, 600), (2, 111920)])
 def test_edge_lengths_and_batches_vs_cpu_oracle(B, T):
     """Utterances shorter than a chunk (L < K, a single frame), odd lengths, and a batch that splits unevenly
-    into stream groups (65) -- shipped chunk geometry K=250/P=125, two blocks."""
+    into stream groups (65), and the longest Libri2Mix-test utterance (111 920 samples, 898 chunks: SURVEY.md 8d)
+    -- shipped chunk geometry K=250/P=125, two blocks."""
     model, sd, cfg = build_model("bss", dict(n_repeats=2), 31, _dev())
     x = make_mixture(B, T, seed=T)
     want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
