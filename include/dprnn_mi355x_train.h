@@ -54,6 +54,12 @@ int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* pac
                   int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                   int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
 
+/* diagnostic: while a device buffer of [workgroups][8] u64 is registered (NULL clears it), dprnn_rnn_bwd with the LSTM
+ * cell runs its stamped twin and wave 0 of every workgroup writes: cycles of the whole step loop, then the cycles spent
+ * in gate derivatives / first barrier / GEMM / second barrier / hand-over, and the 100 MHz ticks of the loop
+ * (tools/bench_recur.py --train 2).  Not used by the product path. */
+void dprnn_debug_bwd_stamps(unsigned long long* stamps);
+
 /* ---- weight gradient of every Linear / 1x1 conv / LSTM weight: dW[m*ldm + n*ldn] (+)= sum_rows P[row][m]*Q[row][n],
  * m < M (multiple of 4), n < n0 + n1; Q is given as up to two blocks of <= 128 columns (Q1 may be NULL; n0 must be
  * 128 when Q1 is used).  A block with dt != 0 reads Q row (row - dt*t_stride) and zero where t - dt leaves [0, T),

@@ -74,6 +74,53 @@ def run_train(st, nwg, T, ndir=2, iters=3):
     return out
 
 
+def bwd_stamps(st, nwg, T, ndir=2):
+    """Phase breakdown of lstm_bwd_kernel from in-kernel cycle stamps of wave 0 (diagnostic twin, LSTM)."""
+    lib = st.lib
+    nseq = nwg * 32 // ndir
+    rows = nseq * T
+    X = torch.randn(rows, 128, device="cuda") * 0.5
+    H = torch.empty(rows, ndir * 128, device="cuda")
+    dH = torch.randn(rows, ndir * 128, device="cuda") * 0.1
+    dX = torch.empty(ndir, rows, 128, device="cuda")
+    dG = torch.empty(rows, ndir * 512, device="cuda")
+    tape = torch.empty(lib.dprnn_rnn_tape_floats(0, nseq, T, ndir), device="cuda")
+    packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
+    packedT = torch.empty(ndir * 512 * 256, device="cuda")
+    bsum = torch.empty(ndir * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    p = lambda t: t.data_ptr()
+    st.call("dprnn_rnn_pack", 0, *[p(t) for t in w], *[p(t) for t in w], p(packed), p(bsum))
+    st.call("dprnn_rnn_pack_bwd", 0, p(w[0]), p(w[1]), p(w[0]), p(w[1]), p(packedT))
+    addr = (nseq, T, nseq, 0, T, 1, ndir)
+    st.call("dprnn_rnn_fwd_train", 0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), p(tape), *addr)
+    buf = torch.zeros(nwg, 8, device="cuda", dtype=torch.int64)
+    fn = lib.dprnn_debug_bwd_stamps
+    fn(buf.data_ptr())
+    try:
+        st.call("dprnn_rnn_bwd", 0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            st.call("dprnn_rnn_bwd", 0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"stamped twin: {ms:.3f} ms per launch = {nseq * T * ndir * 2 * 256 * 512 / ms / 1e9:.1f} TFLOP/s")
+    finally:
+        fn(None)
+    b = buf.cpu().double()
+    tot = b[:, 0].median()
+    names = ["gates+stores+prefetch issue", "barrier 1", "GEMM", "barrier 2", "dh hand-over + dX stores"]
+    clk = float((b[:, 0] / b[:, 6]).median()) * 100.0
+    print(f"lstm_bwd stamps (wave 0, median over {nwg} workgroups, T={T}): {tot / T:.0f} cycles per step, in-kernel clock {clk:.0f} MHz")
+    for i, n in enumerate(names):
+        v = b[:, 1 + i].median()
+        print(f"   {n:30s} {v / T:8.0f} cycles/step  {100 * v / tot:5.1f} %")
+
+
 def stamps(st, seq_tile, per_cu, T, ndir=2):
     ncu = st.lib.dprnn_num_cus()
     nwg = ncu * per_cu
@@ -132,6 +179,9 @@ def main():
     if a.stamps:
         for seq_tile, per_cu in ((32, 1), (32, 2), (64, 1)):
             stamps(st, seq_tile, per_cu, a.T)
+        return
+    if a.train == 2:
+        bwd_stamps(st, ncu * 2, a.T)
         return
     if a.train:
         for k, (ms, tf) in run_train(st, ncu * 2, a.T, iters=5).items():

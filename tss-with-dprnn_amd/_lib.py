@@ -100,6 +100,7 @@ _VOID = {
     "dprnn_set_fast_activations": [c_i],
     "dprnn_set_fast_head_activations": [c_i],
     "dprnn_set_gemm_mode": [c_i],
+    "dprnn_debug_bwd_stamps": [c_fp],
 }
 _SPECIAL = {
     "dprnn_last_error": ([], ctypes.c_char_p),

@@ -21,6 +21,9 @@
 //   * c stays in registers for the whole sequence; h goes registers -> LDS (next step's operand) and
 //     registers -> HBM (64-byte segments, merged in L2).
 #include "recur.h"
+#ifndef DPRNN_CELL_PRIO
+#define DPRNN_CELL_PRIO 1
+#endif
 #include <stdlib.h>
 #include <type_traits>
 using namespace recur;
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1))
 void bilstm_kernel(RecurArgs a) {
     static_assert(NW == 4 || (NW == 8 && NT == 1 && SCHED == 0 && !SAVE && !STAMP), "8 waves: 16-sequence inference tile only");
     constexpr int NU = 8 / NW;                        // 16-unit column tiles per wave and gate
+    constexpr bool PRIO = DPRNN_CELL_PRIO;
     constexpr int THREADS = 64 * NW;
     constexpr int NTAPE = CELL == 2 ? 1 : 5;          // tape slots per (nt, u)
     constexpr int NS = 16 * NT;
@@ -255,6 +259,10 @@ void bilstm_kernel(RecurArgs a) {
         unsigned long long st_a = 0, st_b = 0;
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const int cur = step & 1, nxt = cur ^ 1;
+        // The SIMD arbiter favours the older of two co-resident waves, so one workgroup of a pair would run at its
+        // stand-alone pace and finish ~15 % before the other, which then has the CU to itself at half occupancy.
+        // Alternating the wave priority in blocks of steps shares the matrix pipe evenly.
+        if constexpr (PRIO) { if (((step >> 3) + blockIdx.y) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         const long long t = dir ? (T - 1 - step) : step;
         const bool more = step + 1 < T;
         // keep "offset + constant" inside the loop body so the constant lands in the instruction's immediate field

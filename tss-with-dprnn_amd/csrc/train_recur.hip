@@ -66,9 +66,10 @@ struct BwdArgs {
     long long rows_total;
     int nseq, T, inner_n, ndir;
     long long outer_stride, inner_stride, t_stride;
+    unsigned long long* stamps;   // diagnostic build only: [workgroup][8] cycle counters of wave 0
 };
 
-template <int NT, bool FAST, int CELL = 0>
+template <int NT, bool FAST, int CELL = 0, bool STAMP = false>
 __global__ __launch_bounds__(256, 2)
 void lstm_bwd_kernel(BwdArgs a) {
     constexpr int NS = 16 * NT;
@@ -162,7 +163,22 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[0][j] = wfrag(0, j);
 
+    unsigned long long sp[6] = {0, 0, 0, 0, 0, 0}, tk = 0;
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            if (slot >= 0) sp[slot] += now - tk;
+            tk = now;
+        }
+    };
+    const unsigned long long st_begin = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long st_real = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;       // 100 MHz
     for (int fs = T - 1; fs >= 0; --fs) {
+        stamp(-1);
+        // share the matrix pipe evenly between the two co-resident workgroups (see bilstm_kernel)
+        if (((fs >> 3) + blockIdx.y) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         const long long trow = row0 + t_of(fs) * a.t_stride;
         // keep "offset + constant" inside the loop body so the constant lands in the instruction's immediate field
         // instead of a second, hoisted copy of every offset register
@@ -223,7 +239,9 @@ void lstm_bwd_kernel(BwdArgs a) {
                 for (int u = 0; u < 2; ++u) cc[nt][u] = cp[nt][u];
         }
         if (fs > 0) load_step(fs - 1);          // in flight during the GEMM below
+        stamp(0);                               // gate derivatives, image and dG stores, prefetch issue
         __syncthreads();
+        stamp(1);                               // wait at the first barrier
 
         // ---- [dx | dh] = da @ [W_ih | W_hh]: 32 k-groups, weights of group g+1 in flight while group g computes
         f32x4 acc[NT][4];
@@ -254,7 +272,9 @@ void lstm_bwd_kernel(BwdArgs a) {
                         for (int j = 0; j < 4; ++j) acc[nt][j] = mfma16(av[nt][i], w[half][j][i], acc[nt][j]);
             }
         }
+        stamp(2);                               // GEMM
         __syncthreads();                        // every wave is done reading the image
+        stamp(3);                               // wait at the second barrier
 
         const __amdgpu_buffer_rsrc_t dxs = rsrc_at(a.dX + ((long long)dir * a.rows_total + trow) * F);
 #pragma unroll
@@ -272,6 +292,15 @@ void lstm_bwd_kernel(BwdArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dxs, xoff[nt][e] + 64 * u, 0, 0);
                 }
             }
+        }
+        stamp(4);                               // dh hand-over and dX stores
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = __builtin_amdgcn_s_memtime() - st_begin;
+            for (int i = 0; i < 5; ++i) o[1 + i] = sp[i];
+            o[6] = __builtin_amdgcn_s_memrealtime() - st_real;
         }
     }
 }
@@ -316,6 +345,11 @@ int launch_bwd(const BwdArgs& a, hipStream_t st) {
 }
 }  // namespace
 
+// diagnostic: when set, dprnn_rnn_bwd (LSTM) runs the stamped twin and writes [workgroup][8] u64: total cycles of the
+// step loop, then the cycles wave 0 spent in gates / barrier 1 / GEMM / barrier 2 / tail (tools/bench_recur.py --train 2)
+static unsigned long long* g_bwd_stamps = nullptr;
+extern "C" void dprnn_debug_bwd_stamps(unsigned long long* buf) { g_bwd_stamps = buf; }
+
 extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
                              int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                              int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
@@ -332,7 +366,14 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
         return -1;
     }
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
-              (long long)outer_stride, (long long)inner_stride, (long long)t_stride};
+              (long long)outer_stride, (long long)inner_stride, (long long)t_stride, g_bwd_stamps};
+    if (g_bwd_stamps && cell == 0) {            // diagnostic twin: same kernel with cycle stamps of wave 0 per workgroup
+        const size_t lds = (size_t)32 * (kdim_of(0) + 1) * sizeof(float);
+        auto kern = &lstm_bwd_kernel<2, true, 0, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((a.nseq + 31) / 32, a.ndir), dim3(256), lds, (hipStream_t)stream, a);
+        return dprnn_check_launch("lstm_bwd_kernel(stamped)");
+    }
     switch (cell) {
         case 0: return launch_bwd<0>(a, (hipStream_t)stream);
         case 1: return launch_bwd<1>(a, (hipStream_t)stream);
