@@ -113,6 +113,11 @@ def bwd_stamps(st, nwg, T, ndir=2):
         fn(None)
     b = buf.cpu().double()
     tot = b[:, 0].median()
+    start = (b[:, 7] - b[:, 7].min()) / 100.0
+    end = start + b[:, 6] / 100.0
+    q = torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], dtype=torch.float64)
+    print("   start-time percentiles (us):", [int(v) for v in torch.quantile(start, q).tolist()])
+    print("   end-time percentiles (us)  :", [int(v) for v in torch.quantile(end, q).tolist()])
     names = ["gates+stores+prefetch issue", "barrier 1", "GEMM", "barrier 2", "dh hand-over + dX stores"]
     clk = float((b[:, 0] / b[:, 6]).median()) * 100.0
     print(f"lstm_bwd stamps (wave 0, median over {nwg} workgroups, T={T}): {tot / T:.0f} cycles per step, in-kernel clock {clk:.0f} MHz")
@@ -181,7 +186,8 @@ def main():
             stamps(st, seq_tile, per_cu, a.T)
         return
     if a.train == 2:
-        bwd_stamps(st, ncu * 2, a.T)
+        bwd_stamps(st, ncu, a.T)            # one workgroup per CU: the kernel's own pace
+        bwd_stamps(st, ncu * 2, a.T)        # two per CU: the production occupancy
         return
     if a.train:
         for k, (ms, tf) in run_train(st, ncu * 2, a.T, iters=5).items():

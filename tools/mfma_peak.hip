@@ -1,6 +1,6 @@
 // Sustained fp32-MFMA ceiling of this MI355X: register-only v_mfma_f32_16x16x4_f32 loop on random data,
 // every CU busy, long enough for the clock to settle.  Build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak
-// usage: mfma_peak [waves_per_simd=1] [valu_fma_per_mfma=0] [zero_data=0]
+// usage: mfma_peak [waves_per_simd=1] [valu_fma_per_mfma=0] [zero_data=0] [accumulators=16 (4, 8 or 16: distance between dependent MFMAs)]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     const int wps = argc > 1 ? atoi(argv[1]) : 1;
     const int zero = argc > 3 ? atoi(argv[3]) : 0;
     const int nv = argc > 2 ? atoi(argv[2]) : 0;      // VALU fma per MFMA (0,1,2,4,6)
+    const int nacc = argc > 4 ? atoi(argv[4]) : 16;
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     const int blocks = cus * wps;                 // 256 threads = 4 waves = 1 wave per SIMD per block
@@ -49,7 +50,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 6; ++rep) {
         (void)hipEventRecord(e0);
-        switch (nv) {
+        if (nacc == 4) hipLaunchKernelGGL((mfma_loop<4, 0>), dim3(blocks), dim3(256), 0, 0, in, out, iters * 4);
+        else if (nacc == 8) hipLaunchKernelGGL((mfma_loop<8, 0>), dim3(blocks), dim3(256), 0, 0, in, out, iters * 2);
+        else switch (nv) {
             case 0: hipLaunchKernelGGL((mfma_loop<16, 0>), dim3(blocks), dim3(256), 0, 0, in, out, iters); break;
             case 1: hipLaunchKernelGGL((mfma_loop<16, 1>), dim3(blocks), dim3(256), 0, 0, in, out, iters); break;
             case 2: hipLaunchKernelGGL((mfma_loop<16, 2>), dim3(blocks), dim3(256), 0, 0, in, out, iters); break;
@@ -59,8 +62,8 @@ int main(int argc, char** argv) {
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         const double flop = (double)blocks * 4 * iters * 8 * 16 * 2048.0;
-        printf("rep %d: %.2f ms  %.1f MFMA-TFLOP/s  (waves/SIMD %d, %d v_fma per MFMA, %s data)\n", rep, ms,
-               flop / ms / 1e9, wps, nv, zero ? "zero" : "random");
+        printf("rep %d: %.2f ms  %.1f MFMA-TFLOP/s  (waves/SIMD %d, %d v_fma per MFMA, %s data, %d accumulators)\n", rep, ms,
+               flop / ms / 1e9, wps, nv, zero ? "zero" : "random", nacc);
     }
     return 0;
 }
