@@ -301,6 +301,7 @@ void lstm_bwd_kernel(BwdArgs a) {
             o[0] = __builtin_amdgcn_s_memtime() - st_begin;
             for (int i = 0; i < 5; ++i) o[1 + i] = sp[i];
             o[6] = __builtin_amdgcn_s_memrealtime() - st_real;
+            o[7] = st_real;                                        // absolute start (100 MHz)
         }
     }
 }
