@@ -30,13 +30,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--budget-gb", type=float, default=None)
-    ap.add_argument("--keep-max-first", type=int, default=0)
+    ap.add_argument("--trainer-step", type=int, default=0, help="1: time trainer.train_step instead of the explicit call sequence")
+    ap.add_argument("--keep-max-first", type=int, default=None, help="override training.KEEP_MAX_FIRST (0 / 1)")
     ap.add_argument("--model", default="bss", choices=["bss", "spe"], help="DPRNNTasNet, or DPRNNSpeTasNet ('att' fusion, config_tss.yaml)")
     ap.add_argument("--groups", type=int, default=None, help="training.TRAIN_STREAM_GROUPS")
     ap.add_argument("--min-group", type=int, default=None, help="training.MIN_TRAIN_GROUP")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of training.FusedAdam")
     a = ap.parse_args()
-    training.KEEP_MAX_FIRST = bool(a.keep_max_first)
+    if a.keep_max_first is not None:
+        training.KEEP_MAX_FIRST = bool(a.keep_max_first)
     if a.budget_gb is not None:
         training.SAVE_BUDGET_BYTES = int(a.budget_gb * (1 << 30))
     if a.groups is not None:
@@ -61,6 +63,9 @@ def main():
     ref_len = torch.tensor(float(a.samples), device=dev)
 
     def step():
+        if a.trainer_step and a.model == "bss":           # trainer.train_step: micro-batches with the loss inside
+            from tss_with_dprnn_amd import trainer
+            return trainer.train_step(model, lossm, opt, mix, tgt, clip_norm=5)[0]
         opt.zero_grad()
         if a.model == "bss":
             out = model(mix)

@@ -73,13 +73,44 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0) -> None:
         dist.broadcast(t.data, src)
 
 
+def _micro_batches(model, mix) -> int:
+    """Utterances one forward / backward may process without re-running anything (training.SAVE_BUDGET_BYTES)."""
+    from . import engine, training
+    if not mix.is_cuda or not hasattr(model, "cfg") or not hasattr(model, "separation"):
+        return mix.shape[0]
+    cfg = model.cfg
+    geo = engine.make_geometry(1, mix.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                               cfg["kernel_size"], cfg["stride"])
+    ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in training._paths(model.separation)]
+    return max(1, training.SAVE_BUDGET_BYTES // training.saved_bytes_per_utt(geo, len(ndirs), ndirs))
+
+
 def train_step(model, loss_module, optimizer, mix, target, clip_norm: float = 0.0,
                reducer: Optional[FlatGradAllReducer] = None):
-    """One iteration of Trainer.train (trainer.py:98-118).  Returns (loss tensor, reordered estimates)."""
+    """One iteration of Trainer.train (trainer.py:98-118).  Returns (loss tensor, reordered estimates).
+
+    The loss of the reference (PIT SI-SDR, mean over the batch) is a sum over utterances, so a batch whose activations
+    exceed the budget is processed as balanced micro-batches -- forward, loss and backward each, gradients accumulating
+    in ``param.grad`` with weights n_i / B -- instead of one forward whose backward has to re-run most of it (config 4,
+    64 utterances per GPU: 2 x 32)."""
     optimizer.zero_grad()
-    out = model(mix)
-    loss, est = loss_module(out, target, return_est=True)
-    loss.backward()
+    B = mix.shape[0]
+    mb_max = _micro_batches(model, mix)
+    if B > mb_max:
+        n_mb = -(-B // mb_max)
+        cuts = [round(i * B / n_mb) for i in range(n_mb + 1)]
+        loss, ests = None, []
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            l_i, est_i = loss_module(model(mix[b0:b1]), target[b0:b1], return_est=True)
+            w = (b1 - b0) / B
+            (l_i * w).backward()
+            loss = l_i.detach() * w if loss is None else loss + l_i.detach() * w
+            ests.append(est_i.detach())
+        est = torch.cat(ests)
+    else:
+        out = model(mix)
+        loss, est = loss_module(out, target, return_est=True)
+        loss.backward()
     if reducer is not None:
         reducer.average()
     if isinstance(optimizer, FusedAdam):

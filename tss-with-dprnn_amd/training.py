@@ -21,7 +21,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import engine
-from ._lib import DprnnError
+from ._lib import DprnnError, load_library
 from .engine import F_BUILT, Stage, _norm_params, _p, _param, _rnn_tensors
 
 SAVE_BUDGET_BYTES = 200 << 30        # activations one forward may keep for its backward (of 288 GB HBM3E per GPU)
@@ -32,8 +32,8 @@ PACKT_PER_DIR = 512 * 256
 # Utterances are independent, so a (micro-)batch is processed as TRAIN_STREAM_GROUPS complete forward / backward
 # pipelines on their own HIP streams (as the inference path does): one group's weight-gradient GEMMs and streaming
 # passes fill the CUs another group's serial recurrence launches leave idle.
-TRAIN_STREAM_GROUPS = 2
-MIN_TRAIN_GROUP = 8                  # utterances per group at least
+TRAIN_STREAM_GROUPS = 0              # 0 = choose from the launch geometry (_auto_groups); n > 0 = up to n groups
+MIN_TRAIN_GROUP = 8                  # utterances per group at least (explicit group counts only)
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
@@ -389,8 +389,28 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     return grads
 
 
-def _group_parts(n: int):
-    g = max(1, min(TRAIN_STREAM_GROUPS, n // MIN_TRAIN_GROUP))
+def _auto_groups(n: int, geo: engine.Geometry) -> int:
+    """Stream groups for n utterances, from measurements on MI355X (profiles/r01_train_step.txt).  The recurrence
+    launches are grids of 32-sequence workgroups on 2 x CUs slots and every workgroup lives for a whole launch, so a
+    launch that fills its last round of slots badly (n = 24, 40, 47: 57-73 % on one of the two paths) loses that share
+    of the chip; cut into ~16-utterance pipelines on separate streams the launches of different groups fill each other's
+    gaps (n = 48: 542 -> 495 ms per step).  A launch that fills its rounds (n = 32: 76 % / 98 %) is best left whole
+    (344 vs 351 ms), and groups below 12 utterances lose more per kernel than the overlap wins (n = 16: 194 vs 254 ms)."""
+    slots = 2 * load_library().dprnn_num_cus()
+
+    def fill(nseq):
+        wgs = 2 * -(-nseq // 32)
+        return wgs / (slots * -(-wgs // slots))
+    if min(fill(n * geo.S), fill(n * geo.K)) >= 0.75:
+        return 1
+    return max(1, min(3, n // 12))
+
+
+def _group_parts(n: int, geo: engine.Geometry = None):
+    if TRAIN_STREAM_GROUPS > 0 or geo is None:
+        g = max(1, min(max(1, TRAIN_STREAM_GROUPS), n // MIN_TRAIN_GROUP))
+    else:
+        g = _auto_groups(n, geo)
     cuts = [round(i * n / g) for i in range(g + 1)]
     return [(cuts[i], cuts[i + 1]) for i in range(g)]
 
@@ -425,7 +445,10 @@ def _to_main(t: torch.Tensor, dev):
 
 def _forward_groups(model, wav):
     dev = wav.device
-    parts = _group_parts(wav.shape[0])
+    cfg = model.cfg
+    geo = engine.make_geometry(1, wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                               cfg["kernel_size"], cfg["stride"])
+    parts = _group_parts(wav.shape[0], geo)
     res = _run_groups(dev, parts, lambda b0, b1: forward_train(model, wav[b0:b1].contiguous(), keep=True))
     outs = [_to_main(r[0], dev) for r in res]
     return (outs[0] if len(outs) == 1 else torch.cat(outs)), (parts, [r[1] for r in res])
