@@ -31,7 +31,7 @@ SEQ_TILE = {"intra": 0, "inter": 0}
 # its last workgroups (grid quantisation) or runs a bandwidth-bound stage, the other group's kernels fill
 # the idle CUs.
 STREAM_GROUPS = 4
-MIN_GROUP_BATCH = 16         # utterances per group at least (smaller groups lose more per kernel than overlap wins)
+MIN_GROUP_BATCH = 16         # utterances per group, about (much smaller groups lose more per kernel than overlap wins)
 
 # Fold every GroupNorm + residual into the loader of the stage that consumes it (the next recurrence kernel, or the
 # mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
@@ -267,7 +267,9 @@ def _split(B: int):
         for n_ in GROUP_SIZES:
             cuts.append(cuts[-1] + n_)
         return [(cuts[i], cuts[i + 1]) for i in range(len(GROUP_SIZES))]
-    n = max(1, min(STREAM_GROUPS, B // MIN_GROUP_BATCH))
+    # about MIN_GROUP_BATCH utterances per group, rounded to the nearest count (measured: B = 24 as 2 x 12 runs 11 %
+    # faster than as one group, B = 40 is better as 2 x 20 than as 3; tools/sweep_batch_groups.sh)
+    n = max(1, min(STREAM_GROUPS, round(B / MIN_GROUP_BATCH)))
     cuts = [round(i * B / n) for i in range(n + 1)]
     return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
 
