@@ -33,20 +33,37 @@ CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_siz
         "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
 
 
-def cpu_baseline(sd, cfg, threads, batch=4, iters=3):
+def cpu_baseline(sd, cfg, threads, model, dev, batch=4, iters=3):
+    """The CPU path timed beside the GPU one (the checker's leg of the bench: the only place bench.py touches oracle/),
+    and -- the second half of BASELINE.json's metric, "SI-SDR vs ref" -- the parity of the GPU output with the CPU output
+    on the same `batch` two-source mixtures (SURVEY.md 8d recipe)."""
     from oracle import dprnn_torch_cpu as otc
-    from oracle.weights import make_mixture
+    from oracle.sisdr import pit_si_sdr, si_sdr
+    from oracle.weights import make_sources
     torch.set_num_threads(threads)
     tsd = otc.to_torch_state(sd)
-    x = torch.from_numpy(make_mixture(batch, SAMPLES, seed=1234))
+    src, mix = make_sources(batch, SAMPLES)
+    x = torch.from_numpy(mix)
     otc.tasnet_forward(tsd, cfg, x[:1])                      # warm-up
     t0 = time.perf_counter()
     for _ in range(iters):
-        otc.tasnet_forward(tsd, cfg, x)
+        cpu_out = otc.tasnet_forward(tsd, cfg, x)
     dt = time.perf_counter() - t0
-    return dict(value=batch * iters / dt, unit="utt/s", cores=threads, kind="port",
+    base = dict(value=batch * iters / dt, unit="utt/s", cores=threads, kind="port",
                 sample=f"{iters} forwards of batch {batch} x 3 s @ 8 kHz, oracle/dprnn_torch_cpu.py "
                        f"(stock torch CPU ops), {threads} threads of {os.cpu_count()} logical CPUs, {dt:.1f} s")
+    with torch.no_grad():
+        gpu_out = model(x.to(dev)).cpu().numpy().astype(np.float64)
+    cpu_out = cpu_out.numpy().astype(np.float64)
+    T = min(gpu_out.shape[-1], src.shape[-1])
+    s_gpu, _ = pit_si_sdr(gpu_out[..., :T], src[..., :T].astype(np.float64))      # best-permutation SI-SDR per utterance, dB
+    s_cpu, _ = pit_si_sdr(cpu_out[..., :T], src[..., :T].astype(np.float64))
+    parity = dict(sample=f"{batch} synthetic two-source mixtures x 3 s, GPU output vs the CPU path's output",
+                  rel_l2=float(np.linalg.norm(gpu_out - cpu_out) / np.linalg.norm(cpu_out)),
+                  si_sdr_gpu_vs_cpu_db=float(np.min(si_sdr(gpu_out.reshape(-1, gpu_out.shape[-1]), cpu_out.reshape(-1, cpu_out.shape[-1])))),
+                  max_abs_delta_si_sdr_db=float(np.max(np.abs(np.asarray(s_gpu) - np.asarray(s_cpu)))),
+                  tolerance_db=0.01)
+    return base, parity
 
 
 def main():
@@ -215,7 +232,7 @@ def main():
                                                "bf16-split operands on the bf16 MFMA, fp32 accumulate; NOT part of `value`")
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(sd, cfg, threads)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, threads, model, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
