@@ -1,26 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: DPRNN-TasNet forward throughput (utterances/sec, 3 s @ 8 kHz, batch 64 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W            (any N: with N > 1 and no WORLD_SIZE in the environment the
+                                                              script starts its own N ranks, see _self_launch)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
+    python bench.py --mode train [--gpus N]                   (BASELINE.json configs[3]: training step, 64 per GPU)
 
 A "step" is one forward of the HIP path over one batch of 64 synthetic 3-second mixtures already
 resident in HBM (BASELINE.json configs[1]).  Utterances are independent, so ranks shard the batch with
 no data-path collective (weak scaling: 64 utterances per GPU).  Rank 0 prints ONE JSON line with
-  roofline     : the dominant kernel (fused BiLSTM recurrence, dprnn_bilstm_fwd) timed with HIP events
+  roofline     : the dominant kernel (fused BiLSTM recurrence, dprnn_rnn_fwd) timed with HIP events
                  on its launch stream inside the timed region; achieved = algorithmic FLOPs per launch
                  (rows * 2 dirs * 2*256*512) / mean launch time; peak = 157.3 TFLOP/s fp32 MFMA.
   cpu_baseline : the reference's CPU path (oracle/dprnn_torch_cpu.py: the same ATen CPU ops the
-                 reference dispatches to) timed on this host's cores on a bounded sample (N=1 only).
+                 reference dispatches to) timed on this host's cores per BASELINE.md section 3 (N=1 only).
+  distributed  : what torch.distributed actually saw (world size, backend, one device name per rank).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,44 +35,14 @@ CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_siz
         "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
 
 
-def cpu_baseline(sd, cfg, threads, model, dev, batch=4, iters=3):
-    """The CPU path timed beside the GPU one (the checker's leg of the bench: the only place bench.py touches oracle/),
-    and -- the second half of BASELINE.json's metric, "SI-SDR vs ref" -- the parity of the GPU output with the CPU output
-    on the same `batch` two-source mixtures (SURVEY.md 8d recipe)."""
-    from oracle import dprnn_torch_cpu as otc
-    from oracle.sisdr import pit_si_sdr, si_sdr
-    from oracle.weights import make_sources
-    torch.set_num_threads(threads)
-    tsd = otc.to_torch_state(sd)
-    src, mix = make_sources(batch, SAMPLES)
-    x = torch.from_numpy(mix)
-    otc.tasnet_forward(tsd, cfg, x[:1])                      # warm-up
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        cpu_out = otc.tasnet_forward(tsd, cfg, x)
-    dt = time.perf_counter() - t0
-    base = dict(value=batch * iters / dt, unit="utt/s", cores=threads, kind="port",
-                sample=f"{iters} forwards of batch {batch} x 3 s @ 8 kHz, oracle/dprnn_torch_cpu.py "
-                       f"(stock torch CPU ops), {threads} threads of {os.cpu_count()} logical CPUs, {dt:.1f} s")
-    with torch.no_grad():
-        gpu_out = model(x.to(dev)).cpu().numpy().astype(np.float64)
-    cpu_out = cpu_out.numpy().astype(np.float64)
-    T = min(gpu_out.shape[-1], src.shape[-1])
-    s_gpu, _ = pit_si_sdr(gpu_out[..., :T], src[..., :T].astype(np.float64))      # best-permutation SI-SDR per utterance, dB
-    s_cpu, _ = pit_si_sdr(cpu_out[..., :T], src[..., :T].astype(np.float64))
-    parity = dict(sample=f"{batch} synthetic two-source mixtures x 3 s, GPU output vs the CPU path's output",
-                  rel_l2=float(np.linalg.norm(gpu_out - cpu_out) / np.linalg.norm(cpu_out)),
-                  si_sdr_gpu_vs_cpu_db=float(np.min(si_sdr(gpu_out.reshape(-1, gpu_out.shape[-1]), cpu_out.reshape(-1, cpu_out.shape[-1])))),
-                  max_abs_delta_si_sdr_db=float(np.max(np.abs(np.asarray(s_gpu) - np.asarray(s_cpu)))),
-                  tolerance_db=0.01)
-    return base, parity
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
+                    help="fwd = the headline forward (configs[1]); train = fwd + PIT SI-SDR loss + bwd + gradient all-reduce "
+                         "+ clip + Adam (configs[3], 64 utterances per GPU)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
@@ -82,29 +54,163 @@ def main():
     ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _self_launch(n: int, script=None, argv=None) -> int:
+    """`python bench.py --gpus N` without an outer torchrun: start N ranks as CHILD processes (one per GPU) from this
+    parent, which has not touched the GPU (nothing but the standard library is imported yet) and never will; relay
+    rank 0's JSON line and the children's exit code.  No exec: the parent waits and exits with the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + \
+        list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:                                 # rank 0's JSON line (other ranks print nothing on stdout)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def _host_threads():
+    """Thread count for the CPU leg: the physical cores this process may use."""
+    logical = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = logical
+    cores, model = set(), ""
+    try:
+        phys = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    cores.add((phys, ln.split(":")[1].strip()))
+                elif ln.startswith("model name") and not model:
+                    model = ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    quota = None
+    try:                                                     # cgroup v2 CPU quota of the box's share, if any
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    threads = min(v for v in (physical, allowed, quota) if v)
+    return threads, dict(logical_cpus=logical, physical_cores=physical, affinity_cpus=allowed, cgroup_quota_cpus=quota,
+                         cpu_model=model)
+
+
+def cpu_baseline(sd, cfg, model, dev):
+    """The CPU path timed beside the GPU one (the checker's leg of the bench: the only place bench.py touches oracle/),
+    per BASELINE.md section 3: stock torch CPU ops, torch.set_num_threads(physical cores available), B = 1 (the
+    reference's Inferencer / example.ipynb path, one utterance per call) and B = 8, 3 warm-up + 5 timed forwards each,
+    median -> utt/s.  And -- the second half of BASELINE.json's metric, "SI-SDR vs ref" -- the parity of the GPU output with
+    the CPU output on the same 8 two-source mixtures (SURVEY.md 8d recipe)."""
+    import numpy as np
+    import torch
+    from oracle import dprnn_torch_cpu as otc
+    from oracle.sisdr import pit_si_sdr, si_sdr
+    from tss_with_dprnn_amd.synthetic import make_sources
+    threads, host = _host_threads()
+    torch.set_num_threads(threads)
+    tsd = otc.to_torch_state(sd)
+    src, mix = make_sources(8, SAMPLES)
+    x = torch.from_numpy(mix)
+    res, t_all = {}, time.perf_counter()
+    for b in (1, 8):
+        xb = x[:b]
+        for _ in range(3):
+            cpu_out = otc.tasnet_forward(tsd, cfg, xb)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            cpu_out = otc.tasnet_forward(tsd, cfg, xb)
+            ts.append(time.perf_counter() - t0)
+        res[b] = dict(utt_per_s=b / float(np.median(ts)), median_s=float(np.median(ts)), min_s=min(ts), max_s=max(ts))
+    spent = time.perf_counter() - t_all
+    best = max(res, key=lambda b: res[b]["utt_per_s"])
+    base = dict(value=res[best]["utt_per_s"], unit="utt/s", cores=threads, kind="port",
+                sample=f"oracle/dprnn_torch_cpu.py (stock torch CPU ops, no_grad), B=1 and B=8 x 3 s @ 8 kHz, 3 warm-up + 5 timed "
+                       f"forwards each, median; value = B={best}; {threads} threads; {spent:.0f} s of CPU work",
+                b1_utt_per_s=res[1]["utt_per_s"], b8_utt_per_s=res[8]["utt_per_s"], b1=res[1], b8=res[8], host=host)
+    with torch.no_grad():
+        gpu_out = model(x.to(dev)).cpu().numpy().astype(np.float64)
+    cpu_out = cpu_out.numpy().astype(np.float64)
+    T = min(gpu_out.shape[-1], src.shape[-1])
+    s_gpu, _ = pit_si_sdr(gpu_out[..., :T], src[..., :T].astype(np.float64))      # best-permutation SI-SDR per utterance, dB
+    s_cpu, _ = pit_si_sdr(cpu_out[..., :T], src[..., :T].astype(np.float64))
+    parity = dict(sample="8 synthetic two-source mixtures x 3 s, GPU output vs the CPU path's output",
+                  rel_l2=float(np.linalg.norm(gpu_out - cpu_out) / np.linalg.norm(cpu_out)),
+                  si_sdr_gpu_vs_cpu_db=float(np.min(si_sdr(gpu_out.reshape(-1, gpu_out.shape[-1]), cpu_out.reshape(-1, cpu_out.shape[-1])))),
+                  max_abs_delta_si_sdr_db=float(np.max(np.abs(np.asarray(s_gpu) - np.asarray(s_cpu)))),
+                  tolerance_db=0.01)
+    return base, parity
+
+
+def _launch_stats(events, t_ref):
+    """Per-launch HIP-event durations on the launch streams.  With utterance groups on several streams the launches
+    overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch intervals); kernel_ms is the
+    plain mean launch duration (what rocprofv3 --stats reports)."""
+    import numpy as np
+    spans = sorted((t_ref.elapsed_time(a), t_ref.elapsed_time(b)) for a, b in events)
+    kern_ms = float(np.mean([e - s for s, e in spans])) if spans else float("nan")
+    union_ms, cur_s, cur_e = 0.0, None, None
+    for s_, e_ in spans:
+        if cur_e is None or s_ > cur_e:
+            union_ms += (cur_e - cur_s) if cur_e is not None else 0.0
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    union_ms += (cur_e - cur_s) if cur_e is not None else 0.0
+    conc = sum(e - s_ for s_, e in spans) / union_ms if union_ms > 0 else None
+    return kern_ms, union_ms, conc, len(spans)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but torch.distributed.run started {world} ranks")
     # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): DPRNN_BENCH_BACKEND=gloo DPRNN_BENCH_SHARE_GPU=1
     backend = os.environ.get("DPRNN_BENCH_BACKEND", "nccl")
     if os.environ.get("DPRNN_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
+    dist_info = dict(world_size=1, backend=None, devices=[torch.cuda.get_device_name(dev)])
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
         else:
             dist.init_process_group(backend=backend)
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}")
+        dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), devices=names)
 
     import tss_with_dprnn_amd as pkg
-    from tss_with_dprnn_amd import engine
-    from oracle.weights import full_cfg, make_mixture, make_state
+    from tss_with_dprnn_amd import engine, sharding
+    from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_sources, make_state
 
     cfg = full_cfg()
     model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
@@ -124,7 +230,6 @@ def main():
         engine.GROUP_SIZES = [int(v) for v in args.group_sizes.split(",")]
 
     B = args.batch
-    x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -132,6 +237,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    geo = engine.make_geometry(B, SAMPLES, cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
+                               cfg["kernel_size"], cfg["stride"])
+    lstm_flop_per_step = geo.rows * 2 * (2 * 256 * 512) * 2 * cfg["n_repeats"]      # rows * 2 dirs * (2*256*512) per path
+
+    if args.mode == "train":
+        line = bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, make_sources)
+        if rank == 0:
+            line["distributed"] = dist_info
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
     with torch.no_grad():
         for _ in range(args.warmup):
             out = model(x)
@@ -146,31 +265,13 @@ def main():
         elapsed = time.perf_counter() - t0
         prof, engine.PROFILE = engine.PROFILE, None
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
-
-    from tss_with_dprnn_amd import sharding
     elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
 
-    # dominant kernel: per-launch HIP-event durations on the launch streams.  With utterance groups on several
-    # streams the launches overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch
-    # intervals); kernel_ms is the plain mean launch duration (what rocprofv3 --stats reports).
-    ev = prof["events"].get("dprnn_rnn_fwd", [])
-    spans = sorted((t_ref.elapsed_time(a), t_ref.elapsed_time(b)) for a, b in ev)
-    kern_ms = float(np.mean([e - s for s, e in spans])) if spans else float("nan")
-    union_ms, cur_s, cur_e = 0.0, None, None
-    for s_, e_ in spans:
-        if cur_e is None or s_ > cur_e:
-            union_ms += (cur_e - cur_s) if cur_e is not None else 0.0
-            cur_s, cur_e = s_, e_
-        else:
-            cur_e = max(cur_e, e_)
-    union_ms += (cur_e - cur_s) if cur_e is not None else 0.0
-    geo = engine.make_geometry(B, SAMPLES, cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
-                               cfg["kernel_size"], cfg["stride"])
+    kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get("dprnn_rnn_fwd", []), t_ref)
     n_groups = len(engine._split(B))
     launches_per_step = 2 * cfg["n_repeats"] * n_groups
     flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
-    total_flop = geo.rows * 2 * (2 * 256 * 512) * 2 * cfg["n_repeats"] * args.steps
-    achieved = total_flop / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
+    achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -220,22 +321,79 @@ def main():
                          # the previous norm is folded in: all launches of a forward but the first]
                          "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 *
                          ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
-                         "kernel_ms": kern_ms, "launches_timed": len(ev), "launches_per_step": launches_per_step,
+                         "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": launches_per_step,
                          "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
-                         # achieved = per_launch_tflops x mean_concurrency: the launches of the four pipelines overlap
+                         # achieved = per_launch_tflops x mean_concurrency: the launches of the pipelines overlap
                          "per_launch_tflops": flop_per_launch / (kern_ms * 1e-3) / 1e12,
-                         "mean_concurrency": sum(e - s_ for s_, e in spans) / union_ms if union_ms > 0 else None,
+                         "mean_concurrency": conc,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "distributed": dist_info,
         }
         if optional is not None:
             line["optional_gemm_modes"] = dict(optional, note="opt-in (engine.GEMM_MODE / dprnn_set_gemm_mode): LSTM gate GEMM with "
                                                "bf16-split operands on the bf16 MFMA, fp32 accumulate; NOT part of `value`")
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, threads, model, dev)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, model, dev)
+            line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, make_sources):
+    """BASELINE.json configs[3]: one training step per GPU = forward with tape + PIT SI-SDR loss + backward over 64
+    utterances (balanced micro-batches, trainer.train_step), ONE all-reduce of the flat 14.6 MB gradient bucket (RCCL),
+    clip_grad_norm_(5) + Adam(lr 1e-3, wd 1e-5) (config_bss.yaml:30-33,53).  Weak scaling: global batch = 64 x N."""
+    import torch
+    from tss_with_dprnn_amd import engine, sharding, trainer, training
+    B = args.batch
+    model.train()
+    opt = training.FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    lossm = training.PITSiSdrLoss()
+    trainer.broadcast_parameters(model)
+    reducer = trainer.FlatGradAllReducer(model.parameters())
+    reducer.timing = True
+    src, mix = make_sources(B, SAMPLES, seed=1236 + 2 * rank)
+    mix_d, tgt_d = torch.from_numpy(mix).to(dev), torch.from_numpy(src).to(dev)
+    for _ in range(args.warmup):
+        loss, _ = trainer.train_step(model, lossm, opt, mix_d, tgt_d, clip_norm=5, reducer=reducer)
+    sync()
+    reducer.events.clear()
+    names = {"dprnn_rnn_bwd", "dprnn_lstm_bwd"}
+    engine.PROFILE = {"names": names, "events": {}}
+    t_ref = torch.cuda.Event(enable_timing=True)
+    t_ref.record()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.train_step(model, lossm, opt, mix_d, tgt_d, clip_norm=5, reducer=reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, engine.PROFILE = engine.PROFILE, None
+    on_device = dist is None or dist.get_backend() == "nccl"
+    elapsed = sharding.max_over_ranks(elapsed, device=dev if on_device else None)
+    ar_ms = [a.elapsed_time(b) for a, b in reducer.events]
+    ev = [e for n in names for e in prof["events"].get(n, [])]
+    kern_ms, union_ms, conc, n_ev = _launch_stats(ev, t_ref)
+    achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
+    value = world * B * args.steps / elapsed
+    assert bool(torch.isfinite(loss).all())
+    return {
+        "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet training step", "value": value, "unit": "utt/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DPRNN-TasNet training step (PIT SI-SDR loss, clip 5, Adam), synthetic 3 s @ 8 kHz, "
+                               f"batch={B} per GPU, global batch {B * world} (BASELINE.json configs[3])",
+                   "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"data-parallel x{world}, one flat gradient all-reduce"},
+        "allreduce": {"bytes": reducer.numel * 4, "ms_mean": sum(ar_ms) / len(ar_ms) if ar_ms else None,
+                      "ms_max": max(ar_ms) if ar_ms else None, "calls": len(ar_ms),
+                      "note": "gather copy + all-reduce + scale + scatter copy, HIP events on the step's stream"},
+        "roofline": {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd, BPTT)", "achieved": achieved,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel_ms": kern_ms, "launches_timed": n_ev, "busy_ms_per_step": union_ms / args.steps,
+                     "mean_concurrency": conc,
+                     "whole_step_frac": value / world * 3 * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        "loss": float(loss.item()), "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2**30,
+    }
 
 
 if __name__ == "__main__":

@@ -229,9 +229,10 @@ int dprnn_att_softmax_bwd(const float* d_rs, const float* scores, float* d_score
  * of every g to out[0] (fp64, zeroed by the caller).  dprnn_adam_multi applies, with the clip coefficient
  * c = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping): g' = c*g + weight_decay*p;
  * m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps) -- the update of
- * torch.optim.Adam (amsgrad off); .grad is not modified. */
+ * torch.optim.Adam (amsgrad off); .grad is not modified.  The betas are doubles and the bias corrections 1-b^step are
+ * formed in double on the host, as torch forms them in Python floats (1-0.999^1 in fp32 is 6e-5 off). */
 int dprnn_multi_sumsq(const void* table, int n_tensors, double* out, void* stream);
-int dprnn_adam_multi(const void* table, int n_tensors, float lr, float beta1, float beta2, float eps,
+int dprnn_adam_multi(const void* table, int n_tensors, float lr, double beta1, double beta2, float eps,
                      float weight_decay, int step, float max_norm, const double* sumsq, void* stream);
 
 #ifdef __cplusplus

@@ -76,7 +76,12 @@ CASES = [
     ("spe_wide_small_film", "spe", dict(WIDE, fusion_type="film", norm_type="gLN"), 2, 300, 45, False, False),
     ("ira_tiny_cat", "ira", dict(TINY_SPE, fusion_type="cat", norm_type="ln"), 2, 203, 50, True, False),
     ("ira_wide_small_cat", "ira", dict(WIDE, fusion_type="cat", norm_type="ln"), 2, 300, 51, False, False),
+    # BASELINE.json configs[4]: the two-pass IRA model at the shipped depth / chunk geometry (6 blocks, K 250, P 125), one 3-s
+    # utterance and one at the Libri2Mix-test median length (36 720 samples) with a 3-s reference utterance
+    ("ira_full_b1", "ira", dict(norm_type="ln"), 1, 24000, 52, False, False),
+    ("ira_full_long_b1", "ira", dict(norm_type="ln"), 1, 36720, 53, False, False),
 ]
+AUX_SAMPLES = {"ira_full_long_b1": 24000}       # reference-utterance length where it differs from the mixture's
 
 
 def build(kind, cfg):
@@ -143,11 +148,55 @@ def make_grad_cases(only):
                 save["grad_" + k] = g
             else:
                 save["proj_" + k] = (grad_projection(k, g.shape).astype(np.float64) @ g.reshape(-1).astype(np.float64))
+        gap = None
+        if name in FP64_CASES:
+            gap = fp64_gap(model, mix, tgt, save)
         meta = dict(name=name, kind="bss", cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
-                    torch=torch.__version__)
+                    torch=torch.__version__, ref_fp32_vs_fp64_gap=gap)
         save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
-        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}")
+        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}"
+              + (f"  reference fp32-vs-fp64 gradient gap: worst {gap['worst']:.2e} ({gap['worst_key']})" if gap else ""))
+
+
+FP64_CASES = {"grad_bss_full_b2"}
+
+
+def fp64_gap(model, mix, tgt, save):
+    """The reference's own rounding noise at this size: the SAME reference module and graph evaluated in float64
+    (model.double(), same weights, same input, same permutation search), and the distance of its float32 gradients from
+    that, in the measure tests/test_gpu_train.py uses (whole gradient: rel-L2; projected gradient: largest projection
+    difference / norm).  Stored per parameter (`gap_<key>`) beside the float64 values themselves (`grad64_` / `proj64_` /
+    `norm64_`), so the GPU test can bound its error against the exact gradient by a multiple of the reference's."""
+    from oracle.sisdr import pit_neg_sisdr_torch
+    g32 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    model.double()
+    model.zero_grad()
+    out = model(torch.from_numpy(mix).double())
+    loss, _ = pit_neg_sisdr_torch(out, tgt.double())
+    loss.backward()
+    worst, worst_key, gaps = 0.0, None, {}
+    for k, prm in model.named_parameters():
+        g64 = prm.grad.numpy()
+        nrm = float(np.sqrt((g64 ** 2).sum()))
+        save["norm64_" + k] = np.float64(nrm)
+        a = g32[k].numpy().astype(np.float64)
+        if g64.size <= FULL_MAX:
+            save["grad64_" + k] = g64
+            err = float(np.linalg.norm(a - g64) / (nrm + 1e-30))
+        else:
+            P = grad_projection(k, g64.shape).astype(np.float64)
+            save["proj64_" + k] = P @ g64.reshape(-1)
+            err = max(float(np.abs(P @ a.reshape(-1) - save["proj64_" + k]).max()) / (nrm + 1e-30),
+                      abs(float(np.linalg.norm(a)) - nrm) / (nrm + 1e-30))
+        save["gap_" + k] = np.float64(err)
+        gaps[k] = err
+        if "prelu" not in k and err > worst:
+            worst, worst_key = err, k
+    save["loss64"] = np.float64(loss.item())
+    model.float()
+    return dict(worst=worst, worst_key=worst_key, prelu=gaps.get("separation.prelu.weight"),
+                median=float(np.median(list(gaps.values()))))
 
 
 GRAD_SPE_CASES = [
@@ -246,9 +295,10 @@ def main():
                 out = model(torch.from_numpy(mix))
                 save["out"] = out.numpy()
             else:
-                aux = make_mixture(B, T, seed=2000 + seed)
-                aux_len = np.float32(T)
-                est, logits = model(torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(float(T)))
+                Ta = AUX_SAMPLES.get(name, T)
+                aux = make_mixture(B, Ta, seed=2000 + seed)
+                aux_len = np.float32(Ta)
+                est, logits = model(torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(float(Ta)))
                 save.update(aux=aux, aux_len=aux_len, out=est.numpy(), logits=logits.numpy())
         for h in hooks:
             h.remove()

@@ -129,3 +129,45 @@ def test_geometry_matches_reference_shapes():
     assert (g.L, g.S, g.T_out, g.rows) == (23999, 194, 24000, 64 * 194 * 250)
     g = engine.make_geometry(3, 203, 64, 10, 3, 4, 2)
     assert g.L == 100 and g.S == (100 + 10) // 3 + 1 and g.T_out == 202
+
+
+def test_build_from_clean_in_a_scratch_directory(tmp_path):
+    """build_library(force=True) compiles every HIP source from nothing (the in-tree objects are git-ignored and travel to
+    the GPU box prebuilt, so no other test exercises a cold build); built beside the tree, the shipped library stays."""
+    out = pkg.build_library(force=True, build_dir=str(tmp_path / "cold"))
+    assert out.startswith(str(tmp_path)) and os.path.exists(out)
+    objs = sorted(f for f in os.listdir(tmp_path / "cold") if f.endswith(".o"))
+    srcs = sorted(f[:-4] + ".o" for f in os.listdir(os.path.join(ROOT, "tss-with-dprnn_amd", "csrc")) if f.endswith(".hip"))
+    assert objs == srcs, "the Makefile does not build every csrc/*.hip"
+    lib = ctypes.CDLL(out)
+    for n in _header_functions():
+        assert hasattr(lib, n), n
+    assert os.path.exists(pkg.library_path())
+
+
+def test_workspace_bytes_matches_the_host_geometry(lib_path):
+    """dprnn_workspace_bytes (pure host arithmetic) against engine.make_geometry for the shipped config."""
+    geo = engine.make_geometry(64, 24000, 64, 250, 125, 2, 1)
+    ws = engine.workspace_parts(geo, 6)
+    assert (geo.L, geo.S) == (23999, 194)
+    assert ws["X"] == ws["X2"] == ws["Z"] == geo.rows * 128 * 4 == 64 * 194 * 250 * 512
+    assert ws["H"] == 2 * ws["X"] and ws["Y"] == 64 * 23999 * 512
+    assert ws["stats"] == 13 * 64 * 2 * 8 and ws["taps"] == 64 * 2 * 23999 * 2 * 4 and ws["out"] == 64 * 2 * 24000 * 4
+    assert ws["total"] == sum(v for k, v in ws.items() if k != "total")
+    assert 8.5e9 < ws["total"] < 9.0e9                    # 64 utterances x 3 s in one group: 8.8 GB of the 288 GB
+    short = engine.workspace_parts(engine.make_geometry(2, 300, 64, 250, 125, 2, 1), 6)
+    assert short["H"] >= max(2 * short["X"], 2 * 2 * 299 * 2 * 128 * 4)                     # the mask head's U + V fit too
+    lib = pkg.load_library()
+    assert lib.dprnn_workspace_bytes(1, 1, 64, 250, 125, 2, 1, 6, 0, None) == -1           # T < kernel size
+    assert b"geometry" in lib.dprnn_last_error()
+
+
+def test_dropout_is_the_no_op_it_is_in_the_reference():
+    """dprnn.py:23-28 hands dropout to a num_layers=1 torch RNN: torch validates it, warns and never applies it."""
+    with pytest.warns(UserWarning, match="num_layers greater than 1"):
+        m = pkg.DPRNNTasNet(64, n_repeats=1, dropout=0.3)
+    engine.check_supported(m.cfg)
+    with pytest.raises(ValueError, match=r"range \[0, 1\]"):
+        pkg.DPRNNTasNet(64, n_repeats=1, dropout=1.5)
+    ref = torch.nn.LSTM(4, 4, num_layers=1, dropout=0)            # the same checks torch performs
+    assert ref.dropout == 0

@@ -225,3 +225,35 @@ def test_input_validation_messages():
         a = model(x)
         b = model(x.contiguous())
     assert torch.equal(a, b)
+
+
+def test_headline_batch_b64_full_size():
+    """BASELINE.json configs[1] at its own size through the DEFAULT engine settings (the stream-group split and the
+    sequence-tile heuristics bench.py runs with): 64 x 24 000 samples, shipped config.  Utterances 0, 15, 16 and 63
+    (first / last of a 16-utterance group, first of the next) against the CPU oracle; every utterance against its own
+    batch-of-one forward, which takes the small-batch tiles on a single stream (tolerance 2e-6: the two differ only in
+    the grouping of the fp64 GroupNorm sums and the MFMA tile a sequence lands in)."""
+    from tss_with_dprnn_amd import engine
+    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == 0 and engine.GROUP_SIZES is None
+    model, sd, cfg = build_model("bss", dict(), 0, _dev())
+    B, T = 64, 24000
+    x = make_mixture(B, T, seed=1234)
+    xd = torch.from_numpy(x).to(_dev())
+    with torch.no_grad():
+        got = model(xd)
+        torch.cuda.synchronize()
+        assert got.shape == (B, 2, T) and bool(torch.isfinite(got).all())
+        worst = 0.0
+        for b in range(B):
+            one = model(xd[b:b + 1])
+            r = float(((one[0].double() - got[b].double()).norm() / one[0].double().norm()).item())
+            worst = max(worst, r)
+            assert r <= 2e-6, f"utterance {b}: batched vs batch-of-one rel-L2 {r:.3e}"
+    got = got.cpu().numpy()
+    tsd = otc.to_torch_state(sd)
+    pick = [0, 15, 16, 63]
+    want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(x[pick])).numpy()
+    r = _close(got[pick], want, "B=64 headline batch, utterances 0/15/16/63 vs CPU oracle")
+    src = make_sources(len(pick), T, seed=78)[0]
+    assert np.abs(si_sdr(got[pick], src) - si_sdr(want, src)).max() <= 0.01
+    print(f"B=64 x 24000: rel-L2 vs CPU oracle {r:.2e}; worst batched-vs-single {worst:.2e}")

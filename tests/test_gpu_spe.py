@@ -26,7 +26,9 @@ def _run(model, g, bn_train=False):
 
 
 @pytest.mark.parametrize("name", ["spe_wide_small_cat", "spe_wide_small_cat_bntrain", "spe_full_b1", "ira_wide_small_cat",
-                                  "spe_wide_small_att", "spe_full_att_b1", "spe_wide_small_film"])
+                                  "spe_wide_small_att", "spe_full_att_b1", "spe_wide_small_film",
+                                  # BASELINE.json configs[4]: IRA at the shipped depth / chunk geometry; 3 s and 36 720 samples
+                                  "ira_full_b1", "ira_full_long_b1"])
 def test_spe_matches_reference_golden(name):
     g = load_golden(name)
     m = g["meta"]

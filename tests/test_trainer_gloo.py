@@ -82,3 +82,45 @@ def test_single_process_reducer_is_a_no_op():
     red = trainer.FlatGradAllReducer(model.parameters())
     red.average()
     assert red.flat is None and all(float(p.grad.reshape(-1)[0]) == 1.0 for p in model.parameters())
+
+
+def _worker_buffers(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    from tss_with_dprnn_amd import dprnn_spe, trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)
+        model = dprnn_spe.DPRNNSpeTasNet(64, n_repeats=1)
+        tr = trainer.DistributedTrainer(model, torch.optim.Adam(model.parameters(), lr=1e-3), device=torch.device("cpu"))
+        bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        for b in bufs:                                  # per-rank BatchNorm running statistics drift apart in training
+            b.data.fill_(float(rank + 1))
+        tr._sync_buffers()                              # what eval() and _save_checkpoint() do first
+        same = all(bool((b == 1.0).all()) for b in bufs)
+        err = None
+        try:                                            # loaders of different length would deadlock in the all-reduce
+            tr._check_equal_steps([0] * (3 + rank))
+        except RuntimeError as e:
+            err = str(e)
+        tr._check_equal_steps([0] * 3)                  # equal lengths pass
+        q.put((rank, same, len(bufs), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_buffer_sync_and_step_count_check():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_buffers, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same, n, err in res:
+        assert same and n >= 12                          # 3 ResBlocks x 2 BatchNorm1d x (running_mean, running_var)
+        assert err is not None and "DistributedSampler" in err

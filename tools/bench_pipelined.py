@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tss_with_dprnn_amd as pkg
-from oracle.weights import full_cfg, make_mixture, make_state
+from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_state
 
 CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length", "n_repeats",
         "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]

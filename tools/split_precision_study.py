@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import dprnn_numpy as onp
 from oracle.sisdr import si_sdr
-from oracle.weights import full_cfg, make_mixture, make_sources, make_state
+from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_sources, make_state
 
 
 def bf16(x):

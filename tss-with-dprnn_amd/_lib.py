@@ -9,6 +9,7 @@ import ctypes
 import os
 import subprocess
 import threading
+from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libdprnn_mi355x.so"
@@ -19,6 +20,7 @@ c_fp = ctypes.c_void_p      # device pointers travel as integers (tensor.data_pt
 c_i = ctypes.c_int
 c_i64 = ctypes.c_int64
 c_f = ctypes.c_float
+c_d = ctypes.c_double
 
 # name -> argtypes (all return int unless listed in _VOID / _SPECIAL); mirrors include/dprnn_mi355x.h
 SIGNATURES = {
@@ -94,7 +96,7 @@ SIGNATURES = {
     "dprnn_fusion_bwd": [c_fp] * 12 + [c_i] * 7 + [c_fp],
     "dprnn_att_scale_bwd": [c_fp] * 7 + [c_i64, c_fp],
     "dprnn_att_softmax_bwd": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
-    "dprnn_adam_multi": [c_fp, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_fp, c_fp],
+    "dprnn_adam_multi": [c_fp, c_i, c_f, c_d, c_d, c_f, c_f, c_i, c_f, c_fp, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],
@@ -110,6 +112,7 @@ _SPECIAL = {
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
+    "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
 
@@ -123,18 +126,25 @@ def library_path() -> str:
     return os.environ.get("DPRNN_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, build_dir: Optional[str] = None) -> str:
     """Compile csrc/*.hip for gfx950 into tss-with-dprnn_amd/libdprnn_mi355x.so (hipcc cross-compiles
-    without a GPU)."""
+    without a GPU).  force = `make clean` first.  build_dir: put the objects AND the library there instead (a from-clean
+    build that leaves the in-tree library alone); returns the path of the library built."""
     csrc = os.path.join(_HERE, "csrc")
+    extra = []
+    out = library_path() if build_dir is None else os.path.join(build_dir, _LIB_NAME)
+    if build_dir is not None:
+        os.makedirs(build_dir, exist_ok=True)
+        extra = [f"BUILD={build_dir}", f"OUT={out}"]
     if force:
-        subprocess.run(["make", "-C", csrc, "clean"], check=True, capture_output=not verbose)
-    res = subprocess.run(["make", "-C", csrc, "-j4"], capture_output=True, text=True)
+        subprocess.run(["make", "-C", csrc, "clean"] + extra, check=True, capture_output=not verbose)
+    jobs = max(2, min(8, os.cpu_count() or 2))
+    res = subprocess.run(["make", "-C", csrc, f"-j{jobs}"] + extra, capture_output=True, text=True)
     if res.returncode != 0:
         raise DprnnError("building libdprnn_mi355x.so failed:\n" + res.stdout + res.stderr)
     if verbose:
         print(res.stdout)
-    return library_path()
+    return out
 
 
 def load_library() -> ctypes.CDLL:

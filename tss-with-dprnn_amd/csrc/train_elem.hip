@@ -648,11 +648,12 @@ extern "C" int dprnn_multi_sumsq(const void* table, int n_tensors, double* out, 
     return dprnn_check_launch("multi_sumsq_kernel");
 }
 
-extern "C" int dprnn_adam_multi(const void* table, int n_tensors, float lr, float beta1, float beta2, float eps,
+extern "C" int dprnn_adam_multi(const void* table, int n_tensors, float lr, double beta1, double beta2, float eps,
                                 float weight_decay, int step, float max_norm, const double* sumsq, void* stream) {
     if (!table || n_tensors < 1 || step < 1 || (max_norm > 0.f && !sumsq)) { dprnn_set_error("dprnn_adam_multi: bad arguments"); return -1; }
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);      // in double, as torch does
     hipLaunchKernelGGL(adam_multi_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const AdamEntry*>(table), lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), max_norm, sumsq);
+                       reinterpret_cast<const AdamEntry*>(table), lr, (float)beta1, (float)beta2, eps, weight_decay, (float)bc1,
+                       (float)sqrt(bc2), max_norm, sumsq);
     return dprnn_check_launch("adam_multi_kernel");
 }

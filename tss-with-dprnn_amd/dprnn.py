@@ -8,6 +8,8 @@ are parameter holders; ``DPRNNTasNet.forward`` enqueues the hand-written HIP ker
 (engine.tasnet_forward) and nothing else -- there is no PyTorch/CPU fallback.
 """
 import math
+import numbers
+import warnings
 
 import torch
 from torch import nn
@@ -24,10 +26,19 @@ class _RNNParams(nn.Module):
     (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0 [+ _reverse]) and the same default
     init U(-1/sqrt(H), 1/sqrt(H)); gate order i,f,g,o for LSTM."""
 
-    def __init__(self, rnn_type, input_size, hidden_size, bidirectional):
+    def __init__(self, rnn_type, input_size, hidden_size, bidirectional, dropout=0):
         super().__init__()
         if rnn_type not in _GATES:
             raise AttributeError(f"module 'torch.nn' has no attribute '{rnn_type}'")   # getattr(nn, rnn_type), dprnn.py:23
+        # dropout reaches a num_layers=1 torch RNN in the reference (dprnn.py:23-28), where torch validates the value,
+        # warns, and never applies it (dropout acts between stacked layers only): same checks, same warning, same no-op
+        if not isinstance(dropout, numbers.Number) or not 0 <= dropout <= 1 or isinstance(dropout, bool):
+            raise ValueError("dropout should be a number in range [0, 1] representing the probability of an element being "
+                             "zeroed")
+        if dropout > 0:
+            warnings.warn("dropout option adds dropout after all but last recurrent layer, so non-zero dropout expects "
+                          f"num_layers greater than 1, but got dropout={dropout} and num_layers=1")
+        self.dropout = float(dropout)
         self.mode, self.input_size, self.hidden_size = rnn_type, input_size, hidden_size
         self.bidirectional = bool(bidirectional)
         g = _GATES[rnn_type] * hidden_size
@@ -57,7 +68,7 @@ class SingleRNN(nn.Module):
         super().__init__()
         self.hidden_size = hidden_size
         self.bidirectional = bidirectional
-        self.rnn = _RNNParams(rnn_type, input_size, hidden_size, bidirectional)
+        self.rnn = _RNNParams(rnn_type, input_size, hidden_size, bidirectional, dropout)
 
     def output_size(self):
         return self.hidden_size * (2 if self.bidirectional else 1)

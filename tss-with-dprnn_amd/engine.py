@@ -76,6 +76,23 @@ def make_geometry(B: int, T: int, N: int, K: int, P: int, ks: int, stride: int) 
     return Geometry(B, T, L, K, P, S, ks, stride, N)
 
 
+WS_PARTS = ("Y", "X", "X2", "Z", "H", "stats", "packed", "bsum", "affine", "taps", "out")     # DPRNN_WS_* of the C header
+
+
+def workspace_parts(geo: Geometry, n_blocks: int, split_gemm: bool = False) -> dict:
+    """Bytes of every device buffer of one forward, from the library itself (dprnn_workspace_bytes): the arenas below are
+    sized with it, so a C host calling the same function allocates exactly what this host does."""
+    import ctypes
+    lib = load_library()
+    parts = (ctypes.c_int64 * len(WS_PARTS))()
+    total = lib.dprnn_workspace_bytes(geo.B, geo.T, geo.N, geo.K, geo.P, geo.ks, geo.stride, n_blocks, int(split_gemm), parts)
+    if total < 0:
+        check(lib, int(total), "dprnn_workspace_bytes")
+    out = dict(zip(WS_PARTS, (int(v) for v in parts)))
+    out["total"] = int(total)
+    return out
+
+
 def _p(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
@@ -105,8 +122,8 @@ def check_supported(cfg: dict) -> None:
         bad.append(f"norm_type {cfg['norm_type']!r} (reference leaves the norms undefined, dprnn.py:72-77)")
     if cfg["activation_type"] not in ("sigmoid", "relu"):
         bad.append(f"activation_type {cfg['activation_type']!r} (dprnn.py:161-164)")
-    if cfg.get("dropout", 0) not in (0, 0.0):
-        bad.append("dropout != 0 (a single-layer nn.LSTM ignores it; refusing a silent difference)")
+    # dropout: any value in [0, 1] is accepted and has no effect, exactly as in the reference, whose only use of it is the
+    # num_layers=1 torch RNN constructor (dprnn.py:23-28; the mirror's SingleRNN raises / warns as torch does)
     if cfg["hop_length"] < 1 or cfg["hop_length"] > cfg["chunk_length"]:
         bad.append("hop_length must be in [1, chunk_length]")
     if bad:
@@ -195,12 +212,11 @@ class _Group:
     def __init__(self, st: Stage, geo: Geometry, b0: int, b1: int, dev):
         self.st, self.b0, self.b1 = st, b0, b1
         self.geo = Geometry(b1 - b0, geo.T, geo.L, geo.K, geo.P, geo.S, geo.ks, geo.stride, geo.N)
-        rows, B, L = self.geo.rows, self.geo.B, geo.L
         # one arena: X [rows][F] | X2 [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region.
         # X / X2 ping-pong when the norm is folded into the next recurrence (both directions read the old slab).
-        head_floats = 2 * B * L * 2 * F_BUILT           # U [B*L][2F] + V [B*L*2][F]
-        h_floats = max(rows * 2 * F_BUILT, head_floats)
-        n = rows * F_BUILT
+        ws = workspace_parts(self.geo, 0)
+        n, h_floats = ws["X"] // 4, ws["H"] // 4
+        assert n == self.geo.rows * F_BUILT and ws["X2"] == ws["Z"] == ws["X"]
         self.arena = torch.empty(3 * n + h_floats, device=dev, dtype=torch.float32)
         self.X = self.arena[:n]
         self.X2 = self.arena[n: 2 * n]

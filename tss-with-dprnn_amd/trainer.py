@@ -38,11 +38,23 @@ class FlatGradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat: Optional[torch.Tensor] = None
+        self.timing = False              # bench.py --mode train: HIP events around every average() on the current stream
+        self.events = []
 
     def average(self) -> None:
         world = _world()
         if world == 1:
             return
+        if self.timing and self.params[0].is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._average(world)
+            e1.record()
+            self.events.append((e0, e1))
+        else:
+            self._average(world)
+
+    def _average(self, world: int) -> None:
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.empty(self.numel, device=p0.device, dtype=torch.float32)
@@ -82,7 +94,7 @@ def _micro_batches(model, mix) -> int:
     geo = engine.make_geometry(1, mix.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
                                cfg["kernel_size"], cfg["stride"])
     ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in training._paths(model.separation)]
-    return max(1, training.SAVE_BUDGET_BYTES // training.saved_bytes_per_utt(geo, len(ndirs), ndirs))
+    return max(1, training.save_budget_bytes(mix.device) // training.saved_bytes_per_utt(geo, len(ndirs), ndirs))
 
 
 def train_step(model, loss_module, optimizer, mix, target, clip_norm: float = 0.0,
@@ -183,8 +195,29 @@ class DistributedTrainer:
             dist.all_reduce(t)
         return float(t[0] / max(t[1], 1.0))
 
+    def _sync_buffers(self) -> None:
+        """BatchNorm running statistics (DPRNN-Spe / IRA speaker encoder, dprnn_spe.py:20-21) are updated from each rank's
+        own shard; before they are READ (eval, checkpoint) every rank takes rank 0's, as DistributedDataParallel's default
+        broadcast_buffers does, so all ranks evaluate the same model and the checkpoint matches what was evaluated."""
+        if _world() > 1:
+            for b in self.model.buffers():
+                dist.broadcast(b.data, 0)
+
+    def _check_equal_steps(self, dataloader) -> None:
+        """Every step ends in a collective: ranks whose loaders yield different step counts would deadlock in it."""
+        if _world() == 1 or not hasattr(dataloader, "__len__"):
+            return
+        n = len(dataloader)
+        t = torch.tensor([n, -n], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[0]) != -int(t[1]):
+            raise RuntimeError(f"rank {self.rank}: dataloader yields {n} steps but the ranks disagree (min {-int(t[1])}, max "
+                               f"{int(t[0])}); use a DistributedSampler with drop_last=True so every rank runs the same "
+                               "number of gradient all-reduces")
+
     def train(self, dataloader) -> float:
         self.model.train()
+        self._check_equal_steps(dataloader)
         total, steps = 0.0, 0
         start = time.time()
         for step, batch in enumerate(dataloader):
@@ -206,6 +239,7 @@ class DistributedTrainer:
 
     def eval(self, dataloader) -> float:
         self.model.eval()
+        self._sync_buffers()
         total, steps = 0.0, 0
         start = time.time()
         with torch.no_grad():
@@ -255,6 +289,7 @@ class DistributedTrainer:
         return history
 
     def _save_checkpoint(self, best: bool = False) -> Optional[str]:
+        self._sync_buffers()            # called by every rank (run() decides on the all-reduced eval loss)
         if self.new_checkpoints_path is None or self.rank != 0:
             return None
         cpt = {"epoch": self.cur_epoch, "optimizer": self.optimizer.state_dict(), "model": self.model.state_dict()}

@@ -24,7 +24,8 @@ from . import engine
 from ._lib import DprnnError, load_library
 from .engine import F_BUILT, Stage, _norm_params, _p, _param, _rnn_tensors
 
-SAVE_BUDGET_BYTES = 200 << 30        # activations one forward may keep for its backward (of 288 GB HBM3E per GPU)
+SAVE_BUDGET_BYTES = 200 << 30        # cap on the activations one forward may keep for its backward (of 288 GB HBM3E per GPU)
+SAVE_BUDGET_FRACTION = 0.70          # ... and at most this share of what is free on the device when the forward starts
 # Over-budget batches: True = the first micro-batch is as large as the budget allows (fewest utterances re-run in the
 # backward: B = 64 keeps 47 and re-runs 17, 753 ms per step); False = balanced micro-batches (32 + 32: 793 ms).
 KEEP_MAX_FIRST = True
@@ -39,6 +40,16 @@ _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 def check_supported_train(cfg: dict) -> None:
     engine.check_supported(cfg)          # LSTM, GRU and RNN cells all have forward-with-tape and backward kernels
+
+
+def save_budget_bytes(dev) -> int:
+    """Bytes of activations a forward may keep: SAVE_BUDGET_BYTES, but never more than SAVE_BUDGET_FRACTION of the memory
+    that is actually free on `dev` right now (free HBM + what torch's caching allocator holds unused), so that a second
+    rank on the same GPU, a smaller part or other resident tensors lead to smaller micro-batches instead of a HIP OOM.
+    The fraction is the ratio measured on an otherwise empty MI355X: a 200 GB budget peaks at 205 GiB of 268 GiB."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return max(1, min(SAVE_BUDGET_BYTES, int(SAVE_BUDGET_FRACTION * (free + cached))))
 
 
 def saved_bytes_per_utt(geo: engine.Geometry, n_paths: int, ndirs: List[int]) -> int:
@@ -443,13 +454,13 @@ def _to_main(t: torch.Tensor, dev):
     return t
 
 
-def _forward_groups(model, wav):
+def _forward_groups(model, wav, keep: bool = True):
     dev = wav.device
     cfg = model.cfg
     geo = engine.make_geometry(1, wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
                                cfg["kernel_size"], cfg["stride"])
     parts = _group_parts(wav.shape[0], geo)
-    res = _run_groups(dev, parts, lambda b0, b1: forward_train(model, wav[b0:b1].contiguous(), keep=True))
+    res = _run_groups(dev, parts, lambda b0, b1: forward_train(model, wav[b0:b1].contiguous(), keep=keep))
     outs = [_to_main(r[0], dev) for r in res]
     return (outs[0] if len(outs) == 1 else torch.cat(outs)), (parts, [r[1] for r in res])
 
@@ -478,19 +489,23 @@ class _TasNetFunction(torch.autograd.Function):
                                    cfg["kernel_size"], cfg["stride"])
         ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in _paths(model.separation)]
         per_utt = saved_bytes_per_utt(geo, len(ndirs), ndirs)
-        mb_max = max(1, SAVE_BUDGET_BYTES // per_utt)
+        mb_max = max(1, save_budget_bytes(wav.device) // per_utt)
+        ctx.done = False
         if mb_max >= B:
             out, saved = _forward_groups(model, wav)
             ctx.saved, ctx.wav, ctx.mb = saved, None, B
         else:
-            # too large to keep: balanced micro-batches.  The first one runs the training forward and keeps its
-            # activations; the rest run the plain inference forward now (stream groups, no tape) and are re-run with the
-            # tape inside the backward, one micro-batch at a time.
+            # too large to keep: micro-batches.  The first one runs the training forward and keeps its activations; the
+            # rest run the SAME training kernels now without keeping anything (forward_train(keep=False): the outputs the
+            # loss sees and the gradients the backward recomputes come from one arithmetic, whatever engine.GEMM_MODE
+            # says about the inference path) and are re-run with the tape inside the backward, one micro-batch at a time.
             n_mb = -(-B // mb_max)
             mb = mb_max if KEEP_MAX_FIRST else -(-B // n_mb)
             out0, saved = _forward_groups(model, wav[:mb])
-            with torch.no_grad():
-                out = torch.cat([out0, engine.tasnet_forward(model, wav[mb:].contiguous())])
+            outs = [out0]
+            for b0 in range(mb, B, mb):
+                outs.append(_forward_groups(model, wav[b0:b0 + mb], keep=False)[0])
+            out = torch.cat(outs)
             ctx.saved, ctx.wav, ctx.mb = saved, wav, mb
         return out
 
@@ -502,6 +517,11 @@ class _TasNetFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, d_out):
         model, names = ctx.model, ctx.names
+        if ctx.done:
+            raise DprnnError("DPRNN MI355X training path: backward() was called a second time on the same forward; the "
+                             "saved activations (tape) are released by the first backward (retain_graph is not supported "
+                             "-- run the forward again)")
+        ctx.done = True
         d_out = d_out.contiguous()
         mb = ctx.mb
         grads = _backward_groups(model, ctx.saved, d_out[:mb])
@@ -601,17 +621,23 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("FusedAdam.step does not take a closure")
         import numpy as np
+        work, dev = [], None
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            dev = ps[0].device
             if not ps[0].is_cuda:
                 raise DprnnError("FusedAdam runs on the HIP device only")
+            if dev is not None and ps[0].device != dev:
+                raise DprnnError("FusedAdam: all parameters must live on one device")
+            dev = ps[0].device
             steps = set()
             rec = np.zeros((len(ps), 5), dtype=np.int64)
             for i, p in enumerate(ps):
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32:
+                # .grad is read in place through its pointer, so it must be a contiguous float32 tensor itself (a
+                # .contiguous() temporary could be freed and its block reused before the kernels run)
+                if (p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32
+                        or not p.grad.is_contiguous()):
                     raise DprnnError("FusedAdam expects contiguous float32 parameters and gradients")
                 st_ = self.state[p]
                 if len(st_) == 0:
@@ -620,17 +646,23 @@ class FusedAdam(torch.optim.Optimizer):
                     st_["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st_["step"] += 1
                 steps.add(int(st_["step"].item()))
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                rec[i] = (p.data_ptr(), g.data_ptr(), st_["exp_avg"].data_ptr(), st_["exp_avg_sq"].data_ptr(), p.numel())
+                rec[i] = (p.data_ptr(), p.grad.data_ptr(), st_["exp_avg"].data_ptr(), st_["exp_avg_sq"].data_ptr(), p.numel())
             if len(steps) != 1:
                 raise DprnnError("FusedAdam: parameters of one group must share the step count")
-            with torch.cuda.device(dev):
-                st = Stage(dev)
-                table = torch.from_numpy(rec).to(dev)
-                sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
-                if clip_norm and clip_norm > 0:
-                    st.call("dprnn_multi_sumsq", _p(table), len(ps), _p(sumsq))
+            work.append((group, len(ps), rec, steps.pop()))
+        if not work:
+            return None
+        with torch.cuda.device(dev):
+            st = Stage(dev)
+            tables = [torch.from_numpy(rec).to(dev) for _, _, rec, _ in work]
+            # clip_grad_norm_ clips by the GLOBAL norm over every parameter (trainer.py:115-116): the sum of squares is
+            # accumulated over all groups before the first update is launched
+            sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+            if clip_norm and clip_norm > 0:
+                for (group, n, _, _), table in zip(work, tables):
+                    st.call("dprnn_multi_sumsq", _p(table), n, _p(sumsq))
+            for (group, n, _, step), table in zip(work, tables):
                 b1, b2 = group["betas"]
-                st.call("dprnn_adam_multi", _p(table), len(ps), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                        float(group["weight_decay"]), steps.pop(), float(clip_norm or 0.0), _p(sumsq))
+                st.call("dprnn_adam_multi", _p(table), n, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                        float(group["weight_decay"]), step, float(clip_norm or 0.0), _p(sumsq))
         return None

@@ -139,13 +139,15 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     B = wav.shape[0]
     sep = model.separation
     ndirs = [2 if r.rnn.bidirectional else 1 for r, _, _, _ in training._paths(sep)]
-    need = (2 if ira else 1) * B * training.saved_bytes_per_utt(engine.make_geometry(1, wav.shape[1], N, cfg["chunk_length"],
-                                                                                      cfg["hop_length"], ks, stride), len(ndirs), ndirs)
-    if need > training.SAVE_BUDGET_BYTES:
-        raise DprnnError(f"DPRNN-Spe training step: batch {B} needs {need / 2**30:.0f} GiB of saved activations, above "
-                         f"training.SAVE_BUDGET_BYTES ({training.SAVE_BUDGET_BYTES / 2**30:.0f} GiB); BatchNorm couples the "
-                         "utterances of the speaker branch, so this path does not cut the batch into micro-batches -- lower the "
-                         "batch size (config_tss.yaml ships batch_size 5)")
+    per_utt = (2 if ira else 1) * training.saved_bytes_per_utt(engine.make_geometry(1, wav.shape[1], N, cfg["chunk_length"],
+                                                                                     cfg["hop_length"], ks, stride), len(ndirs), ndirs)
+    budget = training.save_budget_bytes(dev)
+    if B * per_utt > budget:
+        raise DprnnError(f"DPRNN-Spe training step: batch {B} needs {B * per_utt / 2**30:.0f} GiB of saved activations, above the "
+                         f"budget of {budget / 2**30:.0f} GiB (training.save_budget_bytes: SAVE_BUDGET_BYTES capped by the memory "
+                         f"free on {dev}); the largest batch that fits is {budget // per_utt}.  BatchNorm couples the utterances "
+                         "of the speaker branch, so this path does not cut the batch into micro-batches -- lower the batch size "
+                         "(config_tss.yaml ships batch_size 5)")
     se = sep.spk_encoder
     enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
     aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
