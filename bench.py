@@ -71,9 +71,10 @@ def _self_launch(n: int, script=None, argv=None) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    for line in proc.stdout:                                 # rank 0's JSON line (other ranks print nothing on stdout)
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:                                 # rank 0's JSON line -> stdout; library chatter (gloo) -> stderr
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     return proc.wait()
 
 

@@ -109,3 +109,75 @@ def test_ira_att_matches_cpu_oracle():
         est, logits = model(torch.from_numpy(mix).to(DEV), torch.from_numpy(aux).to(DEV), torch.tensor(377.0))
     assert rel_l2(logits.cpu().numpy(), wlog) <= REL_TOL
     assert rel_l2(est.cpu().numpy(), want) <= REL_TOL
+
+
+# ------------------------------------------------------------------ separation-level entry points
+def _enc(sd, cfg, wav):
+    return onp.encoder(sd, cfg, wav)                  # [B, N, L] as the reference's Encoder returns it
+
+
+@pytest.mark.parametrize("nt,act", [("ln", "sigmoid"), ("gLN", "relu")])
+def test_separator_forward_on_materialised_encoder_output(nt, act):
+    """DPRNN.forward (dprnn.py:166-187) called on an encoder output tensor, as code holding [B, N, L] tensors does."""
+    model, sd, cfg = build_model("bss", dict(chunk_length=16, hop_length=8, n_repeats=2, norm_type=nt, activation_type=act), 73, DEV)
+    enc = _enc(sd, cfg, make_mixture(3, 333, seed=8))
+    want = onp.separator(sd, cfg, enc)
+    with torch.no_grad():
+        got = model.separation(torch.from_numpy(enc).to(DEV))
+    assert got.shape == want.shape == (3, 2, 64, 332)
+    assert rel_l2(got.cpu().numpy(), want) <= REL_TOL
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        model.separation(torch.from_numpy(enc).to(DEV))          # grad mode: the backward lives in the TasNet wrappers
+
+
+@pytest.mark.parametrize("fusion,nt", [("cat", "ln"), ("att", "gLN"), ("film", "ln")])
+def test_dprnn_spe_forward_on_materialised_encoder_outputs(fusion, nt):
+    """DPRNNSpe.forward (dprnn_spe.py:125-154) = _auxiliary + bottleneck[0] + _fusion + bottleneck[1] + _dprnn_process."""
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type=fusion, norm_type=nt)
+    model, sd, cfg = build_model("spe", cfg, 74, DEV)
+    B, T, Ta = 2, 402, 377
+    enc, aenc = _enc(sd, cfg, make_mixture(B, T, seed=11)), _enc(sd, cfg, make_mixture(B, Ta, seed=12))
+    emb = onp.auxiliary(sd, cfg, aenc, np.float32(Ta), False)
+    x = onp.channel_norm(sd, "separation.bottleneck.0", enc, nt)
+    x = onp.conv1x1(sd["separation.bottleneck.1.weight"], sd["separation.bottleneck.1.bias"], onp.fusion(sd, cfg, emb, x))
+    want = onp.dprnn_process(sd, cfg, x, enc.shape[-1])
+    wlog = emb @ sd["separation.pred_linear.weight"].T + sd["separation.pred_linear.bias"]
+    with torch.no_grad():
+        masks, logits = model.separation(torch.from_numpy(enc).to(DEV), torch.from_numpy(aenc).to(DEV), torch.tensor(float(Ta)))
+    assert rel_l2(logits.cpu().numpy(), wlog) <= REL_TOL
+    assert rel_l2(masks.cpu().numpy(), want) <= REL_TOL
+
+
+def test_rawnet_style_subclass_uses_the_device_pieces():
+    """src/models/dprnn_rawnet.py:9-105 subclasses DPRNNSpe, swaps the speaker encoder and drives bottleneck[i], _fusion,
+    _dprnn_process and pred_linear itself; the same call sequence on our DPRNNSpe (with a stand-in speaker encoder)."""
+    from tss_with_dprnn_amd.dprnn_spe import DPRNNSpe
+
+    class Sub(DPRNNSpe):
+        def forward(self, input, aux):                      # dprnn_rawnet.py:73-102
+            B, _, L = input.size()
+            aux = self._auxiliary(aux)
+            output = self.bottleneck[0](input)
+            output = self._fusion(aux, output, L)
+            output = self.bottleneck[1](output)
+            output = self._dprnn_process(output, B, L)
+            return output, self.pred_linear(aux)
+
+        def _auxiliary(self, aux):                          # stand-in for RawNet3: any [B, E] embedding
+            return aux.mean(dim=-1).repeat(1, 2) * 3.0
+
+    cfg = dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="mul", norm_type="ln")
+    _, sd, cfg = build_model("spe", cfg, 75, None)
+    sub = Sub(64, 128, 128, 16, 8, 1, True, "LSTM", "ln", "sigmoid", 0, 128, 256, 128, cfg["num_spks"], 2, "mul")
+    sub.load_state_dict({k[len("separation."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items()
+                         if k.startswith("separation.")}, strict=True)
+    sub = sub.eval().to(DEV)
+    enc, aenc = _enc(sd, cfg, make_mixture(2, 300, seed=13)), _enc(sd, cfg, make_mixture(2, 280, seed=14))
+    emb = (np.tile(aenc.mean(-1), (1, 2)) * 3.0).astype(np.float32)
+    x = onp.channel_norm(sd, "separation.bottleneck.0", enc, "ln")
+    x = onp.conv1x1(sd["separation.bottleneck.1.weight"], sd["separation.bottleneck.1.bias"], onp.fusion(sd, cfg, emb, x))
+    want = onp.dprnn_process(sd, cfg, x, enc.shape[-1])
+    with torch.no_grad():
+        masks, logits = sub(torch.from_numpy(enc).to(DEV), torch.from_numpy(aenc).to(DEV))
+    assert rel_l2(masks.cpu().numpy(), want) <= REL_TOL
+    assert rel_l2(logits.cpu().numpy(), emb @ sd["separation.pred_linear.weight"].T + sd["separation.pred_linear.bias"]) <= REL_TOL

@@ -132,9 +132,19 @@ class DPRNN(nn.Module):
         if activation_type == 'relu':
             self.activation = nn.ReLU()
 
+    # Separation-level entry points.  The TasNet wrappers never come here (they start from the waveform and never
+    # materialise the encoder output); these exist for code that holds [B, C, L] tensors and calls the separator or its
+    # pieces itself, as the reference's DPRNNRawNet subclass does (src/models/dprnn_rawnet.py:79-94).  Inference only.
     def forward(self, input):
-        raise DprnnError("DPRNN consumes the raw waveform on the MI355X path (the encoder output is never "
-                         "materialised); call DPRNNTasNet / DPRNNSpeTasNet / DPRNNSpeIRATasNet")
+        """dprnn.py:166-187: encoder output [B, N, L] -> masks [B, 2, N, L] (norm, 1x1 conv and the whole DPRNN stack in
+        HIP kernels)."""
+        return engine.separator_forward(self, input)
+
+    def _dprnn_process(self, output, B, L):
+        """dprnn.py:171-186: bottleneck output [B, F, L] -> masks [B, 2, N, L]."""
+        if tuple(output.shape[::2]) != (B, L):
+            raise DprnnError(f"_dprnn_process: got {tuple(output.shape)} for B={B}, L={L}")
+        return engine.separator_masks(self, output)
 
 
 class DPRNNTasNet(nn.Module):

@@ -79,8 +79,46 @@ class DPRNNSpe(DPRNN):
         )
         self.pred_linear = nn.Linear(embeddings_size, num_spks)
 
+    # Separation-level entry points for code that holds encoder outputs [B, N, L] and drives the pieces itself -- the
+    # reference's DPRNNRawNet subclass overrides _auxiliary and calls bottleneck[i], _fusion, _dprnn_process and pred_linear
+    # (src/models/dprnn_rawnet.py:79-105).  The speaker encoder and the DPRNN stack (99 % of the FLOPs) run in the HIP
+    # kernels; the per-frame glue in between (norm module, fusion broadcast, 1x1 conv, pred_linear) is a handful of torch
+    # device ops here, because its inputs and outputs are torch tensors in the reference's [B, C, L] layout by contract.
+    # DPRNNSpeTasNet / DPRNNSpeIRATasNet do NOT use these: their forward is fused from the waveform (engine.spe_forward).
     def forward(self, input, aux, aux_len):
-        raise DprnnError("DPRNNSpe consumes raw waveforms on the MI355X path; call DPRNNSpeTasNet / DPRNNSpeIRATasNet")
+        """dprnn_spe.py:125-154: (mixture encoding [B,N,L], reference encoding [B,N,La], aux_len) -> (masks [B,2,N,L],
+        speaker logits [B,num_spks])."""
+        B, _, L = input.size()
+        emb = self._auxiliary(aux, aux_len)
+        output = self.bottleneck[0](input)
+        output = self._fusion(emb, output, L)
+        output = self.bottleneck[1](output)
+        return self._dprnn_process(output, B, L), self.pred_linear(emb)
+
+    def _auxiliary(self, aux, aux_len):
+        """dprnn_spe.py:156-163: speaker encoder + time mean, [B,N,La] -> [B,E] (HIP kernels)."""
+        return engine.auxiliary_embedding(self, aux, aux_len)
+
+    def _fusion(self, aux, output, L):
+        """dprnn_spe.py:165-229 on device tensors: aux [B,E], output [B,N,L] (already normalised) -> fused [B,C,L]."""
+        if not output.is_cuda:
+            raise DprnnError(f"_fusion input is on {output.device}: the DPRNN MI355X path runs only on a HIP device")
+        ft = self.fusion_type
+        if ft == 'cat':
+            return torch.cat((output, aux.unsqueeze(-1).expand(-1, -1, L)), dim=1)
+        if ft == 'film':
+            return output * self.fusion_linear_1(aux).unsqueeze(-1) + self.fusion_linear_2(aux).unsqueeze(-1)
+        a = self.fusion_linear(aux).unsqueeze(-1)                        # [B, N, 1]
+        if ft == 'add':
+            return output + a
+        if ft == 'mul':
+            return output * a
+        if ft == 'att':
+            avg = self.average(output)                                    # depth-wise mean over kernel_size frames
+            att = torch.softmax((avg * a).sum(dim=1, keepdim=True), dim=-1)
+            att = att * a + a
+            return output * nn.functional.interpolate(att, size=L, mode='nearest')
+        raise DprnnError(f"unknown fusion_type {ft!r}")
 
 
 def _wants_grad(module):

@@ -291,7 +291,7 @@ def _split(B: int):
 
 
 def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, relu_act: bool,
-                  want_masked: bool = False, debug: Optional[dict] = None):
+                  want_masked: bool = False, debug: Optional[dict] = None, masks_out: Optional[torch.Tensor] = None):
     """Segmentation -> DPRNN blocks -> mask head -> mask*enc -> decoder taps.
 
     reference: dprnn.py:171-186 (== dprnn_spe.py:231-248), dprnn.py:277, encoder_decoder.py:40-42.
@@ -361,9 +361,14 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
         g.st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
                   _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
                   _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), gB * L * 2)
-        g.st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
-                  _p(wav[g.b0:]), _p(enc_w), _p(dec_w), _p(taps[g.b0:]), _p(masked[g.b0:] if want_masked else None),
-                  1 if relu_act else 0, gB, geo.T, L, geo.N, geo.ks, geo.stride)
+        if masks_out is not None:       # separation-level callers (DPRNN._dprnn_process) want the masks themselves
+            g.st.call("dprnn_head_mask_decode_fwd_train", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+                      _p(wav[g.b0:]), _p(enc_w), _p(dec_w), _p(taps[g.b0:]), _p(masks_out[g.b0:]),
+                      _p(masked[g.b0:] if want_masked else None), 1 if relu_act else 0, gB, geo.T, L, geo.N, geo.ks, geo.stride)
+        else:
+            g.st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+                      _p(wav[g.b0:]), _p(enc_w), _p(dec_w), _p(taps[g.b0:]), _p(masked[g.b0:] if want_masked else None),
+                      1 if relu_act else 0, gB, geo.T, L, geo.N, geo.ks, geo.stride)
         if debug is not None:
             debug["ola_conv"] = U.view(B, L, 2 * F_BUILT).clone()
             debug["gated"] = V.view(B, L, 2, F_BUILT).clone()
@@ -616,3 +621,100 @@ def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dic
         logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last)
         est = decode(st, taps, geo, 1)                    # speaker 0 only (dprnn_spe.py:325)
         return est[:, 0, :], logits
+
+
+# ------------------------------------------------------------------- separation-level entry points (materialised frames)
+# The TasNet wrappers above never materialise the encoder output.  Code that subclasses the SEPARATOR modules and calls
+# their pieces on [B, C, L] tensors -- /root/reference/src/models/dprnn_rawnet.py:79-94 does: self._auxiliary,
+# self.bottleneck[i], self._fusion, self._dprnn_process -- gets the same HIP kernels through these functions
+# (inference only: the backward kernels are wired to the TasNet wrappers).
+def _no_grad_only(what: str, *tensors, module=None) -> None:
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor)) or
+                                    (module is not None and any(p.requires_grad for p in module.parameters()))):
+        raise NotImplementedError(
+            f"{what}: the separation-level MI355X entry points are inference-only (call them under torch.no_grad()); "
+            "training goes through DPRNNTasNet / DPRNNSpeTasNet / DPRNNSpeIRATasNet.forward, which own the backward kernels")
+
+
+def _check_frames(x: torch.Tensor, channels: int, what: str) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[1] != channels:
+        raise DprnnError(f"{what} must be a [batch, {channels}, frames] tensor")
+    if not x.is_cuda:
+        raise DprnnError(f"{what} is on {x.device}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise DprnnError(f"{what} must be float32 (got {x.dtype})")
+    return x
+
+
+def separator_masks(sep, frames: torch.Tensor) -> torch.Tensor:
+    """DPRNN._dprnn_process (dprnn.py:171-186 == dprnn_spe.py:231-248): bottleneck output [B, F, L] -> masks [B, 2, N, L]."""
+    cfg = dict(input_size=sep.input_size, feature_size=sep.feature_size, hidden_size=sep.dprnn_blocks[0].intra_rnn.hidden_size,
+               rnn_type=sep.dprnn_blocks[0].intra_rnn.rnn.mode, kernel_size=1, norm_type=sep.norm_type,
+               activation_type=sep.activation_type, hop_length=sep.hop_length, chunk_length=sep.chunk_length)
+    check_supported(cfg)
+    frames = _check_frames(frames, F_BUILT, "bottleneck output")
+    _no_grad_only("_dprnn_process", frames, module=sep)
+    dev = frames.device
+    B, _, L = frames.shape
+    N = sep.input_size
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        Y = frames.transpose(1, 2).contiguous()                       # channels-last frames [B][L][F] (layout plumbing)
+        # the mask kernel also forms decoder taps of mask * encoder(wav); here there is no waveform: a 1-tap all-zero
+        # encoder / decoder over a zero signal of L samples keeps its addressing valid, and the taps are discarded
+        geo = Geometry(B, L, L, sep.chunk_length, sep.hop_length, (L + sep.chunk_length) // sep.hop_length + 1, 1, 1, N)
+        zero_w = torch.zeros(N, device=dev, dtype=torch.float32)
+        zero_x = torch.zeros(B, L, device=dev, dtype=torch.float32)
+        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
+        masks = torch.empty(B, L, 2, N, device=dev, dtype=torch.float32)         # rows (b, l, speaker)
+        dprnn_process(st, sep, Y, zero_x, zero_w, zero_w, geo, stats, sep.activation_type == "relu", masks_out=masks)
+        return masks.permute(0, 2, 3, 1).contiguous()                 # [B, 2, N, L] as dprnn.py:185
+
+
+def _rows_affine(st: Stage, x_cl, norm, B: int, L: int, N: int):
+    """Per-utterance affine (sc, sh) of GroupNorm(1, N) / GlobLN over materialised rows [B*L][N]."""
+    dev = x_cl.device
+    stats = torch.zeros(B, 2, device=dev, dtype=torch.float64)
+    st.call("dprnn_rows_stats", _p(x_cl), _p(stats), B, L, N)
+    gamma, beta, eps = _norm_params(norm)
+    sc = torch.empty(B, N, device=dev, dtype=torch.float32)
+    sh = torch.empty_like(sc)
+    st.call("dprnn_bottleneck_prep", _p(stats), _p(_param(gamma, "norm.weight", dev)), _p(_param(beta, "norm.bias", dev)),
+            eps, 0, 0, _p(sc), _p(sh), B, L, N)
+    return sc, sh
+
+
+def separator_forward(sep, enc: torch.Tensor) -> torch.Tensor:
+    """DPRNN.forward (dprnn.py:166-187) on a materialised encoder output [B, N, L] -> masks [B, 2, N, L]."""
+    enc = _check_frames(enc, sep.input_size, "separator input")
+    _no_grad_only("DPRNN.forward", enc, module=sep)
+    if sep.input_size != N_BUILT or len(sep.bottleneck) != 2:
+        raise NotImplementedError(f"DPRNN MI355X path: input_size must be {N_BUILT} and norm_type 'ln' or 'gLN'")
+    dev = enc.device
+    B, N, L = enc.shape
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        x_cl = enc.transpose(1, 2).contiguous().view(B * L, N)
+        sc, sh = _rows_affine(st, x_cl, sep.bottleneck[0], B, L, N)
+        conv = sep.bottleneck[1]
+        Y = _pointwise(st, x_cl, B * L, N, conv.weight, conv.bias, F_BUILT, in_scale=sc, in_shift=sh, aff_stride=N,
+                       rows_per_utt=L)
+    return separator_masks(sep, Y.view(B, L, F_BUILT).transpose(1, 2))
+
+
+def auxiliary_embedding(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
+    """DPRNNSpe._auxiliary (dprnn_spe.py:156-163): encoder output of the reference utterance [B, N, La] -> [B, E]."""
+    aux = _check_frames(aux, sep.input_size, "aux")
+    _no_grad_only("_auxiliary", aux, module=sep.spk_encoder)
+    dev = aux.device
+    B, N, La = aux.shape
+    se = sep.spk_encoder
+    if N != N_BUILT or se[1].out_channels != 128 or se[5].in_channels != 256 or se[5].out_channels != 128:
+        raise NotImplementedError("DPRNN-Spe MI355X path: speaker encoder must be input_size 64, O=128, P=256, embeddings 128")
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        x_cl = aux.transpose(1, 2).contiguous().view(B * La, N)
+        sc, sh = _rows_affine(st, x_cl, se[0], B, La, N)
+        A0 = _pointwise(st, x_cl, B * La, N, se[1].weight, se[1].bias, 128, in_scale=sc, in_shift=sh, aff_stride=N,
+                        rows_per_utt=La)
+        return speaker_embedding(st, sep, A0, B, La, _aux_len_tensor(aux_len, B, dev), sep.kernel_size)

@@ -15,7 +15,8 @@ LN_EPS = 1e-5     # nn.GroupNorm default, used by norm_type='ln' (dprnn.py:76-77
 
 
 class GlobLN(nn.Module):
-    """Global Layer Normalization (globLN) -- parameters only; evaluated by the fused kernels."""
+    """Global Layer Normalization (globLN): parameter holder for the fused kernels (+ a device-tensor forward for callers
+    that apply the module themselves)."""
 
     def __init__(self, channel_size):
         super().__init__()
@@ -24,4 +25,13 @@ class GlobLN(nn.Module):
         self.beta = nn.Parameter(torch.zeros(channel_size), requires_grad=True)
 
     def forward(self, x, EPS: float = GLN_EPS):
-        raise DprnnError("GlobLN is evaluated inside the fused MI355X kernels; call the TasNet wrapper")
+        """norms.py:6-31 on a device tensor [B, C, ...]: glue for code that calls ``bottleneck[0](x)`` itself
+        (src/models/dprnn_rawnet.py:85); the TasNet wrappers never call it -- their norms are folded into the HIP kernels
+        (dprnn_bottleneck_prep, dprnn_proj_stats_fwd + the consumers' loaders)."""
+        if not x.is_cuda:
+            raise DprnnError(f"GlobLN input is on {x.device}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
+        dims = tuple(range(1, x.dim()))
+        mean = x.mean(dim=dims, keepdim=True)
+        var = (x - mean).pow(2).mean(dim=dims, keepdim=True)               # biased, as torch.var(unbiased=False)
+        shape = (1, -1) + (1,) * (x.dim() - 2)
+        return (x - mean) / (var + EPS).sqrt() * self.gamma.view(shape) + self.beta.view(shape)
