@@ -146,6 +146,59 @@ def test_bilstm_split_gemm_modes(mode, tol, path):
     assert err < tol
 
 
+@pytest.mark.parametrize("seq_tile", [32, 64, 80, 96, 104, -64])
+@pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
+def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
+    """The wide split kernel (one workgroup per CU, 64..104 sequences, swizzled image): every tile size against the numpy
+    oracle, with sequence counts that leave ragged last tiles, tiles straddling utterances on the inter-chunk path, a
+    104-sequence tile (half-empty last 16-row block), and the previous path's norm folded into the loader."""
+    B, S, K = 3, 37, 41             # 111 intra sequences of 41 steps, 123 inter sequences of 37 steps
+    rng = np.random.default_rng(1000 * mode + abs(seq_tile))
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(46)
+    Xn = X
+    if fused:
+        Zr = (rng.standard_normal((B, S, K, 128)) * 1.3 + 0.2).astype(np.float32)
+        gamma = (1 + 0.1 * rng.standard_normal(128)).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(128)).astype(np.float32)
+        zb = Zr.reshape(B, -1).astype(np.float64)
+        mean, var = zb.mean(1)[:, None, None, None], zb.var(1)[:, None, None, None]
+        Xn = (X + ((Zr - mean) / np.sqrt(var + 1e-5)) * gamma + beta).astype(np.float32)
+    if path == "intra":
+        want = onp.single_rnn(sd, p, Xn.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    else:
+        want = onp.single_rnn(sd, p, Xn.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
+        want = want.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    Xd = _t(X)
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    Xo = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    norm = (0, 0, 0, 0, 0.0, 1, 1, 0)
+    if fused:
+        stats = _t(np.stack([zb.sum(1), (zb ** 2).sum(1)], axis=1))
+        Zd, gd, bd = _t(Zr), _t(gamma), _t(beta)
+        norm = (Zd.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, S if path == "intra" else K, S * K, Xo.data_ptr())
+    st.lib.dprnn_set_gemm_mode(mode)
+    try:
+        st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+        st.call("dprnn_rnn_fwd", 0, Xd.data_ptr(), *norm, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, seq_tile)
+        torch.cuda.synchronize()
+    finally:
+        st.lib.dprnn_set_gemm_mode(0)
+    got = H.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = rel_l2(got, want)
+    assert err < tol, f"tile {seq_tile} mode {mode} {path} fused={fused}: rel-L2 {err:.2e}"
+    if fused:
+        assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
+
+
 def test_bilstm_unidirectional():
     B, S, K = 1, 5, 9
     X = np.random.default_rng(3).standard_normal((B, S, K, 128)).astype(np.float32)

@@ -13,7 +13,7 @@ from tss_with_dprnn_amd import engine  # noqa: E402
 
 
 def run(st, seq_tile, nwg, T, ndir=2, iters=3):
-    nseq = nwg * seq_tile // ndir
+    nseq = nwg * abs(seq_tile) // ndir
     X = torch.randn(nseq * T, 128, device="cuda") * 0.5
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
@@ -166,6 +166,36 @@ def stamps(st, seq_tile, per_cu, T, ndir=2):
           f"k-loop {kloop / T:.0f}, cell+stores {cell / T:.0f}, barrier/other {(cyc - kloop - cell) / T:.0f}")
 
 
+def stamps_split(st, seq_tile, T, ndir=2):
+    """In-kernel stamps of the wide bf16-split kernel (gemm mode 1): one workgroup per CU, phase cycles of wave 0."""
+    ncu = st.lib.dprnn_num_cus()
+    nwg = ncu
+    nseq = nwg * seq_tile // ndir
+    X = torch.randn(nseq * T, 128, device="cuda") * 0.5
+    H = torch.empty(nseq * T, ndir * 128, device="cuda")
+    packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
+    bsum = torch.empty(ndir * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    buf = torch.zeros(nwg, 8, device="cuda", dtype=torch.int64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(12):
+        if it == 4:
+            e0.record()
+        st.call("dprnn_bilstm_fwd_stamped", X.data_ptr(), packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), nseq, T,
+                nseq, 0, T, 1, ndir, seq_tile, buf.data_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 8
+    tf = nseq * T * ndir * 2 * 256 * 512 / ms / 1e9
+    b = buf.cpu().double()
+    cyc, ticks, mf, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
+    print(f"split-wide stamps seq_tile={seq_tile}: {ms:.3f} ms = {tf:.1f} TFLOP/s (fp32-equivalent), in-kernel clock {cyc / ticks * 100:.0f} MHz; "
+          f"per step: total {cyc / T:.0f} cyc, MFMA phase {mf / T:.0f}, cell + x staging {cell / T:.0f}, barriers/other {(cyc - mf - cell) / T:.0f}"
+          f"  [bf16 MFMA floor {seq_tile // 16 + (1 if seq_tile % 16 else 0)} tiles x 1536 x 16 / 4 = {((seq_tile + 15) // 16) * 1536 * 4} cyc]")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fast", type=int, default=1)
@@ -181,6 +211,10 @@ def main():
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
+    if a.stamps and a.gemm_mode == 1:
+        for seq_tile in (64, 104):
+            stamps_split(st, seq_tile, a.T)
+        return
     if a.stamps:
         for seq_tile, per_cu in ((32, 1), (32, 2), (64, 1)):
             stamps(st, seq_tile, per_cu, a.T)
@@ -197,6 +231,15 @@ def main():
         seq_tile, per_cu = (int(v) for v in a.only.split(","))
         ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
         print(f"only seq_tile={seq_tile} wgs/CU={per_cu}: {ms:.3f} ms {tf:.1f} TFLOP/s")
+        return
+    if a.gemm_mode != 0:       # bf16-split modes: the two-per-CU form, the round-1 64-sequence form and the wide one-per-CU forms
+        np_ = 6 if a.gemm_mode == 1 else 3
+        print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
+        for seq_tile, per_cu in ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (104, 1)):
+            ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
+            tiles = (abs(seq_tile) + 15) // 16
+            floor_us = per_cu * tiles * 32 * 8 * np_ * 16 / 4 / 2.4e3
+            print(f"{seq_tile:8d} {per_cu:4d} {ms:8.3f} {ms * 1e3 / a.T:8.2f} {tf:8.1f} {floor_us:8.2f}")
         return
     print("seq_tile  wgs/CU   ms     us/step  TFLOP/s  mfma-cycles/step/SIMD(ideal)  implied-util@2.4GHz")
     for seq_tile in (16, 32, 48, 64):

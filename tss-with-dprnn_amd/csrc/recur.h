@@ -33,10 +33,12 @@ struct RecurArgs {
 
 // The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's
 // sequence inside its tile); offsets at or above 2^31 mean "no such sequence".  True when the widest tile (64 sequences)
-// stays below that for a row pitch of pitch_floats: a tile spans at most ceil(64 / inner_n) outer strides.
-inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inner_stride, long long t_stride, long long pitch_floats) {
+// stays below that for a row pitch of pitch_floats: a tile of `tile` sequences (104 in the wide split kernel) spans at most
+// ceil(tile / inner_n) outer strides.
+inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inner_stride, long long t_stride, long long pitch_floats,
+                             int tile = 104) {
     if (outer_stride < 0 || inner_stride < 0 || t_stride < 0) return false;
-    const long long outer_steps = 63 / inner_n + 1, inner_steps = inner_n < 64 ? inner_n - 1 : 63;
+    const long long outer_steps = (tile - 1) / inner_n + 1, inner_steps = inner_n < tile ? inner_n - 1 : tile - 1;
     const long long span_rows = outer_steps * outer_stride + inner_steps * inner_stride + 1;
     return span_rows * pitch_floats * 4 < 0x7fffffffLL;
 }

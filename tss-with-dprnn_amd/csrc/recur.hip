@@ -669,6 +669,10 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
+    if (g_gemm_mode == 1) {                 // wide bf16-split kernel with stamps (seq_tile 64 or 104; packed by dprnn_rnn_pack in mode 1)
+        if (seq_tile != 64 && seq_tile != 104) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64 and 104"); return -1; }
+        return launch_bilstm_split(a, 6, seq_tile, true, st);
+    }
     auto go = [&](auto kern, int NS) {
         const size_t lds = (size_t)2 * NS * XS * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -284,15 +284,395 @@ int launch_split(const RecurArgs& a, hipStream_t st) {
     return dprnn_check_launch("bilstm_split_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// WIDE form: ONE 4-wave workgroup per CU owning NSR = 48 .. 104 sequences of one direction.
+//
+// The two-per-CU form above pulls a direction's 786 KB of split weights from L2 once per 32 sequences and step and is
+// bound by that stream (~65 GB/s per CU, profiles/r01_split_modes.txt) with the bf16 MFMAs busy 40 % of the time.  Here
+// a CU makes ONE pass over the weights per step for up to 104 sequences, which puts the stream below the matrix time
+// (786 KB per 15-18 us at 96-104 sequences).  What that takes:
+//   * image: x/h as three bf16 planes [plane][seq][256] WITHOUT row padding (104 rows x 3 planes x 512 B = 156 KB of the
+//     160 KB); bank conflicts are avoided by XOR-ing the 16-byte chunk index of a row with (row & 15) instead -- the 16
+//     lanes of every ds_read_b128 service group then touch 16 different bank quads (MI355X guide, LDS table);
+//   * registers: one wave per SIMD (512 VGPRs): 16*NT x 128 gate accumulators and the cell state of the wave's 32 hidden
+//     units, the B fragments of one k-slab (double-buffered by slab while NT <= 5, else re-requested piece by piece as
+//     they die) and two A-fragment sets (one piece of all NT tiles each);
+//   * per-row global offsets live in a small LDS table instead of 41 VGPRs; rows that do not exist carry an offset
+//     beyond the buffer range (stores dropped by the hardware) and are never written to the image;
+//   * a last tile of 8 rows (NSR = 104) re-reads existing rows for its missing ones; their results are never stored.
+// Product order per k-slab (A piece, W piece): (1,3) (1,2) (2,2) (1,1) (2,1) (3,1) -- every term of order <= 2^-16.
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false>
+__global__ __launch_bounds__(256, 1)
+void bilstm_split_wide_kernel(RecurArgs a) {
+    constexpr int NT = (NSR + 15) / 16;
+    constexpr int LASTROWS = NSR - 16 * (NT - 1);      // rows of the last 16-row tile that exist (16 or 8)
+    static_assert(NSR % 8 == 0 && (LASTROWS == 16 || LASTROWS == 8), "NSR must be a multiple of 8");
+    constexpr int NXV = NSR / 8;                       // float4 of x per thread and step
+    constexpr int NPC = NP == 6 ? 3 : 2;
+    constexpr int PLANE = NSR * 512;                   // bytes
+    constexpr bool BDB = NT <= 4;
+    constexpr int NBUF = BDB ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char img[];       // [NPC][NSR][512 B] + row tables
+    unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + NPC * PLANE);     // [NSR]  byte offset of the row in X
+    unsigned* const rowoff_h = rowoff_x + NSR;                                     // [16*NT] byte offset in H, or OOB
+    float* const musig = reinterpret_cast<float*>(rowoff_h + 16 * NT);             // [NSR][2] (mean, rstd) of the pending norm
+    float* const gb = musig + 2 * NSR;                                             // [2][128] gamma, beta of the pending norm
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * NSR;
+    const int T = a.T;
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    const long long row0 = rowbase(seq0 < a.nseq ? seq0 : 0);
+    const int hpitch = a.ndir * HD;
+    for (int j = tid; j < 16 * NT; j += 256) {
+        const int seq = seq0 + j;
+        const bool valid = j < NSR && seq < a.nseq;
+        const long long ro = rowbase(valid ? seq : (seq0 < a.nseq ? seq0 : 0)) - row0;
+        if (j < NSR) rowoff_x[j] = (unsigned)(ro * F * 4);          // rows past nseq alias the first row: loads stay in range
+        rowoff_h[j] = valid ? (unsigned)(ro * hpitch * 4) : OOB;
+    }
+    const int c4 = tid & 31, xrow0 = tid >> 5;
+    // image addresses of this thread's x quads: row xrow0 + 8m, chunk (c4>>1) ^ (row & 15), half (c4 & 1)
+    const int xl_even = xrow0 * 512 + (((c4 >> 1) ^ xrow0) << 4) + ((c4 & 1) << 3);
+    const int xl_odd = xrow0 * 512 + (((c4 >> 1) ^ xrow0 ^ 8) << 4) + ((c4 & 1) << 3);
+
+    constexpr bool fuse = FUSE;                        // pending norm of the previous path folded into the x loader
+    // pending norm: per-row (mean, rstd) -- the row's utterance is fixed for the whole kernel -- and gamma / beta live in LDS
+    // tables (a few ds_reads per staged quad instead of 34 registers held through the whole kernel)
+    if (fuse) {
+        for (int j = tid; j < NSR; j += 256) {
+            const int seq = seq0 + j;
+            const int b = (seq < a.nseq ? seq : (seq0 < a.nseq ? seq0 : 0)) / a.seqs_per_utt;
+            const double cnt = (double)a.rows_per_utt * (double)F;
+            const double mean = a.stats[2 * b] / cnt;
+            double var = a.stats[2 * b + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            musig[2 * j] = (float)mean;
+            musig[2 * j + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+        if (tid < 128) { gb[tid] = a.gamma[tid]; gb[128 + tid] = a.beta[tid]; }
+    }
+    auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
+
+    float bias[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+            bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+        }
+
+    // weights: the wave's slice as a buffer resource; fragment (slab, gate*2+u, piece) at scalar offset ((slab*8+gu)*3+piece) KB
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NSLAB * 8 * 3 * 64), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16u;
+    auto wload = [&](int slab, int gu, int pc) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(((slab * 8 + gu) * 3 + pc) * 1024), 0);
+    };
+    constexpr unsigned RANGE = 0x7fffffffu;
+    auto rsrc_at = [&](const float* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, RANGE, 0x00020000);
+    };
+
+    // x of one time step goes into the image as bf16 pieces (pending norm applied), in chunks of XCH quads per thread so
+    // that the cell phase can keep a few chunks in flight instead of all NXV (registers): x_issue requests chunk k,
+    // x_commit splits and stores it
+    constexpr int XCH = (NXV + NT - 1) / NT;           // quads per chunk: one chunk per 16-row cell tile
+    constexpr int NCHUNK = (NXV + XCH - 1) / XCH;
+    f32x4 xv[NXV], zv[NXV];
+    unsigned xo[NXV];
+    auto x_issue = [&](long long t, int k) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
+#pragma unroll
+        for (int m = k * XCH; m < (k + 1) * XCH && m < NXV; ++m) {
+            xo[m] = rowoff_x[xrow0 + 8 * m] + c4 * 16u;
+            xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[m], 0, 0));
+            if (fuse) zv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo[m], 0, 0));
+        }
+    };
+    // `live` false (after the last step): the same code runs on the current step's rows again -- no branch inside the step
+    // loop, the register allocator does badly across them -- and only the x' store is suppressed, by an out-of-range offset
+    auto x_commit = [&](long long t, int k, bool live) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+#pragma unroll
+        for (int m = k * XCH; m < (k + 1) * XCH && m < NXV; ++m) {
+            f32x4 v = xv[m];
+            if (fuse) {
+                const float mu = musig[2 * (xrow0 + 8 * m)], rs = musig[2 * (xrow0 + 8 * m) + 1];
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zv[m][e] - mu) * rs * gam[e] + bet[e]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[m] : OOB, 0, 0);
+            }
+            unsigned p[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+            char* d = img + ((m & 1) ? xl_odd : xl_even) + m * 4096;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc)
+                *reinterpret_cast<u32x2*>(d + pc * PLANE) = u32x2{p[pc][0] | (p[pc][1] << 16), p[pc][2] | (p[pc][3] << 16)};
+        }
+    };
+
+    __syncthreads();                                   // row tables are in place
+    // ---- prologue: x(t0) pieces, h = 0
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) { x_issue(dir ? (T - 1) : 0, k); x_commit(dir ? (T - 1) : 0, k, true); }
+    for (int i = tid; i < NPC * NSR * 64; i += 256) {  // h half of every row (chunks 16..31 map onto themselves under the swizzle)
+        const int pl = i / (NSR * 64), rem = i % (NSR * 64);
+        *reinterpret_cast<unsigned*>(img + pl * PLANE + (rem >> 6) * 512 + 256 + 4 * (rem & 63)) = 0u;
+    }
+    f32x4 c[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A fragment addresses: lane (r, q) of tile nt reads row 16 nt + r, chunk (4 slab + q) ^ r
+    const int rl = (LASTROWS == 16 || r < LASTROWS) ? r : (r - LASTROWS);      // last tile: rows that exist
+    const int abase = r * 512 + ((q ^ (r & 3)) << 4);
+    const int abase_last = (16 * (NT - 1) + rl) * 512 + ((q ^ (rl & 3)) << 4);
+    int sl[4], sl_last[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sl[j] = (j ^ ((r >> 2) & 3)) << 6; sl_last[j] = (j ^ ((rl >> 2) & 3)) << 6; }
+    auto aload = [&](u32x4 (&af)[NT], int pc, int s4, int hs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int off = (nt == NT - 1 && LASTROWS != 16) ? (abase_last + sl_last[s4]) : (nt * 8192 + abase + sl[s4]);
+            af[nt] = *reinterpret_cast<const u32x4*>(img + pc * PLANE + off + hs * 256);
+        }
+    };
+    // element (row 16 nt + 4q + e, unit 32 wave + 16 u + r) of h in the image: + nt*8192 + ((u ^ (e>>1)) << 5) + piece*PLANE
+    // A last tile of 8 rows: its lanes q >= 2 hold exact copies of rows 0..7 (they read those rows as A operands and start
+    // from the same zero state), so they write the same values to the same addresses as lanes q - 2 -- no predication.
+    int hb[4], hb_last[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hb[e] = (4 * q + e) * 512 + 256 + ((wave ^ q) << 6) + (((r >> 3) ^ (e & 1)) << 4) + 2 * (r & 7);
+        const int ql = LASTROWS == 16 ? q : (q & 1);
+        hb_last[e] = (16 * (NT - 1) + 4 * ql + e) * 512 + 256 + ((wave ^ ql) << 6) + (((r >> 3) ^ (e & 1)) << 4) + 2 * (r & 7);
+    }
+    const unsigned hcol = (unsigned)(dir * HD + 32 * wave + r) * 4u;
+
+    u32x4 bw[NBUF][4][2][NPC];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bw[0][g][u][pc] = wload(0, g * 2 + u, pc);
+    __syncthreads();
+
+    unsigned long long st_t0 = 0, st_r0 = 0, st_mfma = 0, st_cell = 0;
+    if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int step = 0; step < T; ++step) {
+        unsigned long long st_a = 0, st_b = 0;
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        const long long t = dir ? (T - 1 - step) : step;
+        const bool more = step + 1 < T;
+        f32x4 acc[NT][4][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        u32x4 fa[NT], fb[NT];                          // two A-fragment sets (one piece of every tile each)
+        auto pass = [&](const u32x4 (&af)[NT], int buf, int wpc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][g][u] = mfma_bf16(af[nt], bw[buf][g][u][wpc], acc[nt][g][u]);
+        };
+        auto wreload = [&](int sn, int buf, int wpc) __attribute__((always_inline)) {     // W piece wpc of slab sn
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) bw[buf][g][u][wpc] = wload(sn, g * 2 + u, wpc);
+        };
+        // one k-slab; P holds piece 0 of this slab on entry when `have_p`, else it is loaded here
+        // The weights of slab 0 are NOT requested from the last slab of a step: they would occupy 96 registers through the
+        // whole cell phase, whose own working set then spills; the cell phase requests them before its last tile instead.
+        auto slab = [&](u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int hs, bool have_p, bool prefetch) __attribute__((always_inline)) {
+            const int s = 4 * hs + s4, sn = (s + 1) & 7;
+            const int cur = BDB ? (s4 & 1) : 0, nxt = BDB ? (cur ^ 1) : 0;
+            const bool wnext = !(s4 == 3 && hs == 1);  // uniform
+            if (!have_p) aload(P, 0, s4, hs);
+            aload(Q, 1, s4, hs);
+            if constexpr (BDB) {                       // all of the next slab's weights, in the order they are used
+                if (wnext) {
+#pragma unroll
+                    for (int pc = NPC - 1; pc >= 0; --pc) wreload(sn, nxt, pc);
+                }
+            }
+            // sched_barrier: the machine scheduler would otherwise hoist every LDS / weight load of the unrolled slabs to the
+            // top (it sees 512 registers) and spill hundreds of them; the loads stay where the pipeline wants them
+            auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+            fence();
+            if constexpr (NP == 6) {
+                pass(P, cur, 2); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 2); }
+                fence();
+                pass(P, cur, 1);
+                fence();
+                pass(Q, cur, 1); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 1); }
+                fence();
+                pass(P, cur, 0);
+                fence();
+                aload(P, 2, s4, hs);                   // piece 3 replaces piece 1 (done)
+                pass(Q, cur, 0);
+                fence();
+                if (prefetch) aload(Q, 0, s4 + 1, hs); // piece 1 of the next slab replaces piece 2 (done)
+                pass(P, cur, 0); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 0); }
+                fence();
+            } else {
+                pass(P, cur, 1); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 1); }
+                fence();
+                pass(P, cur, 0);
+                fence();
+                if (prefetch) aload(P, 0, s4 + 1, hs);
+                pass(Q, cur, 0); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 0); }
+                fence();
+            }
+        };
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {               // x half (slabs 0..3), h half (slabs 4..7); straight-line code: no branches
+            if constexpr (NP == 6) {                   // the prefetched piece 1 lands in Q: roles alternate
+                slab(fa, fb, 0, hs, false, true);
+                slab(fb, fa, 1, hs, true, true);
+                slab(fa, fb, 2, hs, true, true);
+                slab(fb, fa, 3, hs, true, false);
+            } else {                                   // the prefetched piece 1 lands in P
+                slab(fa, fb, 0, hs, false, true);
+                slab(fa, fb, 1, hs, true, true);
+                slab(fa, fb, 2, hs, true, true);
+                slab(fa, fb, 3, hs, true, false);
+            }
+        }
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); st_mfma += st_b - st_a; }
+        __syncthreads();                               // every wave is done reading the image of this step
+
+        // ---- LSTM cell, lane-local; h -> bf16 pieces in the image (next step's operand) and fp32 to HBM.  The next step's x
+        // is requested XDEPTH cell tiles ahead of the point where it is split into the image (its latency hides behind the
+        // cell arithmetic; only XDEPTH chunks of it are in registers at a time).
+        constexpr int XDEPTH = 2;
+        const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
+        const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;       // after the last step: harmless re-staging of x_t
+#pragma unroll
+        for (int k = 0; k < XDEPTH - 1 && k < NCHUNK; ++k) x_issue(tn, k);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt + XDEPTH - 1 < NCHUNK) x_issue(tn, nt + XDEPTH - 1);
+            if (nt == NT - 1) {                        // next step's first k-slab of weights (buffer 0), pieces in the order of use
+#pragma unroll
+                for (int pc = NPC - 1; pc >= 0; --pc) wreload(0, 0, pc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned ho[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ho[e] = rowoff_h[16 * nt + 4 * q + e] + hcol;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ig = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
+                    const float fg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
+                    const float gg = tanh_b<FAST>(acc[nt][2][u][e], bias[2][u]);
+                    const float og = sigmoid_b<FAST>(acc[nt][3][u][e], bias[3][u]);
+                    const float cn = fg * c[nt][u][e] + ig * gg;
+                    c[nt][u][e] = cn;
+                    const float h = og * tanh_f<FAST>(cn);
+                    unsigned p1, p2, p3;
+                    split3(h, p1, p2, p3);
+                    char* d = img + (nt == NT - 1 ? hb_last[e] : hb[e] + nt * 8192) + ((u ^ (e >> 1)) << 5);
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p1;
+                    *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)p2;
+                    if (NPC == 3) *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)p3;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrs, ho[e] + 64 * u, 0, 0);
+                }
+            if (nt < NCHUNK) x_commit(tn, nt, more);
+            __builtin_amdgcn_sched_barrier(0);         // keep the x chunks (and their registers) in this order
+        }
+#pragma unroll
+        for (int k = NT; k < NCHUNK; ++k) x_commit(tn, k, more);
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_cell += __builtin_amdgcn_s_memtime() - st_b; __builtin_amdgcn_sched_barrier(0); }
+        __syncthreads();
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = __builtin_amdgcn_s_memtime() - st_t0;          // shader cycles, whole step loop
+            o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;      // 100 MHz ticks
+            o[2] = st_mfma;                                       // cycles in the MFMA phase (wave 0)
+            o[3] = st_cell;                                       // cycles in cell update + x staging, before the barrier
+            o[4] = st_r0;
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[6] = xcc; o[7] = hwid;
+        }
+    }
+}
+
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false>
+int launch_split_wide(const RecurArgs& a, hipStream_t st) {
+    constexpr int NT = (NSR + 15) / 16;
+    const size_t lds = (size_t)(NP == 6 ? 3 : 2) * NSR * 512 + (size_t)(NSR + 16 * NT + 2 * NSR + 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split_wide): %s", hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    dim3 grid((a.nseq + NSR - 1) / NSR, a.ndir);
+    hipLaunchKernelGGL((bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP>), grid, dim3(256), lds, st, a);
+    return dprnn_check_launch("bilstm_split_wide_kernel");
+}
+
+template <int NSR>
+int launch_split_wide_any(const RecurArgs& a, int products, bool fast, hipStream_t st) {
+    if constexpr (NSR == 64 || NSR == 104) {          // diagnostic build with in-kernel stamps (tools/bench_recur.py --stamps)
+        if (a.stamps && products == 6) return launch_split_wide<NSR, 6, true, false, true>(a, st);
+    }
+    const bool fuse = a.Z != nullptr;
+    if (products == 6) {
+        if (fast) return fuse ? launch_split_wide<NSR, 6, true, true>(a, st) : launch_split_wide<NSR, 6, true, false>(a, st);
+        return fuse ? launch_split_wide<NSR, 6, false, true>(a, st) : launch_split_wide<NSR, 6, false, false>(a, st);
+    }
+    if (fast) return fuse ? launch_split_wide<NSR, 3, true, true>(a, st) : launch_split_wide<NSR, 3, true, false>(a, st);
+    return fuse ? launch_split_wide<NSR, 3, false, true>(a, st) : launch_split_wide<NSR, 3, false, false>(a, st);
+}
+
 }  // namespace
 
 int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st) {
-    // the weight stream from L2 (~70 GB/s per CU) bounds this kernel: 64 sequences per workgroup halve its bytes per FLOP
-    if (seq_tile == 64) {
+    // wide form: one workgroup per CU, one pass over the weights per step for 48 .. 104 sequences
+    switch (seq_tile) {
+        case 64: return launch_split_wide_any<64>(a, products, fast, st);
+        case 80: return launch_split_wide_any<80>(a, products, fast, st);
+        case 96: return launch_split_wide_any<96>(a, products, fast, st);
+        case 104: return launch_split_wide_any<104>(a, products, fast, st);
+        default: break;
+    }
+    // two workgroups per CU (L2-weight-stream bound, ~65 GB/s per CU): small launches; -48 / -64 keep the round-1 forms for A/B
+    if (seq_tile == -64) {
         if (products == 6) return fast ? launch_split<4, 6, true>(a, st) : launch_split<4, 6, false>(a, st);
         return fast ? launch_split<4, 3, true>(a, st) : launch_split<4, 3, false>(a, st);
     }
-    if (seq_tile == 48) {       // two 48-sequence workgroups still fit one CU (2 x 76 KB of LDS): 2/3 of the weight bytes per FLOP
+    if (seq_tile == -48) {
         if (products == 6) return fast ? launch_split<3, 6, true>(a, st) : launch_split<3, 6, false>(a, st);
         return fast ? launch_split<3, 3, true>(a, st) : launch_split<3, 3, false>(a, st);
     }

@@ -41,6 +41,7 @@ FUSE_NORM = True
 # operands on the fp32 MFMA: the default, and what the parity claims and the bench headline refer to.  1 / 2 = bf16-split
 # operands (6 / 3 cross products) on the bf16 MFMA with fp32 accumulation: opt-in, reported separately.
 GEMM_MODE = 0
+SPLIT_ONE_GROUP = True      # bf16-split modes: the whole batch as one pipeline (the wide kernels take one workgroup per CU)
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
@@ -250,7 +251,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     if cell != 0 and tile > 32:
         tile = 32
     if cell == 0 and st.lib.dprnn_get_gemm_mode() != 0:
-        tile = 32                # the split kernel is L2-weight-stream bound: two 32-sequence workgroups per CU
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus())
     if g.pending is None:
         st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
@@ -272,6 +273,26 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         g.pending = (stats_slot, gamma, beta, eps)
     else:
         st.call("dprnn_norm_residual_fwd", _p(g.X), _p(Z), _p(stats_slot), _p(gamma), _p(beta), eps, _p(g.X), B, S * K)
+
+
+# bf16-split gate GEMM: measured cost of one time step of one workgroup, in microseconds (profiles/r02_split_wide.txt), for the
+# two-per-CU 32-sequence form and the wide one-per-CU forms; a launch takes ceil(workgroups / slots) rounds of T steps each
+SPLIT_STEP_US = {32: 24.2, 64: 15.0, 80: 18.5, 96: 21.5, 104: 23.5}
+SPLIT_SLOTS_PER_CU = {32: 2, 64: 1, 80: 1, 96: 1, 104: 1}
+
+
+def split_tile(nseq: int, ndir: int, ncu: int) -> int:
+    """Sequences per workgroup for the bf16-split recurrence over nseq sequences x ndir directions: the tile whose grid
+    takes the least time, rounds x cost of a step.  64 x 3 s at the shipped sizes: intra-chunk 2 x 12 416 -> 104 (240
+    workgroups, one round), inter-chunk 2 x 16 000 -> 64 (500 workgroups, two full rounds)."""
+    best, best_t = 32, None
+    for tile, us in SPLIT_STEP_US.items():
+        wgs = ndir * -(-nseq // tile)
+        rounds = -(-wgs // (ncu * SPLIT_SLOTS_PER_CU[tile]))
+        t = rounds * us * (1.0 if wgs >= ncu * SPLIT_SLOTS_PER_CU[tile] or tile != 32 else 0.6)    # a lone 32-tile per CU runs faster
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = tile, t
+    return best
 
 
 GROUP_SIZES = None        # experiment knob: explicit utterance-group sizes (must sum to the batch), else an even split
@@ -316,6 +337,8 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
     parts = _split(B) if debug is None else [(0, B)]
+    if st.lib.dprnn_get_gemm_mode() != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP:
+        parts = [(0, B)]        # the wide bf16-split kernels fill the chip with one workgroup per CU: one pipeline
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
     else:
