@@ -227,6 +227,8 @@ def main():
     if args.min_group is not None:
         engine.MIN_GROUP_BATCH = args.min_group
     engine.GEMM_MODE = args.gemm_mode
+    if args.groups is not None:
+        engine.SPLIT_ONE_GROUP = False          # an explicit group count also applies to the bf16-split modes
     if args.group_sizes:
         engine.GROUP_SIZES = [int(v) for v in args.group_sizes.split(",")]
 

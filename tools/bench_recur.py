@@ -13,7 +13,7 @@ from tss_with_dprnn_amd import engine  # noqa: E402
 
 
 def run(st, seq_tile, nwg, T, ndir=2, iters=3):
-    nseq = nwg * abs(seq_tile) // ndir
+    nseq = nwg * (abs(seq_tile) % 1000) // ndir       # 1048 / 1064 = overlapped bf16-split forms of 48 / 64 sequences
     X = torch.randn(nseq * T, 128, device="cuda") * 0.5
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
@@ -170,7 +170,7 @@ def stamps_split(st, seq_tile, T, ndir=2):
     """In-kernel stamps of the wide bf16-split kernel (gemm mode 1): one workgroup per CU, phase cycles of wave 0."""
     ncu = st.lib.dprnn_num_cus()
     nwg = ncu
-    nseq = nwg * seq_tile // ndir
+    nseq = nwg * (seq_tile % 1000) // ndir
     X = torch.randn(nseq * T, 128, device="cuda") * 0.5
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
@@ -192,8 +192,10 @@ def stamps_split(st, seq_tile, T, ndir=2):
     b = buf.cpu().double()
     cyc, ticks, mf, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
     print(f"split-wide stamps seq_tile={seq_tile}: {ms:.3f} ms = {tf:.1f} TFLOP/s (fp32-equivalent), in-kernel clock {cyc / ticks * 100:.0f} MHz; "
-          f"per step: total {cyc / T:.0f} cyc, MFMA phase {mf / T:.0f}, cell + x staging {cell / T:.0f}, barriers/other {(cyc - mf - cell) / T:.0f}"
-          f"  [bf16 MFMA floor {seq_tile // 16 + (1 if seq_tile % 16 else 0)} tiles x 1536 x 16 / 4 = {((seq_tile + 15) // 16) * 1536 * 4} cyc]")
+          f"per step: total {cyc / T:.0f} cyc, " + (f"MFMA phase {mf / T:.0f}, cell + x staging {cell / T:.0f}" if seq_tile < 1000 else
+                                                     f"phase 1 (h half + x staging) {mf / T:.0f}, phase 2 (x half + cell) {cell / T:.0f}") +
+          f", barriers/other {(cyc - mf - cell) / T:.0f}  [bf16 MFMA floor {(seq_tile % 1000 + 15) // 16} tiles x 1536 x 16 / 4 = "
+          f"{((seq_tile % 1000 + 15) // 16) * 1536 * 4} cyc]")
 
 
 def main():
@@ -212,7 +214,7 @@ def main():
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
     if a.stamps and a.gemm_mode == 1:
-        for seq_tile in (64, 104):
+        for seq_tile in (64, 1064):
             stamps_split(st, seq_tile, a.T)
         return
     if a.stamps:
@@ -235,9 +237,9 @@ def main():
     if a.gemm_mode != 0:       # bf16-split modes: the two-per-CU form, the round-1 64-sequence form and the wide one-per-CU forms
         np_ = 6 if a.gemm_mode == 1 else 3
         print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
-        for seq_tile, per_cu in ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (104, 1)):
+        for seq_tile, per_cu in ((32, 2), (-48, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (1064, 1)):
             ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
-            tiles = (abs(seq_tile) + 15) // 16
+            tiles = (abs(seq_tile) % 1000 + 15) // 16
             floor_us = per_cu * tiles * 32 * 8 * np_ * 16 / 4 / 2.4e3
             print(f"{seq_tile:8d} {per_cu:4d} {ms:8.3f} {ms * 1e3 / a.T:8.2f} {tf:8.1f} {floor_us:8.2f}")
         return

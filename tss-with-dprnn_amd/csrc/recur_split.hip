@@ -15,6 +15,8 @@
 // pre-split by dprnn_lstm_pack_split into [dir][wave][k-slab 8][gate 4][u 2][piece 3][lane 64] 16-byte fragments
 // (lane (r, q) = unit row r, k = 32*slab + 8*q .. +7: the B operand of v_mfma_f32_16x16x32_bf16).
 #include "recur.h"
+#include <stdlib.h>
+#include <type_traits>
 using namespace recur;
 
 namespace {
@@ -44,11 +46,31 @@ __device__ __forceinline__ void split3(float v, unsigned& p1, unsigned& p2, unsi
     p3 = bf16_bits(r2);
 }
 
+// (v0, v1) -> three words of packed bf16 pieces (low half = v0's piece, high half = v1's)
+__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+template <int NPC>
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = cvt_pk(v0, v1);
+    const float a0 = v0 - __builtin_bit_cast(float, w1 << 16), a1 = v1 - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = cvt_pk(a0, a1);
+    w3 = 0u;
+    if constexpr (NPC == 3) {
+        const float b0 = a0 - __builtin_bit_cast(float, w2 << 16), b1 = a1 - __builtin_bit_cast(float, w2 & 0xffff0000u);
+        w3 = cvt_pk(b0, b1);
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// packed[dir][wave][slab][gate*2+u][piece][lane][4 u32] : bf16 piece `piece` of Wcat[gate*128 + 32*wave + 16*u + r][32*slab + 8*q + j]
+// packed[dir][wave][slab][gate*2+u][piece][lane][4 u32] : bf16 piece `piece` of Wcat[gate*128 + 32*wave + 2*r + u][32*slab + 8*q + j]
+// (a lane's two column tiles u = 0, 1 are the adjacent hidden units 2r, 2r+1: their h pieces share one 32-bit LDS store
+// and their fp32 h one 64-bit global store)
 __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                        const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                        const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
@@ -60,7 +82,7 @@ __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const flo
     const int dw = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, slab = (idx >> 11) & 7;
     const int wave = (idx >> 14) & 3, dir = idx >> 16;
     const int gate = gu >> 1, u = gu & 1, r = lane & 15, q = lane >> 4;
-    const int row = gate * HD + 32 * wave + 16 * u + r;
+    const int row = gate * HD + 32 * wave + 2 * r + u;      // lane r of a wave owns the ADJACENT units 2r, 2r+1 (u = 0, 1)
     const float* wi = dir ? w_ih_r : w_ih;
     const float* wh = dir ? w_hh_r : w_hh;
     unsigned out[3] = {0u, 0u, 0u};
@@ -118,7 +140,7 @@ void bilstm_split_kernel(RecurArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int seq = seq0 + 16 * nt + 4 * q + e;
             hval[nt][e] = seq < a.nseq;
-            hoff[nt][e] = (unsigned)((rowbase(hval[nt][e] ? seq : seq0) - row0) * hpitch + dir * HD + 32 * wave + r) * 4u;
+            hoff[nt][e] = (unsigned)((rowbase(hval[nt][e] ? seq : seq0) - row0) * hpitch + dir * HD + 32 * wave + 2 * r) * 4u;
         }
     const bool fuse = a.Z != nullptr;
     f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f};
@@ -147,7 +169,7 @@ void bilstm_split_kernel(RecurArgs a) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 2 * r + u];
             bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
         }
 
@@ -257,11 +279,11 @@ void bilstm_split_kernel(RecurArgs a) {
                     const float h = og * tanh_f<FAST>(cn);
                     unsigned p1, p2, p3;
                     split3(h, p1, p2, p3);
-                    char* d = img + (16 * nt + 4 * q + e) * PITCH + 2 * (HD + 32 * wave + 16 * u + r);
+                    char* d = img + (16 * nt + 4 * q + e) * PITCH + 2 * (HD + 32 * wave + 2 * r + u);
                     *reinterpret_cast<unsigned short*>(d) = (unsigned short)p1;
                     *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)p2;
                     if (NPC == 3) *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)p3;
-                    if (hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 64 * u) = h;
+                    if (hval[nt][e]) *reinterpret_cast<float*>(hs + hoff[nt][e] + 4 * u) = h;
                 }
         if (more) stage_x(dir ? (t - 1) : (t + 1));
         __syncthreads();
@@ -302,7 +324,9 @@ int launch_split(const RecurArgs& a, hipStream_t st) {
 //     beyond the buffer range (stores dropped by the hardware) and are never written to the image;
 //   * a last tile of 8 rows (NSR = 104) re-reads existing rows for its missing ones; their results are never stored.
 // Product order per k-slab (A piece, W piece): (1,3) (1,2) (2,2) (1,1) (2,1) (3,1) -- every term of order <= 2^-16.
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false>
+// DIAG (stamped diagnostic builds only, wrong results on purpose): 1 = weight fragments loaded once (no L2 stream),
+// 2 = A fragments loaded once per step (no LDS operand traffic), 3 = both: what the MFMA phase costs without its loads.
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, int DIAG = 0>
 __global__ __launch_bounds__(256, 1)
 void bilstm_split_wide_kernel(RecurArgs a) {
     constexpr int NT = (NSR + 15) / 16;
@@ -312,6 +336,9 @@ void bilstm_split_wide_kernel(RecurArgs a) {
     constexpr int NPC = NP == 6 ? 3 : 2;
     constexpr int PLANE = NSR * 512;                   // bytes
     constexpr bool BDB = NT <= 4;
+    // once-touched activation streams (x, z in; h, x' out) are marked non-temporal so that they do not displace the weight
+    // slices, which every CU re-reads each step, from the XCD's L2 (DIAG & 4: default policy, for A/B timing)
+    constexpr int STREAM_AUX = (DIAG & 4) ? 0 : 2;
     constexpr int NBUF = BDB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char img[];       // [NPC][NSR][512 B] + row tables
     unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + NPC * PLANE);     // [NSR]  byte offset of the row in X
@@ -366,7 +393,7 @@ void bilstm_split_wide_kernel(RecurArgs a) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 16 * u + r];
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 2 * r + u];
             bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
         }
 
@@ -396,8 +423,8 @@ void bilstm_split_wide_kernel(RecurArgs a) {
 #pragma unroll
         for (int m = k * XCH; m < (k + 1) * XCH && m < NXV; ++m) {
             xo[m] = rowoff_x[xrow0 + 8 * m] + c4 * 16u;
-            xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[m], 0, 0));
-            if (fuse) zv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo[m], 0, 0));
+            xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[m], 0, STREAM_AUX));
+            if (fuse) zv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo[m], 0, STREAM_AUX));
         }
     };
     // `live` false (after the last step): the same code runs on the current step's rows again -- no branch inside the step
@@ -412,15 +439,14 @@ void bilstm_split_wide_kernel(RecurArgs a) {
                 const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zv[m][e] - mu) * rs * gam[e] + bet[e]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[m] : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[m] : OOB, 0, STREAM_AUX);
             }
-            unsigned p[3][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+            unsigned pa[3], pb[3];
+            split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+            split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
             char* d = img + ((m & 1) ? xl_odd : xl_even) + m * 4096;
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc)
-                *reinterpret_cast<u32x2*>(d + pc * PLANE) = u32x2{p[pc][0] | (p[pc][1] << 16), p[pc][2] | (p[pc][3] << 16)};
+            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PLANE) = u32x2{pa[pc], pb[pc]};
         }
     };
 
@@ -446,23 +472,24 @@ void bilstm_split_wide_kernel(RecurArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sl[j] = (j ^ ((r >> 2) & 3)) << 6; sl_last[j] = (j ^ ((rl >> 2) & 3)) << 6; }
     auto aload = [&](u32x4 (&af)[NT], int pc, int s4, int hs) __attribute__((always_inline)) {
+        if ((DIAG & 2) != 0 && (s4 != 0 || hs != 0 || pc > 1)) return;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int off = (nt == NT - 1 && LASTROWS != 16) ? (abase_last + sl_last[s4]) : (nt * 8192 + abase + sl[s4]);
             af[nt] = *reinterpret_cast<const u32x4*>(img + pc * PLANE + off + hs * 256);
         }
     };
-    // element (row 16 nt + 4q + e, unit 32 wave + 16 u + r) of h in the image: + nt*8192 + ((u ^ (e>>1)) << 5) + piece*PLANE
+    // elements (row 16 nt + 4q + e, units 32 wave + 2r, + 1) of h in the image: one 32-bit word per piece, + nt*8192 + piece*PLANE.
     // A last tile of 8 rows: its lanes q >= 2 hold exact copies of rows 0..7 (they read those rows as A operands and start
     // from the same zero state), so they write the same values to the same addresses as lanes q - 2 -- no predication.
     int hb[4], hb_last[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        hb[e] = (4 * q + e) * 512 + 256 + ((wave ^ q) << 6) + (((r >> 3) ^ (e & 1)) << 4) + 2 * (r & 7);
+        hb[e] = (4 * q + e) * 512 + ((16 | ((wave ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3);
         const int ql = LASTROWS == 16 ? q : (q & 1);
-        hb_last[e] = (16 * (NT - 1) + 4 * ql + e) * 512 + 256 + ((wave ^ ql) << 6) + (((r >> 3) ^ (e & 1)) << 4) + 2 * (r & 7);
+        hb_last[e] = (16 * (NT - 1) + 4 * ql + e) * 512 + ((16 | ((wave ^ ql) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3);
     }
-    const unsigned hcol = (unsigned)(dir * HD + 32 * wave + r) * 4u;
+    const unsigned hcol = (unsigned)(dir * HD + 32 * wave + 2 * r) * 4u;
 
     u32x4 bw[NBUF][4][2][NPC];
 #pragma unroll
@@ -480,24 +507,19 @@ void bilstm_split_wide_kernel(RecurArgs a) {
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const long long t = dir ? (T - 1 - step) : step;
         const bool more = step + 1 < T;
-        f32x4 acc[NT][4][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[nt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+        f32x4 acc[NT][4][2];                           // the first product of a step starts every accumulator from an inline zero
         u32x4 fa[NT], fb[NT];                          // two A-fragment sets (one piece of every tile each)
-        auto pass = [&](const u32x4 (&af)[NT], int buf, int wpc) __attribute__((always_inline)) {
+        auto pass = [&](const u32x4 (&af)[NT], int buf, int wpc, bool first = false) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[nt][g][u] = mfma_bf16(af[nt], bw[buf][g][u][wpc], acc[nt][g][u]);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][g][u] = mfma_bf16(af[nt], bw[buf][g][u][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt][g][u]);
         };
         auto wreload = [&](int sn, int buf, int wpc) __attribute__((always_inline)) {     // W piece wpc of slab sn
+            if constexpr ((DIAG & 1) != 0) return;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -523,7 +545,7 @@ void bilstm_split_wide_kernel(RecurArgs a) {
             auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
             fence();
             if constexpr (NP == 6) {
-                pass(P, cur, 2); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 2); }
+                pass(P, cur, 2, s4 == 0 && hs == 0); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 2); }
                 fence();
                 pass(P, cur, 1);
                 fence();
@@ -538,7 +560,7 @@ void bilstm_split_wide_kernel(RecurArgs a) {
                 pass(P, cur, 0); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 0); }
                 fence();
             } else {
-                pass(P, cur, 1); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 1); }
+                pass(P, cur, 1, s4 == 0 && hs == 0); if constexpr (!BDB) { if (wnext) wreload(sn, 0, 1); }
                 fence();
                 pass(P, cur, 0);
                 fence();
@@ -575,7 +597,9 @@ void bilstm_split_wide_kernel(RecurArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (nt + XDEPTH - 1 < NCHUNK) x_issue(tn, nt + XDEPTH - 1);
-            if (nt == NT - 1) {                        // next step's first k-slab of weights (buffer 0), pieces in the order of use
+            // next step's first k-slab of weights (buffer 0), pieces in the order of use: at once when the weights are
+            // double-buffered (buffer 0 is free through the whole cell phase), else before the last tile (registers)
+            if (nt == (BDB ? 0 : NT - 1)) {
 #pragma unroll
                 for (int pc = NPC - 1; pc >= 0; --pc) wreload(0, 0, pc);
             }
@@ -583,25 +607,30 @@ void bilstm_split_wide_kernel(RecurArgs a) {
             unsigned ho[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) ho[e] = rowoff_h[16 * nt + 4 * q + e] + hcol;
+            float hv[2][4];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float ig = sigmoid_b<FAST>(acc[nt][0][u][e], bias[0][u]);
-                    const float fg = sigmoid_b<FAST>(acc[nt][1][u][e], bias[1][u]);
-                    const float gg = tanh_b<FAST>(acc[nt][2][u][e], bias[2][u]);
-                    const float og = sigmoid_b<FAST>(acc[nt][3][u][e], bias[3][u]);
-                    const float cn = fg * c[nt][u][e] + ig * gg;
-                    c[nt][u][e] = cn;
-                    const float h = og * tanh_f<FAST>(cn);
-                    unsigned p1, p2, p3;
-                    split3(h, p1, p2, p3);
-                    char* d = img + (nt == NT - 1 ? hb_last[e] : hb[e] + nt * 8192) + ((u ^ (e >> 1)) << 5);
-                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p1;
-                    *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)p2;
-                    if (NPC == 3) *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)p3;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrs, ho[e] + 64 * u, 0, 0);
+                for (int p2 = 0; p2 < 2; ++p2) {       // two rows per instruction where the arithmetic allows (v_pk_*)
+                    const f32x2 ig = sigmoid_b2<FAST>(f32x2{acc[nt][0][u][2 * p2], acc[nt][0][u][2 * p2 + 1]}, bias[0][u]);
+                    const f32x2 fg = sigmoid_b2<FAST>(f32x2{acc[nt][1][u][2 * p2], acc[nt][1][u][2 * p2 + 1]}, bias[1][u]);
+                    const f32x2 gg = tanh_b2<FAST>(f32x2{acc[nt][2][u][2 * p2], acc[nt][2][u][2 * p2 + 1]}, bias[2][u]);
+                    const f32x2 og = sigmoid_b2<FAST>(f32x2{acc[nt][3][u][2 * p2], acc[nt][3][u][2 * p2 + 1]}, bias[3][u]);
+                    const f32x2 cn = fg * f32x2{c[nt][u][2 * p2], c[nt][u][2 * p2 + 1]} + ig * gg;
+                    const f32x2 h2 = og * tanh_f2<FAST>(cn);
+                    c[nt][u][2 * p2] = cn[0]; c[nt][u][2 * p2 + 1] = cn[1];
+                    hv[u][2 * p2] = h2[0]; hv[u][2 * p2 + 1] = h2[1];
                 }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned w1, w2, w3;
+                split3_pair<NPC>(hv[0][e], hv[1][e], w1, w2, w3);
+                char* d = img + (nt == NT - 1 ? hb_last[e] : hb[e] + nt * 8192);
+                *reinterpret_cast<unsigned*>(d) = w1;
+                *reinterpret_cast<unsigned*>(d + PLANE) = w2;
+                if (NPC == 3) *reinterpret_cast<unsigned*>(d + 2 * PLANE) = w3;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(hv[0][e]), __float_as_uint(hv[1][e])}, hrs, ho[e], 0, STREAM_AUX);
+            }
             if (nt < NCHUNK) x_commit(tn, nt, more);
             __builtin_amdgcn_sched_barrier(0);         // keep the x chunks (and their registers) in this order
         }
@@ -626,26 +655,379 @@ void bilstm_split_wide_kernel(RecurArgs a) {
     }
 }
 
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, int DIAG = 0>
 int launch_split_wide(const RecurArgs& a, hipStream_t st) {
     constexpr int NT = (NSR + 15) / 16;
     const size_t lds = (size_t)(NP == 6 ? 3 : 2) * NSR * 512 + (size_t)(NSR + 16 * NT + 2 * NSR + 256) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP, DIAG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split_wide): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid((a.nseq + NSR - 1) / NSR, a.ndir);
-    hipLaunchKernelGGL((bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bilstm_split_wide_kernel<NSR, NP, FAST, FUSE, STAMP, DIAG>), grid, dim3(256), lds, st, a);
     return dprnn_check_launch("bilstm_split_wide_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// OVERLAPPED form (NSR = 48 or 64, one 4-wave workgroup per CU): the cell update is vector work -- ~45 instructions per
+// (sequence, unit), half as long as the step's bf16 MFMAs when it runs on its own (profiles/r02_split_wide.txt) -- and a bf16
+// MFMA leaves half of the SIMD's issue slots free.  The x half of the gate GEMM does not depend on h, so a step is cut
+// differently here, with TWO accumulator sets (2 x 16 NT x 128 values, all 256 AGPRs at NT = 4):
+//     phase 1   acc[cur] += h_{t-1} W_hh   (MFMA)   beside   x_{t+1} -> bf16 pieces -> image        (vector)
+//     barrier   (h_{t-1} no longer read; x_{t+1} in place)
+//     phase 2   acc[nxt]  = x_{t+1} W_ih   (MFMA)   beside   cell(t) from acc[cur]: c, h_t -> image, HBM   (vector)
+//     barrier   (h_t in place; x_{t+1} no longer read)
+// sched_group_barrier pins the instruction mix (one MFMA, then two vector instructions, ...): the hardware issues a wave's
+// instructions in order, so only an interleaved stream overlaps the two pipes.  Weight fragments (single-buffered, a piece
+// is re-requested for the next k-slab when its last product of this slab is done) stream continuously across both phases.
+#define DPRNN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+template <int NT, int NP, bool FAST, bool FUSE, bool STAMP = false>
+__global__ __launch_bounds__(256, 1)
+void bilstm_split_ov_kernel(RecurArgs a) {
+    static_assert(NT == 3 || NT == 4, "two accumulator sets fit the register file for 48 or 64 sequences");
+    constexpr int NSR = 16 * NT;
+    constexpr int NXV = NSR / 8;                       // float4 of x per thread and step
+    constexpr int NPC = NP == 6 ? 3 : 2;
+    constexpr int NPASS = NP == 6 ? 6 : 3;
+    constexpr int PLANE = NSR * 512;                   // bytes
+    extern __shared__ __attribute__((aligned(16))) char img[];       // [NPC][NSR][512 B] + row tables
+    unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + NPC * PLANE);
+    unsigned* const rowoff_h = rowoff_x + NSR;
+    float* const musig = reinterpret_cast<float*>(rowoff_h + NSR);
+    float* const gb = musig + 2 * NSR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * NSR;
+    const int T = a.T;
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    const long long row0 = rowbase(seq0);
+    const int hpitch = a.ndir * HD;
+    for (int j = tid; j < NSR; j += 256) {
+        const int seq = seq0 + j;
+        const bool valid = seq < a.nseq;
+        const long long ro = rowbase(valid ? seq : seq0) - row0;
+        rowoff_x[j] = (unsigned)(ro * F * 4);
+        rowoff_h[j] = valid ? (unsigned)(ro * hpitch * 4) : OOB;
+        if (FUSE) {
+            const int b = (valid ? seq : seq0) / a.seqs_per_utt;
+            const double cnt = (double)a.rows_per_utt * (double)F;
+            const double mean = a.stats[2 * b] / cnt;
+            double var = a.stats[2 * b + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            musig[2 * j] = (float)mean;
+            musig[2 * j + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+    }
+    if (FUSE && tid < 128) { gb[tid] = a.gamma[tid]; gb[128 + tid] = a.beta[tid]; }
+    const int c4 = tid & 31, xrow0 = tid >> 5;
+    const int xl_even = xrow0 * 512 + (((c4 >> 1) ^ xrow0) << 4) + ((c4 & 1) << 3);
+    const int xl_odd = xrow0 * 512 + (((c4 >> 1) ^ xrow0 ^ 8) << 4) + ((c4 & 1) << 3);
+    auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
+
+    float bias[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + 32 * wave + 2 * r + u];
+            bias[g][u] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+        }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.Wp) + (size_t)(dir * 4 + wave_u) * NSLAB * 8 * 3 * 64), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16u;
+    auto wload = [&](int slab, int gu, int pc) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(((slab * 8 + gu) * 3 + pc) * 1024), 0);
+    };
+    auto rsrc_at = [&](const float* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffffu, 0x00020000);
+    };
+
+    f32x4 xv[NXV], zv[NXV];
+    unsigned xo[NXV];
+    auto x_issue = [&](long long t, int m0, int m1) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+            xo[m] = rowoff_x[xrow0 + 8 * m] + c4 * 16u;
+            xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[m], 0, 0));
+            if (FUSE) zv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo[m], 0, 0));
+        }
+    };
+    auto x_commit = [&](long long t, int m0, int m1, bool live) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+            f32x4 v = xv[m];
+            if (FUSE) {
+                const float mu = musig[2 * (xrow0 + 8 * m)], rs = musig[2 * (xrow0 + 8 * m) + 1];
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zv[m][e] - mu) * rs * gam[e] + bet[e]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[m] : OOB, 0, 0);
+            }
+            unsigned pa[3], pb[3];
+            split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+            split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+            char* d = img + ((m & 1) ? xl_odd : xl_even) + m * 4096;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PLANE) = u32x2{pa[pc], pb[pc]};
+        }
+    };
+
+    __syncthreads();                                   // row tables are in place
+    x_issue(dir ? (T - 1) : 0, 0, NXV);
+    x_commit(dir ? (T - 1) : 0, 0, NXV, true);
+    for (int i = tid; i < NPC * NSR * 64; i += 256) {  // h half of every row
+        const int pl = i / (NSR * 64), rem = i % (NSR * 64);
+        *reinterpret_cast<unsigned*>(img + pl * PLANE + (rem >> 6) * 512 + 256 + 4 * (rem & 63)) = 0u;
+    }
+    f32x4 c[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c[nt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int abase = r * 512 + ((q ^ (r & 3)) << 4);
+    int sl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sl[j] = (j ^ ((r >> 2) & 3)) << 6;
+    auto aload = [&](u32x4 (&af)[NT], int pc, int s4, int hs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            af[nt] = *reinterpret_cast<const u32x4*>(img + pc * PLANE + nt * 8192 + abase + sl[s4] + hs * 256);
+    };
+    int hb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hb[e] = (4 * q + e) * 512 + ((16 | ((wave ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3);
+    const unsigned hcol = (unsigned)(dir * HD + 32 * wave + 2 * r) * 4u;
+
+    u32x4 bw[4][2][NPC];                               // B fragments of the k-slab in progress
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) bw[g][u][pc] = wload(0, g * 2 + u, pc);
+    f32x4 acc[2][NT][4][2];
+    u32x4 fa[NT], fb[NT];
+    __syncthreads();
+
+    auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    // One pass = the 8 NT MFMAs of weight piece `wpc` against the A fragments in af, in a scheduling region of its own,
+    // together with `work()` (vector instructions that do not depend on these MFMAs) and `loads()` (LDS / weight requests
+    // for later passes).  The sched_group_barrier sequence asks for MFMA, 2 vector, MFMA, 2 vector, ... with the memory
+    // instructions sprinkled in: a wave issues in order, so only an interleaved stream keeps both pipes busy.
+    auto pass = [&](f32x4 (&ac)[NT][4][2], const u32x4 (&af)[NT], int wpc, bool first, auto&& work, auto&& loads)
+                    __attribute__((always_inline)) {
+        fence();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    ac[nt][g][u] = mfma_bf16(af[nt], bw[g][u][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g][u]);
+        loads();
+        work();
+#pragma unroll
+        for (int i = 0; i < 8 * NT; ++i) {
+            DPRNN_SGB(0x008, 1);                       // MFMA
+            DPRNN_SGB(0x406, 2);                       // VALU | SALU | TRANS
+            if (i % 4 == 1) DPRNN_SGB(0x100, 1);       // DS read
+            if (i % 4 == 3) DPRNN_SGB(0x020, 1);       // VMEM read
+            if (i % 8 == 2) DPRNN_SGB(0x200, 1);       // DS write
+            if (i % 16 == 6) DPRNN_SGB(0x040, 1);      // VMEM write
+        }
+        fence();
+    };
+    auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bw[g][u][wpc] = wload(sn, g * 2 + u, wpc);
+    };
+    auto nothing = [&]() __attribute__((always_inline)) {};
+    // the MFMAs of one k-slab (k-slab s = 4 hs + s4; weights of slab s are in bw, those of s + 1 are requested as pieces
+    // die); work(p) = the vector work placed beside pass p
+    auto slab = [&](f32x4 (&ac)[NT][4][2], u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int hs, bool have_p, bool prefetch, bool first,
+                    auto&& work) __attribute__((always_inline)) {
+        const int sn = (4 * hs + s4 + 1) & 7;
+        fence();
+        if (!have_p) aload(P, 0, s4, hs);
+        aload(Q, 1, s4, hs);
+        if constexpr (NP == 6) {
+            pass(ac, P, 2, first, [&]() __attribute__((always_inline)) { work(0); }, [&]() __attribute__((always_inline)) { wreload(sn, 2); });
+            pass(ac, P, 1, false, [&]() __attribute__((always_inline)) { work(1); }, nothing);
+            pass(ac, Q, 1, false, [&]() __attribute__((always_inline)) { work(2); }, [&]() __attribute__((always_inline)) { wreload(sn, 1); });
+            pass(ac, P, 0, false, [&]() __attribute__((always_inline)) { work(3); }, nothing);
+            pass(ac, Q, 0, false, [&]() __attribute__((always_inline)) { work(4); }, [&]() __attribute__((always_inline)) { aload(P, 2, s4, hs); });
+            pass(ac, P, 0, false, [&]() __attribute__((always_inline)) { work(5); },
+                 [&]() __attribute__((always_inline)) { if (prefetch) aload(Q, 0, s4 + 1, hs); wreload(sn, 0); });
+        } else {
+            pass(ac, P, 1, first, [&]() __attribute__((always_inline)) { work(0); work(1); }, [&]() __attribute__((always_inline)) { wreload(sn, 1); });
+            pass(ac, P, 0, false, [&]() __attribute__((always_inline)) { work(2); work(3); }, nothing);
+            pass(ac, Q, 0, false, [&]() __attribute__((always_inline)) { work(4); work(5); },
+                 [&]() __attribute__((always_inline)) { if (prefetch) aload(P, 0, s4 + 1, hs); wreload(sn, 0); });
+        }
+    };
+    // cell update of tile nt from ac (lane-local), h -> image + HBM, cut into 12 units (two per pass of a 6-pass slab):
+    // unit 3e + u (u < 2) = gates and state of (row e, unit u); unit 3e + 2 = split h(e, 0..1) into pieces, store
+    float hh[2];
+    auto cell_unit = [&](f32x4 (&ac)[NT][4][2], int nt, int k, __amdgpu_buffer_rsrc_t hrs) __attribute__((always_inline)) {
+        const int e = k / 3, u = k % 3;
+        if (u < 2) {
+            const float ig = sigmoid_b<FAST>(ac[nt][0][u][e], bias[0][u]);
+            const float fg = sigmoid_b<FAST>(ac[nt][1][u][e], bias[1][u]);
+            const float gg = tanh_b<FAST>(ac[nt][2][u][e], bias[2][u]);
+            const float og = sigmoid_b<FAST>(ac[nt][3][u][e], bias[3][u]);
+            const float cn = fg * c[nt][u][e] + ig * gg;
+            c[nt][u][e] = cn;
+            hh[u] = og * tanh_f<FAST>(cn);
+        } else {
+            unsigned w1, w2, w3;
+            split3_pair<NPC>(hh[0], hh[1], w1, w2, w3);
+            char* d = img + hb[e] + nt * 8192;
+            *reinterpret_cast<unsigned*>(d) = w1;
+            *reinterpret_cast<unsigned*>(d + PLANE) = w2;
+            if (NPC == 3) *reinterpret_cast<unsigned*>(d + 2 * PLANE) = w3;
+            const unsigned ho = rowoff_h[16 * nt + 4 * q + e] + hcol;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(hh[0]), __float_as_uint(hh[1])}, hrs, ho, 0, 0);
+        }
+    };
+    auto no_work = [&](int) __attribute__((always_inline)) {};
+
+    // ---- prologue: acc[0] = x_{t0} W_ih (plain MFMA phase), then everybody is done reading x_{t0}
+    slab(acc[0], fa, fb, 0, 0, false, true, true, no_work);
+    if constexpr (NP == 6) {
+        slab(acc[0], fb, fa, 1, 0, true, true, false, no_work);
+        slab(acc[0], fa, fb, 2, 0, true, true, false, no_work);
+        slab(acc[0], fb, fa, 3, 0, true, false, false, no_work);
+    } else {
+        slab(acc[0], fa, fb, 1, 0, true, true, false, no_work);
+        slab(acc[0], fa, fb, 2, 0, true, true, false, no_work);
+        slab(acc[0], fa, fb, 3, 0, true, false, false, no_work);
+    }
+    __syncthreads();
+
+    unsigned long long st_t0 = 0, st_r0 = 0, st_p1 = 0, st_p2 = 0;
+    if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // one step; acur = accumulator set holding x_t W_ih on entry, anxt receives x_{t+1} W_ih
+    auto one_step = [&](f32x4 (&acur)[NT][4][2], f32x4 (&anxt)[NT][4][2], int step) __attribute__((always_inline)) {
+        unsigned long long st_a = 0, st_b = 0;
+        if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
+        const long long t = dir ? (T - 1 - step) : step;
+        const bool more = step + 1 < T;
+        const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;       // after the last step: harmless re-staging of x_t
+        // ---- phase 1: h half of the gates beside the staging of x_{t+1}: quads requested during slab 0 (first half) and
+        // slab 1 (second half), split into the image one quad per second pass of slabs 1..3
+        constexpr int XH = (NXV + 1) / 2;
+        constexpr int QPS = NP == 6 ? 3 : 3;            // quads committed per slab (passes 0, 2, 4; NP = 3: units 0, 2, 4)
+        auto xwork = [&](int slab_i, int p) __attribute__((always_inline)) {       // slab_i = 1..3
+            if (p % 2 == 0) {
+                const int m = (slab_i - 1) * QPS + p / 2;
+                if (m < NXV) x_commit(tn, m, m + 1, more);
+            }
+        };
+        fence();
+        x_issue(tn, 0, XH);
+        slab(acur, fa, fb, 0, 1, false, true, false, no_work);
+        fence();
+        x_issue(tn, XH, NXV);
+        if constexpr (NP == 6) slab(acur, fb, fa, 1, 1, true, true, false, [&](int p) __attribute__((always_inline)) { xwork(1, p); });
+        else slab(acur, fa, fb, 1, 1, true, true, false, [&](int p) __attribute__((always_inline)) { xwork(1, p); });
+        slab(acur, fa, fb, 2, 1, true, true, false, [&](int p) __attribute__((always_inline)) { xwork(2, p); });
+        if constexpr (NP == 6) slab(acur, fb, fa, 3, 1, true, false, false, [&](int p) __attribute__((always_inline)) { xwork(3, p); });
+        else slab(acur, fa, fb, 3, 1, true, false, false, [&](int p) __attribute__((always_inline)) { xwork(3, p); });
+        fence();
+        if constexpr (STAMP) { st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
+        __syncthreads();                               // h_{t-1} is no longer read; x_{t+1} is in place
+        // ---- phase 2: x half of the next step's gates beside the cell update of this step (one tile per k-slab)
+        const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
+        auto cwork = [&](int nt, int p) __attribute__((always_inline)) {
+            if (nt < NT) { cell_unit(acur, nt, 2 * p, hrs); cell_unit(acur, nt, 2 * p + 1, hrs); }
+        };
+        slab(anxt, fa, fb, 0, 0, false, true, true, [&](int p) __attribute__((always_inline)) { cwork(0, p); });
+        if constexpr (NP == 6) slab(anxt, fb, fa, 1, 0, true, true, false, [&](int p) __attribute__((always_inline)) { cwork(1, p); });
+        else slab(anxt, fa, fb, 1, 0, true, true, false, [&](int p) __attribute__((always_inline)) { cwork(1, p); });
+        slab(anxt, fa, fb, 2, 0, true, true, false, [&](int p) __attribute__((always_inline)) { cwork(2, p); });
+        if constexpr (NP == 6) slab(anxt, fb, fa, 3, 0, true, false, false, [&](int p) __attribute__((always_inline)) { cwork(3, p); });
+        else slab(anxt, fa, fb, 3, 0, true, false, false, [&](int p) __attribute__((always_inline)) { cwork(3, p); });
+        fence();
+        if constexpr (STAMP) { st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
+        __syncthreads();                               // h_t is in place; x_{t+1} is no longer read
+    };
+    for (int step = 0; step < T; step += 2) {
+        one_step(acc[0], acc[1], step);
+        if (step + 1 < T) one_step(acc[1], acc[0], step + 1);
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = __builtin_amdgcn_s_memtime() - st_t0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+            o[2] = st_p1;                                         // cycles in phase 1 (wave 0): h half + x staging
+            o[3] = st_p2;                                         // cycles in phase 2: x half + cell update
+            o[4] = st_r0;
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            o[6] = 0; o[7] = 0;
+        }
+    }
+}
+
+template <int NT, int NP, bool FAST, bool FUSE, bool STAMP = false>
+int launch_split_ov(const RecurArgs& a, hipStream_t st) {
+    constexpr int NSR = 16 * NT;
+    const size_t lds = (size_t)(NP == 6 ? 3 : 2) * NSR * 512 + (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_ov_kernel<NT, NP, FAST, FUSE, STAMP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split_ov): %s", hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    dim3 grid((a.nseq + NSR - 1) / NSR, a.ndir);
+    hipLaunchKernelGGL((bilstm_split_ov_kernel<NT, NP, FAST, FUSE, STAMP>), grid, dim3(256), lds, st, a);
+    return dprnn_check_launch("bilstm_split_ov_kernel");
+}
+
+template <int NT>
+int launch_split_ov_any(const RecurArgs& a, int products, bool fast, hipStream_t st) {
+    if constexpr (NT == 4) {
+        if (a.stamps && products == 6) return launch_split_ov<NT, 6, true, false, true>(a, st);
+    }
+    const bool fuse = a.Z != nullptr;
+    if (products == 6) {
+        if (fast) return fuse ? launch_split_ov<NT, 6, true, true>(a, st) : launch_split_ov<NT, 6, true, false>(a, st);
+        return fuse ? launch_split_ov<NT, 6, false, true>(a, st) : launch_split_ov<NT, 6, false, false>(a, st);
+    }
+    if (fast) return fuse ? launch_split_ov<NT, 3, true, true>(a, st) : launch_split_ov<NT, 3, true, false>(a, st);
+    return fuse ? launch_split_ov<NT, 3, false, true>(a, st) : launch_split_ov<NT, 3, false, false>(a, st);
 }
 
 template <int NSR>
 int launch_split_wide_any(const RecurArgs& a, int products, bool fast, hipStream_t st) {
-    if constexpr (NSR == 64 || NSR == 104) {          // diagnostic build with in-kernel stamps (tools/bench_recur.py --stamps)
-        if (a.stamps && products == 6) return launch_split_wide<NSR, 6, true, false, true>(a, st);
+    if constexpr (NSR == 64) {                         // diagnostic builds with in-kernel stamps (tools/bench_recur.py --stamps)
+        if (a.stamps && products == 6) {
+            const char* dg = getenv("DPRNN_DIAG");
+            switch (dg ? atoi(dg) : 0) {
+                case 1: return launch_split_wide<NSR, 6, true, false, true, 1>(a, st);
+                case 2: return launch_split_wide<NSR, 6, true, false, true, 2>(a, st);
+                case 3: return launch_split_wide<NSR, 6, true, false, true, 3>(a, st);
+                case 4: return launch_split_wide<NSR, 6, true, false, true, 4>(a, st);
+                default: return launch_split_wide<NSR, 6, true, false, true>(a, st);
+            }
+        }
     }
     const bool fuse = a.Z != nullptr;
     if (products == 6) {
@@ -661,6 +1043,8 @@ int launch_split_wide_any(const RecurArgs& a, int products, bool fast, hipStream
 int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st) {
     // wide form: one workgroup per CU, one pass over the weights per step for 48 .. 104 sequences
     switch (seq_tile) {
+        case 1048: return launch_split_ov_any<3>(a, products, fast, st);      // overlapped forms (cell update beside the x-half MFMAs)
+        case 1064: return launch_split_ov_any<4>(a, products, fast, st);
         case 64: return launch_split_wide_any<64>(a, products, fast, st);
         case 80: return launch_split_wide_any<80>(a, products, fast, st);
         case 96: return launch_split_wide_any<96>(a, products, fast, st);

@@ -277,7 +277,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
 
 # bf16-split gate GEMM: measured cost of one time step of one workgroup, in microseconds (profiles/r02_split_wide.txt), for the
 # two-per-CU 32-sequence form and the wide one-per-CU forms; a launch takes ceil(workgroups / slots) rounds of T steps each
-SPLIT_STEP_US = {32: 24.2, 64: 15.0, 80: 18.5, 96: 21.5, 104: 23.5}
+SPLIT_STEP_US = {32: 25.5, 64: 20.3, 80: 23.4, 96: 32.2, 104: 53.4}
 SPLIT_SLOTS_PER_CU = {32: 2, 64: 1, 80: 1, 96: 1, 104: 1}
 
 
