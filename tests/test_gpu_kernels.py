@@ -146,7 +146,7 @@ def test_bilstm_split_gemm_modes(mode, tol, path):
     assert err < tol
 
 
-@pytest.mark.parametrize("seq_tile", [32, 64, 80, 96, 104, -64, 1048, 1064])
+@pytest.mark.parametrize("seq_tile", [32, 64, 80, 96, 104, -64, 1048, 1064, 2064, 2080, 2096, 3048, 3064])
 @pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
 @pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
 def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):

@@ -155,7 +155,7 @@ def test_optional_split_gemm_modes_full_size(mode, tol):
         with torch.no_grad():
             out = model(x).cpu().numpy()
     finally:
-        engine.GEMM_MODE = 0
+        engine.GEMM_MODE = engine.DEFAULT_GEMM_MODE
     with torch.no_grad():
         exact = model(x).cpu().numpy()
     r = rel_l2(out, g["out"])
@@ -234,7 +234,7 @@ def test_headline_batch_b64_full_size():
     batch-of-one forward, which takes the small-batch tiles on a single stream (tolerance 2e-6: the two differ only in
     the grouping of the fp64 GroupNorm sums and the MFMA tile a sequence lands in)."""
     from tss_with_dprnn_amd import engine
-    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == 0 and engine.GROUP_SIZES is None
+    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
     model, sd, cfg = build_model("bss", dict(), 0, _dev())
     B, T = 64, 24000
     x = make_mixture(B, T, seed=1234)

@@ -214,7 +214,7 @@ def main():
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
     if a.stamps and a.gemm_mode == 1:
-        for seq_tile in (64, 1064):
+        for seq_tile in (64, 2064, 3064):
             stamps_split(st, seq_tile, a.T)
         return
     if a.stamps:
@@ -237,7 +237,7 @@ def main():
     if a.gemm_mode != 0:       # bf16-split modes: the two-per-CU form, the round-1 64-sequence form and the wide one-per-CU forms
         np_ = 6 if a.gemm_mode == 1 else 3
         print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
-        for seq_tile, per_cu in ((32, 2), (-48, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (1064, 1)):
+        for seq_tile, per_cu in ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1)):
             ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
             tiles = (abs(seq_tile) % 1000 + 15) // 16
             floor_us = per_cu * tiles * 32 * 8 * np_ * 16 / 4 / 2.4e3

@@ -670,7 +670,7 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
     if (g_gemm_mode == 1) {                 // wide bf16-split kernel with stamps (seq_tile 64 or 104; packed by dprnn_rnn_pack in mode 1)
-        if (seq_tile != 64 && seq_tile != 1064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64 and 1064"); return -1; }
+        if (seq_tile != 64 && seq_tile != 1064 && seq_tile != 2064 && seq_tile != 3064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64, 1064, 2064, 3064"); return -1; }
         return launch_bilstm_split(a, 6, seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {

@@ -9,6 +9,7 @@ those kernels.  Stage order follows the reference forward:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -40,8 +41,9 @@ FUSE_NORM = True
 # OPTIONAL arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).  0 = exact fp32
 # operands on the fp32 MFMA: the default, and what the parity claims and the bench headline refer to.  1 / 2 = bf16-split
 # operands (6 / 3 cross products) on the bf16 MFMA with fp32 accumulation: opt-in, reported separately.
-GEMM_MODE = 0
-SPLIT_ONE_GROUP = True      # bf16-split modes: the whole batch as one pipeline (the wide kernels take one workgroup per CU)
+DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "0"))
+GEMM_MODE = DEFAULT_GEMM_MODE
+SPLIT_ONE_GROUP = True      # bf16-split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
@@ -251,7 +253,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     if cell != 0 and tile > 32:
         tile = 32
     if cell == 0 and st.lib.dprnn_get_gemm_mode() != 0:
-        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus())
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent)
     if g.pending is None:
         st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
@@ -275,21 +277,25 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         st.call("dprnn_norm_residual_fwd", _p(g.X), _p(Z), _p(stats_slot), _p(gamma), _p(beta), eps, _p(g.X), B, S * K)
 
 
-# bf16-split gate GEMM: measured cost of one time step of one workgroup, in microseconds (profiles/r02_split_wide.txt), for the
-# two-per-CU 32-sequence form and the wide one-per-CU forms; a launch takes ceil(workgroups / slots) rounds of T steps each
-SPLIT_STEP_US = {32: 25.5, 64: 20.3, 80: 23.4, 96: 32.2, 104: 53.4}
-SPLIT_SLOTS_PER_CU = {32: 2, 64: 1, 80: 1, 96: 1, 104: 1}
+# bf16-split gate GEMM: measured cost of one time step of one workgroup, in microseconds (profiles/r02_split_wide.txt): the
+# two-per-CU 32-sequence form and the one-per-CU eight-wave forms (seq_tile code 2000 + sequences); a launch takes
+# ceil(workgroups / slots) rounds of T steps each
+SPLIT_STEP_US = {32: 25.0, 2064: 18.8, 2080: 23.0}
+SPLIT_SLOTS_PER_CU = {32: 2, 2064: 1, 2080: 1}
+SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split modes: one group's launches rarely fill 256 CUs exactly
 
 
-def split_tile(nseq: int, ndir: int, ncu: int) -> int:
-    """Sequences per workgroup for the bf16-split recurrence over nseq sequences x ndir directions: the tile whose grid
-    takes the least time, rounds x cost of a step.  64 x 3 s at the shipped sizes: intra-chunk 2 x 12 416 -> 104 (240
-    workgroups, one round), inter-chunk 2 x 16 000 -> 64 (500 workgroups, two full rounds)."""
+def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1) -> int:
+    """seq_tile code for the bf16-split recurrence over nseq sequences x ndir directions: the form whose grid takes the
+    least time, rounds x cost of a step (64 x 3 s in two groups: 194 / 250 workgroups of 64 sequences per launch)."""
     best, best_t = 32, None
     for tile, us in SPLIT_STEP_US.items():
-        wgs = ndir * -(-nseq // tile)
-        rounds = -(-wgs // (ncu * SPLIT_SLOTS_PER_CU[tile]))
-        t = rounds * us * (1.0 if wgs >= ncu * SPLIT_SLOTS_PER_CU[tile] or tile != 32 else 0.6)    # a lone 32-tile per CU runs faster
+        wgs = ndir * -(-nseq // (tile % 1000))
+        slots = ncu * SPLIT_SLOTS_PER_CU[tile]
+        rounds = -(-wgs * concurrent // slots) / concurrent
+        t = rounds * us
+        if tile == 32 and wgs * concurrent <= ncu:     # one 32-sequence workgroup per CU runs at the MFMA's pace, not the L2's
+            t *= 0.6
         if best_t is None or t < best_t - 1e-9:
             best, best_t = tile, t
     return best
@@ -337,8 +343,11 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
     parts = _split(B) if debug is None else [(0, B)]
-    if st.lib.dprnn_get_gemm_mode() != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP:
-        parts = [(0, B)]        # the wide bf16-split kernels fill the chip with one workgroup per CU: one pipeline
+    if st.lib.dprnn_get_gemm_mode() != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
+        # the wide bf16-split kernels take one workgroup per CU: few, large pipelines (two: their launches interleave)
+        n = max(1, min(SPLIT_GROUPS, B // 16))
+        cuts = [round(i * B / n) for i in range(n + 1)]
+        parts = [(cuts[i], cuts[i + 1]) for i in range(n)]
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
     else:
