@@ -48,8 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
-    ap.add_argument("--gemm-mode", type=int, default=0,
-                    help="0 exact fp32 MFMA (headline); 1/2 = optional bf16-split gate GEMM with 6/3 products")
+    ap.add_argument("--gemm-mode", type=int, default=None,
+                    help="LSTM gate GEMM: 1 = fp32 operands as three bf16 pieces, six products on the bf16 MFMA, fp32 accumulate "
+                         "(the engine's default, fp32-equivalent); 0 = exact fp32 MFMA; 2 = three products (2^-16, opt-in)")
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
     ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
@@ -226,6 +227,8 @@ def main():
         engine.STREAM_GROUPS = args.groups
     if args.min_group is not None:
         engine.MIN_GROUP_BATCH = args.min_group
+    if args.gemm_mode is None:
+        args.gemm_mode = engine.DEFAULT_GEMM_MODE
     engine.GEMM_MODE = args.gemm_mode
     if args.groups is not None:
         engine.SPLIT_ONE_GROUP = False          # an explicit group count also applies to the bf16-split modes
@@ -271,27 +274,31 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
 
     kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get("dprnn_rnn_fwd", []), t_ref)
-    n_groups = len(engine._split(B))
+    n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
     launches_per_step = 2 * cfg["n_repeats"] * n_groups
     flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
     achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
-    traffic = None
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pm = json.load(f)["bilstm_kernel"]
+        name = "r02_pmc_traffic.json" if args.gemm_mode == 1 else "r01_pmc_traffic.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            pm = json.load(f)["bilstm_split8_kernel" if args.gemm_mode == 1 else "bilstm_kernel"]
         if pm["group_batch"] * n_groups == B:
-            traffic = pm["traffic_GB_per_launch"]
+            traffic, traffic_src = pm["traffic_GB_per_launch"], name
     except (OSError, KeyError, ValueError):
         pass
 
-    # Optional arithmetic modes of the gate GEMM, timed AFTER (and outside) the headline region: same batch, same
-    # protocol, 3 steps each; deviation is measured against the exact-fp32 output of this very run.
+    # The other arithmetic modes of the gate GEMM, timed AFTER (and outside) the headline region: same batch, same
+    # protocol, 3 steps each; deviation is measured against the output of the headline mode of this very run.
+    mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 2: "bf16_split_3_products"}
     optional = None
-    if world == 1 and args.gemm_mode == 0 and not args.no_optional_modes:
+    if world == 1 and not args.no_optional_modes:
         optional = {}
         ref_out = out.double()
         with torch.no_grad():
-            for mode, name in ((1, "bf16_split_6_products"), (2, "bf16_split_3_products")):
+            for mode in (0, 1, 2):
+                if mode == args.gemm_mode:
+                    continue
                 engine.GEMM_MODE = mode
                 o = model(x)
                 sync()
@@ -300,25 +307,40 @@ def main():
                     o = model(x)
                 sync()
                 dt = (time.perf_counter() - t1) / 3
-                optional[name] = {"value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt,
-                                  "rel_l2_vs_exact_fp32_path": float((o.double() - ref_out).norm() / ref_out.norm())}
-            engine.GEMM_MODE = 0
+                optional[mode_names[mode]] = {"value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt,
+                                              "rel_l2_vs_headline_mode": float((o.double() - ref_out).norm() / ref_out.norm())}
+            engine.GEMM_MODE = args.gemm_mode
+    # roofline of the dominant kernel.  Exact mode: the fp32 MFMA peak.  Six-product bf16 split: every algorithmic FLOP costs
+    # six bf16 MFMA FLOPs, so the kernel's ceiling in algorithmic (fp32-equivalent) TFLOP/s is the dense bf16 peak / 6.
+    BF16_PEAK = 2500.0
+    products = {0: 1, 1: 6, 2: 3}[args.gemm_mode]
+    peak = PEAK_F32_MFMA_TFLOPS if args.gemm_mode == 0 else BF16_PEAK / products
+    kernel_name = "bilstm_kernel (dprnn_rnn_fwd, LSTM cell, exact fp32 MFMA)" if args.gemm_mode == 0 else \
+        f"bilstm_split8_kernel (dprnn_rnn_fwd, LSTM cell, fp32 operands as bf16 pieces, {products} products on the bf16 MFMA)"
+    dtype = "f32" if args.gemm_mode == 0 else (f"f32 via 3 x bf16 split, {products} products, f32 accumulate" if args.gemm_mode == 1
+                                               else "f32 via 2 x bf16 split, 3 products (2^-16), f32 accumulate")
     if rank == 0:
         value = world * B * args.steps / elapsed
         line = {
             "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.gemm_mode == 0 else "f32 via bf16-split operands, f32 accumulate",
+            "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": "DPRNN-TasNet BSS inference, synthetic 3 s @ 8 kHz, batch=64 per GPU "
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS,
-                       "gemm_mode": ["exact fp32 MFMA", "bf16-split x6 on bf16 MFMA (opt-in)", "bf16-split x3 on bf16 MFMA (opt-in)"][args.gemm_mode]},
-            "roofline": {"bound": "mfma", "kernel": "bilstm_kernel (dprnn_rnn_fwd, LSTM cell)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01_pmc_traffic.json)",
+                       "stream_groups_used": n_groups,
+                       "gemm_mode": ["exact fp32 MFMA (DPRNN_GEMM_MODE=0)", "fp32-equivalent bf16 split, 6 products (default)",
+                                     "bf16 split, 3 products (opt-in, 2^-16)"][args.gemm_mode]},
+            "roofline": {"bound": "mfma", "kernel": kernel_name,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": f"GB per launch (PMC, profiles/{traffic_src})",
+                         "peak_note": "157.3 = fp32 MFMA peak" if args.gemm_mode == 0 else
+                         f"{BF16_PEAK:.0f} TFLOP/s dense bf16 MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
+                         f"{PEAK_F32_MFMA_TFLOPS} (achieved / that = {achieved / PEAK_F32_MFMA_TFLOPS:.2f})",
+                         "executed_bf16_mfma_tflops": None if args.gemm_mode == 0 else achieved * products,
                          "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                          # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
                          # the previous norm is folded in: all launches of a forward but the first]
@@ -329,12 +351,13 @@ def main():
                          # achieved = per_launch_tflops x mean_concurrency: the launches of the pipelines overlap
                          "per_launch_tflops": flop_per_launch / (kern_ms * 1e-3) / 1e12,
                          "mean_concurrency": conc,
-                         "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                         "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / peak,
+                         "whole_forward_tflops": value / world * FLOP_PER_UTT / 1e12},
             "distributed": dist_info,
         }
         if optional is not None:
-            line["optional_gemm_modes"] = dict(optional, note="opt-in (engine.GEMM_MODE / dprnn_set_gemm_mode): LSTM gate GEMM with "
-                                               "bf16-split operands on the bf16 MFMA, fp32 accumulate; NOT part of `value`")
+            line["other_gemm_modes"] = dict(optional, note="the same batch under the other settings of engine.GEMM_MODE / "
+                                            "DPRNN_GEMM_MODE, 3 steps each after the timed region; NOT part of `value`")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, model, dev)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Forward time of DPRNN-TasNet by batch size under both gate-GEMM modes (engine.GEMM_MODE 0 = exact fp32 MFMA,
+1 = fp32-equivalent bf16 split) with the engine's own tile / group choices: where does which mode win?"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tss_with_dprnn_amd as pkg
+from tss_with_dprnn_amd import engine
+from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_state
+
+CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length", "n_repeats",
+        "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
+cfg = full_cfg()
+model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state("bss", cfg, 0).items()})
+model = model.to("cuda:0")
+sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128]
+for B in sizes:
+    x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
+    row = []
+    for mode in (0, 1):
+        engine.GEMM_MODE = mode
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 4 if B >= 32 else 8
+            for _ in range(n):
+                model(x)
+            torch.cuda.synchronize()
+        row.append((time.perf_counter() - t0) / n * 1e3)
+    print(f"B={B:3d}: exact fp32 {row[0]:8.2f} ms ({B / row[0] * 1e3:6.1f} utt/s)   bf16 split x6 {row[1]:8.2f} ms ({B / row[1] * 1e3:6.1f} utt/s)   "
+          f"ratio {row[0] / row[1]:.2f}", flush=True)

@@ -38,10 +38,15 @@ MIN_GROUP_BATCH = 16         # utterances per group, about (much smaller groups 
 # mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
 FUSE_NORM = True
 
-# OPTIONAL arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).  0 = exact fp32
-# operands on the fp32 MFMA: the default, and what the parity claims and the bench headline refer to.  1 / 2 = bf16-split
-# operands (6 / 3 cross products) on the bf16 MFMA with fp32 accumulation: opt-in, reported separately.
-DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "0"))
+# Arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).
+#   1 (default) = every fp32 operand as a sum of three bf16 pieces, the six cross products of order <= 2^-16 on the bf16 MFMA
+#                 with fp32 accumulation (recur_split.hip): product error ~2^-24, end to end the same 2e-7 rel-L2 against the
+#                 reference as the exact path -- every golden (BSS, Spe, IRA; the B = 64 headline batch) passes at the same
+#                 tolerances (the whole -m gpu suite is run in both modes, profiles/r02_mode1_suite.txt);
+#   0           = exact fp32 operands on the fp32 MFMA (recur.hip): bit-for-bit an fma chain; DPRNN_GEMM_MODE=0 selects it;
+#   2           = two pieces / three products (product error ~2^-16): opt-in only, never a default.
+# GRU / Elman cells and the training path (forward with tape, backward) always run the exact fp32 kernels.
+DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "1"))
 GEMM_MODE = DEFAULT_GEMM_MODE
 SPLIT_ONE_GROUP = True      # bf16-split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
 
@@ -280,7 +285,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
 # bf16-split gate GEMM: measured cost of one time step of one workgroup, in microseconds (profiles/r02_split_wide.txt): the
 # two-per-CU 32-sequence form and the one-per-CU eight-wave forms (seq_tile code 2000 + sequences); a launch takes
 # ceil(workgroups / slots) rounds of T steps each
-SPLIT_STEP_US = {32: 25.0, 2064: 18.8, 2080: 23.0}
+SPLIT_STEP_US = {32: 25.0, 2064: 18.6, 2080: 23.3}
 SPLIT_SLOTS_PER_CU = {32: 2, 2064: 1, 2080: 1}
 SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split modes: one group's launches rarely fill 256 CUs exactly
 
@@ -302,6 +307,33 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1) -> int:
 
 
 GROUP_SIZES = None        # experiment knob: explicit utterance-group sizes (must sum to the batch), else an even split
+
+
+SPLIT_MIN_BATCH = int(os.environ.get("DPRNN_SPLIT_MIN_BATCH", "20"))    # below this the exact fp32 kernels' small tiles are faster (profiles/r02_split_wide.txt: B = 16 62 vs 54 ms)
+
+
+def effective_gemm_mode(B: int, blocks=None) -> int:
+    """GEMM_MODE as it applies to a batch of B: the bf16-split kernels need launches that fill the chip, and only the
+    LSTM cell has them; everything else runs the exact fp32 kernels (which are never less accurate)."""
+    if GEMM_MODE == 0 or B < SPLIT_MIN_BATCH:
+        return 0
+    if blocks is not None and not all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in blocks):
+        return 0
+    return GEMM_MODE
+
+
+def _split_mode_parts(B: int):
+    """Utterance groups of the bf16-split modes: the wide kernels take one workgroup per CU, so few, large pipelines."""
+    n = max(1, min(SPLIT_GROUPS, B // 16))
+    cuts = [round(i * B / n) for i in range(n + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(n)]
+
+
+def group_parts(B: int, gemm_mode: int):
+    """The utterance groups dprnn_process will use for a batch of B (bench.py sizes its roofline arithmetic with it)."""
+    if gemm_mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP:
+        return _split_mode_parts(B)
+    return _split(B)
 
 
 def _split(B: int):
@@ -328,7 +360,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
     blocks = list(sep.dprnn_blocks)
 
-    st.lib.dprnn_set_gemm_mode(GEMM_MODE if all(b.intra_rnn.rnn.mode == "LSTM" for b in blocks) else 0)
+    st.lib.dprnn_set_gemm_mode(effective_gemm_mode(B, blocks))
     # pack every LSTM once, on the caller's stream, before the groups fork
     packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
     bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
@@ -344,10 +376,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
     parts = _split(B) if debug is None else [(0, B)]
     if st.lib.dprnn_get_gemm_mode() != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
-        # the wide bf16-split kernels take one workgroup per CU: few, large pipelines (two: their launches interleave)
-        n = max(1, min(SPLIT_GROUPS, B // 16))
-        cuts = [round(i * B / n) for i in range(n + 1)]
-        parts = [(cuts[i], cuts[i + 1]) for i in range(n)]
+        parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
     else:
