@@ -190,6 +190,23 @@ int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* s
                                  const float* beta, float eps, const float* prelu_w, const float* W2d,
                                  const float* b2d, float* U, int B, int L, int K, int P, int S, void* stream);
 
+/* ---- ragged batches (utterances of DIFFERENT lengths through one launch per DPRNN path; the reference evaluates full-length
+ * test utterances one at a time, src/inferencers/inferencer.py:54-58, inferencer_spe.py:27-32, because zero-padding would
+ * change the per-utterance GroupNorm statistics).  The slab is the concatenation of the utterances' [S_u][K][F] slabs; per
+ * utterance tables replace the uniform (B, S) arithmetic:
+ *   dprnn_rnn_fwd_ragged: SingleRNN.forward (dprnn.py:33-37) for one path, bf16-split gate GEMM (dprnn_set_gemm_mode 1|2), LSTM.
+ *     intra-chunk: wg_desc NULL, n_items = total chunks, T = K, seq_utt[chunk] = its utterance;
+ *     inter-chunk: wg_desc[n_items][8] = {row0 lo, row0 hi, T = S_u, sequences <= 64, u, 0, 0, 0} per 64-sequence workgroup
+ *       (tiles never straddle utterances), seq_utt NULL.
+ *     Z != NULL folds the previous path's norm + residual into the loader as dprnn_bilstm_norm_fwd does (stats[u], count
+ *     utt_rows[u] * F).
+ *   dprnn_proj_stats_ragged_fwd: dprnn_proj_stats_fwd with utterance u owning rows [utt_starts[u], utt_starts[u+1]). */
+int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                         float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
+                         float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir, void* stream);
+int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
+                                int64_t M, const int64_t* utt_starts, int n_utt, int kdim, void* stream);
+
 /* ---- mask head part 2: tanh(out conv) * sigmoid(gate conv) (dprnn.py:157-158,180) on rows
  * (b,l,spk) of U viewed as [B*L*2][F] -> V [B*L*2][F] */
 int dprnn_head_gate_fwd(const float* U, const float* Wo, const float* bo, const float* Wg, const float* bg,

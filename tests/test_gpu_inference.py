@@ -89,3 +89,65 @@ def test_batched_inferencer_matches_per_utterance_loop(tmp_path):
     assert len(rows) == len(lengths) + 1
     got = np.array([[float(v) for v in r.split(",")[1:]] for r in rows[1:]])
     assert np.allclose(got, want, atol=2e-3)
+
+
+@pytest.mark.parametrize("kind", ["bss", "spe", "ira", "spe_att_bntrain"])
+def test_ragged_batch_equals_one_by_one(kind):
+    """SURVEY.md 8f-3 / inferencer_spe.py:27-32: utterances of different lengths through ONE launch per DPRNN path must
+    give what the reference's one-at-a-time loop gives.  Lengths leave ragged tiles everywhere (chunk counts 11 .. 47,
+    K = 40 chunk positions against 64-sequence tiles); the speaker branch keeps batch-of-one BatchNorm statistics."""
+    from tss_with_dprnn_amd import engine, inference
+    from conftest import build_model
+    from oracle.weights import make_mixture
+    over = dict(chunk_length=40, hop_length=20, n_repeats=2)
+    if kind != "bss":
+        over.update(fusion_type="att" if "att" in kind else "cat", norm_type="ln")
+    model, _, cfg = build_model("bss" if kind == "bss" else ("ira" if kind == "ira" else "spe"), over, 81, DEV)
+    if "bntrain" in kind:
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.train()
+    lens = [901, 377, 640, 233, 901, 512, 777, 300, 845, 199]
+    wavs = [torch.from_numpy(make_mixture(1, n, seed=300 + i)[0]).to(DEV) for i, n in enumerate(lens)]
+    extra = None
+    if kind != "bss":
+        alen = [400, 333, 512, 400, 280, 333, 450, 512, 300, 400]
+        extra = [(torch.from_numpy(make_mixture(1, n, seed=400 + i)[0]).to(DEV), float(n)) for i, n in enumerate(alen)]
+    assert engine.ragged_supported(model.separation)
+    bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    got = inference.separate_many(model, wavs, extra_inputs=extra, ragged=True)
+    bn_ragged = {k: v.clone() for k, v in model.state_dict().items() if k in bn0}
+    model.load_state_dict({**model.state_dict(), **bn0})          # the one-by-one loop starts from the same running statistics
+    with torch.no_grad():
+        for i, w in enumerate(wavs):
+            if extra is None:
+                want = model(w[None])[0]
+                assert got[i].shape == want.shape == (2, lens[i])
+                r = float(((got[i].double() - want.double()).norm() / want.double().norm()).item())
+                assert r <= 2e-6, (i, r)
+            else:
+                est, logits = model(w[None], extra[i][0][None], torch.tensor(extra[i][1]))
+                r = float(((got[i][0].double() - est[0].double()).norm() / est[0].double().norm()).item())
+                rl = float(((got[i][1].double() - logits[0].double()).norm() / logits[0].double().norm()).item())
+                assert r <= 2e-6 and rl <= 2e-6, (i, r, rl)
+    if "bntrain" in kind:                                         # ... and leaves the same running statistics behind
+        for k, v in model.state_dict().items():
+            if k in bn0 and v.dtype.is_floating_point:
+                assert torch.allclose(v, bn_ragged[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_ragged_full_config_against_cpu_oracle():
+    """Shipped depth / chunk geometry (6 blocks, K 250 / P 125), four lengths between 1.2 and 3.6 s in one ragged batch,
+    against the torch-CPU oracle of each utterance."""
+    from tss_with_dprnn_amd import inference
+    from conftest import build_model
+    from oracle import dprnn_torch_cpu as otc
+    from oracle.weights import make_mixture
+    model, sd, cfg = build_model("bss", dict(), 82, DEV)
+    lens = [28800, 9600, 17001, 24000]
+    xs = [make_mixture(1, n, seed=500 + i) for i, n in enumerate(lens)]
+    got = inference.separate_many(model, [torch.from_numpy(x[0]).to(DEV) for x in xs], ragged=True)
+    tsd = otc.to_torch_state(sd)
+    for i, x in enumerate(xs):
+        want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(x)).numpy()[0]
+        assert rel_l2(got[i].cpu().numpy(), want) <= 1e-5, (i, rel_l2(got[i].cpu().numpy(), want))

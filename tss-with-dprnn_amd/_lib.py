@@ -40,6 +40,8 @@ SIGNATURES = {
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
+    "dprnn_proj_stats_ragged_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_i, c_i, c_fp],
+    "dprnn_rnn_fwd_ragged": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_head_conv_ola_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],

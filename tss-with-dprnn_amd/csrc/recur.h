@@ -29,6 +29,11 @@ struct RecurArgs {
     long long rows_per_utt;
     int cell;                                         // 0 LSTM, 1 GRU, 2 Elman RNN (tanh)
     float* tape;                                      // training forward only: activated gates + cell state per step
+    // ---- ragged batches (utterances of different lengths in one launch; bf16-split eight-wave kernel only)
+    const int* wg_desc;                               // per workgroup of a direction: {row0 lo, row0 hi, T, sequences, utterance, 0, 0, 0}:
+                                                      // its sequences are rows row0 + j * inner_stride, it runs T steps (inter-chunk path)
+    const int* seq_utt;                               // utterance of every sequence (intra-chunk path; wg_desc == nullptr)
+    const long long* utt_rows;                        // rows of every utterance (count of its pending norm); nullptr: rows_per_utt
 };
 
 // The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's

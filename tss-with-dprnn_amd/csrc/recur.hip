@@ -611,6 +611,39 @@ extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const doubl
     return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
 }
 
+// ---- ragged batches: one recurrence launch over utterances of DIFFERENT lengths (bf16-split modes, LSTM cell, 64-sequence
+// eight-wave kernel).  The slab is the concatenation of the utterances' [S_u][K][F] slabs.
+//   intra-chunk (wg_desc == NULL): n_items = total number of chunks, T = K; sequence q is rows q*K .. q*K + K-1; seq_utt[q]
+//       names its utterance (needed only with a pending norm).
+//   inter-chunk (wg_desc != NULL): n_items = workgroups per direction; workgroup w runs the sequences row0 + j (j < count)
+//       for T steps of stride K rows: wg_desc[w] = {row0 lo, row0 hi, T = S_u, count <= 64, u, 0, 0, 0}; tiles never
+//       straddle utterances (sort them by T, longest first: they end at different times).
+// utt_rows[u] = S_u * K (the count of the pending norm; stats[u] as everywhere).
+extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                                    float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
+                                    float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
+                                    void* stream) {
+    if (!X || !packed || !bsum || !H) { dprnn_set_error("dprnn_rnn_fwd_ragged: null pointer"); return -1; }
+    if (g_gemm_mode == 0) { dprnn_set_error("dprnn_rnn_fwd_ragged: needs a bf16-split gemm mode (dprnn_set_gemm_mode 1 or 2)"); return -1; }
+    if (n_items <= 0 || K <= 0 || (ndir != 1 && ndir != 2) || (!wg_desc && T <= 0)) {
+        dprnn_set_error("dprnn_rnn_fwd_ragged: bad sizes n_items=%d T=%d K=%d ndir=%d", n_items, T, K, ndir);
+        return -1;
+    }
+    if (Z && (!stats || !gamma || !beta || !Xout || Xout == X || !utt_rows || (!wg_desc && !seq_utt))) {
+        dprnn_set_error("dprnn_rnn_fwd_ragged: the pending norm needs stats, gamma, beta, utt_rows, (seq_utt) and an Xout different from X");
+        return -1;
+    }
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = n_items; a.T = T; a.ndir = ndir; a.cell = 0;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Xout = Xout;
+    a.seqs_per_utt = 1; a.rows_per_utt = 1; a.utt_rows = reinterpret_cast<const long long*>(utt_rows);
+    a.seq_utt = seq_utt; a.wg_desc = wg_desc;
+    if (wg_desc) { a.inner_n = 1 << 30; a.outer_stride = 0; a.inner_stride = 1; a.t_stride = K; }
+    else { a.inner_n = n_items; a.outer_stride = 0; a.inner_stride = K; a.t_stride = 1; }
+    if ((long long)64 * K * ndir * HD * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_fwd_ragged: chunk_length too large"); return -1; }
+    return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, 2064, g_fast_act != 0, (hipStream_t)stream);
+}
+
 // ---- training forward: dprnn_rnn_fwd for the LSTM cell on 32-sequence tiles, plus the gate tape for dprnn_lstm_bwd
 extern "C" int64_t dprnn_rnn_tape_floats(int cell, int nseq, int T, int ndir) {
     return (int64_t)ndir * ((nseq + 31) / 32) * T * (32 * HD * (cell == 2 ? 1 : 5));

@@ -1054,23 +1054,27 @@ void bilstm_split8_kernel(RecurArgs a) {
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * NSR;
-    const int T = a.T;
     constexpr unsigned OOB = 0x80000000u;
 
     auto rowbase = [&](int seq) {
         return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
     };
-    const long long row0 = rowbase(seq0);
+    // Ragged batch, inter-chunk path: this workgroup's sequences, step count and utterance come from its descriptor
+    // (tiles never straddle utterances there, their lengths differ); otherwise the uniform addressing of the launch.
+    const int* const desc = a.wg_desc ? a.wg_desc + 8 * blockIdx.x : nullptr;
+    const int T = __builtin_amdgcn_readfirstlane(desc ? desc[2] : a.T);
+    const int nhere = desc ? desc[3] : (a.nseq - seq0 < NSR ? a.nseq - seq0 : NSR);      // sequences that exist in this tile
+    const long long row0 = desc ? (((long long)desc[1] << 32) | (unsigned)desc[0]) : rowbase(seq0);
     const int hpitch = a.ndir * HD;
     for (int j = tid; j < NSR; j += 512) {
-        const int seq = seq0 + j;
-        const bool valid = seq < a.nseq;
-        const long long ro = rowbase(valid ? seq : seq0) - row0;
-        rowoff_x[j] = (unsigned)(ro * F * 4);          // rows past nseq alias the first row: loads stay in range
+        const bool valid = j < nhere;
+        const int seq = valid ? seq0 + j : seq0;
+        const long long ro = desc ? (long long)(valid ? j : 0) * a.inner_stride : rowbase(seq) - row0;
+        rowoff_x[j] = (unsigned)(ro * F * 4);          // rows that do not exist alias the first row: loads stay in range
         rowoff_h[j] = valid ? (unsigned)(ro * hpitch * 4) : OOB;
         if (FUSE) {
-            const int b = (valid ? seq : seq0) / a.seqs_per_utt;
-            const double cnt = (double)a.rows_per_utt * (double)F;
+            const int b = desc ? desc[4] : (a.seq_utt ? a.seq_utt[seq] : seq / a.seqs_per_utt);
+            const double cnt = (double)(a.utt_rows ? a.utt_rows[b] : a.rows_per_utt) * (double)F;
             const double mean = a.stats[2 * b] / cnt;
             double var = a.stats[2 * b + 1] / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -1326,7 +1330,7 @@ int launch_split8(const RecurArgs& a, hipStream_t st) {
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
-    dim3 grid((a.nseq + NSR - 1) / NSR, a.ndir);
+    dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
     hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP>), grid, dim3(512), lds, st, a);
     return dprnn_check_launch("bilstm_split8_kernel");
 }

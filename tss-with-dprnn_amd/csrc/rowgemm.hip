@@ -47,9 +47,24 @@ extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float*
     }
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
-    EpProjStats<RT, 8> ep{Z, bias, stats, (long long)rows_per_utt};
+    EpProjStats<RT, 8> ep{Z, bias, stats, (long long)rows_per_utt, nullptr, 0};
     if (kdim == 256) return launch_rowgemm<256, 128, RT, false, PROJ_NW>("proj_stats256", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
     return launch_rowgemm<128, 128, RT, false, PROJ_NW>("proj_stats128", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+}
+
+// ragged batch: utterance u owns rows [utt_starts[u], utt_starts[u + 1]) of the concatenated slab
+extern "C" int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
+                                           int64_t M, const int64_t* utt_starts, int n_utt, int kdim, void* stream) {
+    if (!H || !W || !bias || !Z || !stats || !utt_starts) { dprnn_set_error("dprnn_proj_stats_ragged_fwd: null pointer"); return -1; }
+    if (M <= 0 || n_utt < 1 || (kdim != 256 && kdim != 128)) {
+        dprnn_set_error("dprnn_proj_stats_ragged_fwd: bad sizes M=%lld n_utt=%d kdim=%d", (long long)M, n_utt, kdim);
+        return -1;
+    }
+    constexpr int RT = 4;
+    PlainRows<RT> al{H, kdim};
+    EpProjStats<RT, 8> ep{Z, bias, stats, 1, reinterpret_cast<const long long*>(utt_starts), n_utt};
+    if (kdim == 256) return launch_rowgemm<256, 128, RT, false, PROJ_NW>("proj_stats256r", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+    return launch_rowgemm<128, 128, RT, false, PROJ_NW>("proj_stats128r", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
 }
 
 // The PReLU slope is a device scalar (nn.PReLU weight): the loader reads it through its pointer.

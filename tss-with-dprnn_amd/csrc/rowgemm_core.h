@@ -192,6 +192,7 @@ struct EpStore {                // out[row*pitch + col] = acc: plain store, one 
 template <int RT, int NCT>
 struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in double
     float* Z; const float* bias; double* stats; long long rows_per_b;
+    const long long* starts; int n_utt;        // ragged batches: first row of every utterance ([n_utt + 1]); nullptr = uniform
     double d1, d2; long long cur_b;
     __device__ void begin() { d1 = 0.0; d2 = 0.0; cur_b = -1; }
     __device__ void flush(int lane) {
@@ -202,13 +203,21 @@ struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in
         d1 = 0.0; d2 = 0.0;
     }
     __device__ void end(int lane) { flush(lane); cur_b = -1; }
+    // utterance of a row; a wave walks its row tiles in increasing order, so the scan resumes from the current utterance
+    __device__ long long utt_of(long long row) const {
+        if (!starts) return row / rows_per_b;
+        long long b = cur_b >= 0 && starts[cur_b] <= row ? cur_b : 0;
+        while (b + 1 < n_utt && starts[b + 1] <= row) ++b;
+        return b;
+    }
+    __device__ long long first_row(long long b) const { return starts ? starts[b] : b * rows_per_b; }
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int r, int q, int lane, long long M) {
         float bv[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) bv[ct] = bias[16 * ct + r];
         const long long last = (row0 + 16 * RT - 1 < M ? row0 + 16 * RT - 1 : M - 1);
-        const long long b_first = row0 / rows_per_b;
-        const long long next_start = (b_first + 1) * rows_per_b;
+        const long long b_first = utt_of(row0);
+        const long long next_start = first_row(b_first + 1);
         if (row0 + 16 * RT <= M && last < next_start) {
             // fast path (almost every tile): all 16*RT rows exist and belong to one utterance -- no per-row tests,
             // one base pointer per row, immediate column offsets (fp32 VALU work costs matrix time on gfx950)
@@ -230,10 +239,11 @@ struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in
             return;
         }
         // general path: ragged last tile and tiles that straddle utterances (one utterance at a time)
-        const long long b_last = last / rows_per_b;
+        long long b_last = b_first;
+        if (starts) { while (b_last + 1 < n_utt && starts[b_last + 1] <= last) ++b_last; } else b_last = last / rows_per_b;
         for (long long b = b_first; b <= b_last; ++b) {
             if (b != cur_b) { flush(lane); cur_b = b; }
-            const long long lo = b * rows_per_b, hi = lo + rows_per_b;
+            const long long lo = first_row(b), hi = first_row(b + 1);
             float p1 = 0.f, p2 = 0.f;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)

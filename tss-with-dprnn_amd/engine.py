@@ -779,3 +779,196 @@ def auxiliary_embedding(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
         A0 = _pointwise(st, x_cl, B * La, N, se[1].weight, se[1].bias, 128, in_scale=sc, in_shift=sh, aff_stride=N,
                         rows_per_utt=La)
         return speaker_embedding(st, sep, A0, B, La, _aux_len_tensor(aux_len, B, dev), sep.kernel_size)
+
+
+# ------------------------------------------------------------------------------------------------ ragged batches
+# Full-length test utterances differ in length (Libri2Mix test: 3 .. 14 s), and the reference evaluates them one at a time
+# (src/inferencers/inferencer.py:54-58, inferencer_spe.py:27-32): zero-padding to a common length would change the
+# per-utterance GroupNorm statistics.  Here utterances of DIFFERENT lengths go through ONE launch per DPRNN path: their
+# [S_u][K][F] slabs are concatenated, the intra-chunk recurrence sees sum(S_u) sequences of K steps, the inter-chunk
+# recurrence gets one 64-sequence workgroup descriptor per (utterance, 64 chunk positions) with its own step count S_u, and
+# the per-utterance statistics are indexed through small tables.  Everything before the slab (encoder statistics,
+# bottleneck, speaker branch) and after it (mask head, decoder) is launched per utterance: < 3 % of the work.
+# Needs the bf16-split gate GEMM (the eight-wave 64-sequence kernel) and LSTM cells; callers fall back to per-length
+# batches on streams otherwise (inference.separate_many).
+def ragged_supported(sep) -> bool:
+    return GEMM_MODE != 0 and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
+
+
+def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act: bool, want_masked: bool = False):
+    """dprnn_process for utterances of different lengths.  Ys[u]: frames [1][L_u][F]; wavs[u]: [1][T_u]; geos[u]: Geometry
+    with B = 1.  Returns (taps list [1][2][L_u][ks], masked list [1][L_u][N] or None)."""
+    import numpy as np
+    dev = Ys[0].device
+    n = len(Ys)
+    K, P, ks, N = geos[0].K, geos[0].P, geos[0].ks, geos[0].N
+    blocks = list(sep.dprnn_blocks)
+    if not ragged_supported(sep):
+        raise DprnnError("ragged batches need engine.GEMM_MODE 1 or 2 and LSTM cells")
+    st.lib.dprnn_set_gemm_mode(GEMM_MODE)
+    rows = np.array([g.S * K for g in geos], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    total = int(starts[-1])
+    chunks = np.array([g.S for g in geos], dtype=np.int64)
+    seq_utt = np.repeat(np.arange(n, dtype=np.int32), chunks)
+    desc = []
+    for u in np.argsort(-chunks, kind="stable"):                 # longest utterances first: their workgroups run longest
+        for k0 in range(0, K, 64):
+            r0 = int(starts[u]) + k0
+            desc.append((r0 & 0xFFFFFFFF, r0 >> 32, int(chunks[u]), min(64, K - k0), int(u), 0, 0, 0))
+    desc = np.array(desc, dtype=np.int64).astype(np.uint32).view(np.int32)
+    tables = torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), seq_utt, desc.reshape(-1)])).to(dev)
+    o = 0
+    utt_rows = tables[o: o + 2 * n]; o += 2 * n
+    utt_starts = tables[o: o + 2 * (n + 1)]; o += 2 * (n + 1)
+    seq_utt_d = tables[o: o + seq_utt.size]; o += seq_utt.size
+    desc_d = tables[o:]
+    n_tiles = desc.shape[0]
+
+    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
+    bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+    for i, blk in enumerate(blocks):
+        for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
+            _, fw, bw = _rnn_tensors(rnn, dev)
+            st.call("dprnn_rnn_pack", 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
+
+    m = total * F_BUILT
+    arena = torch.empty(5 * m, device=dev, dtype=torch.float32)
+    X, X2, Z, H = arena[:m], arena[m: 2 * m], arena[2 * m: 3 * m], arena[3 * m:]
+    stats = torch.zeros(2 * len(blocks), n, 2, device=dev, dtype=torch.float64)
+    for u in range(n):
+        st.call("dprnn_segment_fwd", _p(Ys[u]), _p(X[int(starts[u]) * F_BUILT:]), 1, geos[u].L, K, P, geos[u].S)
+    pending = None
+    for i, blk in enumerate(blocks):
+        for intra in (True, False):
+            rnn, lin, norm = (blk.intra_rnn, blk.intra_linear, blk.intra_norm) if intra else \
+                (blk.inter_rnn, blk.inter_linear, blk.inter_norm)
+            slot = 2 * i + (0 if intra else 1)
+            ndir = 2 if rnn.rnn.bidirectional else 1
+            pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
+            st.call("dprnn_rnn_fwd_ragged", _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
+                    int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
+                    K if intra else 0, K, ndir)
+            if pending is not None:
+                X, X2 = X2, X
+            w = _param(lin.weight, "linear.weight", dev)
+            if w.shape != (F_BUILT, ndir * F_BUILT):
+                raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+            st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
+                    total, _p(utt_starts), n, ndir * F_BUILT)
+            gamma, beta, eps = _norm_params(norm)
+            pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
+
+    taps, masked = [], []
+    head_w = (_p(_param(sep.prelu.weight, "prelu.weight", dev)), _p(_param(sep.conv2d.weight, "conv2d.weight", dev)),
+              _p(_param(sep.conv2d.bias, "conv2d.bias", dev)))
+    for u in range(n):
+        g = geos[u]
+        r0 = int(starts[u])
+        Hu = H[r0 * 2 * F_BUILT: (r0 + int(rows[u])) * 2 * F_BUILT]          # this utterance's share of H: U | V scratch
+        U, V = Hu[: g.L * 2 * F_BUILT], Hu[g.L * 2 * F_BUILT: 2 * g.L * 2 * F_BUILT]
+        if pending is None:
+            st.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
+        else:
+            st.call("dprnn_head_conv_ola_norm_fwd", _p(X[r0 * F_BUILT:]), _p(Z[r0 * F_BUILT:]), _p(pending[0][u]), _p(pending[1]),
+                    _p(pending[2]), pending[3], *head_w, _p(U), 1, g.L, K, P, g.S)
+        st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+                _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
+                _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), g.L * 2)
+        t = torch.empty(1, 2, g.L, ks, device=dev, dtype=torch.float32)
+        mk = torch.empty(1, g.L, N, device=dev, dtype=torch.float32) if want_masked else None
+        st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+                _p(wavs[u]), _p(enc_w), _p(dec_w), _p(t), _p(mk), 1 if relu_act else 0, 1, g.T, g.L, N, ks, g.stride)
+        taps.append(t)
+        masked.append(mk)
+    return taps, (masked if want_masked else None)
+
+
+def tasnet_forward_ragged(model, wavs):
+    """DPRNNTasNet.forward for a list of 1-D waveforms of different lengths -> list of [2, T_out_u] (each equal to the
+    batch-of-one forward of that utterance)."""
+    cfg = model.cfg
+    check_supported(cfg)
+    dev = wavs[0].device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        sep = model.separation
+        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
+        ws = [check_input(w.reshape(1, -1)) for w in wavs]
+        geos = [make_geometry(1, w.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"],
+                              cfg["stride"]) for w in ws]
+        stats0 = torch.zeros(len(ws), 1, 2, device=dev, dtype=torch.float64)
+        Ys = [frames_from_waveform(st, w, enc_w, sep.bottleneck[0], sep.bottleneck[1], g, stats0[u])
+              for u, (w, g) in enumerate(zip(ws, geos))]
+        taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, cfg["activation_type"] == "relu")
+        return [decode(st, t, g, 2)[0] for t, g in zip(taps, geos)]
+
+
+def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
+    """DPRNNSpeTasNet / DPRNNSpeIRATasNet forward for lists of mixtures and reference utterances of different lengths ->
+    list of (estimate [T_out_u], logits [num_spks]); every utterance keeps batch-of-one semantics (BatchNorm statistics of
+    the speaker branch included, as the reference's one-at-a-time loop has them)."""
+    cfg = model.cfg
+    check_supported_spe(cfg)
+    dev = wavs[0].device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
+        sep = model.separation
+        se = sep.spk_encoder
+        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
+        relu_act = cfg["activation_type"] == "relu"
+        n = len(wavs)
+        ws = [check_input(w.reshape(1, -1)) for w in wavs]
+        axs = [check_input(a.reshape(1, -1), "aux") for a in auxs]
+        geos = [make_geometry(1, w.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride) for w in ws]
+        stats = torch.zeros(n, 4, 1, 2, device=dev, dtype=torch.float64)     # per utterance: bottleneck, aux, d0 statistics
+        v0s, Ys, scs, alens = [], [], [], []
+        for u in range(n):
+            geo_a = make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+            alen = _aux_len_tensor(aux_lens[u], 1, dev)
+            sc_a, sh_a = bottleneck_affine(st, axs[u], enc_w, se[0], geo_a, stats[u, 1])
+            A0 = bottleneck_frames(st, axs[u], enc_w, sc_a, sh_a, se[1], geo_a).view(geo_a.L, F_BUILT)
+            v0 = speaker_embedding(st, sep, A0, 1, geo_a.L, alen, ks)
+            mul, add, row_bias = _fusion_operands(st, sep, cfg, v0)
+            sc, sh = bottleneck_affine(st, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
+            row_scale = _att_row_scale(st, sep, cfg, ws[u], enc_w, geos[u], stats[u, 0], mul) if cfg["fusion_type"] == "att" else None
+            Ys.append(bottleneck_frames(st, ws[u], enc_w, sc, sh, sep.bottleneck[1], geos[u], row_bias, row_scale))
+            v0s.append(v0); scs.append((sc, sh)); alens.append(alen)
+        v_last = v0s
+        if not ira:
+            taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act)
+        else:
+            taps, d0s = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act, want_masked=True)
+            Ys2, v1s = [], []
+            g0, b0, _ = _norm_params(se[0])
+            for u in range(n):
+                geo = geos[u]
+                st.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
+                sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
+                sh_d = torch.empty_like(sc_d)
+                st.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
+                        _p(_param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, _p(sc_d), _p(sh_d), 1, geo.L, N)
+                A0d = _pointwise(st, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
+                                 aff_stride=N, rows_per_utt=geo.L)
+                v1 = speaker_embedding(st, sep, A0d, 1, geo.L, alens[u], ks)
+                v1 = _linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous())
+                mul2, add2, row_bias2 = _fusion_operands(st, sep, cfg, v1)
+                sc, sh = scs[u]
+                if mul2 is not None or add2 is not None:
+                    g, b_, eps = _norm_params(sep.bottleneck[0])
+                    st.call("dprnn_bottleneck_prep", _p(stats[u, 0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh), 1, geo.L, N)
+                row_scale2 = _att_row_scale(st, sep, cfg, ws[u], enc_w, geo, stats[u, 0], mul2) if cfg["fusion_type"] == "att" else None
+                Ys2.append(bottleneck_frames(st, ws[u], enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2))
+                v1s.append(v1)
+            del Ys, d0s
+            taps, _ = dprnn_process_ragged(st, sep, Ys2, ws, enc_w, dec_w, geos, relu_act)
+            v_last = v1s
+        out = []
+        for u in range(n):
+            logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last[u])
+            est = decode(st, taps[u], geos[u], 1)
+            out.append((est[0, 0, :], logits[0]))
+        return out

@@ -29,16 +29,50 @@ import torch
 from ._lib import DprnnError, check, load_library
 
 
-def separate_many(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, extra_inputs=None) -> List:
+RAGGED_MIN_UTTS = 8          # fewer utterances than this do not fill the chip through one ragged launch per path
+RAGGED_MAX_UTTS = 64         # utterances per ragged batch (bounds the slab arena: ~0.2 GB per 5-s utterance)
+
+
+def separate_ragged(model, wavs: Sequence[torch.Tensor], extra_inputs=None) -> List:
+    """Utterances of DIFFERENT lengths through one launch per DPRNN path (engine.dprnn_process_ragged): every output equals
+    that utterance's batch-of-one forward (the reference's semantics, inferencer.py:54-58 / inferencer_spe.py:27-32)."""
+    from . import engine
+    outs: List = [None] * len(wavs)
+    # original order: the speaker branch's BatchNorm layers (when in train mode, as in the reference's Inferencer) update their
+    # running statistics utterance by utterance as the one-at-a-time loop does (for IRA the two speaker passes of an
+    # utterance are not adjacent here: outputs are unaffected, the running buffers end slightly differently); the
+    # recurrence launches order their workgroups by length themselves
+    order = list(range(len(wavs)))
+    ira = bool(getattr(model, "_ira", False))
+    with torch.no_grad():
+        for c0 in range(0, len(order), RAGGED_MAX_UTTS):
+            idx = order[c0: c0 + RAGGED_MAX_UTTS]
+            if extra_inputs is None:
+                res = engine.tasnet_forward_ragged(model, [wavs[i] for i in idx])
+            else:
+                res = engine.spe_forward_ragged(model, [wavs[i] for i in idx], [extra_inputs[i][0] for i in idx],
+                                                [extra_inputs[i][1] for i in idx], ira=ira)
+            for i, r in zip(idx, res):
+                outs[i] = r
+    return outs
+
+
+def separate_many(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, extra_inputs=None, ragged=None) -> List:
     """Run `model` over utterances of arbitrary (different) lengths; returns one output per utterance, in order.
 
     wavs: 1-D float32 device tensors.  For DPRNN-Spe / IRA models pass extra_inputs = [(aux 1-D tensor, aux_len)]
-    and each output is (estimate, logits)."""
+    and each output is (estimate, logits).  ragged: None = one ragged launch per path when the model and the gate-GEMM mode
+    support it and there are at least RAGGED_MIN_UTTS utterances, else equal-length batches on streams; True / False force."""
     if len(wavs) == 0:
         return []
     dev = wavs[0].device
     if not all(w.is_cuda and w.dim() == 1 and w.dtype == torch.float32 for w in wavs):
         raise DprnnError("separate_many expects 1-D float32 tensors on a HIP device")
+    from . import engine
+    if ragged is None:
+        ragged = len(wavs) >= RAGGED_MIN_UTTS and engine.ragged_supported(model.separation)
+    if ragged:
+        return separate_ragged(model, wavs, extra_inputs)
     buckets = defaultdict(list)
     for i, w in enumerate(wavs):
         key = (w.numel(),) if extra_inputs is None else (w.numel(), extra_inputs[i][0].numel(), float(extra_inputs[i][1]))
