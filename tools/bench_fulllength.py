@@ -21,16 +21,46 @@ m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state(kin
 m = m.to(dev)
 rng = np.random.default_rng(0)
 lens = np.clip(np.exp(rng.normal(np.log(36720), 0.38, 3000)), 24000, 111920).astype(int)
-mine = sharding.shard_by_length(lens.tolist(), 8)[0][:48]
+share = sharding.shard_by_length(lens.tolist(), 8)[0]          # this rank's length-balanced 1/8 of the 3000 test utterances
+mine = share[:48]
 wavs = [torch.from_numpy(make_mixture(1, int(lens[i]), seed=100 + i)[0]).to(dev) for i in mine]
 aux = None if kind == "bss" else [(torch.from_numpy(make_mixture(1, 24000, seed=900 + i)[0]).to(dev), 24000.0) for i in mine]
 secs = float(sum(lens[i] for i in mine)) / 8000.0
+def timed(fn, reps=2):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 with torch.no_grad():
-    for tile in (0, 16, 32):
-        engine.SEQ_TILE["intra"] = engine.SEQ_TILE["inter"] = tile
-        for ns in (8, 16, 48):
-            fn = lambda: inference.separate_many(m, wavs, max_streams=ns, extra_inputs=aux)
-            fn(); torch.cuda.synchronize()
-            t0 = time.perf_counter(); fn(); fn(); torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 2
-            print(f"{kind} tile={tile:2d} streams={ns:2d}: {dt:.3f} s = {len(mine) / dt:6.1f} utt/s, {secs / dt:5.0f}x real time", flush=True)
+    # one ragged launch per DPRNN path over all utterances (engine.dprnn_process_ragged; bf16-split gate GEMM, the default)
+    dt = timed(lambda: inference.separate_many(m, wavs, extra_inputs=aux, ragged=True))
+    print(f"{kind} ragged batch ({len(mine)} utterances, {secs:.0f} s of audio): {dt:.3f} s = {len(mine) / dt:6.1f} utt/s, {secs / dt:5.0f}x real time", flush=True)
+    if os.environ.get("FL_ONLY") == "ragged":
+        sys.exit(0)
+    if os.environ.get("FL_SHARE", "1") == "1":
+        # the rank's whole share (375 utterances), sorted by length so that the utterances of a ragged batch (64 at a time)
+        # are of similar length and the inter-chunk launches have short tails
+        order = sorted(share, key=lambda i: -lens[i])
+        w_all = [torch.from_numpy(make_mixture(1, int(lens[i]), seed=100 + i)[0]).to(dev) for i in order]
+        a_all = None if kind == "bss" else [(torch.from_numpy(make_mixture(1, 24000, seed=900 + i)[0]).to(dev), 24000.0) for i in order]
+        s_all = float(sum(lens[i] for i in order)) / 8000.0
+        dt = timed(lambda: inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True), reps=1)
+        print(f"{kind} ragged, the rank's whole share ({len(order)} utterances sorted by length, {s_all:.0f} s of audio): {dt:.3f} s = "
+              f"{len(order) / dt:6.1f} utt/s, {s_all / dt:5.0f}x real time", flush=True)
+        del w_all, a_all
+    # the round-1 path: equal-length batches (here: single utterances) on streams, exact fp32 kernels at these sizes
+    for ns in (16, 48):
+        dt = timed(lambda: inference.separate_many(m, wavs, max_streams=ns, extra_inputs=aux, ragged=False))
+        print(f"{kind} streams={ns:2d} (one utterance per pipeline): {dt:.3f} s = {len(mine) / dt:6.1f} utt/s, {secs / dt:5.0f}x real time", flush=True)
+    # parity of the two paths on this very workload
+    a_ = inference.separate_many(m, wavs[:6], extra_inputs=None if aux is None else aux[:6], ragged=False)
+    b_ = inference.separate_many(m, wavs[:6] + wavs[6:12], extra_inputs=None if aux is None else aux[:12], ragged=True)[:6]
+    worst = 0.0
+    for x, y in zip(a_, b_):
+        x0, y0 = (x[0], y[0]) if isinstance(x, tuple) else (x, y)
+        worst = max(worst, float(((x0.double() - y0.double()).norm() / x0.double().norm()).item()))
+    print(f"ragged vs one-by-one outputs: worst rel-L2 {worst:.2e}")

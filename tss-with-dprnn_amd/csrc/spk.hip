@@ -153,17 +153,30 @@ __global__ __launch_bounds__(256) void resblock_pool_kernel(const f32x4* __restr
 }
 
 // emb[b][c] = sum_t E[b][t][c] / aux_T,  aux_T = ((((len - ks) // (ks//2)) + 1) // 3 // 3 // 3)   (dprnn_spe.py:156-163)
-__global__ void time_mean_kernel(const float* __restrict__ E, const float* __restrict__ aux_len, int n_len,
-                                 float* __restrict__ emb, int T3, int C, int ks) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
-    const float len = aux_len[n_len > 1 ? b : 0];
-    float aT = floorf((len - (float)ks) / (float)(ks / 2)) + 1.f;
-    aT = floorf(floorf(floorf(aT / 3.f) / 3.f) / 3.f);
+// One block per utterance: TSL time slices x C channels (C <= 128), fixed-order combination (run-to-run deterministic).
+constexpr int TSL = 8;
+__global__ __launch_bounds__(1024)
+void time_mean_kernel(const float* __restrict__ E, const float* __restrict__ aux_len, int n_len,
+                      float* __restrict__ emb, int T3, int C, int ks) {
+    __shared__ float part[TSL][128];
+    const int b = blockIdx.x, c = threadIdx.x % 128, sl = threadIdx.x / 128;
     float s = 0.f;
-    const float* p = E + (long long)b * T3 * C + c;
-    for (int t = 0; t < T3; ++t) s += p[(long long)t * C];
-    emb[b * C + c] = s / aT;
+    if (c < C) {
+        const int per = (T3 + TSL - 1) / TSL, t0 = sl * per, t1 = t0 + per < T3 ? t0 + per : T3;
+        const float* p = E + (long long)b * T3 * C + c;
+        for (int t = t0; t < t1; ++t) s += p[(long long)t * C];
+    }
+    part[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < TSL; ++i) tot += part[i][c];
+        const float len = aux_len[n_len > 1 ? b : 0];
+        float aT = floorf((len - (float)ks) / (float)(ks / 2)) + 1.f;
+        aT = floorf(floorf(floorf(aT / 3.f) / 3.f) / 3.f);
+        emb[b * C + c] = tot / aT;
+    }
 }
 
 // out[b][o] = sum_k W[o*ldw + k0 + k] * in[b*in_pitch + k] + bias[o]
@@ -313,8 +326,8 @@ extern "C" int dprnn_resblock_pool_fwd(const float* Y2, const float* scale, cons
 extern "C" int dprnn_time_mean_fwd(const float* E, const float* aux_len, int n_len, float* emb, int B, int T3, int C, int ks,
                                    void* stream) {
     if (!E || !aux_len || !emb) { dprnn_set_error("dprnn_time_mean_fwd: null pointer"); return -1; }
-    if (C > 1024 || ks < 2 || (n_len != 1 && n_len != B)) { dprnn_set_error("dprnn_time_mean_fwd: bad sizes C=%d ks=%d n_len=%d", C, ks, n_len); return -1; }
-    hipLaunchKernelGGL(time_mean_kernel, dim3(B), dim3(((C + 63) / 64) * 64), 0, (hipStream_t)stream, E, aux_len, n_len, emb, T3, C, ks);
+    if (C > 128 || ks < 2 || (n_len != 1 && n_len != B)) { dprnn_set_error("dprnn_time_mean_fwd: bad sizes C=%d ks=%d n_len=%d", C, ks, n_len); return -1; }
+    hipLaunchKernelGGL(time_mean_kernel, dim3(B), dim3(128 * TSL), 0, (hipStream_t)stream, E, aux_len, n_len, emb, T3, C, ks);
     return dprnn_check_launch("time_mean_kernel");
 }
 

@@ -791,6 +791,60 @@ def auxiliary_embedding(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
 # bottleneck, speaker branch) and after it (mask head, decoder) is launched per utterance: < 3 % of the work.
 # Needs the bf16-split gate GEMM (the eight-wave 64-sequence kernel) and LSTM cells; callers fall back to per-length
 # batches on streams otherwise (inference.separate_many).
+RAGGED_STREAMS = 8           # side streams for the per-utterance launches around the ragged slab (small kernels: they overlap)
+_FAN_POOL: dict = {}
+
+
+class _Fan:
+    """Independent per-utterance work dealt round-robin over persistent side streams; join() makes the caller's stream wait
+    for all of it (and hands the tensors produced there over to it)."""
+
+    def __init__(self, st: Stage, n_items: int, enable: bool = True):
+        self.main = st
+        n = min(RAGGED_STREAMS, n_items) if enable else 0
+        if n > 1:
+            pool = _FAN_POOL.setdefault(st.device, [])
+            while len(pool) < n:
+                pool.append(torch.cuda.Stream(device=st.device))
+            fork = torch.cuda.Event()
+            fork.record(st.tstream)
+            self.stages = [Stage(st.device, s) for s in pool[:n]]
+            for sg in self.stages:
+                sg.tstream.wait_event(fork)
+        else:
+            self.stages = []
+        self.made = []
+
+    def run(self, u: int, fn):
+        """fn(stage) on the side stream of item u; tensors it returns are kept alive / handed over at join()."""
+        if not self.stages:
+            return fn(self.main)
+        sg = self.stages[u % len(self.stages)]
+        with torch.cuda.stream(sg.tstream):
+            out = fn(sg)
+        self.made.append(out)
+        return out
+
+    def join(self):
+        def walk(o):
+            if isinstance(o, torch.Tensor):
+                o.record_stream(self.main.tstream)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        for sg in self.stages:
+            ev = torch.cuda.Event()
+            ev.record(sg.tstream)
+            self.main.tstream.wait_event(ev)
+        walk(self.made)
+        self.made = []
+
+
+def _bn_training(module) -> bool:
+    """BatchNorm in train mode updates its running buffers in place per utterance: such work stays on one stream, in order."""
+    return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in module.modules())
+
+
 def ragged_supported(sep) -> bool:
     return GEMM_MODE != 0 and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
 
@@ -836,8 +890,11 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     arena = torch.empty(5 * m, device=dev, dtype=torch.float32)
     X, X2, Z, H = arena[:m], arena[m: 2 * m], arena[2 * m: 3 * m], arena[3 * m:]
     stats = torch.zeros(2 * len(blocks), n, 2, device=dev, dtype=torch.float64)
+    fan = _Fan(st, n)
     for u in range(n):
-        st.call("dprnn_segment_fwd", _p(Ys[u]), _p(X[int(starts[u]) * F_BUILT:]), 1, geos[u].L, K, P, geos[u].S)
+        fan.run(u, lambda sg, u=u: sg.call("dprnn_segment_fwd", _p(Ys[u]), _p(X[int(starts[u]) * F_BUILT:]), 1, geos[u].L, K, P,
+                                           geos[u].S))
+    fan.join()
     pending = None
     for i, blk in enumerate(blocks):
         for intra in (True, False):
@@ -862,25 +919,30 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     taps, masked = [], []
     head_w = (_p(_param(sep.prelu.weight, "prelu.weight", dev)), _p(_param(sep.conv2d.weight, "conv2d.weight", dev)),
               _p(_param(sep.conv2d.bias, "conv2d.bias", dev)))
-    for u in range(n):
+    def head(sg, u):
         g = geos[u]
         r0 = int(starts[u])
         Hu = H[r0 * 2 * F_BUILT: (r0 + int(rows[u])) * 2 * F_BUILT]          # this utterance's share of H: U | V scratch
         U, V = Hu[: g.L * 2 * F_BUILT], Hu[g.L * 2 * F_BUILT: 2 * g.L * 2 * F_BUILT]
         if pending is None:
-            st.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
+            sg.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
         else:
-            st.call("dprnn_head_conv_ola_norm_fwd", _p(X[r0 * F_BUILT:]), _p(Z[r0 * F_BUILT:]), _p(pending[0][u]), _p(pending[1]),
+            sg.call("dprnn_head_conv_ola_norm_fwd", _p(X[r0 * F_BUILT:]), _p(Z[r0 * F_BUILT:]), _p(pending[0][u]), _p(pending[1]),
                     _p(pending[2]), pending[3], *head_w, _p(U), 1, g.L, K, P, g.S)
-        st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+        sg.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
                 _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
                 _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), g.L * 2)
         t = torch.empty(1, 2, g.L, ks, device=dev, dtype=torch.float32)
         mk = torch.empty(1, g.L, N, device=dev, dtype=torch.float32) if want_masked else None
-        st.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+        sg.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
                 _p(wavs[u]), _p(enc_w), _p(dec_w), _p(t), _p(mk), 1 if relu_act else 0, 1, g.T, g.L, N, ks, g.stride)
-        taps.append(t)
-        masked.append(mk)
+        return t, mk
+
+    fan = _Fan(st, n)
+    res = [fan.run(u, lambda sg, u=u: head(sg, u)) for u in range(n)]
+    fan.join()
+    taps = [r[0] for r in res]
+    masked = [r[1] for r in res]
     return taps, (masked if want_masked else None)
 
 
@@ -899,10 +961,15 @@ def tasnet_forward_ragged(model, wavs):
         geos = [make_geometry(1, w.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"],
                               cfg["stride"]) for w in ws]
         stats0 = torch.zeros(len(ws), 1, 2, device=dev, dtype=torch.float64)
-        Ys = [frames_from_waveform(st, w, enc_w, sep.bottleneck[0], sep.bottleneck[1], g, stats0[u])
-              for u, (w, g) in enumerate(zip(ws, geos))]
+        fan = _Fan(st, len(ws))
+        Ys = [fan.run(u, lambda sg, u=u: frames_from_waveform(sg, ws[u], enc_w, sep.bottleneck[0], sep.bottleneck[1], geos[u],
+                                                                stats0[u])) for u in range(len(ws))]
+        fan.join()
         taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, cfg["activation_type"] == "relu")
-        return [decode(st, t, g, 2)[0] for t, g in zip(taps, geos)]
+        fan = _Fan(st, len(ws))
+        outs = [fan.run(u, lambda sg, u=u: decode(sg, taps[u], geos[u], 2)) for u in range(len(ws))]
+        fan.join()
+        return [o[0] for o in outs]
 
 
 def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
@@ -925,50 +992,63 @@ def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
         axs = [check_input(a.reshape(1, -1), "aux") for a in auxs]
         geos = [make_geometry(1, w.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride) for w in ws]
         stats = torch.zeros(n, 4, 1, 2, device=dev, dtype=torch.float64)     # per utterance: bottleneck, aux, d0 statistics
-        v0s, Ys, scs, alens = [], [], [], []
-        for u in range(n):
+        parallel = not _bn_training(sep)               # train-mode BatchNorm updates its buffers per utterance, in order
+
+        def first(sg, u):
             geo_a = make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
             alen = _aux_len_tensor(aux_lens[u], 1, dev)
-            sc_a, sh_a = bottleneck_affine(st, axs[u], enc_w, se[0], geo_a, stats[u, 1])
-            A0 = bottleneck_frames(st, axs[u], enc_w, sc_a, sh_a, se[1], geo_a).view(geo_a.L, F_BUILT)
-            v0 = speaker_embedding(st, sep, A0, 1, geo_a.L, alen, ks)
-            mul, add, row_bias = _fusion_operands(st, sep, cfg, v0)
-            sc, sh = bottleneck_affine(st, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
-            row_scale = _att_row_scale(st, sep, cfg, ws[u], enc_w, geos[u], stats[u, 0], mul) if cfg["fusion_type"] == "att" else None
-            Ys.append(bottleneck_frames(st, ws[u], enc_w, sc, sh, sep.bottleneck[1], geos[u], row_bias, row_scale))
-            v0s.append(v0); scs.append((sc, sh)); alens.append(alen)
+            sc_a, sh_a = bottleneck_affine(sg, axs[u], enc_w, se[0], geo_a, stats[u, 1])
+            A0 = bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a).view(geo_a.L, F_BUILT)
+            v0 = speaker_embedding(sg, sep, A0, 1, geo_a.L, alen, ks)
+            mul, add, row_bias = _fusion_operands(sg, sep, cfg, v0)
+            sc, sh = bottleneck_affine(sg, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
+            row_scale = _att_row_scale(sg, sep, cfg, ws[u], enc_w, geos[u], stats[u, 0], mul) if cfg["fusion_type"] == "att" else None
+            Y = bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geos[u], row_bias, row_scale)
+            return v0, Y, sc, sh, alen
+
+        fan = _Fan(st, n, parallel)
+        r1 = [fan.run(u, lambda sg, u=u: first(sg, u)) for u in range(n)]
+        fan.join()
+        v0s, Ys = [r[0] for r in r1], [r[1] for r in r1]
+        scs, alens = [(r[2], r[3]) for r in r1], [r[4] for r in r1]
         v_last = v0s
         if not ira:
             taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act)
         else:
             taps, d0s = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act, want_masked=True)
-            Ys2, v1s = [], []
             g0, b0, _ = _norm_params(se[0])
-            for u in range(n):
+
+            def second(sg, u):
                 geo = geos[u]
-                st.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
+                sg.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
                 sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
                 sh_d = torch.empty_like(sc_d)
-                st.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
+                sg.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
                         _p(_param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, _p(sc_d), _p(sh_d), 1, geo.L, N)
-                A0d = _pointwise(st, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
+                A0d = _pointwise(sg, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
                                  aff_stride=N, rows_per_utt=geo.L)
-                v1 = speaker_embedding(st, sep, A0d, 1, geo.L, alens[u], ks)
-                v1 = _linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous())
-                mul2, add2, row_bias2 = _fusion_operands(st, sep, cfg, v1)
+                v1 = speaker_embedding(sg, sep, A0d, 1, geo.L, alens[u], ks)
+                v1 = _linear_small(sg, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous())
+                mul2, add2, row_bias2 = _fusion_operands(sg, sep, cfg, v1)
                 sc, sh = scs[u]
                 if mul2 is not None or add2 is not None:
                     g, b_, eps = _norm_params(sep.bottleneck[0])
-                    st.call("dprnn_bottleneck_prep", _p(stats[u, 0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh), 1, geo.L, N)
-                row_scale2 = _att_row_scale(st, sep, cfg, ws[u], enc_w, geo, stats[u, 0], mul2) if cfg["fusion_type"] == "att" else None
-                Ys2.append(bottleneck_frames(st, ws[u], enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2))
-                v1s.append(v1)
+                    sg.call("dprnn_bottleneck_prep", _p(stats[u, 0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh), 1, geo.L, N)
+                row_scale2 = _att_row_scale(sg, sep, cfg, ws[u], enc_w, geo, stats[u, 0], mul2) if cfg["fusion_type"] == "att" else None
+                return v1, bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2)
+
+            fan = _Fan(st, n, parallel)
+            r2 = [fan.run(u, lambda sg, u=u: second(sg, u)) for u in range(n)]
+            fan.join()
             del Ys, d0s
-            taps, _ = dprnn_process_ragged(st, sep, Ys2, ws, enc_w, dec_w, geos, relu_act)
-            v_last = v1s
-        out = []
-        for u in range(n):
-            logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last[u])
-            est = decode(st, taps[u], geos[u], 1)
-            out.append((est[0, 0, :], logits[0]))
-        return out
+            taps, _ = dprnn_process_ragged(st, sep, [r[1] for r in r2], ws, enc_w, dec_w, geos, relu_act)
+            v_last = [r[0] for r in r2]
+
+        def last(sg, u):
+            logits = _linear_small(sg, sep.pred_linear.weight, sep.pred_linear.bias, v_last[u])
+            return decode(sg, taps[u], geos[u], 1), logits
+
+        fan = _Fan(st, n)
+        r3 = [fan.run(u, lambda sg, u=u: last(sg, u)) for u in range(n)]
+        fan.join()
+        return [(est[0, 0, :], logits[0]) for est, logits in r3]
