@@ -266,6 +266,32 @@ def test_proj_stats_and_norm_residual(kdim):
         assert rel_l2(Xd.cpu().numpy().reshape(B, rows_per, 128), want) < 1e-6
 
 
+@pytest.mark.parametrize("kdim", [256, 128])
+def test_proj_stats_ragged(kdim):
+    """dprnn_proj_stats_ragged_fwd: utterance boundaries from a table of first rows (ragged batches), boundaries inside row
+    tiles and a last partial tile."""
+    rng = np.random.default_rng(kdim + 7)
+    rows = [77, 130, 45]
+    starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    M = int(starts[-1])
+    H = rng.standard_normal((M, kdim)).astype(np.float32)
+    W = (rng.standard_normal((128, kdim)) / np.sqrt(kdim)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    Zw = H.astype(np.float64) @ W.T.astype(np.float64) + b
+    st = _st()
+    Z = torch.full((M, 128), float("nan"), device=DEV)
+    stats = torch.zeros(len(rows), 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_proj_stats_ragged_fwd", _t(H).data_ptr(), _t(W).data_ptr(), _t(b).data_ptr(), Z.data_ptr(),
+            stats.data_ptr(), M, _t(starts).data_ptr(), len(rows), kdim)
+    torch.cuda.synchronize()
+    assert rel_l2(Z.cpu().numpy(), Zw) < 1e-6
+    got = stats.cpu().numpy()
+    for u in range(len(rows)):
+        zu = Zw[starts[u]: starts[u + 1]]
+        assert abs(got[u, 0] - zu.sum()) <= 1e-5 * np.abs(zu).sum()
+        assert abs(got[u, 1] - (zu ** 2).sum()) <= 1e-6 * (zu ** 2).sum()
+
+
 @pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (8, 8, 40), (250, 125, 700)])
 def test_segment_matches_unfold(K, P, L):
     B = 2

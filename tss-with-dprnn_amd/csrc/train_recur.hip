@@ -21,6 +21,7 @@
 //             weight pack carries zero blocks where n_x has no h part and n_h no x part; dh_{t-1} also gets dh_t * z directly
 //   RNN  (2): tape h;  da = dh_t * (1 - h^2), K = 128.
 #include "recur.h"
+#include <stdlib.h>
 using namespace recur;
 
 namespace {
@@ -69,9 +70,13 @@ struct BwdArgs {
     unsigned long long* stamps;   // diagnostic build only: [workgroup][8] cycle counters of wave 0
 };
 
-template <int NT, bool FAST, int CELL = 0, bool STAMP = false>
+// NTS: the once-touched streams (tape and dH in, dG and dX out) carry the non-temporal cache policy, so that they do not push
+// the 1 MB of transposed weight fragments -- re-read by every workgroup every step -- out of the XCD's L2 (PMC, round 1:
+// 6.6 GB read per launch against 4.8 GB algorithmic, the difference being weights re-fetched from HBM).
+template <int NT, bool FAST, int CELL = 0, bool STAMP = false, bool NTS = true>
 __global__ __launch_bounds__(256, 2)
 void lstm_bwd_kernel(BwdArgs a) {
+    constexpr int SAUX = NTS ? 2 : 0;
     constexpr int NS = 16 * NT;
     constexpr int KG = kdim_of(CELL), GS = KG + 1, NGB = KG / 16;     // da image: KG columns + 1 pad (odd stride), k-groups of 16
     constexpr int NTAPE = CELL == 2 ? 1 : 5;
@@ -122,7 +127,9 @@ void lstm_bwd_kernel(BwdArgs a) {
     const __amdgpu_buffer_rsrc_t trs = rsrc_at(reinterpret_cast<const f32x4*>(a.tape) +
                                                ((size_t)dir * gridDim.x + blockIdx.x) * T * 4 * (NT * 2 * NTAPE * 64));
     const unsigned tlane = (unsigned)(wave * (NT * 2 * NTAPE * 64) + lane) * 16u;
-    auto tape_ld = [&](int fs, int x) __attribute__((always_inline)) { return bload4(trs, tlane, (unsigned)fs * TSTEP + (unsigned)x * 1024u); };
+    auto tape_ld = [&](int fs, int x) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tlane, (unsigned)fs * TSTEP + (unsigned)x * 1024u, SAUX));
+    };
     auto t_of = [&](int fs) { return (long long)(dir ? (T - 1 - fs) : fs); };      // forward step -> time index
 
     f32x4 gi[NT][2], gf[NT][2], gg[NT][2], go[NT][2], cc[NT][2], cp[NT][2], dho[NT][2];
@@ -145,7 +152,7 @@ void lstm_bwd_kernel(BwdArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    dho[nt][u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dhs, hoff[nt][e] + 64 * u, 0, 0));
+                    dho[nt][u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dhs, hoff[nt][e] + 64 * u, 0, SAUX));
             }
     };
     {
@@ -222,13 +229,13 @@ void lstm_bwd_kernel(BwdArgs a) {
                     const unsigned go_ = goff[nt][e] + 64 * u;
                     const float v0 = da0[e];
                     d[0] = v0;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), dgs, go_, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), dgs, go_, 0, SAUX);
                     if constexpr (CELL != 2) {
                         const float v1 = da1[e], v2 = da2[e], v3 = da3[e];
                         d[HD] = v1; d[2 * HD] = v2; d[3 * HD] = v3;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), dgs, go_ + 4 * HD, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v2), dgs, go_ + 8 * HD, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), dgs, go_ + 12 * HD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), dgs, go_ + 4 * HD, 0, SAUX);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v2), dgs, go_ + 8 * HD, 0, SAUX);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), dgs, go_ + 12 * HD, 0, SAUX);
                     }
                 }
             }
@@ -289,7 +296,7 @@ void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc[nt][u][e];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dxs, xoff[nt][e] + 64 * u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dxs, xoff[nt][e] + 64 * u, 0, SAUX);
                 }
             }
         }
@@ -334,7 +341,9 @@ int launch_bwd(const BwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)16 * NT * (kdim_of(CELL) + 1) * sizeof(float);
     // the LSTM's tanh(c_t) is recomputed from the tape with the same form (v_exp_f32 / libm) the forward used
     const bool fast = dprnn_fast_activations_enabled() != 0;
-    auto kern = fast ? &lstm_bwd_kernel<NT, true, CELL> : &lstm_bwd_kernel<NT, false, CELL>;
+    static const bool nts = !(getenv("DPRNN_BWD_NT") && atoi(getenv("DPRNN_BWD_NT")) == 0);      // A/B knob: DPRNN_BWD_NT=0 = default policy
+    auto kern = fast ? (nts ? &lstm_bwd_kernel<NT, true, CELL> : &lstm_bwd_kernel<NT, true, CELL, false, false>)
+                     : (nts ? &lstm_bwd_kernel<NT, false, CELL> : &lstm_bwd_kernel<NT, false, CELL, false, false>);
     static bool attr_set[2] = {false, false};
     if (!attr_set[fast]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
