@@ -38,10 +38,12 @@ def main():
             raise SystemExit("no forward found")
         i0 = starts[-1]
         t0 = rows[i0][1]
+        ends = [i for i, r in enumerate(rows) if "decoder_kernel" in r[0] and i > i0]
+        i1 = ends[-1] + 1 if ends else len(rows)          # what follows the decoder is the harness (isfinite checks), not the path
         with open(a.timeline, "w", newline="") as f:
             tw = csv.writer(f)
             tw.writerow(["kernel", "start_us", "end_us", "duration_us", "stream", "queue", "workgroups", "threads_per_workgroup"])
-            for name, st, en, sid, qid, gx, gy, gz, wx, wy, wz in rows[i0:]:
+            for name, st, en, sid, qid, gx, gy, gz, wx, wy, wz in rows[i0:i1]:
                 wgs = (gx // max(wx, 1)) * (gy // max(wy, 1)) * (gz // max(wz, 1))
                 tw.writerow([short(name), round((st - t0) / 1e3, 1), round((en - t0) / 1e3, 1), round((en - st) / 1e3, 1), sid, qid,
                              wgs, wx * wy * wz])
