@@ -208,10 +208,35 @@ GRAD_SPE_CASES = [
     ("grad_spe_wide_film", dict(WIDE, fusion_type="film", norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 84, True),
     ("grad_spe_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 301, 411, 85, True),
     ("grad_spe_wide_att_k4", dict(WIDE, fusion_type="att", norm_type="gLN", kernel_size=4, n_repeats=1, num_spks=11), 2, 302, 411, 86, True),
-    ("grad_ira_wide_cat", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 2, 300, 411, 87, True),
-    ("grad_ira_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 211, 300, 88, True),
+    # seeds 87 / 387 (cat) and 88 / 288 (att) put a MaxPool1d(3) / PReLU decision of the second speaker pass within one ulp
+    # of a tie: the reference's own fp32 and float64 gradients then differ by 2e-3 (spe_fp64_gap below refuses such seeds)
+    ("grad_ira_wide_cat", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 2, 300, 411, 187, True),
+    ("grad_ira_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 211, 300, 488, True),
     ("grad_ira_wide_film_bneval", dict(WIDE, fusion_type="film", norm_type="gLN", n_repeats=1, num_spks=11), 2, 211, 300, 89, False),
 ]
+
+
+WELL_POSED = 2e-5         # a gradient fixture is kept only if the reference's fp32 and float64 gradients agree to this ...
+WELL_POSED_PRELU = 1e-4   # ... (PReLU slopes: one scalar summed over every frame with both signs, looser)
+
+
+def spe_fp64_gap(model, mix, aux, Ta, tgt, spk_idx):
+    """The same reference module and step in float64 against its float32 gradients (already in .grad): the speaker encoder's
+    MaxPool1d(3) and PReLU make the gradient a discontinuous function of the weights, and a seed that lands within rounding
+    of such a decision has no well-defined fp32 answer (any summation order flips it).  Returns the per-parameter rel-L2."""
+    from oracle.sisdr import pit_neg_sisdr_torch
+    g32 = {k: p.grad.detach().clone().double() for k, p in model.named_parameters() if p.grad is not None}
+    model.double()
+    model.zero_grad()
+    est, logits = model(torch.from_numpy(mix).double(), torch.from_numpy(aux).double(), torch.tensor(float(Ta)))
+    l, _ = pit_neg_sisdr_torch(est.unsqueeze(1), tgt.double().unsqueeze(1))
+    (l + 0.5 * torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(spk_idx))).backward()
+    gaps = {k: float((g32[k] - p.grad).norm() / (p.grad.norm() + 1e-30)) for k, p in model.named_parameters() if k in g32}
+    model.float()
+    model.zero_grad()
+    worst = max((k for k in gaps if "prelu" not in k), key=gaps.get)
+    prelu = max((k for k in gaps if "prelu" in k), key=gaps.get)
+    return dict(worst=gaps[worst], worst_key=worst, prelu=gaps[prelu], prelu_key=prelu)
 
 
 def make_grad_spe_cases(only):
@@ -253,12 +278,17 @@ def make_grad_spe_cases(only):
                 save["proj_" + k] = (grad_projection(k, g.shape).astype(np.float64) @ g.reshape(-1).astype(np.float64))
         for k, v in model.state_dict().items():
             if "running_" in k:
-                save["buf_" + k] = v.numpy()
+                save["buf_" + k] = v.numpy().copy()
+        gap = spe_fp64_gap(model, mix, aux, Ta, tgt, spk_idx)
+        if gap["worst"] > WELL_POSED or gap["prelu"] > WELL_POSED_PRELU:
+            raise SystemExit(f"{name}: seed {seed} sits on a MaxPool/PReLU tie (reference fp32 vs float64 gradients: {gap}); "
+                             f"pick another seed")
         meta = dict(name=name, kind=kind, cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed,
-                    bn_training=bn_train, torch=torch.__version__)
+                    bn_training=bn_train, torch=torch.__version__, ref_fp32_vs_fp64_gap=gap)
         save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
-        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}")
+        print(f"{name:32s} loss {loss.item():.5f} params {sum(p.numel() for p in model.parameters())}  reference fp32-vs-fp64 "
+              f"gradient gap {gap['worst']:.1e} ({gap['worst_key']}), PReLU {gap['prelu']:.1e}")
 
 
 def main():

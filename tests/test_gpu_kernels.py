@@ -19,6 +19,15 @@ def _st():
     return engine.Stage(torch.device(DEV))
 
 
+@pytest.fixture(autouse=True)
+def _exact_gemm_mode():
+    """The gate-GEMM mode is process-wide library state: every kernel test starts (and leaves the library) in mode 0."""
+    lib = _st().lib
+    lib.dprnn_set_gemm_mode(0)
+    yield
+    lib.dprnn_set_gemm_mode(0)
+
+
 _KEEP = []
 
 

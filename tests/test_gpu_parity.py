@@ -150,14 +150,17 @@ def test_optional_split_gemm_modes_full_size(mode, tol):
     m = g["meta"]
     model, _, _ = build_model("bss", m["cfg"], m["seed"], _dev())
     x = torch.from_numpy(g["mix"]).to(_dev())
-    engine.GEMM_MODE = mode
+    old = engine.GEMM_MODE, engine.SPLIT_MIN_BATCH
+    engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = mode, 0       # two utterances: force the split kernels at this size
     try:
+        assert engine.effective_gemm_mode(2) == mode
         with torch.no_grad():
             out = model(x).cpu().numpy()
+        engine.GEMM_MODE = 0
+        with torch.no_grad():
+            exact = model(x).cpu().numpy()
     finally:
-        engine.GEMM_MODE = engine.DEFAULT_GEMM_MODE
-    with torch.no_grad():
-        exact = model(x).cpu().numpy()
+        engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = old
     r = rel_l2(out, g["out"])
     tgt, _ = make_sources(2, 24000, seed=77)
     d = np.abs(si_sdr(out, tgt) - si_sdr(g["out"], tgt)).max()
@@ -285,6 +288,8 @@ def test_goldens_with_the_split_gate_gemm_forced(name):
                 out, logits = model(torch.from_numpy(g["mix"]).to(_dev()), torch.from_numpy(g["aux"]).to(_dev()),
                                     torch.tensor(float(g["aux_len"])))
         torch.cuda.synchronize()
+        # the mode is process-wide library state: a forward hands the library back in the exact mode
+        assert engine.Stage(_dev()).lib.dprnn_get_gemm_mode() == 0
     finally:
         engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = old
     r = _close(out.cpu().numpy(), g["out"], name + " (split gate GEMM forced)")

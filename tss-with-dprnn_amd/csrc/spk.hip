@@ -159,10 +159,10 @@ __global__ __launch_bounds__(1024)
 void time_mean_kernel(const float* __restrict__ E, const float* __restrict__ aux_len, int n_len,
                       float* __restrict__ emb, int T3, int C, int ks) {
     __shared__ float part[TSL][128];
-    const int b = blockIdx.x, c = threadIdx.x % 128, sl = threadIdx.x / 128;
+    const int b = blockIdx.x, c = threadIdx.x % 128, sl = threadIdx.x / 128, nsl = blockDim.x / 128;
     float s = 0.f;
     if (c < C) {
-        const int per = (T3 + TSL - 1) / TSL, t0 = sl * per, t1 = t0 + per < T3 ? t0 + per : T3;
+        const int per = (T3 + nsl - 1) / nsl, t0 = sl * per, t1 = t0 + per < T3 ? t0 + per : T3;
         const float* p = E + (long long)b * T3 * C + c;
         for (int t = t0; t < t1; ++t) s += p[(long long)t * C];
     }
@@ -171,7 +171,7 @@ void time_mean_kernel(const float* __restrict__ E, const float* __restrict__ aux
     if (sl == 0 && c < C) {
         float tot = 0.f;
 #pragma unroll
-        for (int i = 0; i < TSL; ++i) tot += part[i][c];
+        for (int i = 0; i < TSL; ++i) tot += i < nsl ? part[i][c] : 0.f;
         const float len = aux_len[n_len > 1 ? b : 0];
         float aT = floorf((len - (float)ks) / (float)(ks / 2)) + 1.f;
         aT = floorf(floorf(floorf(aT / 3.f) / 3.f) / 3.f);
@@ -327,7 +327,8 @@ extern "C" int dprnn_time_mean_fwd(const float* E, const float* aux_len, int n_l
                                    void* stream) {
     if (!E || !aux_len || !emb) { dprnn_set_error("dprnn_time_mean_fwd: null pointer"); return -1; }
     if (C > 128 || ks < 2 || (n_len != 1 && n_len != B)) { dprnn_set_error("dprnn_time_mean_fwd: bad sizes C=%d ks=%d n_len=%d", C, ks, n_len); return -1; }
-    hipLaunchKernelGGL(time_mean_kernel, dim3(B), dim3(128 * TSL), 0, (hipStream_t)stream, E, aux_len, n_len, emb, T3, C, ks);
+    static const int nsl = getenv("DPRNN_TIME_SLICES") ? atoi(getenv("DPRNN_TIME_SLICES")) : TSL;   // A/B knob (1 .. 8)
+    hipLaunchKernelGGL(time_mean_kernel, dim3(B), dim3(128 * (nsl < 1 ? 1 : nsl > TSL ? TSL : nsl)), 0, (hipStream_t)stream, E, aux_len, n_len, emb, T3, C, ks);
     return dprnn_check_launch("time_mean_kernel");
 }
 

@@ -9,6 +9,7 @@ those kernels.  Stage order follows the reference forward:
 """
 from __future__ import annotations
 
+import functools
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -322,6 +323,19 @@ def effective_gemm_mode(B: int, blocks=None) -> int:
     return GEMM_MODE
 
 
+def _leaves_exact_mode(fn):
+    """The gate-GEMM mode is process-wide library state (dprnn_set_gemm_mode) that decides both how dprnn_rnn_pack lays the
+    weights out and which recurrence kernels read them.  A forward selects its mode and, whatever happens, hands the library
+    back in the exact fp32 mode, so that no later caller of the C ABI packs or launches under a mode it did not ask for."""
+    @functools.wraps(fn)
+    def run(st, *args, **kwargs):
+        try:
+            return fn(st, *args, **kwargs)
+        finally:
+            st.lib.dprnn_set_gemm_mode(0)
+    return run
+
+
 def _split_mode_parts(B: int):
     """Utterance groups of the bf16-split modes: the wide kernels take one workgroup per CU, so few, large pipelines."""
     n = max(1, min(SPLIT_GROUPS, B // 16))
@@ -349,6 +363,7 @@ def _split(B: int):
     return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
 
 
+@_leaves_exact_mode
 def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, relu_act: bool,
                   want_masked: bool = False, debug: Optional[dict] = None, masks_out: Optional[torch.Tensor] = None):
     """Segmentation -> DPRNN blocks -> mask head -> mask*enc -> decoder taps.
@@ -849,6 +864,7 @@ def ragged_supported(sep) -> bool:
     return GEMM_MODE != 0 and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
 
 
+@_leaves_exact_mode
 def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act: bool, want_masked: bool = False):
     """dprnn_process for utterances of different lengths.  Ys[u]: frames [1][L_u][F]; wavs[u]: [1][T_u]; geos[u]: Geometry
     with B = 1.  Returns (taps list [1][2][L_u][ks], masked list [1][L_u][N] or None)."""
