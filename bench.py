@@ -280,9 +280,10 @@ def main():
     achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
     traffic, traffic_src = None, None
     try:
-        name = "r02_pmc_traffic.json" if args.gemm_mode == 1 else "r01_pmc_traffic.json"
+        name, key = {0: ("r01_pmc_traffic.json", "bilstm_kernel"), 1: ("r02_pmc_traffic.json", "bilstm_split8_kernel"),
+                     3: ("r02_pmc_traffic.json", "bilstm_split8_kernel_f16")}[args.gemm_mode]
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            pm = json.load(f)["bilstm_split8_kernel" if args.gemm_mode == 1 else "bilstm_kernel"]
+            pm = json.load(f)[key]
         if pm["group_batch"] * n_groups == B:
             traffic, traffic_src = pm["traffic_GB_per_launch"], name
     except (OSError, KeyError, ValueError):
@@ -290,13 +291,13 @@ def main():
 
     # The other arithmetic modes of the gate GEMM, timed AFTER (and outside) the headline region: same batch, same
     # protocol, 3 steps each; deviation is measured against the output of the headline mode of this very run.
-    mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 2: "bf16_split_3_products"}
+    mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 2: "bf16_split_3_products", 3: "f16_pieces_3_products"}
     optional = None
     if world == 1 and not args.no_optional_modes:
         optional = {}
         ref_out = out.double()
         with torch.no_grad():
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 if mode == args.gemm_mode:
                     continue
                 engine.GEMM_MODE = mode
@@ -313,12 +314,14 @@ def main():
     # roofline of the dominant kernel.  Exact mode: the fp32 MFMA peak.  Six-product bf16 split: every algorithmic FLOP costs
     # six bf16 MFMA FLOPs, so the kernel's ceiling in algorithmic (fp32-equivalent) TFLOP/s is the dense bf16 peak / 6.
     BF16_PEAK = 2500.0
-    products = {0: 1, 1: 6, 2: 3}[args.gemm_mode]
+    products = {0: 1, 1: 6, 2: 3, 3: 3}[args.gemm_mode]
     peak = PEAK_F32_MFMA_TFLOPS if args.gemm_mode == 0 else BF16_PEAK / products
+    piece = "f16" if args.gemm_mode == 3 else "bf16"
     kernel_name = "bilstm_kernel (dprnn_rnn_fwd, LSTM cell, exact fp32 MFMA)" if args.gemm_mode == 0 else \
-        f"bilstm_split8_kernel (dprnn_rnn_fwd, LSTM cell, fp32 operands as bf16 pieces, {products} products on the bf16 MFMA)"
-    dtype = "f32" if args.gemm_mode == 0 else (f"f32 via 3 x bf16 split, {products} products, f32 accumulate" if args.gemm_mode == 1
-                                               else "f32 via 2 x bf16 split, 3 products (2^-16), f32 accumulate")
+        f"bilstm_split8_kernel (dprnn_rnn_fwd, LSTM cell, fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)"
+    dtype = {0: "f32", 1: "f32 via 3 x bf16 split, 6 products, f32 accumulate",
+             2: "f32 via 2 x bf16 split, 3 products (2^-16), f32 accumulate",
+             3: "f32 via 2 x f16 pieces of 2^e-scaled operands (22+ bits), 3 products, f32 accumulate"}[args.gemm_mode]
     if rank == 0:
         value = world * B * args.steps / elapsed
         line = {
@@ -332,15 +335,17 @@ def main():
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS,
                        "stream_groups_used": n_groups,
-                       "gemm_mode": ["exact fp32 MFMA (DPRNN_GEMM_MODE=0)", "fp32-equivalent bf16 split, 6 products (default)",
-                                     "bf16 split, 3 products (opt-in, 2^-16)"][args.gemm_mode]},
+                       "gemm_mode": ["exact fp32 MFMA (DPRNN_GEMM_MODE=0)", "fp32-equivalent bf16 split, 6 products (DPRNN_GEMM_MODE=1)",
+                                     "bf16 split, 3 products (opt-in, 2^-16)",
+                                     "fp32-equivalent f16 pieces, 3 products (DPRNN_GEMM_MODE=3)"][args.gemm_mode]
+                       + (" (default)" if args.gemm_mode == engine.DEFAULT_GEMM_MODE else "")},
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": f"GB per launch (PMC, profiles/{traffic_src})",
                          "peak_note": "157.3 = fp32 MFMA peak" if args.gemm_mode == 0 else
-                         f"{BF16_PEAK:.0f} TFLOP/s dense bf16 MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
+                         f"{BF16_PEAK:.0f} TFLOP/s dense {piece} MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
                          f"{PEAK_F32_MFMA_TFLOPS} (achieved / that = {achieved / PEAK_F32_MFMA_TFLOPS:.2f})",
-                         "executed_bf16_mfma_tflops": None if args.gemm_mode == 0 else achieved * products,
+                         "executed_mfma_tflops": None if args.gemm_mode == 0 else achieved * products,
                          "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                          # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
                          # the previous norm is folded in: all launches of a forward but the first]

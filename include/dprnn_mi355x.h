@@ -44,13 +44,22 @@ void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
  * recurrence entry points, so set it before packing): 0 = exact fp32 operands on the fp32 MFMA (default, what every
  * parity claim and the bench headline refer to); 1 = operands split into three bf16 pieces, the six cross products of
  * order <= 2^-16 on the bf16 MFMA with fp32 accumulation (product error ~2^-24: end-to-end deviation identical to the
- * fp32 path's own rounding noise); 2 = two pieces / three products (product error ~2^-16) -- recur_split.hip. */
+ * fp32 path's own rounding noise); 2 = two bf16 pieces / three products (product error ~2^-16); 3 = two f16 pieces of
+ * power-of-two-scaled operands (activations x 2^4, weights x a per-LSTM 2^e), three products on the f16 MFMA: 22+ operand
+ * bits, product error ~2^-24 like mode 1 at half its MFMA work (eight-wave kernels, seq_tile 2032 .. 2096 and the ragged
+ * entry; |x| is clamped to 4062 in the piece conversion) -- recur_split.hip.  The mode is a property of the PACKED weights
+ * as much as of the launch: pack and launch under the same mode, and hand the library back in mode 0 (the Python host's
+ * forwards do: engine._leaves_exact_mode). */
 void dprnn_set_gemm_mode(int mode);
 int dprnn_get_gemm_mode(void);
-/* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order) */
+/* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order; the f16 form uses
+ * two planes and keeps its scale 2^e, and 1 / (2^4 2^e), in words 512 and 513 of the third) */
 int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                           const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                           void* packed, float* bsum, void* stream);
+int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                        const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                        void* packed, float* bsum, void* stream);
 
 /* ---- device memory of one DPRNNTasNet forward (B utterances of T samples; encoder N filters of ks taps, stride; chunks
  * of K frames, hop P; n_blocks DPRNN blocks): returns the total number of bytes, or a negative DPRNN_E* code, and -- when

@@ -208,6 +208,86 @@ def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
         assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
 
 
+@pytest.mark.parametrize("seq_tile", [2032, 2048, 2064, 2080, 2096, 3048, 3064])
+@pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
+@pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (37.0, 0.02), (1e-3, 40.0)])
+def test_bilstm_f16_pieces(seq_tile, path, fused, wscale, xscale):
+    """Gate-GEMM mode 3 (two f16 pieces of 2^e-scaled operands, three products, eight-wave kernels): fp32-class accuracy
+    against the numpy oracle at every tile size, with the pending norm folded in, and with weights / activations far from
+    unit scale (the per-LSTM weight exponent and the f16 subnormal second pieces are what keeps those exact)."""
+    B, S, K = 3, 37, 41
+    rng = np.random.default_rng(seq_tile + int(10 * wscale))
+    X = (xscale * rng.standard_normal((B, S, K, 128))).astype(np.float32)
+    sd, p = _lstm_sd(46)
+    sd = {k: (v * np.float32(wscale) if ".rnn.weight_" in k else v) for k, v in sd.items()}
+    Xn = X
+    if fused:
+        Zr = (rng.standard_normal((B, S, K, 128)) * 1.3 + 0.2).astype(np.float32)
+        gamma = (xscale * (1 + 0.1 * rng.standard_normal(128))).astype(np.float32)
+        beta = (xscale * 0.1 * rng.standard_normal(128)).astype(np.float32)
+        zb = Zr.reshape(B, -1).astype(np.float64)
+        mean, var = zb.mean(1)[:, None, None, None], zb.var(1)[:, None, None, None]
+        Xn = (X + ((Zr - mean) / np.sqrt(var + 1e-5)) * gamma + beta).astype(np.float32)
+    if path == "intra":
+        want = onp.single_rnn(sd, p, Xn.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    else:
+        want = onp.single_rnn(sd, p, Xn.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
+        want = want.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    Xd = _t(X)
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    Xo = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    norm = (0, 0, 0, 0, 0.0, 1, 1, 0)
+    if fused:
+        stats = _t(np.stack([zb.sum(1), (zb ** 2).sum(1)], axis=1))
+        Zd, gd, bd = _t(Zr), _t(gamma), _t(beta)
+        norm = (Zd.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, S if path == "intra" else K, S * K, Xo.data_ptr())
+    results = {}
+    for mode in (3, 0):                     # the exact fp32 MFMA kernels on the same input: the yardstick
+        st.lib.dprnn_set_gemm_mode(mode)
+        st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+        st.call("dprnn_rnn_fwd", 0, Xd.data_ptr(), *norm, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2,
+                seq_tile if mode else 32)
+        torch.cuda.synchronize()
+        got = H.cpu().numpy()
+        assert np.isfinite(got).all()
+        results[mode] = rel_l2(got, want)
+    assert results[3] < max(1e-6, 3 * results[0]), f"tile {seq_tile} {path} fused={fused} w x{wscale} x x{xscale}: f16 pieces " \
+        f"{results[3]:.2e}, exact fp32 kernels {results[0]:.2e}"
+    if fused:
+        assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
+
+
+def test_bilstm_f16_pieces_stay_finite_on_huge_activations():
+    """|x| beyond the f16 range (16 |x| > 65504) is clamped in the piece conversion: results stay finite (the gates are
+    saturated there anyway) and the rows next to it are untouched."""
+    B, S, K = 1, 3, 40
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    X[0, 1, 7, :] = 1e6
+    sd, p = _lstm_sd(46)
+    want = onp.single_rnn(sd, p, X.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    st.lib.dprnn_set_gemm_mode(3)
+    st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    st.call("dprnn_rnn_fwd", 0, _t(X).data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+            B * S, K, B * S, 0, K, 1, 2, 2064)
+    torch.cuda.synchronize()
+    got = H.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_l2(got[0, [0, 2]], want[0, [0, 2]]) < 1e-6          # other chunks (sequences) are independent of the huge row
+
+
 def test_bilstm_unidirectional():
     B, S, K = 1, 5, 9
     X = np.random.default_rng(3).standard_normal((B, S, K, 128)).astype(np.float32)

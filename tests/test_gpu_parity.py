@@ -141,10 +141,11 @@ def test_fused_and_explicit_norm_agree():
     assert rel_l2(outs[0], outs[1]) < 1e-6
 
 
-@pytest.mark.parametrize("mode,tol", [(1, 1e-6), (2, 1e-5)])
+@pytest.mark.parametrize("mode,tol", [(1, 1e-6), (2, 1e-5), (3, 1e-6)])
 def test_optional_split_gemm_modes_full_size(mode, tol):
-    """engine.GEMM_MODE 1 / 2 (bf16-split gate GEMM, opt-in): the 6-product form must sit at the fp32 path's own
-    noise level against the reference output, the 3-product form inside the 1e-5 parity tolerance."""
+    """engine.GEMM_MODE 1 / 3 (fp32-class split gate GEMMs: six bf16 products, three products of f16 pieces) must sit at
+    the fp32 path's own noise level against the reference output, the 3-product bf16 form (mode 2, opt-in) inside the 1e-5
+    parity tolerance."""
     from tss_with_dprnn_amd import engine
     g = load_golden("bss_full_b2")
     m = g["meta"]
@@ -262,12 +263,17 @@ def test_headline_batch_b64_full_size():
     print(f"B=64 x 24000: rel-L2 vs CPU oracle {r:.2e}; worst batched-vs-single {worst:.2e}")
 
 
-@pytest.mark.parametrize("name", ["bss_full_b2", "bss_wide_k250", "bss_wide_small", "spe_full_b1", "spe_full_att_b1",
-                                  "spe_wide_small_cat_bntrain", "ira_full_b1", "ira_full_long_b1"])
-def test_goldens_with_the_split_gate_gemm_forced(name):
-    """The default gate-GEMM mode (fp32 operands as three bf16 pieces, six products) only engages from 20 utterances up
-    (smaller launches are faster on the exact kernels), so the reference goldens -- one or two utterances each -- are run here
-    with the split kernels FORCED at every size: same tolerances as the exact path (rel-L2 1e-5, |dSI-SDR| 0.01 dB)."""
+# every forward golden at the width the HIP path is built for (the "tiny" ones pin the oracle only; grad_* are training steps)
+FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_") and "tiny" not in n]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("name", FORWARD_GOLDENS)
+def test_every_golden_in_every_fp32_class_gate_gemm_mode(name, mode):
+    """EVERY forward golden generated from the reference classes (BSS, Spe, IRA; LSTM cells) under each fp32-class arithmetic
+    of the gate GEMM, forced at every size: 0 = exact fp32 MFMA, 1 = six bf16 products, 3 = three products of f16 pieces
+    (the default).  Same tolerances in all three (rel-L2 1e-5, |dSI-SDR| 0.01 dB).  GRU / Elman goldens always run the
+    exact kernels (effective_gemm_mode), whatever the mode."""
     from tss_with_dprnn_amd import engine
     g = load_golden(name)
     m = g["meta"]
@@ -277,9 +283,9 @@ def test_goldens_with_the_split_gate_gemm_forced(name):
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.train()
     old = engine.GEMM_MODE, engine.SPLIT_MIN_BATCH
-    engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = 1, 0
+    engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = mode, 0
     try:
-        assert engine.effective_gemm_mode(1) == 1
+        assert engine.effective_gemm_mode(1) == mode
         with torch.no_grad():
             if m["kind"] == "bss":
                 out = model(torch.from_numpy(g["mix"]).to(_dev()))
@@ -292,7 +298,7 @@ def test_goldens_with_the_split_gate_gemm_forced(name):
         assert engine.Stage(_dev()).lib.dprnn_get_gemm_mode() == 0
     finally:
         engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = old
-    r = _close(out.cpu().numpy(), g["out"], name + " (split gate GEMM forced)")
+    r = _close(out.cpu().numpy(), g["out"], f"{name} (gate GEMM mode {mode})")
     if logits is not None:
         assert rel_l2(logits.cpu().numpy(), g["logits"]) <= REL_TOL
-    print(f"{name}: rel-L2 vs reference {r:.2e} with the six-product bf16 split")
+    print(f"{name}: rel-L2 vs reference {r:.2e} in gate-GEMM mode {mode}")

@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
-    ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3")
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3, 3 f16 pieces x3")
     ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
@@ -213,8 +213,8 @@ def main():
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
-    if a.stamps and a.gemm_mode == 1:
-        for seq_tile in (64, 2064, 3064):
+    if a.stamps and a.gemm_mode in (1, 3):
+        for seq_tile in ((64, 2064, 3064) if a.gemm_mode == 1 else (2064, 3064)):
             stamps_split(st, seq_tile, a.T)
         return
     if a.stamps:
@@ -237,7 +237,10 @@ def main():
     if a.gemm_mode != 0:       # bf16-split modes: the two-per-CU form, the round-1 64-sequence form and the wide one-per-CU forms
         np_ = 6 if a.gemm_mode == 1 else 3
         print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
-        for seq_tile, per_cu in ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1)):
+        forms = ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1))
+        if a.gemm_mode == 3:    # f16 pieces: the eight-wave kernels only
+            forms = ((2032, 1), (2032, 2), (2048, 1), (2048, 2), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1))
+        for seq_tile, per_cu in forms:
             ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
             tiles = (abs(seq_tile) % 1000 + 15) // 16
             floor_us = per_cu * tiles * 32 * 8 * np_ * 16 / 4 / 2.4e3

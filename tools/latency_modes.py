@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Forward time of DPRNN-TasNet by batch size under both gate-GEMM modes (engine.GEMM_MODE 0 = exact fp32 MFMA,
-1 = fp32-equivalent bf16 split) with the engine's own tile / group choices: where does which mode win?"""
+"""Forward time of DPRNN-TasNet by batch size under the fp32-class gate-GEMM modes (engine.GEMM_MODE 0 = exact fp32 MFMA,
+1 = bf16 split x6, 3 = f16 pieces x3) with the engine's own tile / group choices and the split kernels forced at every
+size (engine.SPLIT_MIN_BATCH = 0): where does which mode win?"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +19,8 @@ sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2
 for B in sizes:
     x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
     row = []
-    for mode in (0, 1):
-        engine.GEMM_MODE = mode
+    for mode in (0, 1, 3):
+        engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = mode, 0
         with torch.no_grad():
             for _ in range(2):
                 model(x)
@@ -31,4 +32,4 @@ for B in sizes:
             torch.cuda.synchronize()
         row.append((time.perf_counter() - t0) / n * 1e3)
     print(f"B={B:3d}: exact fp32 {row[0]:8.2f} ms ({B / row[0] * 1e3:6.1f} utt/s)   bf16 split x6 {row[1]:8.2f} ms ({B / row[1] * 1e3:6.1f} utt/s)   "
-          f"ratio {row[0] / row[1]:.2f}", flush=True)
+          f"f16 pieces x3 {row[2]:8.2f} ms ({B / row[2] * 1e3:6.1f} utt/s)   exact / f16 {row[0] / row[2]:.2f}", flush=True)

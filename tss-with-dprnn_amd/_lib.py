@@ -38,6 +38,7 @@ SIGNATURES = {
     "dprnn_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
                       c_i64, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
+    "dprnn_lstm_pack_f16": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
     "dprnn_proj_stats_ragged_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_i, c_i, c_fp],

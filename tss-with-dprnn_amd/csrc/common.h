@@ -64,6 +64,26 @@ template <bool FAST> __device__ __forceinline__ f32x2 tanh_b2(f32x2 x, float bk)
     }
 }
 template <bool FAST> __device__ __forceinline__ f32x2 tanh_f2(f32x2 x) { return tanh_b2<FAST>(x, 0.f); }
+// the same with the pre-activation scaled: sigmoid(k' x + b), tanh(k' x + b); FAST: k = k' * (-log2 e | 2 log2 e), bk as above
+template <bool FAST> __device__ __forceinline__ f32x2 sigmoid_k2(f32x2 x, float k, float bk) {
+    const f32x2 a = x * f32x2{k, k} + f32x2{bk, bk};
+    if constexpr (FAST) {
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    } else {
+        return f32x2{sigmoid_acc(a[0]), sigmoid_acc(a[1])};
+    }
+}
+template <bool FAST> __device__ __forceinline__ f32x2 tanh_k2(f32x2 x, float k, float bk) {
+    const f32x2 a = x * f32x2{k, k} + f32x2{bk, bk};
+    if constexpr (FAST) {
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return f32x2{1.f, 1.f} - f32x2{2.f, 2.f} * r;
+    } else {
+        return f32x2{tanh_acc(a[0]), tanh_acc(a[1])};
+    }
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

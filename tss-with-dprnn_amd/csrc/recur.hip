@@ -504,17 +504,22 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
 
 // 0 exact fp32 MFMA (default); bf16-split: 1 = 6 products, 2 = 3 products (recur_split.hip)
 static int g_gemm_mode = 0;
-extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
+static int split_products() { return g_gemm_mode == 1 ? 6 : g_gemm_mode == 2 ? 3 : 2; }   // 2 = the f16 form's code (three products of two f16 pieces)
+extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode >= 1 && mode <= 3) ? mode : 0; }
 extern "C" int dprnn_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" int dprnn_lstm_pack_split(const float*, const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, void*, float*, void*);
+extern "C" int dprnn_lstm_pack_f16(const float*, const float*, const float*, const float*, const float*, const float*,
+                                   const float*, const float*, void*, float*, void*);
 
 extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                               const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                               float* packed, float* bsum, void* stream) {
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_rnn_pack: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (cell == 0 && g_gemm_mode != 0)       // optional split modes: bf16 piece planes instead of fp32 fragments
+    if (cell == 0 && g_gemm_mode == 3)       // f16 form: two f16 piece planes of 2^e * W
+        return dprnn_lstm_pack_f16(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
+    if (cell == 0 && g_gemm_mode != 0)       // bf16 split modes: bf16 piece planes instead of fp32 fragments
         return dprnn_lstm_pack_split(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_rnn_pack: incomplete reverse direction"); return -1; }
@@ -563,7 +568,7 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
     }
     if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (g_gemm_mode != 0) return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, seq_tile, fast, st);
+    if (g_gemm_mode != 0) return launch_bilstm_split(a, split_products(), seq_tile, fast, st);
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true, 0, false, 8>(a, st) : launch_bilstm<1, false, 0, false, 8>(a, st);
         case -16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
@@ -641,7 +646,7 @@ extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double
     if (wg_desc) { a.inner_n = 1 << 30; a.outer_stride = 0; a.inner_stride = 1; a.t_stride = K; }
     else { a.inner_n = n_items; a.outer_stride = 0; a.inner_stride = K; a.t_stride = 1; }
     if ((long long)64 * K * ndir * HD * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_fwd_ragged: chunk_length too large"); return -1; }
-    return launch_bilstm_split(a, g_gemm_mode == 1 ? 6 : 3, 2064, g_fast_act != 0, (hipStream_t)stream);
+    return launch_bilstm_split(a, split_products(), 2064, g_fast_act != 0, (hipStream_t)stream);
 }
 
 // ---- training forward: dprnn_rnn_fwd for the LSTM cell on 32-sequence tiles, plus the gate tape for dprnn_lstm_bwd
@@ -702,9 +707,11 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
-    if (g_gemm_mode == 1) {                 // wide bf16-split kernel with stamps (seq_tile 64 or 104; packed by dprnn_rnn_pack in mode 1)
-        if (seq_tile != 64 && seq_tile != 1064 && seq_tile != 2064 && seq_tile != 3064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64, 1064, 2064, 3064"); return -1; }
-        return launch_bilstm_split(a, 6, seq_tile, true, st);
+    if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // split kernels with stamps (packed by dprnn_rnn_pack in the same mode)
+        const bool ok = g_gemm_mode == 1 ? (seq_tile == 64 || seq_tile == 1064 || seq_tile == 2064 || seq_tile == 3064)
+                                         : (seq_tile == 2064 || seq_tile == 3064);
+        if (!ok) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64, 1064, 2064, 3064 (mode 1) and 2064, 3064 (mode 3)"); return -1; }
+        return launch_bilstm_split(a, split_products(), seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {
         const size_t lds = (size_t)2 * NS * XS * sizeof(float);

@@ -68,6 +68,31 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- f16 form (gemm mode 3): v -> two f16 pieces of S * v (11 significant bits each, so v1 + v2 carries 22+ bits and the
+// three products v1w1 + v1w2 + v2w1 leave v2w2 ~ 2^-24 |v||w| behind -- the size of one fp32 product rounding), at HALF the
+// MFMA work of the six bf16 products.  f16 has 5 exponent bits, so operands are scaled by powers of two into its range:
+// activations by F16_XS = 2^4 (x clamped to +-4062; |h| < 1), weights by a per-LSTM 2^e that puts max|W| in [2^13, 2^14)
+// (lstm_absmax_kernel); second pieces may be f16 subnormals, which v_cvt_pk_f16_f32 produces and the MFMA consumes
+// without flushing (tools/probes/mfma_f16_denorm.hip).  The accumulators come out scaled by S_x * S_w, a power of two that the
+// gate nonlinearity's first multiply-add removes (inv, read from the packed weights).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_XS = 16.f;
+constexpr float F16_XMAX = 65000.f;                // clamp of S_x * x (f16 max 65504): finite results for any input
+constexpr int F16_SCALE_WORD = 2 * 256;            // packed word of S_w (then 1 / (S_x S_w)): plane 2 of fragment 0 is unused in this form
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+// (s0, s1), already scaled -> two words of packed f16 pieces (low half = s0's piece, high half = s1's)
+__device__ __forceinline__ void split2_pair_f16(float s0, float s1, unsigned& w1, unsigned& w2) {
+    w1 = cvt_pk_f16(s0, s1);
+    const f16x2 h = __builtin_bit_cast(f16x2, w1);
+    w2 = cvt_pk_f16(s0 - (float)h[0], s1 - (float)h[1]);       // the differences are exact in fp32
+}
+
 // packed[dir][wave][slab][gate*2+u][piece][lane][4 u32] : bf16 piece `piece` of Wcat[gate*128 + 32*wave + 2*r + u][32*slab + 8*q + j]
 // (a lane's two column tiles u = 0, 1 are the adjacent hidden units 2r, 2r+1: their h pieces share one 32-bit LDS store
 // and their fp32 h one 64-bit global store)
@@ -97,6 +122,69 @@ __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const flo
     const size_t base = ((((size_t)(dir * 4 + wave) * NSLAB + slab) * 8 + gu) * 3) * 256 + lane * 4 + dw;
 #pragma unroll
     for (int p = 0; p < 3; ++p) packed[base + (size_t)p * 256] = out[p];
+    if (idx < ndir * 4 * HD) {
+        const int d = idx / (4 * HD), n = idx % (4 * HD);
+        bsum[idx] = (d ? b_ih_r : b_ih)[n] + (d ? b_hh_r : b_hh)[n];
+    }
+}
+
+// S_w of one LSTM: the power of two that puts max|W_ih, W_hh| (all directions) in [2^13, 2^14); one block
+__global__ __launch_bounds__(1024)
+void lstm_absmax_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ w_ih_r,
+                        const float* __restrict__ w_hh_r, float* __restrict__ packed_f) {
+    __shared__ float part[16];
+    const float* src[4] = {w_ih, w_hh, w_ih_r, w_hh_r};
+    float m = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        if (!src[k]) continue;
+        const f32x4* p = reinterpret_cast<const f32x4*>(src[k]);
+        for (int i = threadIdx.x; i < 4 * HD * F / 4; i += 1024) {          // W_ih [4H][F] and W_hh [4H][H] have the same size (F == H)
+            const f32x4 v = p[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
+        int ex = 0;
+        if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);                           // m = f * 2^ex, f in [0.5, 1)
+        ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+        const float sw = ldexpf(1.f, 14 - ex);
+        packed_f[F16_SCALE_WORD] = sw;
+        packed_f[F16_SCALE_WORD + 1] = 1.f / (F16_XS * sw);
+    }
+}
+
+// same fragment layout as lstm_pack_split_kernel, planes 0 and 1 = the two f16 pieces of S_w * W (plane 2 stays unused)
+__global__ void lstm_pack_f16_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                     const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                     const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
+                                     const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
+                                     unsigned* __restrict__ packed, float* __restrict__ bsum, int ndir) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_dir = 4 * NSLAB * 8 * 64 * 4;
+    if (idx >= ndir * per_dir) return;
+    const float sw = reinterpret_cast<const float*>(packed)[F16_SCALE_WORD];
+    const int dw = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, slab = (idx >> 11) & 7;
+    const int wave = (idx >> 14) & 3, dir = idx >> 16;
+    const int gate = gu >> 1, u = gu & 1, r = lane & 15, q = lane >> 4;
+    const int row = gate * HD + 32 * wave + 2 * r + u;
+    const float* wi = dir ? w_ih_r : w_ih;
+    const float* wh = dir ? w_hh_r : w_hh;
+    float v[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int k = 32 * slab + 8 * q + 2 * dw + half;
+        v[half] = sw * (k < F ? wi[row * F + k] : wh[row * HD + (k - F)]);
+    }
+    unsigned w1, w2;
+    split2_pair_f16(v[0], v[1], w1, w2);
+    const size_t base = ((((size_t)(dir * 4 + wave) * NSLAB + slab) * 8 + gu) * 3) * 256 + lane * 4 + dw;
+    packed[base] = w1;
+    packed[base + 256] = w2;
     if (idx < ndir * 4 * HD) {
         const int d = idx / (4 * HD), n = idx % (4 * HD);
         bsum[idx] = (d ? b_ih_r : b_ih)[n] + (d ? b_hh_r : b_hh)[n];
@@ -1031,10 +1119,11 @@ int launch_split_ov_any(const RecurArgs& a, int products, bool fast, hipStream_t
 //   cell update while its matrix pipe works on the other's x half.  Costs: a second accumulator set, x double-buffered
 //   in LDS (NSR <= 64).
 // Image: regions h | x0 (| x1), each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2)
 void bilstm_split8_kernel(RecurArgs a) {
     static_assert(NSR % 16 == 0 && NSR >= 32 && NSR <= 96, "whole 16-row tiles");
+    static_assert(!F16 || NP == 3, "the f16 form has two pieces and three products");
     constexpr int NT = NSR / 16;
     constexpr int NPC = NP == 6 ? 3 : 2;
     constexpr int PL = NSR * 256;                      // bytes of one piece plane of one region
@@ -1094,6 +1183,10 @@ void bilstm_split8_kernel(RecurArgs a) {
         const float b = a.bsum[dir * 4 * HD + g * HD + unit0];
         bias[g] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
     }
+    // f16 form: the accumulators are S_x S_w times the gate pre-activations; inv = 1 / (S_x S_w) rides on the multiply the
+    // nonlinearity starts with anyway
+    const float inv = F16 ? a.Wp[F16_SCALE_WORD + 1] : 1.f;
+    const float ksig = FAST ? -1.4426950408889634f * inv : inv, ktanh = FAST ? 2.8853900817779268f * inv : inv;
     const int w4_u = __builtin_amdgcn_readfirstlane(w4), wu_u = __builtin_amdgcn_readfirstlane(wu);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.Wp) + (size_t)(dir * 4 + w4_u) * NSLAB * 8 * 3 * 64), 0, 0x7fffffff, 0x00020000);
@@ -1138,8 +1231,15 @@ void bilstm_split8_kernel(RecurArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[i] : OOB, 0, 0);
                 }
                 unsigned pa[3], pb[3];
-                split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
-                split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+                if constexpr (F16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                    split2_pair_f16(v[0], v[1], pa[0], pa[1]);
+                    split2_pair_f16(v[2], v[3], pb[0], pb[1]);
+                } else {
+                    split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+                    split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+                }
                 char* d = xreg + xb * REG + xl + m * 4096;
 #pragma unroll
                 for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PL) = u32x2{pa[pc], pb[pc]};
@@ -1148,9 +1248,59 @@ void bilstm_split8_kernel(RecurArgs a) {
         fence();
     };
 
+    // The same in two parts (XPF: plain form up to 64 sequences, where the registers allow it): the loads of x_{t+1} are
+    // issued at the start of the LAST k-slab of step t and land under its MFMAs, barrier A and the cell update, instead of
+    // being waited for right after they are issued.  (vmcnt retires in order: loads issued earlier in the step would sit in
+    // front of every weight wait; from the last slab on, the only younger loads are next step's slab-0 weights.)
+    constexpr bool XPF = !STAG && NT <= 4;
+    f32x4 xq[XPF ? NT : 1], zq[XPF ? NT : 1];
+    auto x_issue = [&](long long t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
+        fence();
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
+            xq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0));
+            if (FUSE) zq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo, 0, 0));
+        }
+        fence();
+    };
+    auto x_finish = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+        fence();
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            f32x4 v = xq[m];
+            if (FUSE) {
+                const float mu = musig[2 * (xrow0 + 16 * m)], rs = musig[2 * (xrow0 + 16 * m) + 1];
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
+                const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo : OOB, 0, 0);
+            }
+            unsigned pa[3], pb[3];
+            if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                split2_pair_f16(v[0], v[1], pa[0], pa[1]);
+                split2_pair_f16(v[2], v[3], pb[0], pb[1]);
+            } else {
+                split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+                split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+            }
+            char* d = xreg + xb * REG + xl + m * 4096;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PL) = u32x2{pa[pc], pb[pc]};
+        }
+        fence();
+    };
+
     __syncthreads();                                   // row tables are in place
     const long long tfirst = dir ? (T - 1) : 0, tsecond = T > 1 ? (dir ? (T - 2) : 1) : tfirst;
-    x_stage(tfirst, 0, true);
+    if constexpr (XPF) { x_issue(tfirst); x_finish(tfirst, 0, true); }
+    else x_stage(tfirst, 0, true);
     if (STAG) x_stage(tsecond, 1, T > 1);
     for (int i = tid; i < REG / 4; i += 512) reinterpret_cast<unsigned*>(hreg)[i] = 0u;
     f32x4 c[NT];
@@ -1184,7 +1334,8 @@ void bilstm_split8_kernel(RecurArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                ac[nt][g] = mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
+                ac[nt][g] = F16 ? mfma_f16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g])
+                                : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
 #pragma unroll
@@ -1214,16 +1365,18 @@ void bilstm_split8_kernel(RecurArgs a) {
         }
     };
     // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end
-    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first) __attribute__((always_inline)) {
+    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0) __attribute__((always_inline)) {
         if constexpr (NP == 6) {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
             slab(ac, reg, fb, fa, 1, s0 + 2, true, true, false);
             slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false);
+            if (xhook) x_issue(tx);
             slab(ac, reg, fb, fa, 3, (s0 + 4) & 7, true, false, false);
         } else {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
             slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false);
             slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false);
+            if (xhook) x_issue(tx);
             slab(ac, reg, fa, fb, 3, (s0 + 4) & 7, true, false, false);
         }
     };
@@ -1236,16 +1389,25 @@ void bilstm_split8_kernel(RecurArgs a) {
             float hv[4];
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
-                const f32x2 ig = sigmoid_b2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, bias[0]);
-                const f32x2 fg = sigmoid_b2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, bias[1]);
-                const f32x2 gg = tanh_b2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, bias[2]);
-                const f32x2 og = sigmoid_b2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, bias[3]);
+                f32x2 ig, fg, gg, og;
+                if constexpr (F16) {
+                    ig = sigmoid_k2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, bias[0]);
+                    fg = sigmoid_k2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, bias[1]);
+                    gg = tanh_k2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, bias[2]);
+                    og = sigmoid_k2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, bias[3]);
+                } else {
+                    ig = sigmoid_b2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, bias[0]);
+                    fg = sigmoid_b2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, bias[1]);
+                    gg = tanh_b2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, bias[2]);
+                    og = sigmoid_b2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, bias[3]);
+                }
                 const f32x2 cn = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
                 const f32x2 h2 = og * tanh_f2<FAST>(cn);
                 c[nt][2 * p2] = cn[0]; c[nt][2 * p2 + 1] = cn[1];
                 hv[2 * p2] = h2[0]; hv[2 * p2 + 1] = h2[1];
-                unsigned w1, w2, w3;                   // pieces of rows e = 2 p2 (low halves) and 2 p2 + 1 (high halves)
-                split3_pair<NPC>(h2[0], h2[1], w1, w2, w3);
+                unsigned w1, w2, w3 = 0u;              // pieces of rows e = 2 p2 (low halves) and 2 p2 + 1 (high halves)
+                if constexpr (F16) split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1, w2);
+                else split3_pair<NPC>(h2[0], h2[1], w1, w2, w3);
                 char* d0 = hreg + hb[2 * p2] + nt * 4096;
                 char* d1 = hreg + hb[2 * p2 + 1] + nt * 4096;
                 *reinterpret_cast<unsigned short*>(d0) = (unsigned short)w1;
@@ -1273,12 +1435,14 @@ void bilstm_split8_kernel(RecurArgs a) {
             if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
             const long long t = dir ? (T - 1 - step) : step;
             const bool more = step + 1 < T;
+            const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             half(acc[0], xreg, 0, true);
-            half(acc[0], hreg, 4, false);
+            half(acc[0], hreg, 4, false, XPF, tn);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             __syncthreads();                           // every wave is done reading the image of this step
             cell(acc[0], t);
-            x_stage(more ? (dir ? (t - 1) : (t + 1)) : t, 0, more);
+            if constexpr (XPF) x_finish(tn, 0, more);
+            else x_stage(tn, 0, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
             __syncthreads();
         }
@@ -1320,18 +1484,18 @@ void bilstm_split8_kernel(RecurArgs a) {
     }
 }
 
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(STAG ? 3 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 + (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
-    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>), grid, dim3(512), lds, st, a);
     return dprnn_check_launch("bilstm_split8_kernel");
 }
 
@@ -1339,8 +1503,15 @@ template <int NSR, bool STAG>
 int launch_split8_any(const RecurArgs& a, int products, bool fast, hipStream_t st) {
     if constexpr (NSR == 64) {
         if (a.stamps && products == 6) return launch_split8<NSR, 6, true, false, STAG, true>(a, st);
+        if (a.stamps && products == 2) return launch_split8<NSR, 3, true, false, STAG, true, true>(a, st);
     }
     const bool fuse = a.Z != nullptr;
+    if (products == 2) {                                   // f16 form: two pieces, three products
+        if (fast) return fuse ? launch_split8<NSR, 3, true, true, STAG, false, true>(a, st)
+                              : launch_split8<NSR, 3, true, false, STAG, false, true>(a, st);
+        return fuse ? launch_split8<NSR, 3, false, true, STAG, false, true>(a, st)
+                    : launch_split8<NSR, 3, false, false, STAG, false, true>(a, st);
+    }
     if (products == 6) {
         if (fast) return fuse ? launch_split8<NSR, 6, true, true, STAG>(a, st) : launch_split8<NSR, 6, true, false, STAG>(a, st);
         return fuse ? launch_split8<NSR, 6, false, true, STAG>(a, st) : launch_split8<NSR, 6, false, false, STAG>(a, st);
@@ -1375,6 +1546,15 @@ int launch_split_wide_any(const RecurArgs& a, int products, bool fast, hipStream
 }  // namespace
 
 int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st) {
+    if (products == 2) {                                   // f16 form (gemm mode 3): the eight-wave kernels only
+        if (seq_tile == 2080) return launch_split8_any<80, false>(a, 2, fast, st);
+        if (seq_tile == 2096) return launch_split8_any<96, false>(a, 2, fast, st);
+        if (seq_tile == 2032) return launch_split8_any<32, false>(a, 2, fast, st);
+        if (seq_tile == 2048) return launch_split8_any<48, false>(a, 2, fast, st);
+        if (seq_tile == 3048) return launch_split8_any<48, true>(a, 2, fast, st);
+        if (seq_tile == 3064) return launch_split8_any<64, true>(a, 2, fast, st);
+        return launch_split8_any<64, false>(a, 2, fast, st);
+    }
     // wide form: one workgroup per CU, one pass over the weights per step for 48 .. 104 sequences
     switch (seq_tile) {
         case 2064: return launch_split8_any<64, false>(a, products, fast, st);  // eight-wave forms (two waves per SIMD)
@@ -1401,6 +1581,19 @@ int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, b
     }
     if (products == 6) return fast ? launch_split<2, 6, true>(a, st) : launch_split<2, 6, false>(a, st);
     return fast ? launch_split<2, 3, true>(a, st) : launch_split<2, 3, false>(a, st);
+}
+
+extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                   const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                                   void* packed, float* bsum, void* stream) {
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_lstm_pack_f16: null pointer"); return -1; }
+    const int ndir = w_ih_r ? 2 : 1;
+    if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_lstm_pack_f16: incomplete reverse direction"); return -1; }
+    hipLaunchKernelGGL(lstm_absmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, w_ih_r, w_hh_r, (float*)packed);
+    const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
+    hipLaunchKernelGGL(lstm_pack_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
+    return dprnn_check_launch("lstm_pack_f16_kernel");
 }
 
 extern "C" int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,

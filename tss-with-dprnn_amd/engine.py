@@ -40,14 +40,19 @@ MIN_GROUP_BATCH = 16         # utterances per group, about (much smaller groups 
 FUSE_NORM = True
 
 # Arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).
-#   1 (default) = every fp32 operand as a sum of three bf16 pieces, the six cross products of order <= 2^-16 on the bf16 MFMA
-#                 with fp32 accumulation (recur_split.hip): product error ~2^-24, end to end the same 2e-7 rel-L2 against the
-#                 reference as the exact path -- every golden (BSS, Spe, IRA; the B = 64 headline batch) passes at the same
-#                 tolerances (the whole -m gpu suite is run in both modes, profiles/r02_mode1_suite.txt);
+#   3 (default) = every fp32 operand as a sum of TWO f16 pieces of a power-of-two multiple of it (activations x 2^4, weights x
+#                 a per-LSTM 2^e that puts max|W| in [2^13, 2^14)): 22+ operand bits, three cross products on the f16 MFMA
+#                 with fp32 accumulation, the dropped product v2 w2 ~ 2^-24 |v||w| -- one fp32 product rounding
+#                 (recur_split.hip; tools/split_precision_study.py).  End to end the same 1.4e-7 rel-L2 between this, mode 1
+#                 and the exact path as each has against float64; every golden (BSS, Spe, IRA; the B = 64 headline batch)
+#                 passes at the same tolerances with every batch size on these kernels.  Faster than the exact kernels at
+#                 EVERY batch size (B = 1: 16 vs 24 ms; B = 64: 97 vs 188 ms; profiles/r02_f16_pieces.txt);
+#   1           = three bf16 pieces, the six cross products of order <= 2^-16 on the bf16 MFMA (product error ~2^-24, no
+#                 range assumption at all: bf16 has fp32's exponent); from SPLIT_MIN_BATCH utterances up;
 #   0           = exact fp32 operands on the fp32 MFMA (recur.hip): bit-for-bit an fma chain; DPRNN_GEMM_MODE=0 selects it;
-#   2           = two pieces / three products (product error ~2^-16): opt-in only, never a default.
+#   2           = two bf16 pieces / three products (product error ~2^-16): opt-in only, never a default.
 # GRU / Elman cells and the training path (forward with tape, backward) always run the exact fp32 kernels.
-DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "1"))
+DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "3"))
 GEMM_MODE = DEFAULT_GEMM_MODE
 SPLIT_ONE_GROUP = True      # bf16-split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
 
@@ -259,7 +264,8 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     if cell != 0 and tile > 32:
         tile = 32
     if cell == 0 and st.lib.dprnn_get_gemm_mode() != 0:
-        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent)
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent,
+                                                                     st.lib.dprnn_get_gemm_mode())
     if g.pending is None:
         st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
@@ -287,20 +293,24 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
 # two-per-CU 32-sequence form and the one-per-CU eight-wave forms (seq_tile code 2000 + sequences); a launch takes
 # ceil(workgroups / slots) rounds of T steps each
 SPLIT_STEP_US = {32: 25.0, 2064: 18.6, 2080: 23.3}
-SPLIT_SLOTS_PER_CU = {32: 2, 2064: 1, 2080: 1}
 SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split modes: one group's launches rarely fill 256 CUs exactly
 
 
-def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1) -> int:
-    """seq_tile code for the bf16-split recurrence over nseq sequences x ndir directions: the form whose grid takes the
+# gate-GEMM mode 3 (f16 pieces), eight-wave kernels only (profiles/r02_f16_pieces.txt): 32 sequences two-per-CU, 64 / 80 one-per-CU
+SPLIT_STEP_US_F16 = {2032: 14.1, 2064: 12.2, 2080: 15.1}
+
+
+def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1) -> int:
+    """seq_tile code for the split recurrence over nseq sequences x ndir directions: the form whose grid takes the
     least time, rounds x cost of a step (64 x 3 s in two groups: 194 / 250 workgroups of 64 sequences per launch)."""
-    best, best_t = 32, None
-    for tile, us in SPLIT_STEP_US.items():
+    best, best_t = None, None
+    for tile, us in (SPLIT_STEP_US_F16 if mode == 3 else SPLIT_STEP_US).items():
         wgs = ndir * -(-nseq // (tile % 1000))
-        slots = ncu * SPLIT_SLOTS_PER_CU[tile]
+        two_per_cu = tile % 1000 == 32
+        slots = ncu * (2 if two_per_cu else 1)
         rounds = -(-wgs * concurrent // slots) / concurrent
         t = rounds * us
-        if tile == 32 and wgs * concurrent <= ncu:     # one 32-sequence workgroup per CU runs at the MFMA's pace, not the L2's
+        if two_per_cu and wgs * concurrent <= ncu:     # one 32-sequence workgroup per CU runs at the MFMA's pace, not the L2's
             t *= 0.6
         if best_t is None or t < best_t - 1e-9:
             best, best_t = tile, t
@@ -310,13 +320,13 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1) -> int:
 GROUP_SIZES = None        # experiment knob: explicit utterance-group sizes (must sum to the batch), else an even split
 
 
-SPLIT_MIN_BATCH = int(os.environ.get("DPRNN_SPLIT_MIN_BATCH", "20"))    # below this the exact fp32 kernels' small tiles are faster (profiles/r02_split_wide.txt: B = 16 62 vs 54 ms)
+SPLIT_MIN_BATCH = int(os.environ.get("DPRNN_SPLIT_MIN_BATCH", "20"))    # bf16 modes 1 / 2: below this the exact fp32 kernels' small tiles are faster (profiles/r02_split_wide.txt: B = 16 62 vs 54 ms)
 
 
 def effective_gemm_mode(B: int, blocks=None) -> int:
     """GEMM_MODE as it applies to a batch of B: the bf16-split kernels need launches that fill the chip, and only the
     LSTM cell has them; everything else runs the exact fp32 kernels (which are never less accurate)."""
-    if GEMM_MODE == 0 or B < SPLIT_MIN_BATCH:
+    if GEMM_MODE == 0 or (GEMM_MODE != 3 and B < SPLIT_MIN_BATCH):      # the f16 form wins at every size, down to one utterance
         return 0
     if blocks is not None and not all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in blocks):
         return 0
@@ -874,7 +884,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     K, P, ks, N = geos[0].K, geos[0].P, geos[0].ks, geos[0].N
     blocks = list(sep.dprnn_blocks)
     if not ragged_supported(sep):
-        raise DprnnError("ragged batches need engine.GEMM_MODE 1 or 2 and LSTM cells")
+        raise DprnnError("ragged batches need engine.GEMM_MODE 1, 2 or 3 and LSTM cells")
     st.lib.dprnn_set_gemm_mode(GEMM_MODE)
     rows = np.array([g.S * K for g in geos], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
