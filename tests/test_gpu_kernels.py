@@ -323,8 +323,10 @@ def test_bilstm_rejects_tiles_wider_than_the_32_bit_offsets():
 
 
 @pytest.mark.parametrize("kdim", [256, 128])
-def test_proj_stats_and_norm_residual(kdim):
-    B, rows_per = 3, 77                    # utterance boundaries fall inside 64-row tiles
+@pytest.mark.parametrize("mode,rows_per", [(0, 77), (3, 77), (0, 2111), (3, 2111)])
+def test_proj_stats_and_norm_residual(kdim, mode, rows_per):
+    """mode 3: the f16-pieces row GEMM (rowgemm_f16_kernel) takes the projection over; same tolerance as the fp32 MFMA form."""
+    B = 3                                  # utterance boundaries fall inside 64-row tiles
     M = B * rows_per
     rng = np.random.default_rng(kdim)
     H = rng.standard_normal((M, kdim)).astype(np.float32)
@@ -337,9 +339,11 @@ def test_proj_stats_and_norm_residual(kdim):
     st = _st()
     Z = torch.empty(M, 128, device=DEV)
     stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.lib.dprnn_set_gemm_mode(mode)
     st.call("dprnn_proj_stats_fwd", _t(H).data_ptr(), _t(W).data_ptr(), _t(b).data_ptr(), Z.data_ptr(),
             stats.data_ptr(), M, rows_per, kdim)
     torch.cuda.synchronize()
+    st.lib.dprnn_set_gemm_mode(0)
     assert rel_l2(Z.cpu().numpy(), Zw) < 1e-6
     zb = Zw.reshape(B, -1)
     assert np.allclose(stats.cpu().numpy()[:, 0], zb.sum(1), rtol=1e-6, atol=1e-3)
@@ -355,8 +359,9 @@ def test_proj_stats_and_norm_residual(kdim):
         assert rel_l2(Xd.cpu().numpy().reshape(B, rows_per, 128), want) < 1e-6
 
 
+@pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("kdim", [256, 128])
-def test_proj_stats_ragged(kdim):
+def test_proj_stats_ragged(kdim, mode):
     """dprnn_proj_stats_ragged_fwd: utterance boundaries from a table of first rows (ragged batches), boundaries inside row
     tiles and a last partial tile."""
     rng = np.random.default_rng(kdim + 7)
@@ -370,6 +375,7 @@ def test_proj_stats_ragged(kdim):
     st = _st()
     Z = torch.full((M, 128), float("nan"), device=DEV)
     stats = torch.zeros(len(rows), 2, device=DEV, dtype=torch.float64)
+    st.lib.dprnn_set_gemm_mode(mode)
     st.call("dprnn_proj_stats_ragged_fwd", _t(H).data_ptr(), _t(W).data_ptr(), _t(b).data_ptr(), Z.data_ptr(),
             stats.data_ptr(), M, _t(starts).data_ptr(), len(rows), kdim)
     torch.cuda.synchronize()
@@ -393,9 +399,11 @@ def test_segment_matches_unfold(K, P, L):
     assert np.array_equal(X.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("mode", [0, 3])        # 3: the f16-pieces row GEMM takes over the mask head (rowgemm_f16_kernel)
 @pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (250, 125, 700)])
-def test_head_conv_ola_matches_oracle(K, P, L):
+def test_head_conv_ola_matches_oracle(K, P, L, mode):
     B = 2
+    _st().lib.dprnn_set_gemm_mode(mode)
     rng = np.random.default_rng(L)
     S = onp.n_chunks(L, K, P)
     X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
@@ -412,10 +420,12 @@ def test_head_conv_ola_matches_oracle(K, P, L):
     assert rel_l2(U.cpu().numpy(), want) < 2e-6
 
 
+@pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("ks,stride,T,relu", [(2, 1, 300, 0), (4, 2, 203, 1), (2, 1, 65, 1)])
-def test_encoder_bottleneck_and_decode_chain(ks, stride, T, relu):
+def test_encoder_bottleneck_and_decode_chain(ks, stride, T, relu, mode):
     """encoder stats -> bottleneck and mask/decode chain vs oracle with random V (stage inputs)."""
     B, N = 3, 64
+    _st().lib.dprnn_set_gemm_mode(mode)
     rng = np.random.default_rng(T)
     cfg = full_cfg(kernel_size=ks, stride=stride, n_repeats=1)
     wav = (0.1 * rng.standard_normal((B, T))).astype(np.float32)

@@ -38,12 +38,27 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
 #define PROJ_NW 8
 #endif
 
+extern "C" int dprnn_get_gemm_mode(void);
+// gate-GEMM mode 3 (f16 pieces) covers the Linear that follows the recurrence too: its rows are RNN outputs, |h| < 1
+#ifndef PROJ_F16_RT
+#define PROJ_F16_RT 2
+#endif
+#ifndef HEAD_F16_NW
+#define HEAD_F16_NW 8
+#endif
+
 extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
                                     int64_t M, int64_t rows_per_utt, int kdim, void* stream) {
     if (!H || !W || !bias || !Z || !stats) { dprnn_set_error("dprnn_proj_stats_fwd: null pointer"); return -1; }
     if (M <= 0 || rows_per_utt <= 0 || (kdim != 256 && kdim != 128)) {
         dprnn_set_error("dprnn_proj_stats_fwd: bad sizes M=%lld rows_per_utt=%lld kdim=%d", (long long)M, (long long)rows_per_utt, kdim);
         return -1;
+    }
+    if (dprnn_get_gemm_mode() == 3) {
+        PlainRows<PROJ_F16_RT> al{H, kdim};
+        EpProjStats<PROJ_F16_RT, 8> ep{Z, bias, stats, (long long)rows_per_utt, nullptr, 0};
+        if (kdim == 256) return launch_rowgemm_f16<256, 128, PROJ_F16_RT, 8, false>("proj_stats256_f16", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+        return launch_rowgemm_f16<128, 128, PROJ_F16_RT, 8, false>("proj_stats128_f16", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
     }
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
@@ -59,6 +74,12 @@ extern "C" int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const
     if (M <= 0 || n_utt < 1 || (kdim != 256 && kdim != 128)) {
         dprnn_set_error("dprnn_proj_stats_ragged_fwd: bad sizes M=%lld n_utt=%d kdim=%d", (long long)M, n_utt, kdim);
         return -1;
+    }
+    if (dprnn_get_gemm_mode() == 3) {
+        PlainRows<PROJ_F16_RT> al{H, kdim};
+        EpProjStats<PROJ_F16_RT, 8> ep{Z, bias, stats, 1, reinterpret_cast<const long long*>(utt_starts), n_utt};
+        if (kdim == 256) return launch_rowgemm_f16<256, 128, PROJ_F16_RT, 8, false>("proj_stats256r_f16", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+        return launch_rowgemm_f16<128, 128, PROJ_F16_RT, 8, false>("proj_stats128r_f16", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
     }
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
@@ -89,6 +110,8 @@ static int head_conv_ola(const float* X, const float* Z, const double* stats, co
     constexpr int RT = 2;
     OlaGatherP<RT> al{OlaGather<RT>{X, 0.f, L, K, P, S, Z, stats, gamma, beta, eps}, prelu_w};
     EpHeadConv<RT> ep{U, b2d, L, K, P, S};
+    if (dprnn_get_gemm_mode() == 3)        // f16 pieces (rowgemm_f16_kernel): the rows are the residual stream the recurrences read too
+        return launch_rowgemm_f16<128, 256, RT, HEAD_F16_NW, true>("head_conv_ola_f16", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
     return launch_rowgemm<128, 256, RT>("head_conv_ola", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
 }
 
@@ -111,6 +134,8 @@ static int head_gate(const float* U, const float* Wo, const float* bo, const flo
     PlainRows<RT> al{U, 128};
     if (g_fast_head) {
         EpGate<RT, true> ep{V, bo, bg, TG};
+        if (dprnn_get_gemm_mode() == 3 && !TG)
+            return launch_rowgemm_f16<128, 256, RT, HEAD_F16_NW, true>("head_gate_f16", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
         return launch_rowgemm<128, 256, RT>("head_gate", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
     }
     EpGate<RT, false> ep{V, bo, bg, TG};
@@ -158,6 +183,8 @@ static int head_mask_decode(const float* V, const float* Wend, const float* wav,
     const Geo geo{B, T, L, N, ks, stride};
     if (g_fast_head) {
         EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
+        if (dprnn_get_gemm_mode() == 3 && !mask_all)       // rows are tanh * sigmoid products, |v| < 1
+            return launch_rowgemm_f16<128, 64, RT, HEAD_F16_NW, true>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
         return launch_rowgemm<128, 64, RT>("head_mask_decode", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
     }
     EpMaskDecode<RT, 4, false> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
