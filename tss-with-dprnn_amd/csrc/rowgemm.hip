@@ -39,6 +39,220 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
 #endif
 
 extern "C" int dprnn_get_gemm_mode(void);
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Linear 256|128 -> 128 + GroupNorm sums in f16 pieces (gate-GEMM mode 3): the one row GEMM that runs 24 times per forward,
+// written for the HBM stream it is bound by (1 KB in, 512 B out per row):
+//  * the MFMA operands are SWAPPED against rowgemm_f16_kernel -- weights as the A operand (16 output columns), 16 rows of H
+//    as the B operand -- so a lane ends up with FOUR ADJACENT output columns of ONE row: 16-byte stores (a wave's store
+//    instruction writes 1 KB instead of 256 B), and one row, hence one utterance, per lane in the GroupNorm sums;
+//  * the rows of the NEXT 32-row tile are requested while the current one is still in the MFMAs (the rotating slab buffers
+//    run on across tiles), so a wave always has three k-slabs (12 KB) of loads in flight, epilogue included.
+namespace {
+typedef rg_u32x4 u32x4_t;
+
+template <int KD>
+__global__ __launch_bounds__(512, 1)
+void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ H,
+                     float* __restrict__ Z, double* __restrict__ stats, long long M, long long rows_per_b,
+                     const long long* __restrict__ starts, int n_utt) {
+    constexpr int ND = 128, NCT = 8, NS = KD / 32, K8 = KD / 8, RT = 2, NW = 8, PF = 3;
+    static_assert(NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
+    extern __shared__ __attribute__((aligned(16))) u32x4_t wl16[];      // [NS][NCT][2][64] + bias
+    __shared__ float red[NW];
+    float* const bias_l = reinterpret_cast<float*>(wl16 + NS * NCT * 2 * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+
+    float m = 0.f;
+    for (int idx = tid; idx < ND * KD / 4; idx += 64 * NW) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(W)[idx];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    if (tid < ND) bias_l[tid] = bias[tid];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) m = fmaxf(m, red[i]);
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+    ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+    const float sw = ldexpf(1.f, 14 - ex);
+    for (int idx = tid; idx < ND * K8; idx += 64 * NW) {
+        const int col = idx / K8, k8 = idx % K8;                        // lane (col % 16, k8 % 4): k = 8 k8 .. 8 k8 + 7
+        const f32x4* src = reinterpret_cast<const f32x4*>(W + (long long)col * KD + 8 * k8);
+        f32x4 lo = src[0], hi = src[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] *= sw; hi[e] *= sw; }
+        u32x4_t w1, w2;
+        f16_pieces8(lo, hi, w1, w2);
+        const int s = k8 >> 2, ln = (k8 & 3) * 16 + (col & 15);
+        wl16[((s * NCT + (col >> 4)) * 2 + 0) * 64 + ln] = w1;
+        wl16[((s * NCT + (col >> 4)) * 2 + 1) * 64 + ln] = w2;
+    }
+    __syncthreads();
+    const float inv = 1.f / (F16P_XS * sw);
+
+    constexpr int ROWS_IT = NW * RT * 16;
+    const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
+    const long long per = (nchunk + gridDim.x - 1) / gridDim.x;
+    const long long c0 = per * blockIdx.x;
+    long long c1 = c0 + per;
+    if (c1 > nchunk) c1 = nchunk;
+
+    auto rowptr = [&](long long ch, int rt) {
+        long long row = ch * ROWS_IT + wave * RT * 16 + 16 * rt + c;
+        if (row >= M) row = M - 1;
+        return H + row * KD + 8 * q;
+    };
+    // per-utterance sums of the current utterance (wave-uniform cur_b), flushed when a tile moves on to another one
+    double d1 = 0.0, d2 = 0.0;
+    long long cur_b = -1;
+    auto flush = [&]() {
+        if (cur_b >= 0) {
+            const double s1 = wave_sum(d1), s2 = wave_sum(d2);
+            if (lane == 0) { atomicAdd(&stats[2 * cur_b], s1); atomicAdd(&stats[2 * cur_b + 1], s2); }
+        }
+        d1 = 0.0; d2 = 0.0;
+    };
+    auto utt_of = [&](long long row) {
+        if (!starts) return row / rows_per_b;
+        long long b = cur_b >= 0 && starts[cur_b] <= row ? cur_b : 0;
+        while (b + 1 < n_utt && starts[b + 1] <= row) ++b;
+        return b;
+    };
+    auto first_row = [&](long long b) { return starts ? starts[b] : b * rows_per_b; };
+
+    f32x4 a[PF + 1][RT][2];
+    if (c0 < c1) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* p = rowptr(c0, rt) + 32 * s;
+                a[s][rt][0] = *reinterpret_cast<const f32x4*>(p);
+                a[s][rt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+    }
+    for (long long ch = c0; ch < c1; ++ch) {
+        const long long row0 = ch * ROWS_IT + wave * RT * 16;
+        const long long chn = ch + 1 < c1 ? ch + 1 : ch;               // last tile: re-request its own rows (never used)
+        f32x4 acc[RT][NCT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cb = s % (PF + 1);
+            __builtin_amdgcn_sched_barrier(0);                          // keep the slabs apart: without it the scheduler hoists every
+            {                                                           // weight fragment of the tile (512 registers) above the first MFMA
+                const int sn = s + PF;                                  // slab to request: this tile's, or the next tile's
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float* p = (sn < NS ? rowptr(ch, rt) + 32 * sn : rowptr(chn, rt) + 32 * (sn - NS));
+                    a[sn % (PF + 1)][rt][0] = *reinterpret_cast<const f32x4*>(p);
+                    a[sn % (PF + 1)][rt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+            }
+            u32x4_t h1[RT], h2[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                }
+                f16_pieces8(lo, hi, h1[rt], h2[rt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if ((ct & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const u32x4_t w1 = wl16[((s * NCT + ct) * 2 + 0) * 64 + lane], w2 = wl16[((s * NCT + ct) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {                       // D[col 4q+e of tile ct][row c] (weights are the A operand)
+                    acc[rt][ct] = mfma_f16p(w1, h2[rt], acc[rt][ct]);
+                    acc[rt][ct] = mfma_f16p(w2, h1[rt], acc[rt][ct]);
+                    acc[rt][ct] = mfma_f16p(w1, h1[rt], acc[rt][ct]);
+                }
+            }
+        }
+        if (row0 >= M) continue;
+        // epilogue: lane (c, q) holds columns 16 ct + 4 q .. + 3 of row row0 + 16 rt + c
+        const long long last = (row0 + 16 * RT - 1 < M ? row0 + 16 * RT - 1 : M - 1);
+        const long long b_first = utt_of(row0);
+        long long b_last = b_first;
+        if (starts) { while (b_last + 1 < n_utt && starts[b_last + 1] <= last) ++b_last; } else b_last = last / rows_per_b;
+        const bool whole = row0 + 16 * RT <= M && b_last == b_first;
+        if (b_first != cur_b) { flush(); cur_b = b_first; }
+        float p1 = 0.f, p2 = 0.f, o1 = 0.f, o2 = 0.f;                  // o*: rows of later utterances in a straddling tile
+        const long long hi_first = first_row(b_first + 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            const bool ok = whole || row < M;
+            const bool mine = whole || row < hi_first;
+            float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + 16 * ct + 4 * q);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[rt][ct][e], inv, bv[e]); r1 += v[e]; r2 = fmaf(v[e], v[e], r2); }
+                if (ok) *reinterpret_cast<f32x4*>(Z + row * ND + 16 * ct + 4 * q) = v;
+            }
+            if (ok && mine) { p1 += r1; p2 += r2; }
+            else if (ok) { o1 += r1; o2 += r2; }
+        }
+        d1 += (double)p1; d2 += (double)p2;
+        if (!whole && b_last != b_first) {
+            // rows of the later utterances of this tile (rare: one tile per utterance boundary): one utterance at a time
+            for (long long b = b_first + 1; b <= b_last; ++b) {
+                flush(); cur_b = b;
+                const long long lo = first_row(b), hi = first_row(b + 1);
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const long long row = row0 + 16 * rt + c;
+                    if (row < M && row >= lo && row < hi) {
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + 16 * ct + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float v = fmaf(acc[rt][ct][e], inv, bv[e]); t1 += v; t2 = fmaf(v, v, t2); }
+                        }
+                    }
+                }
+                d1 += (double)t1; d2 += (double)t2;
+            }
+        }
+        (void)o1; (void)o2;
+    }
+    flush();
+}
+
+template <int KD>
+int launch_proj_f16(const char* what, const float* W, const float* bias, const float* H, float* Z, double* stats, long long M,
+                    long long rows_per_b, const long long* starts, int n_utt, hipStream_t st) {
+    const size_t lds = (size_t)KD * 128 * 4 + 128 * 4;
+    auto kern = &proj_f16_kernel<KD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    const long long nchunk = (M + 255) / 256;
+    long long grid = nchunk < num_cus() ? nchunk : num_cus();
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, H, Z, stats, M, rows_per_b, starts, n_utt);
+    return dprnn_check_launch(what);
+}
+}  // namespace
+
 // gate-GEMM mode 3 (f16 pieces) covers the Linear that follows the recurrence too: its rows are RNN outputs, |h| < 1
 #ifndef PROJ_F16_RT
 #define PROJ_F16_RT 2
@@ -55,10 +269,8 @@ extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float*
         return -1;
     }
     if (dprnn_get_gemm_mode() == 3) {
-        PlainRows<PROJ_F16_RT> al{H, kdim};
-        EpProjStats<PROJ_F16_RT, 8> ep{Z, bias, stats, (long long)rows_per_utt, nullptr, 0};
-        if (kdim == 256) return launch_rowgemm_f16<256, 128, PROJ_F16_RT, 8, false>("proj_stats256_f16", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
-        return launch_rowgemm_f16<128, 128, PROJ_F16_RT, 8, false>("proj_stats128_f16", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+        if (kdim == 256) return launch_proj_f16<256>("proj_f16_256", W, bias, H, Z, stats, M, rows_per_utt, nullptr, 0, (hipStream_t)stream);
+        return launch_proj_f16<128>("proj_f16_128", W, bias, H, Z, stats, M, rows_per_utt, nullptr, 0, (hipStream_t)stream);
     }
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
@@ -76,10 +288,9 @@ extern "C" int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const
         return -1;
     }
     if (dprnn_get_gemm_mode() == 3) {
-        PlainRows<PROJ_F16_RT> al{H, kdim};
-        EpProjStats<PROJ_F16_RT, 8> ep{Z, bias, stats, 1, reinterpret_cast<const long long*>(utt_starts), n_utt};
-        if (kdim == 256) return launch_rowgemm_f16<256, 128, PROJ_F16_RT, 8, false>("proj_stats256r_f16", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
-        return launch_rowgemm_f16<128, 128, PROJ_F16_RT, 8, false>("proj_stats128r_f16", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+        const long long* st_ = reinterpret_cast<const long long*>(utt_starts);
+        if (kdim == 256) return launch_proj_f16<256>("proj_f16_256r", W, bias, H, Z, stats, M, 1, st_, n_utt, (hipStream_t)stream);
+        return launch_proj_f16<128>("proj_f16_128r", W, bias, H, Z, stats, M, 1, st_, n_utt, (hipStream_t)stream);
     }
     constexpr int RT = 4;
     PlainRows<RT> al{H, kdim};
