@@ -281,7 +281,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         name, key = {0: ("r01_pmc_traffic.json", "bilstm_kernel"), 1: ("r02_pmc_traffic.json", "bilstm_split8_kernel"),
-                     3: ("r02_pmc_traffic.json", "bilstm_split8_kernel_f16")}[args.gemm_mode]
+                     3: ("r02_pmc_traffic_f16.json", "bilstm_split8_kernel_f16")}[args.gemm_mode]
         with open(os.path.join(ROOT, "profiles", name)) as f:
             pm = json.load(f)[key]
         if pm["group_batch"] * n_groups == B:

@@ -11,6 +11,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace_mo
 P="--steps 1 --warmup 1 --no-cpu-baseline --no-optional-modes"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -- python3 bench.py $P > gpurun_out/${tag}_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -- python3 bench.py $P > gpurun_out/${tag}_pmc_write.log 2>&1 || exit 1
-python tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py $P (two separate passes, MI355X, B=64, default gate-GEMM mode 3: f16 pieces, two utterance groups of 32)" > gpurun_out/${tag}_pmc_traffic.json || exit 1
+python tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py $P (two separate passes, MI355X, B=64, default gate-GEMM mode 3: f16 pieces, two utterance groups of 32)" bilstm_split8_kernel_f16 32 1552000 > gpurun_out/${tag}_pmc_traffic.json || exit 1
 rm -rf gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write
 echo collected

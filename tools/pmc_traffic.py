@@ -48,6 +48,21 @@ def main():
             "hbm_read_GB": round(2 * ft[name] / n * 1024 / 1e9, 4),
             "hbm_write_GB": round(wt.get(name, 0.0) / max(wc.get(name, 1), 1) * 1024 / 1e9, 4),
         }
+    if len(sys.argv) > 5:
+        # recurrence summary for bench.py's roofline.traffic: KEY GROUP_BATCH ROWS_PER_GROUP  (rows of the [rows][128] fp32 slab)
+        key, group_batch, rows = sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+        unit = rows * 128 * 4 / 1e9
+        rec = {k: v for k, v in out["per_launch"].items() if k.startswith("bilstm_split8_kernel") or k.startswith("bilstm_kernel")}
+        n = sum(v["launches"] for v in rec.values())
+        traffic = sum(v["launches"] * (v["hbm_read_GB"] + v["hbm_write_GB"]) for v in rec.values()) / n
+        # with the pending norm folded in (template flag FUSE = true, the 4th argument): X and Z per direction, x' once, H = 7 units;
+        # the first launch of a forward has no pending norm: X per direction + H = 4 units
+        fused = sum(v["launches"] for k, v in rec.items() if re.match(r"bilstm_split8_kernel<\d+, \d+, \w+, true", k))
+        algo = (7 * fused + 4 * (n - fused)) * unit / n
+        out[key] = {"group_batch": group_batch, "traffic_GB_per_launch": round(traffic, 4), "algorithmic_GB_per_launch": round(algo, 4),
+                    "note": f"mean over the {n} recurrence launches of the profiled forwards ({fused} with the pending norm folded in: 7 slab "
+                            f"units of {unit:.3f} GB, the others 4); the packed weight pieces come from L2.  traffic / algorithmic = "
+                            f"{traffic / algo:.3f}"}
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -128,17 +128,20 @@ __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const flo
     }
 }
 
-// S_w of one LSTM: the power of two that puts max|W_ih, W_hh| (all directions) in [2^13, 2^14); one block
-__global__ __launch_bounds__(1024)
+// S_w of one LSTM: the power of two that puts max|W_ih, W_hh| (all directions) in [2^13, 2^14).  ABSMAX_BLOCKS blocks leave
+// their partial maxima in the unused third plane of the packed buffer; every thread of the pack kernel folds them (uniform
+// loads), so there is no atomic, no memset and no one-block pass on the critical path of a forward.
+constexpr int ABSMAX_BLOCKS = 32;
+__global__ __launch_bounds__(256)
 void lstm_absmax_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ w_ih_r,
                         const float* __restrict__ w_hh_r, float* __restrict__ packed_f) {
-    __shared__ float part[16];
+    __shared__ float part[4];
     const float* src[4] = {w_ih, w_hh, w_ih_r, w_hh_r};
     float m = 0.f;
     for (int k = 0; k < 4; ++k) {
         if (!src[k]) continue;
         const f32x4* p = reinterpret_cast<const f32x4*>(src[k]);
-        for (int i = threadIdx.x; i < 4 * HD * F / 4; i += 1024) {          // W_ih [4H][F] and W_hh [4H][H] have the same size (F == H)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < 4 * HD * F / 4; i += ABSMAX_BLOCKS * 256) {   // W_ih [4H][F], W_hh [4H][H]: same size (F == H)
             const f32x4 v = p[i];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
@@ -147,15 +150,16 @@ void lstm_absmax_kernel(const float* __restrict__ w_ih, const float* __restrict_
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
-        int ex = 0;
-        if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);                           // m = f * 2^ex, f in [0.5, 1)
-        ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
-        const float sw = ldexpf(1.f, 14 - ex);
-        packed_f[F16_SCALE_WORD] = sw;
-        packed_f[F16_SCALE_WORD + 1] = 1.f / (F16_XS * sw);
-    }
+    if (threadIdx.x == 0) packed_f[F16_SCALE_WORD + 2 + blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+__device__ __forceinline__ float f16_weight_scale(const float* packed_f) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < ABSMAX_BLOCKS; ++i) m = fmaxf(m, packed_f[F16_SCALE_WORD + 2 + i]);
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);                               // m = f * 2^ex, f in [0.5, 1)
+    ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+    return ldexpf(1.f, 14 - ex);
 }
 
 // same fragment layout as lstm_pack_split_kernel, planes 0 and 1 = the two f16 pieces of S_w * W (plane 2 stays unused)
@@ -167,7 +171,11 @@ __global__ void lstm_pack_f16_kernel(const float* __restrict__ w_ih, const float
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_dir = 4 * NSLAB * 8 * 64 * 4;
     if (idx >= ndir * per_dir) return;
-    const float sw = reinterpret_cast<const float*>(packed)[F16_SCALE_WORD];
+    const float sw = f16_weight_scale(reinterpret_cast<const float*>(packed));
+    if (idx == 0) {                                     // what the recurrence reads: S_w and 1 / (S_x S_w)
+        reinterpret_cast<float*>(packed)[F16_SCALE_WORD] = sw;
+        reinterpret_cast<float*>(packed)[F16_SCALE_WORD + 1] = 1.f / (F16_XS * sw);
+    }
     const int dw = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, slab = (idx >> 11) & 7;
     const int wave = (idx >> 14) & 3, dir = idx >> 16;
     const int gate = gu >> 1, u = gu & 1, r = lane & 15, q = lane >> 4;
@@ -1589,7 +1597,7 @@ extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const f
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_lstm_pack_f16: null pointer"); return -1; }
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_lstm_pack_f16: incomplete reverse direction"); return -1; }
-    hipLaunchKernelGGL(lstm_absmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, w_ih_r, w_hh_r, (float*)packed);
+    hipLaunchKernelGGL(lstm_absmax_kernel, dim3(ABSMAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh, w_ih_r, w_hh_r, (float*)packed);
     const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
     hipLaunchKernelGGL(lstm_pack_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
