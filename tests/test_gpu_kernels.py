@@ -155,13 +155,13 @@ def test_bilstm_split_gemm_modes(mode, tol, path):
     assert err < tol
 
 
-@pytest.mark.parametrize("seq_tile", [32, 64, 80, 96, 104, -64, 1048, 1064, 2064, 2080, 2096, 3048, 3064])
+@pytest.mark.parametrize("seq_tile", [32, 2064, 2080, 2096])
 @pytest.mark.parametrize("mode,tol", [(1, 2e-6), (2, 3e-5)])
 @pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
 def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
-    """The wide split kernel (one workgroup per CU, 64..104 sequences, swizzled image): every tile size against the numpy
-    oracle, with sequence counts that leave ragged last tiles, tiles straddling utterances on the inter-chunk path, a
-    104-sequence tile (half-empty last 16-row block), and the previous path's norm folded into the loader."""
+    """The bf16-split kernels (two 32-sequence workgroups per CU; the eight-wave form with 64 / 80 / 96 sequences, one workgroup
+    per CU, swizzled image): every tile size against the numpy oracle, with sequence counts that leave ragged last tiles, tiles
+    straddling utterances on the inter-chunk path, and the previous path's norm folded into the loader."""
     B, S, K = 3, 37, 41             # 111 intra sequences of 41 steps, 123 inter sequences of 37 steps
     rng = np.random.default_rng(10000 * mode + abs(seq_tile))
     X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
@@ -208,7 +208,7 @@ def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
         assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
 
 
-@pytest.mark.parametrize("seq_tile", [2032, 2048, 2064, 2080, 2096, 3048, 3064])
+@pytest.mark.parametrize("seq_tile", [2032, 2048, 2064, 2080, 2096])
 @pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
 @pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (37.0, 0.02), (1e-3, 40.0)])
 def test_bilstm_f16_pieces(seq_tile, path, fused, wscale, xscale):

@@ -13,7 +13,7 @@ from tss_with_dprnn_amd import engine  # noqa: E402
 
 
 def run(st, seq_tile, nwg, T, ndir=2, iters=3):
-    nseq = nwg * (abs(seq_tile) % 1000) // ndir       # 1048 / 1064 = overlapped bf16-split forms of 48 / 64 sequences
+    nseq = nwg * (abs(seq_tile) % 1000) // ndir       # 2000 + n: eight-wave split forms of n sequences
     X = torch.randn(nseq * T, 128, device="cuda") * 0.5
     H = torch.empty(nseq * T, ndir * 128, device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
@@ -191,11 +191,13 @@ def stamps_split(st, seq_tile, T, ndir=2):
     tf = nseq * T * ndir * 2 * 256 * 512 / ms / 1e9
     b = buf.cpu().double()
     cyc, ticks, mf, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
-    print(f"split-wide stamps seq_tile={seq_tile}: {ms:.3f} ms = {tf:.1f} TFLOP/s (fp32-equivalent), in-kernel clock {cyc / ticks * 100:.0f} MHz; "
-          f"per step: total {cyc / T:.0f} cyc, " + (f"MFMA phase {mf / T:.0f}, cell + x staging {cell / T:.0f}" if seq_tile < 1000 else
-                                                     f"phase 1 (h half + x staging) {mf / T:.0f}, phase 2 (x half + cell) {cell / T:.0f}") +
-          f", barriers/other {(cyc - mf - cell) / T:.0f}  [bf16 MFMA floor {(seq_tile % 1000 + 15) // 16} tiles x 1536 x 16 / 4 = "
-          f"{((seq_tile % 1000 + 15) // 16) * 1536 * 4} cyc]")
+    tiles = (seq_tile % 1000 + 15) // 16
+    products = 3 if st.lib.dprnn_get_gemm_mode() == 3 else 6
+    floor = tiles * 8 * 4 * products * 16 * 2            # MFMAs of a wave x 16 cycles x two waves per SIMD
+    print(f"split8 stamps seq_tile={seq_tile} (wave 0 of every workgroup, medians): {ms:.3f} ms = {tf:.1f} TFLOP/s (fp32-equivalent), in-kernel clock "
+          f"{cyc / ticks * 100:.0f} MHz; per step: total {cyc / T:.0f} cyc = MFMA phase as seen by the wave {mf / T:.0f} + wait at barrier A, "
+          f"cell update and x staging {cell / T:.0f} + barrier B / loop {(cyc - mf - cell) / T:.0f}  [MFMA floor per SIMD: {tiles} tiles x 8 slabs x "
+          f"4 gates x {products} products x 16 cyc x 2 waves = {floor} cyc]")
 
 
 def main():
@@ -214,7 +216,7 @@ def main():
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
     if a.stamps and a.gemm_mode in (1, 3):
-        for seq_tile in ((64, 2064, 3064) if a.gemm_mode == 1 else (2064, 3064)):
+        for seq_tile in (2064,):
             stamps_split(st, seq_tile, a.T)
         return
     if a.stamps:
@@ -237,9 +239,9 @@ def main():
     if a.gemm_mode != 0:       # bf16-split modes: the two-per-CU form, the round-1 64-sequence form and the wide one-per-CU forms
         np_ = 6 if a.gemm_mode == 1 else 3
         print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
-        forms = ((32, 2), (-64, 1), (64, 1), (80, 1), (96, 1), (1048, 1), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1))
+        forms = ((32, 2), (2064, 1), (2080, 1), (2096, 1))
         if a.gemm_mode == 3:    # f16 pieces: the eight-wave kernels only
-            forms = ((2032, 1), (2032, 2), (2048, 1), (2048, 2), (2064, 1), (2080, 1), (2096, 1), (3048, 1), (3064, 1))
+            forms = ((2032, 1), (2032, 2), (2048, 1), (2048, 2), (2064, 1), (2080, 1), (2096, 1))
         for seq_tile, per_cu in forms:
             ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
             tiles = (abs(seq_tile) % 1000 + 15) // 16

@@ -48,6 +48,8 @@ inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inne
     return span_rows * pitch_floats * 4 < 0x7fffffffLL;
 }
 
-// optional bf16-split gate GEMM (recur_split.hip): products = 6 or 3
+// split gate GEMMs (recur_split.hip): products = 6 or 3 (bf16 pieces), 2 = two f16 pieces / three products
 int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
+int launch_split8_bf16(const RecurArgs& a, int products, int nsr, bool stag, bool fast, hipStream_t st);   // recur_split8_bf16.hip
+int launch_split8_f16(const RecurArgs& a, int nsr, bool stag, bool fast, hipStream_t st);                  // recur_split8_f16.hip
 }  // namespace recur

@@ -707,10 +707,8 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
-    if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // split kernels with stamps (packed by dprnn_rnn_pack in the same mode)
-        const bool ok = g_gemm_mode == 1 ? (seq_tile == 64 || seq_tile == 1064 || seq_tile == 2064 || seq_tile == 3064)
-                                         : (seq_tile == 2064 || seq_tile == 3064);
-        if (!ok) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 64, 1064, 2064, 3064 (mode 1) and 2064, 3064 (mode 3)"); return -1; }
+    if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // eight-wave split kernel with stamps (packed by dprnn_rnn_pack in the same mode)
+        if (seq_tile != 2064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064"); return -1; }
         return launch_bilstm_split(a, split_products(), seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {

@@ -1,0 +1,431 @@
+// Eight-wave split recurrence kernel (template) and its launcher; instantiated by recur_split8_bf16.hip (three bf16 pieces,
+// gate-GEMM modes 1 / 2) and recur_split8_f16.hip (two f16 pieces, mode 3) so that the two sets build in parallel.
+#pragma once
+#include "recur_split.h"
+
+namespace rsplit {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// EIGHT-WAVE form (one 512-thread workgroup per CU, NSR = 48 .. 96 sequences, wave w owns the 16 hidden units of weight
+// fragment column tile (w >> 1, w & 1) for all four gates).  Why: profiles/r02_split_wide.txt -- with ONE wave per SIMD
+// every weight request (buffer_load_dwordx4, ~33 cycles of issue) stops that SIMD's MFMA stream, 27 % of the MFMA phase
+// at 64 sequences; with two waves per SIMD one wave's memory and vector instructions issue under the other's MFMAs.
+//   STAG = false: [gate GEMM (8 k-slabs)] barrier [cell update + staging of x_{t+1}] barrier        (as the wide form)
+//   STAG = true : the x half of the gate GEMM does not depend on h, so between the two barriers that the recurrence needs
+//       all waves     : h half of step t                                  (MFMA)
+//       barrier A       (h_{t-1} no longer read)
+//       waves 0..3    : cell(t), stage x_{t+2}   then   x half of step t+1
+//       waves 4..7    : x half of step t+1       then   cell(t), stage x_{t+2}
+//       barrier B       (h_t in place)
+//   each SIMD holds one wave of either group (waves w and w + 4 share a SIMD), so its vector pipe works on one group's
+//   cell update while its matrix pipe works on the other's x half.  Costs: a second accumulator set, x double-buffered
+//   in LDS (NSR <= 64).
+// Image: regions h | x0 (| x1), each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
+__global__ __launch_bounds__(512, 2)
+void bilstm_split8_kernel(RecurArgs a) {
+    static_assert(NSR % 16 == 0 && NSR >= 32 && NSR <= 96, "whole 16-row tiles");
+    static_assert(!F16 || NP == 3, "the f16 form has two pieces and three products");
+    constexpr int NT = NSR / 16;
+    constexpr int NPC = NP == 6 ? 3 : 2;
+    constexpr int PL = NSR * 256;                      // bytes of one piece plane of one region
+    constexpr int REG = NPC * PL;                      // bytes of one region
+    constexpr int NXB = STAG ? 2 : 1;                  // x buffers
+    extern __shared__ __attribute__((aligned(16))) char img[];
+    char* const hreg = img;
+    char* const xreg = img + REG;                      // + xb * REG
+    unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + (1 + NXB) * REG);
+    unsigned* const rowoff_h = rowoff_x + NSR;
+    float* const musig = reinterpret_cast<float*>(rowoff_h + NSR);
+    float* const gb = musig + 2 * NSR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int w4 = wave >> 1, wu = wave & 1;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * NSR;
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto rowbase = [&](int seq) {
+        return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
+    };
+    // Ragged batch, inter-chunk path: this workgroup's sequences, step count and utterance come from its descriptor
+    // (tiles never straddle utterances there, their lengths differ); otherwise the uniform addressing of the launch.
+    const int* const desc = a.wg_desc ? a.wg_desc + 8 * blockIdx.x : nullptr;
+    const int T = __builtin_amdgcn_readfirstlane(desc ? desc[2] : a.T);
+    const int nhere = desc ? desc[3] : (a.nseq - seq0 < NSR ? a.nseq - seq0 : NSR);      // sequences that exist in this tile
+    const long long row0 = desc ? (((long long)desc[1] << 32) | (unsigned)desc[0]) : rowbase(seq0);
+    const int hpitch = a.ndir * HD;
+    for (int j = tid; j < NSR; j += 512) {
+        const bool valid = j < nhere;
+        const int seq = valid ? seq0 + j : seq0;
+        const long long ro = desc ? (long long)(valid ? j : 0) * a.inner_stride : rowbase(seq) - row0;
+        rowoff_x[j] = (unsigned)(ro * F * 4);          // rows that do not exist alias the first row: loads stay in range
+        rowoff_h[j] = valid ? (unsigned)(ro * hpitch * 4) : OOB;
+        if (FUSE) {
+            const int b = desc ? desc[4] : (a.seq_utt ? a.seq_utt[seq] : seq / a.seqs_per_utt);
+            const double cnt = (double)(a.utt_rows ? a.utt_rows[b] : a.rows_per_utt) * (double)F;
+            const double mean = a.stats[2 * b] / cnt;
+            double var = a.stats[2 * b + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            musig[2 * j] = (float)mean;
+            musig[2 * j + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+    }
+    if (FUSE && tid < 128) { gb[tid] = a.gamma[tid]; gb[128 + tid] = a.beta[tid]; }
+    const int c4 = tid & 31, xrow0 = tid >> 5;         // x quad: row xrow0 + 16 m, floats 4 c4 .. 4 c4 + 3
+    const int xl = xrow0 * 256 + (((c4 >> 1) ^ xrow0) << 4) + ((c4 & 1) << 3);
+    auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
+    const int unit0 = 32 * w4 + 2 * r + wu;             // this lane's hidden unit
+
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float b = a.bsum[dir * 4 * HD + g * HD + unit0];
+        bias[g] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+    }
+    // f16 form: the accumulators are S_x S_w times the gate pre-activations; inv = 1 / (S_x S_w) rides on the multiply the
+    // nonlinearity starts with anyway
+    const float inv = F16 ? a.Wp[F16_SCALE_WORD + 1] : 1.f;
+    const float ksig = FAST ? -1.4426950408889634f * inv : inv, ktanh = FAST ? 2.8853900817779268f * inv : inv;
+    const int w4_u = __builtin_amdgcn_readfirstlane(w4), wu_u = __builtin_amdgcn_readfirstlane(wu);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.Wp) + (size_t)(dir * 4 + w4_u) * NSLAB * 8 * 3 * 64), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16u;
+    auto wload = [&](int slab, int g, int pc) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (unsigned)(((slab * 8 + g * 2 + wu_u) * 3 + pc) * 1024), 0);
+    };
+    auto rsrc_at = [&](const float* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffffu, 0x00020000);
+    };
+
+    auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    // x of one time step -> bf16 pieces in x buffer xb, one quad (4 floats of one row) per thread and m; XG quads are in
+    // flight together (registers: the partner wave on the SIMD covers the rest of the latency)
+    auto x_stage = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+        constexpr int XG = STAG ? 1 : 2;
+#pragma unroll
+        for (int m0 = 0; m0 < NT; m0 += XG) {
+            f32x4 xv[XG], zv[XG];
+            unsigned xo[XG];
+            fence();
+#pragma unroll
+            for (int i = 0; i < XG; ++i) {
+                const int m = m0 + i < NT ? m0 + i : NT - 1;
+                xo[i] = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[i], 0, 0));
+                if (FUSE) zv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo[i], 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < XG; ++i) {
+                const int m = m0 + i;
+                if (m >= NT) break;
+                f32x4 v = xv[i];
+                if (FUSE) {
+                    const float mu = musig[2 * (xrow0 + 16 * m)], rs = musig[2 * (xrow0 + 16 * m) + 1];
+                    const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zv[i][e] - mu) * rs * gam[e] + bet[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[i] : OOB, 0, 0);
+                }
+                unsigned pa[3], pb[3];
+                if constexpr (F16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                    split2_pair_f16(v[0], v[1], pa[0], pa[1]);
+                    split2_pair_f16(v[2], v[3], pb[0], pb[1]);
+                } else {
+                    split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+                    split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+                }
+                char* d = xreg + xb * REG + xl + m * 4096;
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PL) = u32x2{pa[pc], pb[pc]};
+            }
+        }
+        fence();
+    };
+
+    // The same in two parts (XPF: plain form up to 64 sequences, where the registers allow it): the loads of x_{t+1} are
+    // issued at the start of the LAST k-slab of step t and land under its MFMAs, barrier A and the cell update, instead of
+    // being waited for right after they are issued.  (vmcnt retires in order: loads issued earlier in the step would sit in
+    // front of every weight wait; from the last slab on, the only younger loads are next step's slab-0 weights.)
+    constexpr bool XPF = !STAG && NT <= 4;
+    f32x4 xq[XPF ? NT : 1], zq[XPF ? NT : 1];
+    auto x_issue = [&](long long t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
+        const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
+        fence();
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
+            xq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0));
+            if (FUSE) zq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo, 0, 0));
+        }
+        fence();
+    };
+    auto x_finish = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+        fence();
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            f32x4 v = xq[m];
+            if (FUSE) {
+                const float mu = musig[2 * (xrow0 + 16 * m)], rs = musig[2 * (xrow0 + 16 * m) + 1];
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
+                const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo : OOB, 0, 0);
+            }
+            unsigned pa[3], pb[3];
+            if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                split2_pair_f16(v[0], v[1], pa[0], pa[1]);
+                split2_pair_f16(v[2], v[3], pb[0], pb[1]);
+            } else {
+                split3_pair<NPC>(v[0], v[1], pa[0], pa[1], pa[2]);
+                split3_pair<NPC>(v[2], v[3], pb[0], pb[1], pb[2]);
+            }
+            char* d = xreg + xb * REG + xl + m * 4096;
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x2*>(d + pc * PL) = u32x2{pa[pc], pb[pc]};
+        }
+        fence();
+    };
+
+    __syncthreads();                                   // row tables are in place
+    const long long tfirst = dir ? (T - 1) : 0, tsecond = T > 1 ? (dir ? (T - 2) : 1) : tfirst;
+    if constexpr (XPF) { x_issue(tfirst); x_finish(tfirst, 0, true); }
+    else x_stage(tfirst, 0, true);
+    if (STAG) x_stage(tsecond, 1, T > 1);
+    for (int i = tid; i < REG / 4; i += 512) reinterpret_cast<unsigned*>(hreg)[i] = 0u;
+    f32x4 c[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A fragments: lane (r, q) of tile nt reads row 16 nt + r, chunk (4 s4 + q) ^ r of the region
+    const int abase = r * 256 + ((q ^ (r & 3)) << 4);
+    int sl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sl[j] = (j ^ ((r >> 2) & 3)) << 6;
+    auto aload = [&](u32x4 (&af)[NT], const char* reg, int pc, int s4) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt] = *reinterpret_cast<const u32x4*>(reg + pc * PL + nt * 4096 + abase + sl[s4]);
+    };
+    // h element (row 16 nt + 4q + e, this lane's unit): + nt * 4096 + piece * PL
+    int hb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hb[e] = (4 * q + e) * 256 + ((((w4 ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3) + 2 * wu;
+    const unsigned hcol = (unsigned)(dir * HD + unit0) * 4u;
+
+    u32x4 bw[4][NPC];                                  // B fragments of the k-slab in progress (single-buffered: a piece is
+#pragma unroll                                         // re-requested for the next slab when its last product is done)
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) bw[g][pc] = wload(STAG ? 0 : 0, g, pc);
+    f32x4 acc[STAG ? 2 : 1][NT][4];
+    u32x4 fa[NT], fb[NT];
+    auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                ac[nt][g] = F16 ? mfma_f16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g])
+                                : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
+    };
+    auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[g][wpc] = wload(sn, g, wpc);
+    };
+    // k-slab s4 of region reg (weights of global slab `s` are in bw; those of slab `sn` are requested as pieces die)
+    auto slab = [&](f32x4 (&ac)[NT][4], const char* reg, u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int sn, bool have_p, bool prefetch,
+                    bool first) __attribute__((always_inline)) {
+        fence();
+        if (!have_p) aload(P, reg, 0, s4);
+        aload(Q, reg, 1, s4);
+        fence();
+        if constexpr (NP == 6) {
+            pass(ac, P, 2, first); wreload(sn, 2); fence();
+            pass(ac, P, 1, false); fence();
+            pass(ac, Q, 1, false); wreload(sn, 1); fence();
+            pass(ac, P, 0, false); fence();
+            aload(P, reg, 2, s4);
+            pass(ac, Q, 0, false); fence();
+            if (prefetch) aload(Q, reg, 0, s4 + 1);
+            pass(ac, P, 0, false); wreload(sn, 0); fence();
+        } else {
+            pass(ac, P, 1, first); wreload(sn, 1); fence();
+            pass(ac, P, 0, false); fence();
+            if (prefetch) aload(P, reg, 0, s4 + 1);
+            pass(ac, Q, 0, false); wreload(sn, 0); fence();
+        }
+    };
+    // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end
+    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0) __attribute__((always_inline)) {
+        if constexpr (NP == 6) {
+            slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
+            slab(ac, reg, fb, fa, 1, s0 + 2, true, true, false);
+            slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false);
+            if (xhook) x_issue(tx);
+            slab(ac, reg, fb, fa, 3, (s0 + 4) & 7, true, false, false);
+        } else {
+            slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
+            slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false);
+            slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false);
+            if (xhook) x_issue(tx);
+            slab(ac, reg, fa, fb, 3, (s0 + 4) & 7, true, false, false);
+        }
+    };
+    // LSTM cell of this wave's 16 units for every row, h -> image (3 pieces) and HBM
+    auto cell = [&](f32x4 (&ac)[NT][4], long long t) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            fence();
+            float hv[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                f32x2 ig, fg, gg, og;
+                if constexpr (F16) {
+                    ig = sigmoid_k2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, bias[0]);
+                    fg = sigmoid_k2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, bias[1]);
+                    gg = tanh_k2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, bias[2]);
+                    og = sigmoid_k2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, bias[3]);
+                } else {
+                    ig = sigmoid_b2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, bias[0]);
+                    fg = sigmoid_b2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, bias[1]);
+                    gg = tanh_b2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, bias[2]);
+                    og = sigmoid_b2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, bias[3]);
+                }
+                const f32x2 cn = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
+                const f32x2 h2 = og * tanh_f2<FAST>(cn);
+                c[nt][2 * p2] = cn[0]; c[nt][2 * p2 + 1] = cn[1];
+                hv[2 * p2] = h2[0]; hv[2 * p2 + 1] = h2[1];
+                unsigned w1, w2, w3 = 0u;              // pieces of rows e = 2 p2 (low halves) and 2 p2 + 1 (high halves)
+                if constexpr (F16) split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1, w2);
+                else split3_pair<NPC>(h2[0], h2[1], w1, w2, w3);
+                char* d0 = hreg + hb[2 * p2] + nt * 4096;
+                char* d1 = hreg + hb[2 * p2 + 1] + nt * 4096;
+                *reinterpret_cast<unsigned short*>(d0) = (unsigned short)w1;
+                *reinterpret_cast<unsigned short*>(d1) = (unsigned short)(w1 >> 16);
+                *reinterpret_cast<unsigned short*>(d0 + PL) = (unsigned short)w2;
+                *reinterpret_cast<unsigned short*>(d1 + PL) = (unsigned short)(w2 >> 16);
+                if (NPC == 3) {
+                    *reinterpret_cast<unsigned short*>(d0 + 2 * PL) = (unsigned short)w3;
+                    *reinterpret_cast<unsigned short*>(d1 + 2 * PL) = (unsigned short)(w3 >> 16);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv[e]), hrs, rowoff_h[16 * nt + 4 * q + e] + hcol, 0, 0);
+        }
+        fence();
+    };
+
+    unsigned long long st_t0 = 0, st_r0 = 0, st_p1 = 0, st_p2 = 0;
+    if constexpr (!STAG) {
+        __syncthreads();
+        if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+        for (int step = 0; step < T; ++step) {
+            unsigned long long st_a = 0, st_b = 0;
+            if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
+            const long long t = dir ? (T - 1 - step) : step;
+            const bool more = step + 1 < T;
+            const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
+            half(acc[0], xreg, 0, true);
+            half(acc[0], hreg, 4, false, XPF, tn);
+            if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
+            __syncthreads();                           // every wave is done reading the image of this step
+            cell(acc[0], t);
+            if constexpr (XPF) x_finish(tn, 0, more);
+            else x_stage(tn, 0, more);
+            if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        half(acc[0], xreg, 0, true);                   // x half of the first step
+        if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+        auto one_step = [&](f32x4 (&acur)[NT][4], f32x4 (&anxt)[NT][4], int step) __attribute__((always_inline)) {
+            unsigned long long st_a = 0, st_b = 0;
+            if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
+            const long long t = dir ? (T - 1 - step) : step;
+            // x_{t+1} sits in buffer (step + 1) & 1; x_{t+2} goes to buffer step & 1 (last read by the x half of step t)
+            const long long t2 = step + 2 < T ? (dir ? (t - 2) : (t + 2)) : t;
+            const char* const xnext = xreg + ((step + 1) & 1) * REG;
+            half(acur, hreg, 4, false);
+            if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
+            __syncthreads();                           // barrier A: h_{t-1} is no longer read
+            // one copy of the MFMA code, the (much shorter) vector code before it for waves 0..3 and after it for waves 4..7
+            if (grp == 0) { cell(acur, t); x_stage(t2, step & 1, step + 2 < T); }
+            half(anxt, xnext, 0, true);
+            if (grp != 0) { cell(acur, t); x_stage(t2, step & 1, step + 2 < T); }
+            if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
+            __syncthreads();                           // barrier B: h_t and x_{t+2} are in place
+        };
+        for (int step = 0; step < T; step += 2) {
+            one_step(acc[0], acc[STAG ? 1 : 0], step);
+            if (step + 1 < T) one_step(acc[STAG ? 1 : 0], acc[0], step + 1);
+        }
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = __builtin_amdgcn_s_memtime() - st_t0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+            o[2] = st_p1;                                         // MFMA phase (STAG: h half)
+            o[3] = st_p2;                                         // cell + staging (STAG: cell + staging + x half)
+            o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = 0; o[7] = 0;
+        }
+    }
+}
+
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
+int launch_split8(const RecurArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(STAG ? 3 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 + (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
+    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>), grid, dim3(512), lds, st, a);
+    return dprnn_check_launch("bilstm_split8_kernel");
+}
+
+// One tile size of one piece format: FAST / FUSE / STAMP variants.  The libm-activation variants (dprnn_set_fast_activations(0))
+// are built for the 64-sequence tile only; other tile sizes fall back to it (any tile size serves any launch).
+template <int NSR, bool STAG, bool F16>
+int launch_split8_form(const RecurArgs& a, int products, bool fast, hipStream_t st) {
+    constexpr int NPF = 3;
+    const bool fuse = a.Z != nullptr;
+    if constexpr (NSR == 64 && !STAG) {
+        if (a.stamps) {                                    // in-kernel stamps (tools/bench_recur.py --stamps): fast, no pending norm
+            if constexpr (F16) return launch_split8<64, NPF, true, false, false, true, true>(a, st);
+            else if (products == 6) return launch_split8<64, 6, true, false, false, true, false>(a, st);
+        }
+    }
+    if (!fast) {
+        if constexpr (NSR != 64 || STAG) return launch_split8_form<64, false, F16>(a, products, false, st);
+        else if constexpr (F16) return fuse ? launch_split8<64, NPF, false, true, false, false, true>(a, st)
+                                            : launch_split8<64, NPF, false, false, false, false, true>(a, st);
+        else if (products == 6) return fuse ? launch_split8<64, 6, false, true, false>(a, st) : launch_split8<64, 6, false, false, false>(a, st);
+        else return fuse ? launch_split8<64, 3, false, true, false>(a, st) : launch_split8<64, 3, false, false, false>(a, st);
+    }
+    if constexpr (F16) {
+        return fuse ? launch_split8<NSR, NPF, true, true, STAG, false, true>(a, st) : launch_split8<NSR, NPF, true, false, STAG, false, true>(a, st);
+    } else {
+        if (products == 6) return fuse ? launch_split8<NSR, 6, true, true, STAG>(a, st) : launch_split8<NSR, 6, true, false, STAG>(a, st);
+        return fuse ? launch_split8<NSR, 3, true, true, STAG>(a, st) : launch_split8<NSR, 3, true, false, STAG>(a, st);
+    }
+}
+
+}  // namespace rsplit
