@@ -52,4 +52,5 @@ inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inne
 int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
 int launch_split8_bf16(const RecurArgs& a, int products, int nsr, bool stag, bool fast, hipStream_t st);   // recur_split8_bf16.hip
 int launch_split8_f16(const RecurArgs& a, int nsr, bool stag, bool fast, hipStream_t st);                  // recur_split8_f16.hip
+int launch_split8_f16_train(const RecurArgs& a, bool fast, hipStream_t st);                                // ... with the gate tape (a.tape)
 }  // namespace recur

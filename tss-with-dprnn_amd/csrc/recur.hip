@@ -662,7 +662,10 @@ extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, con
                                    int64_t t_stride, int ndir, void* stream) {
     if (!tape) { dprnn_set_error("dprnn_lstm_fwd_train: tape is null"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_fwd_train: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (g_gemm_mode != 0) { dprnn_set_error("dprnn_lstm_fwd_train: the training path uses the exact fp32 gate GEMM (gemm mode 0)"); return -1; }
+    if (g_gemm_mode != 0 && !(g_gemm_mode == 3 && cell == 0)) {
+        dprnn_set_error("dprnn_rnn_fwd_train: the training forward runs in gate-GEMM mode 0 (any cell) or 3 (LSTM), not %d", g_gemm_mode);
+        return -1;
+    }
     RecurArgs a{};
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
@@ -683,6 +686,7 @@ extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, con
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (g_gemm_mode == 3) return launch_split8_f16_train(a, g_fast_act != 0, st);      // f16 pieces, same tape
     if (cell == 1) return g_fast_act ? launch_bilstm<2, true, 1, true>(a, st) : launch_bilstm<2, false, 1, true>(a, st);
     if (cell == 2) return g_fast_act ? launch_bilstm<2, true, 2, true>(a, st) : launch_bilstm<2, false, 2, true>(a, st);
     return g_fast_act ? launch_bilstm<2, true, 0, true>(a, st) : launch_bilstm<2, false, 0, true>(a, st);

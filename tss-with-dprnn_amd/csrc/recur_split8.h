@@ -21,9 +21,13 @@ namespace rsplit {
 //   cell update while its matrix pipe works on the other's x half.  Costs: a second accumulator set, x double-buffered
 //   in LDS (NSR <= 64).
 // Image: regions h | x0 (| x1), each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
+// SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
+// state to a.tape in the layout of the fp32 training kernel (recur.hip: [dir][32-sequence workgroup][step][wave][nt][u][slot]
+// [lane] float4 over four sequences), which is what the backward kernels read: a 64-sequence tile is two of those workgroups.
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
 __global__ __launch_bounds__(512, 2)
 void bilstm_split8_kernel(RecurArgs a) {
+    static_assert(!SAVE || (NSR == 64 && !STAG), "the tape layout is written for 64-sequence tiles");
     static_assert(NSR % 16 == 0 && NSR >= 32 && NSR <= 96, "whole 16-row tiles");
     static_assert(!F16 || NP == 3, "the f16 form has two pieces and three products");
     constexpr int NT = NSR / 16;
@@ -283,12 +287,18 @@ void bilstm_split8_kernel(RecurArgs a) {
         }
     };
     // LSTM cell of this wave's 16 units for every row, h -> image (3 pieces) and HBM
-    auto cell = [&](f32x4 (&ac)[NT][4], long long t) __attribute__((always_inline)) {
+    // tape (SAVE): float index inside a 32-sequence workgroup's step = ((nt_b*2 + u)*5 + slot)*256 + wave_b*5120 + lane_b*4 + e with
+    // wave_b = unit / 32, u = (unit % 32) / 16, lane_b = 16 q + unit % 16 -- per lane a constant plus (nt_b*10 + slot) KiB
+    const int tv = 2 * r + wu;                          // unit index inside its 32-unit group
+    const unsigned toff = (unsigned)(w4 * 5120 + (tv >> 4) * 5 * 256 + (q * 16 + (tv & 15)) * 4) * 4u;
+    const int nwg_b = (a.nseq + 31) / 32;
+    auto cell = [&](f32x4 (&ac)[NT][4], long long t, int step = 0) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             fence();
             float hv[4];
+            f32x4 sv[SAVE ? 5 : 1];
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 f32x2 ig, fg, gg, og;
@@ -307,6 +317,13 @@ void bilstm_split8_kernel(RecurArgs a) {
                 const f32x2 h2 = og * tanh_f2<FAST>(cn);
                 c[nt][2 * p2] = cn[0]; c[nt][2 * p2 + 1] = cn[1];
                 hv[2 * p2] = h2[0]; hv[2 * p2 + 1] = h2[1];
+                if constexpr (SAVE) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        sv[0][2 * p2 + k] = ig[k]; sv[1][2 * p2 + k] = fg[k]; sv[2][2 * p2 + k] = gg[k];
+                        sv[3][2 * p2 + k] = og[k]; sv[4][2 * p2 + k] = cn[k];
+                    }
+                }
                 unsigned w1, w2, w3 = 0u;              // pieces of rows e = 2 p2 (low halves) and 2 p2 + 1 (high halves)
                 if constexpr (F16) split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1, w2);
                 else split3_pair<NPC>(h2[0], h2[1], w1, w2, w3);
@@ -324,6 +341,14 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv[e]), hrs, rowoff_h[16 * nt + 4 * q + e] + hcol, 0, 0);
+            if constexpr (SAVE) {
+                const int wg_b = 2 * blockIdx.x + (nt >> 1);           // the 32-sequence workgroup of the tape layout
+                const __amdgpu_buffer_rsrc_t trs = rsrc_at(a.tape + (((size_t)dir * nwg_b + wg_b) * T + step) * 20480);
+                const unsigned live = wg_b < nwg_b ? toff + (unsigned)((nt & 1) * 10 * 1024) : OOB;
+#pragma unroll
+                for (int x = 0; x < 5; ++x)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[x]), trs, live + (unsigned)(x * 1024), 0, 0);   // soffset stays 0: see the store hazard note in recur.hip
+            }
         }
         fence();
     };
@@ -342,7 +367,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             half(acc[0], hreg, 4, false, XPF, tn);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             __syncthreads();                           // every wave is done reading the image of this step
-            cell(acc[0], t);
+            cell(acc[0], t, step);
             if constexpr (XPF) x_finish(tn, 0, more);
             else x_stage(tn, 0, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
@@ -386,18 +411,18 @@ void bilstm_split8_kernel(RecurArgs a) {
     }
 }
 
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(STAG ? 3 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 + (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
         attr_set = true;
     }
     dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
-    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>), grid, dim3(512), lds, st, a);
     return dprnn_check_launch("bilstm_split8_kernel");
 }
 

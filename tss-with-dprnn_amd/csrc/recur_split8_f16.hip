@@ -15,3 +15,11 @@ int recur::launch_split8_f16(const RecurArgs& a, int nsr, bool stag, bool fast, 
         default: return launch_split8_form<64, false, true>(a, 2, fast, st);
     }
 }
+
+// training forward (dprnn_rnn_fwd_train in mode 3): 64-sequence tiles, gate tape in the fp32 training kernel's layout
+int recur::launch_split8_f16_train(const RecurArgs& a, bool fast, hipStream_t st) {
+    using namespace rsplit;
+    const bool fuse = a.Z != nullptr;
+    if (fast) return fuse ? launch_split8<64, 3, true, true, false, false, true, true>(a, st) : launch_split8<64, 3, true, false, false, false, true, true>(a, st);
+    return fuse ? launch_split8<64, 3, false, true, false, false, true, true>(a, st) : launch_split8<64, 3, false, false, false, false, true, true>(a, st);
+}

@@ -16,6 +16,7 @@ backward (forward recomputation, +1 forward per step), smaller batches keep ever
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -35,6 +36,11 @@ PACKT_PER_DIR = 512 * 256
 # passes fill the CUs another group's serial recurrence launches leave idle.
 TRAIN_STREAM_GROUPS = 0              # 0 = choose from the launch geometry (_auto_groups); n > 0 = up to n groups
 MIN_TRAIN_GROUP = 8                  # utterances per group at least (explicit group counts only)
+# Gate-GEMM arithmetic of the training FORWARD (recurrence with tape + the Linear after it): 3 = two f16 pieces / three products
+# as in inference (engine.GEMM_MODE 3; LSTM cells only, others fall back), 0 = exact fp32 MFMA.  The backward kernels (BPTT,
+# data and weight gradients) always run on the exact fp32 MFMA: gradients span too many orders of magnitude for f16 pieces
+# without per-tensor exponents.  DPRNN_TRAIN_GEMM_MODE overrides.
+TRAIN_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_GEMM_MODE", "3"))
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
@@ -94,6 +100,8 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     f32 = dict(device=dev, dtype=torch.float32)
     stats = torch.zeros(1 + npth, B, 2, device=dev, dtype=torch.float64)
     lib.dprnn_set_gemm_mode(0)
+    lstm_only = all(rnn.rnn.mode == "LSTM" for rnn, _, _, _ in paths)
+    fwd_mode = 3 if (TRAIN_GEMM_MODE == 3 and lstm_only) else 0
     fusion = fusion or {}
     sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], fusion.get("mul"), fusion.get("add"))
     Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"), fusion.get("row_scale"))
@@ -102,34 +110,55 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     Z, H, tapes = [], [], []
     st.call("dprnn_segment_fwd", _p(Y), _p(X[0]), B, L, K, P, S)
     del Y
-    packed = torch.empty(2 * engine.PACK_PER_DIR, **f32)
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, **f32)
     bsum = torch.empty(2 * 4 * F_BUILT, **f32)
-    # Norm + residual stay a separate streaming pass here: folded into the next recurrence's loader (as the inference
-    # path does) the extra vector work inside the MFMA-bound kernel cost more than the pass it saves once the tape
-    # stores are in the same kernel (measured at B = 32: 109.6 ms against 101.4 + 5.7 ms).
-    for p, (rnn, lin, norm, intra) in enumerate(paths):
-        ndir, fw, bw = _rnn_tensors(rnn, dev)
-        cell = engine.CELL_ID[rnn.rnn.mode]
-        st.call("dprnn_rnn_pack", cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
-        addr = _addr(geo, intra)
-        Hp = torch.empty(rows, ndir * F_BUILT, **f32)
-        tape = torch.empty(lib.dprnn_rnn_tape_floats(cell, addr[0], addr[1], ndir), **f32)
-        st.call("dprnn_rnn_fwd_train", cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
-        w = _param(lin.weight, "linear.weight", dev)
-        if w.shape != (F_BUILT, ndir * F_BUILT):
-            raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
-        Zp = torch.empty(rows, F_BUILT, **f32)
-        st.call("dprnn_proj_stats_fwd", _p(Hp), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Zp), _p(stats[1 + p]),
-                rows, S * K, ndir * F_BUILT)
-        gamma, beta, eps = _norm_params(norm)
-        Xn = torch.empty(rows, F_BUILT, **f32)
-        st.call("dprnn_norm_residual_fwd", _p(X[p]), _p(Zp), _p(stats[1 + p]), _p(_param(gamma, "norm.weight", dev)),
-                _p(_param(beta, "norm.bias", dev)), eps, _p(Xn), B, S * K)
-        X.append(Xn)
-        if keep:
-            Z.append(Zp); H.append(Hp); tapes.append(tape)
-        else:
-            X[p] = None
+    # Exact fp32 forward: norm + residual stay a separate streaming pass -- folded into the next recurrence's loader (as the
+    # inference path does) the extra vector work inside the fp32-MFMA-bound kernel cost more than the pass it saves once the tape
+    # stores are in the same kernel (measured at B = 32: 109.6 ms against 101.4 + 5.7 ms).  f16-pieces forward: vector work rides
+    # under the f16 MFMAs, so the pending norm of path p-1 is applied by the loader of path p (which writes x' = X[p] once, for
+    # the backward); only the last path's norm is an explicit pass.
+    fold = fwd_mode == 3
+    lib.dprnn_set_gemm_mode(fwd_mode)       # pack, recurrence and projection of every path; back to the exact mode whatever happens
+    try:
+        pending = None
+        for p, (rnn, lin, norm, intra) in enumerate(paths):
+            ndir, fw, bw = _rnn_tensors(rnn, dev)
+            cell = engine.CELL_ID[rnn.rnn.mode]
+            st.call("dprnn_rnn_pack", cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+            addr = _addr(geo, intra)
+            Hp = torch.empty(rows, ndir * F_BUILT, **f32)
+            tape = torch.empty(lib.dprnn_rnn_tape_floats(cell, addr[0], addr[1], ndir), **f32)
+            if pending is None:
+                st.call("dprnn_rnn_fwd_train", cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+            else:               # X[p] = X[p-1] + norm(Z[p-1]) on the fly
+                Zq, sq, gq, bq, eq = pending
+                Xn = torch.empty(rows, F_BUILT, **f32)
+                st.call("dprnn_rnn_fwd_train", cell, _p(X[p - 1]), _p(Zq), _p(sq), _p(gq), _p(bq), eq, S if intra else K, S * K, _p(Xn),
+                        _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+                X.append(Xn)
+                if not keep:
+                    X[p - 1] = None
+                pending = None
+            w = _param(lin.weight, "linear.weight", dev)
+            if w.shape != (F_BUILT, ndir * F_BUILT):
+                raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+            Zp = torch.empty(rows, F_BUILT, **f32)
+            st.call("dprnn_proj_stats_fwd", _p(Hp), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Zp), _p(stats[1 + p]),
+                    rows, S * K, ndir * F_BUILT)
+            gamma, beta, eps = _norm_params(norm)
+            gq, bq = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
+            if fold and p + 1 < npth:
+                pending = (Zp, stats[1 + p], gq, bq, eps)
+            else:
+                Xn = torch.empty(rows, F_BUILT, **f32)
+                st.call("dprnn_norm_residual_fwd", _p(X[p]), _p(Zp), _p(stats[1 + p]), _p(gq), _p(bq), eps, _p(Xn), B, S * K)
+                X.append(Xn)
+                if not keep:
+                    X[p] = None
+            if keep:
+                Z.append(Zp); H.append(Hp); tapes.append(tape)
+    finally:
+        lib.dprnn_set_gemm_mode(0)
     R = B * L * 2
     U = torch.empty(B * L, 2 * F_BUILT, **f32)
     V = torch.empty(R, F_BUILT, **f32)
