@@ -21,6 +21,14 @@ namespace rsplit {
 //   cell update while its matrix pipe works on the other's x half.  Costs: a second accumulator set, x double-buffered
 //   in LDS (NSR <= 64).
 // Image: regions h | x0 (| x1), each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
+#ifndef DPRNN_SPLIT8_DB
+#define DPRNN_SPLIT8_DB 1
+#endif
+#ifndef DPRNN_SPLIT8_PRIO
+#define DPRNN_SPLIT8_PRIO 1
+#endif
+constexpr bool split8_double_buffered(int nsr, bool f16, bool stag) { return DPRNN_SPLIT8_DB && f16 && !stag && nsr <= 64; }
+
 // SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
 // state to a.tape in the layout of the fp32 training kernel (recur.hip: [dir][32-sequence workgroup][step][wave][nt][u][slot]
 // [lane] float4 over four sequences), which is what the backward kernels read: a 64-sequence tile is two of those workgroups.
@@ -34,11 +42,17 @@ void bilstm_split8_kernel(RecurArgs a) {
     constexpr int NPC = NP == 6 ? 3 : 2;
     constexpr int PL = NSR * 256;                      // bytes of one piece plane of one region
     constexpr int REG = NPC * PL;                      // bytes of one region
-    constexpr int NXB = STAG ? 2 : 1;                  // x buffers
+    // DB (f16 pieces, up to 64 sequences: 128 KB): h and x images double-buffered by step parity, which removes the barrier
+    // between the gate GEMM and the cell update -- a wave that is through its MFMAs starts its cell update while its SIMD
+    // partner still multiplies (they share the matrix pipe, so one of them always finishes first), instead of both waiting
+    // and then both doing vector work with the matrix pipe idle.
+    constexpr bool DB = split8_double_buffered(NSR, F16, STAG);
+    constexpr int NHB = DB ? 2 : 1;                    // h buffers
+    constexpr int NXB = (STAG || DB) ? 2 : 1;          // x buffers
     extern __shared__ __attribute__((aligned(16))) char img[];
-    char* const hreg = img;
-    char* const xreg = img + REG;                      // + xb * REG
-    unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + (1 + NXB) * REG);
+    char* const hreg = img;                            // + hb * REG
+    char* const xreg = img + NHB * REG;                // + xb * REG
+    unsigned* const rowoff_x = reinterpret_cast<unsigned*>(img + (NHB + NXB) * REG);
     unsigned* const rowoff_h = rowoff_x + NSR;
     float* const musig = reinterpret_cast<float*>(rowoff_h + NSR);
     float* const gb = musig + 2 * NSR;
@@ -46,6 +60,9 @@ void bilstm_split8_kernel(RecurArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int w4 = wave >> 1, wu = wave & 1;
+#if DPRNN_SPLIT8_PRIO
+    if (DB && wave < 4) __builtin_amdgcn_s_setprio(DPRNN_SPLIT8_PRIO);     // one wave of every SIMD pair runs ahead through the MFMAs
+#endif
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * NSR;
@@ -292,7 +309,8 @@ void bilstm_split8_kernel(RecurArgs a) {
     const int tv = 2 * r + wu;                          // unit index inside its 32-unit group
     const unsigned toff = (unsigned)(w4 * 5120 + (tv >> 4) * 5 * 256 + (q * 16 + (tv & 15)) * 4) * 4u;
     const int nwg_b = (a.nseq + 31) / 32;
-    auto cell = [&](f32x4 (&ac)[NT][4], long long t, int step = 0) __attribute__((always_inline)) {
+    auto cell = [&](f32x4 (&ac)[NT][4], long long t, int step = 0, char* hw = nullptr) __attribute__((always_inline)) {
+        if (!hw) hw = hreg;
         const __amdgpu_buffer_rsrc_t hrs = rsrc_at(a.H + tbase(t) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -327,8 +345,8 @@ void bilstm_split8_kernel(RecurArgs a) {
                 unsigned w1, w2, w3 = 0u;              // pieces of rows e = 2 p2 (low halves) and 2 p2 + 1 (high halves)
                 if constexpr (F16) split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1, w2);
                 else split3_pair<NPC>(h2[0], h2[1], w1, w2, w3);
-                char* d0 = hreg + hb[2 * p2] + nt * 4096;
-                char* d1 = hreg + hb[2 * p2 + 1] + nt * 4096;
+                char* d0 = hw + hb[2 * p2] + nt * 4096;
+                char* d1 = hw + hb[2 * p2 + 1] + nt * 4096;
                 *reinterpret_cast<unsigned short*>(d0) = (unsigned short)w1;
                 *reinterpret_cast<unsigned short*>(d1) = (unsigned short)(w1 >> 16);
                 *reinterpret_cast<unsigned short*>(d0 + PL) = (unsigned short)w2;
@@ -363,13 +381,14 @@ void bilstm_split8_kernel(RecurArgs a) {
             const long long t = dir ? (T - 1 - step) : step;
             const bool more = step + 1 < T;
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
-            half(acc[0], xreg, 0, true);
-            half(acc[0], hreg, 4, false, XPF, tn);
+            const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
+            half(acc[0], xreg + rb * REG, 0, true);
+            half(acc[0], hreg + rb * REG, 4, false, XPF, tn);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
-            __syncthreads();                           // every wave is done reading the image of this step
-            cell(acc[0], t, step);
-            if constexpr (XPF) x_finish(tn, 0, more);
-            else x_stage(tn, 0, more);
+            if constexpr (!DB) __syncthreads();        // single-buffered: every wave is done reading the image of this step
+            cell(acc[0], t, step, hreg + wb * REG);
+            if constexpr (XPF) x_finish(tn, wb, more);
+            else x_stage(tn, wb, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
             __syncthreads();
         }
@@ -413,7 +432,8 @@ void bilstm_split8_kernel(RecurArgs a) {
 
 template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(STAG ? 3 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 + (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
+    const size_t lds = (size_t)(STAG ? 3 : (split8_double_buffered(NSR, F16, STAG) ? 4 : 2)) * (NP == 6 ? 3 : 2) * NSR * 256 +
+                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>),
