@@ -24,7 +24,7 @@ def collect(directory, counter):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("rsplit::", "").replace("void ", "")
             name = re.sub(r"\(.*", "", name)                     # drop the argument list
             tot[name] += float(row["Counter_Value"])
             cnt[name] += 1

@@ -15,7 +15,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").replace("rsplit::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
 
 
