@@ -260,6 +260,9 @@ int launch_proj_f16(const char* what, const float* W, const float* bias, const f
 #ifndef HEAD_F16_NW
 #define HEAD_F16_NW 8
 #endif
+#ifndef HEAD_F16T_RT
+#define HEAD_F16T_RT 1                  // 16-row tiles per wave in the transposed-tile head kernels (256 output columns: 2 spill)
+#endif
 
 extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
                                     int64_t M, int64_t rows_per_utt, int kdim, void* stream) {
@@ -321,8 +324,11 @@ static int head_conv_ola(const float* X, const float* Z, const double* stats, co
     constexpr int RT = 2;
     OlaGatherP<RT> al{OlaGather<RT>{X, 0.f, L, K, P, S, Z, stats, gamma, beta, eps}, prelu_w};
     EpHeadConv<RT> ep{U, b2d, L, K, P, S};
-    if (dprnn_get_gemm_mode() == 3)        // f16 pieces (rowgemm_f16_kernel): the rows are the residual stream the recurrences read too
-        return launch_rowgemm_f16<128, 256, RT, HEAD_F16_NW, true>("head_conv_ola_f16", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
+    if (dprnn_get_gemm_mode() == 3) {      // f16 pieces, transposed tiles: the rows are the residual stream the recurrences read too
+        OlaGatherP<HEAD_F16T_RT> alt{OlaGather<HEAD_F16T_RT>{X, 0.f, L, K, P, S, Z, stats, gamma, beta, eps}, prelu_w};
+        EpTHeadConv<HEAD_F16T_RT> ept{U, b2d, L, K, P, S};
+        return launch_rowgemm_f16t<128, 256, HEAD_F16T_RT, false>("head_conv_ola_f16", W2d, 128, 256, nullptr, 0, (long long)B * L, alt, ept, (hipStream_t)stream);
+    }
     return launch_rowgemm<128, 256, RT>("head_conv_ola", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
 }
 
@@ -345,8 +351,11 @@ static int head_gate(const float* U, const float* Wo, const float* bo, const flo
     PlainRows<RT> al{U, 128};
     if (g_fast_head) {
         EpGate<RT, true> ep{V, bo, bg, TG};
-        if (dprnn_get_gemm_mode() == 3 && !TG)
-            return launch_rowgemm_f16<128, 256, RT, HEAD_F16_NW, true>("head_gate_f16", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
+        if (dprnn_get_gemm_mode() == 3 && !TG) {
+            PlainRows<HEAD_F16T_RT> alt{U, 128};
+            EpTGate<HEAD_F16T_RT, true> ept{V, bo, bg};
+            return launch_rowgemm_f16t<128, 256, HEAD_F16T_RT, true>("head_gate_f16", Wo, 128, 128, Wg, 128, rows, alt, ept, (hipStream_t)stream);
+        }
         return launch_rowgemm<128, 256, RT>("head_gate", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
     }
     EpGate<RT, false> ep{V, bo, bg, TG};

@@ -638,4 +638,195 @@ int launch_rowgemm_f16(const char* what, const float* W0, int ldw0, int nd0, con
     return dprnn_check_launch(what);
 }
 
+// ------------------------------------------------------------------------------------------------ f16 pieces, transposed tiles
+// rowgemm_f16_kernel with the MFMA operands swapped (weights as the A operand, 16 rows of the input as the B operand), as in
+// proj_f16_kernel (rowgemm.hip): acc[rt][ct][e] is row row0 + 16 rt + c, column 16 ct + 4 q + e (c = lane & 15, q = lane >> 4), so
+// an epilogue stores 16 bytes per lane and a wave's store instruction writes 1 KB instead of 256 B -- the 4-byte stores of the
+// plain layout, not HBM, bound the mask-head kernels (1.2-1.5 TB/s).  XC: the loader is cheap enough to keep a second copy
+// for the next row tile, whose k-slabs are requested while the current tile is in the MFMAs (PlainRows).
+template <int RT, bool FAST>
+struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigmoid(acc[128 + col] + bg[col])
+    float* V; const float* bo; const float* bg;
+    __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bo + 16 * ct + 4 * q), b2 = *reinterpret_cast<const f32x4*>(bg + 16 * ct + 4 * q);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = tanh_f<FAST>(fmaf(acc[rt][ct][e], inv, b1[e])) * sigmoid_f<FAST>(fmaf(acc[rt][ct + 8][e], inv, b2[e]));
+                *reinterpret_cast<f32x4*>(V + row * F + 16 * ct + 4 * q) = v;
+            }
+        }
+    }
+};
+
+template <int RT>
+struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 columns
+    float* U; const float* bias; int L, K, P, S;
+    __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+            const int l = (int)(row % L);
+            const float cnt = (float)(OlaGather<1>::s_hi(l, K, P, S) - OlaGather<1>::s_lo(l, P) + 1);
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * ct + 4 * q);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(cnt, b[e], acc[rt][ct][e] * inv);
+                *reinterpret_cast<f32x4*>(U + row * 256 + 16 * ct + 4 * q) = v;
+            }
+        }
+    }
+};
+
+template <int KD, int ND, int RT, bool XC, class AL, class EPT>
+__global__ __launch_bounds__(512, 1)
+void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
+                         long long M, AL al, EPT ep) {
+    constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8, NW = 8;
+    constexpr int PF = XC ? (NS >= 4 ? 3 : NS - 1) : (NS >= 4 ? 2 : 1);
+    static_assert(!XC || NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
+    extern __shared__ __attribute__((aligned(16))) rg_u32x4 wl16[];     // [NS][NCT][2][64]
+    __shared__ float red[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+
+    auto wrow = [&](int col) { return col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1; };
+    float m = 0.f;
+    for (int idx = tid; idx < ND * KD / 4; idx += 64 * NW) {
+        const int col = idx / (KD / 4), k4 = idx % (KD / 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow(col) + 4 * k4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) m = fmaxf(m, red[i]);
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+    ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+    const float sw = ldexpf(1.f, 14 - ex);
+    for (int idx = tid; idx < ND * K8; idx += 64 * NW) {               // slot (s, qq, i): k = 32 s + 4 qq + i (i < 4), 32 s + 16 + 4 qq + i - 4
+        const int col = idx / K8, k8 = idx % K8;
+        const int s = k8 >> 2, qq = k8 & 3;
+        const float* src = wrow(col) + 32 * s + 4 * qq;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] *= sw; hi[e] *= sw; }
+        rg_u32x4 w1, w2;
+        f16_pieces8(lo, hi, w1, w2);
+        const int ln = qq * 16 + (col & 15);
+        wl16[((s * NCT + (col >> 4)) * 2 + 0) * 64 + ln] = w1;
+        wl16[((s * NCT + (col >> 4)) * 2 + 1) * 64 + ln] = w2;
+    }
+    __syncthreads();
+    const float inv = 1.f / (F16P_XS * sw);
+
+    constexpr int ROWS_IT = NW * RT * 16;
+    const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
+    const long long per = (nchunk + gridDim.x - 1) / gridDim.x;
+    const long long c0 = per * blockIdx.x;
+    long long c1 = c0 + per;
+    if (c1 > nchunk) c1 = nchunk;
+
+    f32x4 a[PF + 1][RT][2];
+    AL aln = al;                                                       // XC: loader of the next tile
+    if (c0 < c1) {
+        const long long row0 = c0 * ROWS_IT + wave * RT * 16;
+        al.init(row0 < M ? row0 : M - 1, c, q, M);
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
+    }
+    for (long long ch = c0; ch < c1; ++ch) {
+        const long long row0 = ch * ROWS_IT + wave * RT * 16;
+        if constexpr (XC) {
+            const long long rown = (ch + 1 < c1 ? ch + 1 : ch) * ROWS_IT + wave * RT * 16;
+            aln.init(rown < M ? rown : M - 1, c, q, M);
+        }
+        f32x4 acc[RT][NCT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cb = s % (PF + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int sn = s + PF;
+            if (sn < NS) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) { a[sn % (PF + 1)][rt][0] = al.load(rt, 2 * sn); a[sn % (PF + 1)][rt][1] = al.load(rt, 2 * sn + 1); }
+            } else if constexpr (XC) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    a[sn % (PF + 1)][rt][0] = aln.load(rt, 2 * (sn - NS)); a[sn % (PF + 1)][rt][1] = aln.load(rt, 2 * (sn - NS) + 1);
+                }
+            }
+            rg_u32x4 h1[RT], h2[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                }
+                f16_pieces8(lo, hi, h1[rt], h2[rt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if ((ct & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const rg_u32x4 w1 = wl16[((s * NCT + ct) * 2 + 0) * 64 + lane], w2 = wl16[((s * NCT + ct) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][ct] = mfma_f16p(w1, h2[rt], acc[rt][ct]);
+                    acc[rt][ct] = mfma_f16p(w2, h1[rt], acc[rt][ct]);
+                    acc[rt][ct] = mfma_f16p(w1, h1[rt], acc[rt][ct]);
+                }
+            }
+        }
+        if (row0 < M) ep(acc, row0, c, q, M, inv);
+        if constexpr (XC) al = aln;
+        else if (ch + 1 < c1) {                                         // no lookahead across tiles: start the next tile's first slabs now
+            const long long rown = (ch + 1) * ROWS_IT + wave * RT * 16;
+            al.init(rown < M ? rown : M - 1, c, q, M);
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
+        }
+    }
+}
+
+template <int KD, int ND, int RT, bool XC, class AL, class EPT>
+int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
+                        const AL& al, const EPT& ep, hipStream_t st) {
+    const size_t lds = (size_t)KD * ND * 4;
+    auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
+        attr_set = true;
+    }
+    constexpr int ROWS_IT = 8 * RT * 16;
+    long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
+    long long grid = nchunk < num_cus() ? nchunk : num_cus();
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
+    return dprnn_check_launch(what);
+}
+
 }  // namespace rg
