@@ -357,6 +357,10 @@ def main():
                          "per_launch_tflops": flop_per_launch / (kern_ms * 1e-3) / 1e12,
                          "mean_concurrency": conc,
                          "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / peak,
+                         # the HBM side of the same forward -- 1.433 GB per utterance with ideal fusion
+                         # against 8 TB/s (the path is matrix-bound: this stays a small fraction)
+                         "whole_forward_hbm_tb_s": value / world * 1.433e9 / 1e12,
+                         "whole_forward_hbm_frac": value / world * 1.433e9 / 8e12,
                          "whole_forward_tflops": value / world * FLOP_PER_UTT / 1e12},
             "distributed": dist_info,
         }

@@ -254,9 +254,6 @@ int launch_proj_f16(const char* what, const float* W, const float* bias, const f
 }  // namespace
 
 // gate-GEMM mode 3 (f16 pieces) covers the Linear that follows the recurrence too: its rows are RNN outputs, |h| < 1
-#ifndef PROJ_F16_RT
-#define PROJ_F16_RT 2
-#endif
 #ifndef HEAD_F16_NW
 #define HEAD_F16_NW 8
 #endif
