@@ -91,8 +91,20 @@ def test_batched_inferencer_matches_per_utterance_loop(tmp_path):
     assert np.allclose(got, want, atol=2e-3)
 
 
+
+@pytest.fixture
+def split_gate_gemm():
+    """The ragged kernels exist in the split gate-GEMM modes only: with DPRNN_GEMM_MODE=0 in the environment the ragged tests
+    run in mode 3."""
+    from tss_with_dprnn_amd import engine
+    old = engine.GEMM_MODE
+    if old == 0:
+        engine.GEMM_MODE = 3
+    yield
+    engine.GEMM_MODE = old
+
 @pytest.mark.parametrize("kind", ["bss", "spe", "ira", "spe_att_bntrain"])
-def test_ragged_batch_equals_one_by_one(kind):
+def test_ragged_batch_equals_one_by_one(kind, split_gate_gemm):
     """SURVEY.md 8f-3 / inferencer_spe.py:27-32: utterances of different lengths through ONE launch per DPRNN path must
     give what the reference's one-at-a-time loop gives.  Lengths leave ragged tiles everywhere (chunk counts 11 .. 47,
     K = 40 chunk positions against 64-sequence tiles); the speaker branch keeps batch-of-one BatchNorm statistics."""
@@ -136,7 +148,7 @@ def test_ragged_batch_equals_one_by_one(kind):
                 assert torch.allclose(v, bn_ragged[k], rtol=1e-5, atol=1e-7), k
 
 
-def test_ragged_full_config_against_cpu_oracle():
+def test_ragged_full_config_against_cpu_oracle(split_gate_gemm):
     """Shipped depth / chunk geometry (6 blocks, K 250 / P 125), four lengths between 1.2 and 3.6 s in one ragged batch,
     against the torch-CPU oracle of each utterance."""
     from tss_with_dprnn_amd import inference
