@@ -412,21 +412,37 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
     achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
     value = world * B * args.steps / elapsed
     assert bool(torch.isfinite(loss).all())
+    from tss_with_dprnn_amd import training as _tr
+    f16_bwd, f16_fwd = _tr.TRAIN_BWD_GEMM_MODE == 3, _tr.TRAIN_GEMM_MODE == 3
+    # BPTT in f16 pieces is bound by its HBM streams, not by the matrix pipe: per slab row and both directions it reads the
+    # tape (2 x 128 units x 5 floats) and dH (256) and writes dG (1024) and dX (2 x 128): 11 264 bytes
+    geo = engine.make_geometry(B, SAMPLES, 64, 250, 125, 2, 1)
+    bwd_gb_per_step = 12 * geo.rows * 11264 / 1e9
+    hbm = bwd_gb_per_step * args.steps / (union_ms * 1e-3) / 1e3 if union_ms > 0 else float("nan")
+    if f16_bwd:
+        roof = {"bound": "hbm", "kernel": "lstm_bwd8_f16_kernel (dprnn_rnn_bwd, BPTT, step GEMM in f16 pieces)", "achieved": hbm,
+                "peak": 8.0, "unit": "TB/s", "frac": hbm / 8.0, "traffic": None,
+                "algorithmic_gb_per_step": bwd_gb_per_step, "matrix_tflops_algorithmic": achieved,
+                "matrix_frac_of_f16_pieces_ceiling": achieved / (2500.0 / 3)}
+    else:
+        roof = {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd, BPTT, fp32 MFMA)", "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
     return {
         "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet training step", "value": value, "unit": "utt/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" + ("; recurrence GEMMs via 2 x f16 pieces of 2^e-scaled operands, 3 products, f32 accumulate ("
+                          + " and ".join(n for n, on in (("forward", f16_fwd), ("BPTT", f16_bwd)) if on) + ")" if (f16_fwd or f16_bwd) else ""),
+        "data": "synthetic",
         "config": {"workload": "DPRNN-TasNet training step (PIT SI-SDR loss, clip 5, Adam), synthetic 3 s @ 8 kHz, "
                                f"batch={B} per GPU, global batch {B * world} (BASELINE.json configs[3])",
                    "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"data-parallel x{world}, one flat gradient all-reduce"},
         "allreduce": {"bytes": reducer.numel * 4, "ms_mean": sum(ar_ms) / len(ar_ms) if ar_ms else None,
                       "ms_max": max(ar_ms) if ar_ms else None, "calls": len(ar_ms),
                       "note": "gather copy + all-reduce + scale + scatter copy, HIP events on the step's stream"},
-        "roofline": {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd, BPTT)", "achieved": achieved,
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel_ms": kern_ms, "launches_timed": n_ev, "busy_ms_per_step": union_ms / args.steps,
-                     "mean_concurrency": conc,
-                     "whole_step_frac": value / world * 3 * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        "roofline": dict(roof, kernel_ms=kern_ms, launches_timed=n_ev, busy_ms_per_step=union_ms / args.steps, mean_concurrency=conc,
+                         whole_step_tflops=value / world * 3 * FLOP_PER_UTT / 1e12,
+                         whole_step_frac_of_fp32_mfma_peak=value / world * 3 * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS),
         "loss": float(loss.item()), "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2**30,
     }
 

@@ -38,6 +38,14 @@ int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, flo
                    int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                    int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
 
+/* Arithmetic of the step GEMM of the LSTM backward (process-wide; pack and launch under the same setting): 0 = exact fp32 MFMA,
+ * 3 = two f16 pieces / three products (train_recur_f16.hip: da scaled by a power of two taken from max|dH| of the launch, which
+ * dprnn_rnn_bwd finds with one extra pass over dH; weights by a per-LSTM 2^e).  GRU / Elman cells always use the fp32 kernel.
+ * packedT must hold dprnn_rnn_pack_bwd_floats(ndir) floats in either mode (ndir * 131072 fragments + 128 of scales). */
+void dprnn_set_bwd_gemm_mode(int mode);
+int dprnn_get_bwd_gemm_mode(void);
+int64_t dprnn_rnn_pack_bwd_floats(int ndir);
+
 /* ---- the same three entry points for every rnn_type the reference accepts (getattr(nn, rnn_type), dprnn.py:23):
  * cell 0 = LSTM, 1 = GRU, 2 = RNN (tanh), packing as dprnn_rnn_pack.  dG per row and direction: LSTM [i,f,g,o] (512),
  * GRU [r, z, n_x, n_h] (512: dW_ih rows (r,z,n) pair with (r,z,n_x), dW_hh rows with (r,z,n_h); b_ih / b_hh likewise),

@@ -48,13 +48,13 @@ def run_train(st, nwg, T, ndir=2, iters=3):
     dG = torch.empty(rows, ndir * 512, device="cuda")
     tape = torch.empty(lib.dprnn_rnn_tape_floats(0, nseq, T, ndir), device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
-    packedT = torch.empty(ndir * 512 * 256, device="cuda")
+    packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(ndir), device="cuda")
     bsum = torch.empty(ndir * 512, device="cuda")
     w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
          torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
     p = lambda t: t.data_ptr()
     st.call("dprnn_rnn_pack", 0, *[p(t) for t in w], *[p(t) for t in w], p(packed), p(bsum))
-    st.call("dprnn_rnn_pack_bwd", 0, p(w[0]), p(w[1]), p(w[0]), p(w[1]), p(packedT))
+    st.call("dprnn_rnn_pack_bwd", 0, p(w[0]), p(w[1]), p(w[0]), p(w[1]), p(packedT))      # layout follows dprnn_set_bwd_gemm_mode
     addr = (nseq, T, nseq, 0, T, 1, ndir)
     calls = {"fwd_train": ("dprnn_rnn_fwd_train", (0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), p(tape), *addr)),
              "bwd": ("dprnn_rnn_bwd", (0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr))}
@@ -86,7 +86,7 @@ def bwd_stamps(st, nwg, T, ndir=2):
     dG = torch.empty(rows, ndir * 512, device="cuda")
     tape = torch.empty(lib.dprnn_rnn_tape_floats(0, nseq, T, ndir), device="cuda")
     packed = torch.empty(ndir * engine.PACK_PER_DIR_MAX, device="cuda")
-    packedT = torch.empty(ndir * 512 * 256, device="cuda")
+    packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(ndir), device="cuda")
     bsum = torch.empty(ndir * 512, device="cuda")
     w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
          torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
@@ -228,8 +228,14 @@ def main():
         bwd_stamps(st, ncu * 2, a.T)        # two per CU: the production occupancy
         return
     if a.train:
-        for k, (ms, tf) in run_train(st, ncu * 2, a.T, iters=5).items():
-            print(f"train {k}: {ms:.3f} ms {tf:.1f} TFLOP/s = {tf / 157.3:.2f} of the fp32 MFMA peak")
+        # the training recurrences on a full grid (two 32-sequence tiles per CU = one 64-sequence tile per CU), in both arithmetics:
+        # forward with tape under --gemm-mode 0 | 3, BPTT under dprnn_set_bwd_gemm_mode 0 | 3 (bwd time includes the dH max pass)
+        for bmode in (0, 3):
+            lib.dprnn_set_gemm_mode(bmode)
+            lib.dprnn_set_bwd_gemm_mode(bmode)
+            for k, (ms, tf) in run_train(st, ncu * 2, a.T, iters=5).items():
+                print(f"train {k} ({'f16 pieces' if bmode else 'fp32 MFMA'}): {ms:.3f} ms {tf:.1f} TFLOP/s = {tf / 157.3:.2f} of the fp32 MFMA peak")
+        lib.dprnn_set_gemm_mode(0); lib.dprnn_set_bwd_gemm_mode(0)
         return
     if a.only:
         seq_tile, per_cu = (int(v) for v in a.only.split(","))

@@ -315,12 +315,24 @@ void lstm_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
+// Arithmetic of the step GEMM of the LSTM backward: 0 = exact fp32 MFMA (lstm_bwd_kernel), 3 = two f16 pieces / three products
+// (train_recur_f16.hip).  Process-wide like dprnn_set_gemm_mode; it decides the layout dprnn_rnn_pack_bwd writes and the kernel
+// dprnn_rnn_bwd launches, so pack and launch under the same setting.  GRU / Elman cells always use the fp32 kernel.
+static int g_bwd_gemm_mode = 0;
+extern "C" void dprnn_set_bwd_gemm_mode(int mode) { g_bwd_gemm_mode = mode == 3 ? 3 : 0; }
+extern "C" int dprnn_get_bwd_gemm_mode(void) { return g_bwd_gemm_mode; }
+int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, float* packedT, hipStream_t st);
+int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packedT, float* dX, float* dG, long long rows_total,
+                         int nseq, int T, int inner_n, long long outer_stride, long long inner_stride, long long t_stride, int ndir,
+                         bool fast, hipStream_t st);
+
 extern "C" int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
                                   float* packedT, void* stream) {
     if (!w_ih || !w_hh || !packedT) { dprnn_set_error("dprnn_rnn_pack_bwd: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && !w_hh_r) { dprnn_set_error("dprnn_rnn_pack_bwd: incomplete reverse direction"); return -1; }
+    if (cell == 0 && g_bwd_gemm_mode == 3) return recur_bwd_f16_pack(w_ih, w_hh, w_ih_r, w_hh_r, packedT, (hipStream_t)stream);
     const int n = ndir * PACKT_PER_DIR;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, w_ih_r, w_hh_r, packedT, ndir, cell);
@@ -375,6 +387,10 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
                         (long long)outer_stride, T);
         return -1;
     }
+    if (cell == 0 && g_bwd_gemm_mode == 3 && !g_bwd_stamps)
+        return recur_bwd_f16_launch(dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, (long long)outer_stride,
+                                    (long long)inner_stride, (long long)t_stride, ndir, dprnn_fast_activations_enabled() != 0,
+                                    (hipStream_t)stream);
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride, g_bwd_stamps};
     if (g_bwd_stamps && cell == 0) {            // diagnostic twin: same kernel with cycle stamps of wave 0 per workgroup

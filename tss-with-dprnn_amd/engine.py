@@ -51,7 +51,7 @@ FUSE_NORM = True
 #                 range assumption at all: bf16 has fp32's exponent); from SPLIT_MIN_BATCH utterances up;
 #   0           = exact fp32 operands on the fp32 MFMA (recur.hip): bit-for-bit an fma chain; DPRNN_GEMM_MODE=0 selects it;
 #   2           = two bf16 pieces / three products (product error ~2^-16): opt-in only, never a default.
-# GRU / Elman cells and the backward kernels always run the exact fp32 kernels (training forward: training.TRAIN_GEMM_MODE).
+# GRU / Elman cells always run the exact fp32 kernels (training: training.TRAIN_GEMM_MODE / TRAIN_BWD_GEMM_MODE).
 DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "3"))
 GEMM_MODE = DEFAULT_GEMM_MODE
 SPLIT_ONE_GROUP = True      # bf16-split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)

@@ -41,6 +41,10 @@ MIN_TRAIN_GROUP = 8                  # utterances per group at least (explicit g
 # data and weight gradients) always run on the exact fp32 MFMA: gradients span too many orders of magnitude for f16 pieces
 # without per-tensor exponents.  DPRNN_TRAIN_GEMM_MODE overrides.
 TRAIN_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_GEMM_MODE", "3"))
+# Step GEMM of the LSTM backward (BPTT): 3 = two f16 pieces / three products with a per-launch power-of-two gradient scale
+# (train_recur_f16.hip), 0 = exact fp32 MFMA.  DPRNN_TRAIN_BWD_GEMM_MODE overrides.  Weight and data gradients of the Linears
+# stay on the fp32 MFMA.
+TRAIN_BWD_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_BWD_GEMM_MODE", "3"))
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
@@ -294,7 +298,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     # ---- DPRNN blocks in reverse (dprnn.py:79-99)
     dXd = torch.zeros(2, rows, F_BUILT, **f32)
     dZ = torch.empty(rows, F_BUILT, **f32)
-    packedT = torch.empty(2 * PACKT_PER_DIR, **f32)
+    packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), **f32)
     have_dx = False
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
     for p in range(npth - 1, -1, -1):
@@ -323,9 +327,13 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         addr = _addr(geo, intra)
         cell = engine.CELL_ID[rnn.rnn.mode]
         kg = F_BUILT if cell == 2 else 4 * F_BUILT          # gate-gradient columns per direction: LSTM i,f,g,o; GRU r,z,n_x,n_h; RNN a
-        st.call("dprnn_rnn_pack_bwd", cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
         dG = torch.empty(rows, ndir * kg, **f32)
-        st.call("dprnn_rnn_bwd", cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
+        lib.dprnn_set_bwd_gemm_mode(3 if (TRAIN_BWD_GEMM_MODE == 3 and cell == 0) else 0)     # layout of the pack = kernel of the launch
+        try:
+            st.call("dprnn_rnn_pack_bwd", cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
+            st.call("dprnn_rnn_bwd", cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
+        finally:
+            lib.dprnn_set_bwd_gemm_mode(0)
         del dH
         pre = f"{blk}_rnn.rnn."
         for d in range(ndir):
