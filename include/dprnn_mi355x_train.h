@@ -45,6 +45,11 @@ int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, flo
 void dprnn_set_bwd_gemm_mode(int mode);
 int dprnn_get_bwd_gemm_mode(void);
 int64_t dprnn_rnn_pack_bwd_floats(int ndir);
+/* Weight gradients of an LSTM whose BPTT ran in mode 3: dprnn_wgrad_use_f16_pieces(packedT + dprnn_rnn_bwd_gradmax_offset(ndir))
+ * makes the NEXT dprnn_wgrad call (only that one) run dG^T [x | h_prev] in f16 pieces (wgrad_f16_kernel: rows as the MFMA k
+ * dimension through ds_read_b64_tr_b16), with P scaled by the power of two the BPTT launch took from max|dH| and Q by 2^4. */
+void dprnn_wgrad_use_f16_pieces(const float* grad_max);
+int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);
 
 /* ---- the same three entry points for every rnn_type the reference accepts (getattr(nn, rnn_type), dprnn.py:23):
  * cell 0 = LSTM, 1 = GRU, 2 = RNN (tanh), packing as dprnn_rnn_pack.  dG per row and direction: LSTM [i,f,g,o] (512),

@@ -106,6 +106,7 @@ _VOID = {
     "dprnn_set_fast_head_activations": [c_i],
     "dprnn_set_gemm_mode": [c_i],
     "dprnn_set_bwd_gemm_mode": [c_i],
+    "dprnn_wgrad_use_f16_pieces": [c_fp],
     "dprnn_debug_bwd_stamps": [c_fp],
 }
 _SPECIAL = {
@@ -116,6 +117,7 @@ _SPECIAL = {
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
+    "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),
     "dprnn_get_bwd_gemm_mode": ([], c_i),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),

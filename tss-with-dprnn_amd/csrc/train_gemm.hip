@@ -163,6 +163,205 @@ void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- the same block GEMM in f16 pieces (LSTM weight gradients when the BPTT ran in f16 pieces, dprnn_wgrad_use_f16_pieces):
+// chunks of 32 rows; P (x S_g, the gradient scale of the BPTT launch that produced dG) and Q (x 2^4) are split into two f16
+// pieces while they are staged, row-major as they arrive: [piece][k row][column] with 8-byte units XOR-swizzled by the row.  The
+// row index is the MFMA k dimension, so a lane needs eight consecutive ROWS of one column: ds_read_b64_tr_b16 reads a 4-row x
+// 16-column block per 16 lanes and hands lane i column i (tools/probes/ds_read_tr16.hip), two reads per operand fragment.
+// Three products on v_mfma_f32_16x16x32_f16: 48 matrix instructions per 32 rows and wave against 256 on the fp32 MFMA; the
+// kernel is left to the HBM streams of P and Q.  Same block / split / workspace plan and the same reduce kernel as above.
+constexpr int WF_R = 32;
+constexpr int WF_PPL = WF_R * WG_MB * 2, WF_QPL = WF_R * WG_NB * 2;          // bytes of one piece plane of a P / Q chunk
+constexpr int WF_BUF = 2 * WF_PPL + 2 * WF_QPL;                              // one buffer: P pieces, Q pieces (48 KB)
+typedef short wf_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned wf_swz(int row) { return (unsigned)(((row & 3) << 2) ^ (((row >> 3) & 1) << 4)); }
+
+__global__ __launch_bounds__(WG_THREADS, 2)
+void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax) {
+    extern __shared__ __attribute__((aligned(16))) char wimg[];           // [buf 2][P piece 0 | P piece 1 | Q piece 0 | Q piece 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mb = blockIdx.x, nb = blockIdx.y, ks = blockIdx.z;
+    const QDesc qd = a.q[nb];
+    const long long r0 = (long long)ks * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > a.rows) r1 = a.rows;
+
+    // gradient scale: the largest |dH| of the BPTT launch sits at 2^6 (train_recur_f16.hip)
+    float sg;
+    {
+        const float m = *pmax;
+        int ex = 0;
+        if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+        ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+        sg = ldexpf(1.f, 6 - ex);
+    }
+    const float inv = 1.f / (sg * F16P_XS);
+
+    constexpr unsigned OOB = 0x80000000u;
+    const int pc4 = tid & 63, prow = tid >> 6;          // P: rows prow + 8 j (j < 4), float4 column chunk pc4
+    const int qc4 = tid & 31, qrow = tid >> 5;          // Q: rows qrow + 16 j (j < 2), chunk qc4
+    const int pcol = mb * WG_MB + 4 * pc4;
+    const bool pok = pcol < a.M;
+    const bool qok = 4 * qc4 < qd.cols;
+    unsigned poff[4], qoff[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) poff[j] = pok ? (unsigned)(((prow + 8 * j) * a.ldp + pcol) * 4) : OOB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) qoff[j] = qok ? (unsigned)(((qrow + 16 * j) * qd.ld + 4 * qc4) * 4) : OOB;
+    const int ts = (int)a.t_stride;
+    int tq[2] = {0, 0}, remq[2] = {0, 0};
+    if (qd.dt != 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long row = r0 + qrow + 16 * j;
+            tq[j] = (int)((row / a.t_stride) % a.T);
+            remq[j] = (int)(row % a.t_stride);
+        }
+    }
+    f32x4 pv[4], qv[2], psum = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](long long row0) __attribute__((always_inline)) {
+        const long long leftp = (r1 - row0) * (long long)a.ldp * 4;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.P + row0 * a.ldp), 0, leftp > 0x7fffffffLL ? 0x7fffffffu : (unsigned)leftp, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, poff[j], 0, 0));
+        const long long shift = (long long)qd.dt * a.t_stride;
+        const long long leftq = (r1 - row0) * (long long)qd.ld * 4;
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(qd.p + (row0 - shift) * qd.ld), 0, leftq > 0x7fffffffLL ? 0x7fffffffu : (unsigned)leftq, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned qo = qoff[j];
+            if (qd.dt != 0) {
+                const int t = tq[j] - qd.dt;
+                if (t < 0 || t >= a.T) qo = OOB;
+            }
+            qv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, qo, 0, 0));
+            if (qd.dt != 0) {                            // advance the time index to the next chunk's row
+                if (ts == 1) { tq[j] += WF_R; while (tq[j] >= a.T) tq[j] -= a.T; }
+                else { remq[j] += WF_R; while (remq[j] >= ts) { remq[j] -= ts; if (++tq[j] == a.T) tq[j] = 0; } }
+            }
+        }
+    };
+    // element unit (row, 8-byte unit u) of a plane with `pitch` bytes per row: row*pitch + ((u ^ swz(row)) << 3)
+    auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
+        unsigned a1, a2, b1, b2;
+        f16_pieces2(c[0], c[1], a1, a2);
+        f16_pieces2(c[2], c[3], b1, b2);
+        lo = (unsigned long long)a1 | ((unsigned long long)b1 << 32);
+        hi = (unsigned long long)a2 | ((unsigned long long)b2 << 32);
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+        char* const pb = wimg + buf * WF_BUF;
+        char* const qb = pb + 2 * WF_PPL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = prow + 8 * j;
+            unsigned long long lo, hi;
+            pieces4(pv[j], sg, lo, hi);
+            char* d = pb + row * (WG_MB * 2) + (((unsigned)pc4 ^ wf_swz(row)) << 3);
+            *reinterpret_cast<unsigned long long*>(d) = lo;
+            *reinterpret_cast<unsigned long long*>(d + WF_PPL) = hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) psum[e] += pv[j][e];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = qrow + 16 * j;
+            unsigned long long lo, hi;
+            pieces4(qv[j], F16P_XS, lo, hi);
+            char* d = qb + row * (WG_NB * 2) + (((unsigned)qc4 ^ wf_swz(row)) << 3);
+            *reinterpret_cast<unsigned long long*>(d) = lo;
+            *reinterpret_cast<unsigned long long*>(d + WF_QPL) = hi;
+        }
+    };
+
+    // transposed fragment reads: lane (g = lane >> 4, l = lane & 15, q' = l >> 2, p = l & 3) supplies row 8 g + 4 h + q',
+    // unit (U + p) ^ swz(row) = U ^ (p | q' << 2 | (g & 1) << 4) of a 16-column tile whose first unit U is a multiple of 4
+    const int g = lane >> 4, l = lane & 15, qq = l >> 2, pp = l & 3;
+    const unsigned ub = (unsigned)(pp | (qq << 2) | ((g & 1) << 4));
+    unsigned pa[4], qa[4];                               // byte offsets of the h = 0 read of tile jm / jn inside a piece plane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pa[j] = (unsigned)((8 * g + qq) * (WG_MB * 2)) + ((((unsigned)(16 * wm + 4 * j)) ^ ub) << 3);
+        qa[j] = (unsigned)((8 * g + qq) * (WG_NB * 2)) + ((((unsigned)(16 * wn + 4 * j)) ^ ub) << 3);
+    }
+    auto tr8 = [&](const char* plane, unsigned off, int pitch) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) wf_s4* lptr;
+        const wf_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off));
+        const wf_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off + 4 * pitch));
+        rg_u32x4 out;
+        const unsigned long long a0 = __builtin_bit_cast(unsigned long long, lo), a1 = __builtin_bit_cast(unsigned long long, hi);
+        out[0] = (unsigned)a0; out[1] = (unsigned)(a0 >> 32); out[2] = (unsigned)a1; out[3] = (unsigned)(a1 >> 32);
+        return out;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (r0 < r1) {
+        load(r0);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long row0 = r0; row0 < r1; row0 += WF_R, buf ^= 1) {
+            const bool more = row0 + WF_R < r1;
+            if (more) load(row0 + WF_R);
+            const char* const pb = wimg + buf * WF_BUF;
+            const char* const qb = pb + 2 * WF_PPL;
+            rg_u32x4 q1[4], q2[4];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) { q1[jn] = tr8(qb, qa[jn], WG_NB * 2); q2[jn] = tr8(qb + WF_QPL, qa[jn], WG_NB * 2); }
+#pragma unroll
+            for (int jm = 0; jm < 4; ++jm) {
+                const rg_u32x4 p1 = tr8(pb, pa[jm], WG_MB * 2), p2 = tr8(pb + WF_PPL, pa[jm], WG_MB * 2);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) {
+                    acc[jm][jn] = mfma_f16p(p1, q2[jn], acc[jm][jn]);
+                    acc[jm][jn] = mfma_f16p(p2, q1[jn], acc[jm][jn]);
+                    acc[jm][jn] = mfma_f16p(p1, q1[jn], acc[jm][jn]);
+                }
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // acc[jm][jn][e] = dW[m][n], m = 256 mb + 64 wm + 16 jm + 4 g + e, n = 128 nb + 64 wn + 16 jn + l
+    float* const out = a.part + (long long)ks * a.Mpad * a.Npad;
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = WG_MB * mb + 64 * wm + 16 * jm + 4 * g + e;
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) out[(long long)m * a.Npad + WG_NB * nb + 64 * wn + 16 * jn + l] = acc[jm][jn][e] * inv;
+        }
+    if (a.part_b && nb == 0) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(wimg);
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 64) {
+            f32x4 s = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const f32x4 v = red[tid + 64 * j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += v[e];
+            }
+            *reinterpret_cast<f32x4*>(a.part_b + (long long)ks * a.Mpad + WG_MB * mb + 4 * tid) = s;
+        }
+    }
+}
+
 // dW[m*ldm + n*ldn] = (accumulate ? dW : 0) + sum_s part[s][m][n];  db likewise (two optional destinations: the
 // LSTM's b_ih and b_hh receive the same gradient).  A workgroup of 4 waves sums 64 float4 column groups: wave w adds the
 // partials s = w, w+4, ... (eight independent loads in flight), the four wave sums are added in wave order -- a fixed
@@ -225,7 +424,7 @@ static void wgrad_plan(int M, int N, long long rows, int& mblocks, int& nblocks,
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     per = (rows + splits - 1) / splits;
-    per = (per + WG_R - 1) / WG_R * WG_R;
+    per = (per + 31) / 32 * 32;                        // whole chunks of either kernel (16 rows fp32, 32 rows f16 pieces)
     splits = (rows + per - 1) / per;
 }
 
@@ -234,6 +433,11 @@ extern "C" int64_t dprnn_wgrad_workspace_floats(int M, int N, int64_t rows) {
     wgrad_plan(M, N, rows > 0 ? rows : 1, mblocks, nblocks, splits, per);
     return splits * ((int64_t)mblocks * WG_MB * nblocks * WG_NB + mblocks * WG_MB);
 }
+
+// One-shot selector: the NEXT dprnn_wgrad call on this thread of control multiplies in f16 pieces, scaling P by the power of two
+// that the BPTT launch derived from *grad_max (device pointer to max|dH|, dprnn_rnn_bwd_gradmax_offset); cleared by that call.
+static const float* g_wgrad_f16_pmax = nullptr;
+extern "C" void dprnn_wgrad_use_f16_pieces(const float* grad_max) { g_wgrad_f16_pmax = grad_max; }
 
 extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
                            const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
@@ -258,8 +462,22 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     a.rows_per_split = per;
     a.part = workspace;
     a.part_b = (db0 || db1) ? workspace + splits * (long long)a.Mpad * a.Npad : nullptr;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
-    int rc = dprnn_check_launch("wgrad_kernel");
+    const float* const pmax = g_wgrad_f16_pmax;
+    g_wgrad_f16_pmax = nullptr;
+    int rc;
+    if (pmax) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WF_BUF);
+            if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(wgrad_f16): %s", hipGetErrorString(e)); return -2; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_f16_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, pmax);
+        rc = dprnn_check_launch("wgrad_f16_kernel");
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        rc = dprnn_check_launch("wgrad_kernel");
+    }
     if (rc) return rc;
     const int items = M * (N / 4) + (a.part_b ? M / 4 : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, (hipStream_t)stream,

@@ -362,3 +362,5 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
 }
 
 extern "C" int64_t dprnn_rnn_pack_bwd_floats(int ndir) { return (int64_t)ndir * BWD_PACK_WORDS_PER_DIR + BWD_EXTRA; }
+// float offset inside packedT of max|dH| of the last dprnn_rnn_bwd launch in mode 3 (for dprnn_wgrad_use_f16_pieces)
+extern "C" int64_t dprnn_rnn_bwd_gradmax_offset(int ndir) { return (int64_t)ndir * BWD_PACK_WORDS_PER_DIR + EX_DHMAX; }

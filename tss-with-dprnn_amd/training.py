@@ -45,6 +45,8 @@ TRAIN_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_GEMM_MODE", "3"))
 # (train_recur_f16.hip), 0 = exact fp32 MFMA.  DPRNN_TRAIN_BWD_GEMM_MODE overrides.  Weight and data gradients of the Linears
 # stay on the fp32 MFMA.
 TRAIN_BWD_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_BWD_GEMM_MODE", "3"))
+# ... and, with it, the LSTM weight-gradient GEMMs dG^T [x | h_prev] in f16 pieces with the same gradient scale (wgrad_f16_kernel)
+TRAIN_WGRAD_F16 = os.environ.get("DPRNN_TRAIN_WGRAD_F16", "1") != "0"
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 
 
@@ -343,6 +345,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
             if cell == 0:         # one GEMM: dG^T [x | h_prev] -> [W_ih | W_hh] (torch rows i,f,g,o)
                 gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
                 gbias = torch.empty(4 * F_BUILT, **f32)
+                if TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16:      # dG^T [x | h_prev] in f16 pieces, dG scaled like the BPTT's da
+                    lib.dprnn_wgrad_use_f16_pieces(packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir))
                 wgrad(gbase, ndir * kg, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, *hprev, rows, addr[5], addr[1],
                       gcat, 2 * F_BUILT, 1, gbias, None)
                 g_ih, g_hh = gcat[:, :F_BUILT].contiguous(), gcat[:, F_BUILT:].contiguous()
