@@ -39,6 +39,24 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert sorted(_lib.ALL_SYMBOLS) == names, "python binding table and header disagree"
 
 
+def test_binding_table_has_one_argtype_per_header_parameter():
+    """A ctypes call with fewer argtypes than arguments passes the extra ones as C ints: a 64-bit stream handle is then cut to
+    32 bits and only the default stream (0) survives.  Every entry of the binding table must list as many argument types as
+    the header prototype has parameters (the trailing `void* stream` included)."""
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if h.endswith(".h"))
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(dprnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)}
+    tables = dict(_lib.SIGNATURES)
+    tables.update(_lib._VOID)
+    tables.update({k: v[0] for k, v in _lib._SPECIAL.items()})
+    assert set(tables) == set(protos)
+    for name, args in tables.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        assert len(args) == n, f"{name}: {len(args)} argtypes in _lib.py, {n} parameters in the header"
+
+
 def test_library_loads_and_reports_abi(lib_path):
     lib = pkg.load_library()
     assert lib.dprnn_abi_version() == 1

@@ -64,6 +64,7 @@ SIGNATURES = {
     "dprnn_rnn_fwd_train": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
                             c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_rnn_pack_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_absmax": [c_fp, c_i64, c_fp, c_fp],
     "dprnn_rnn_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,

@@ -91,7 +91,7 @@ __global__ void pack_bwd_f16_kernel(const float* __restrict__ w_ih, const float*
 
 // max |dH| of the launch, as float bits (non-negative floats order like their bit patterns)
 __global__ __launch_bounds__(256)
-void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restrict__ extra) {
+void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restrict__ slot) {
     float m = 0.f;
     const f32x4* p = reinterpret_cast<const f32x4*>(dH);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -100,7 +100,7 @@ void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(extra + EX_DHMAX), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
 }
 
 struct Bwd16Args {
@@ -346,7 +346,7 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
                          bool fast, hipStream_t st) {
     float* extra = const_cast<float*>(packedT) + (size_t)ndir * BWD_PACK_WORDS_PER_DIR;
     const long long n4 = rows_total * ndir * HD / 4;
-    hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra);
+    hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra + EX_DHMAX);
     Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, rows_total, nseq, T, inner_n, ndir,
                 outer_stride, inner_stride, t_stride};
     const size_t lds = (size_t)2 * 64 * 512 * 2 + 3 * 64 * 4;
@@ -359,6 +359,15 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
     }
     hipLaunchKernelGGL(kern, dim3((nseq + 63) / 64, ndir), dim3(512), lds, st, a);
     return dprnn_check_launch("lstm_bwd8_f16_kernel");
+}
+
+// max |x| over n floats (n a multiple of 4) into *out, for dprnn_wgrad_use_f16_pieces with a P that no BPTT launch has measured
+extern "C" int dprnn_absmax(const float* x, int64_t n, float* out, void* stream) {
+    if (!x || !out || n <= 0 || (n % 4)) { dprnn_set_error("dprnn_absmax: null pointer or n not a multiple of 4"); return -1; }
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { dprnn_set_error("dprnn_absmax: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, x, (long long)(n / 4), out);
+    return dprnn_check_launch("dh_absmax_kernel");
 }
 
 extern "C" int64_t dprnn_rnn_pack_bwd_floats(int ndir) { return (int64_t)ndir * BWD_PACK_WORDS_PER_DIR + BWD_EXTRA; }

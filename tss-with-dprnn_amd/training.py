@@ -301,6 +301,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     dXd = torch.zeros(2, rows, F_BUILT, **f32)
     dZ = torch.empty(rows, F_BUILT, **f32)
     packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), **f32)
+    zmax = torch.zeros(1, **f32)
     have_dx = False
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
     for p in range(npth - 1, -1, -1):
@@ -322,6 +323,9 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
         Hp = H[p]
+        if TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16:      # dZ^T H in f16 pieces: dZ scaled by a power of two from its own maximum
+            st.call("dprnn_absmax", _p(dZ), rows * F_BUILT, _p(zmax))
+            lib.dprnn_wgrad_use_f16_pieces(zmax.data_ptr())
         wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
               F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None)
         grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
