@@ -141,7 +141,8 @@ int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
  * seq_tile: sequences per workgroup (16, 32, 48 or 64; 0 = choose).  16 runs on eight waves of 16 hidden units each
  * (the small-batch latency form); -16 selects the four-wave form of the same tile (for A/B measurements).  In the split
  * gate-GEMM modes the codes are: 32 (modes 1 / 2: two 32-sequence workgroups per CU), 2000 + n (the eight-wave kernel with n
- * sequences per workgroup, one per CU: n = 64, 80, 96 in modes 1 / 2; 32, 48, 64, 80, 96 in mode 3); anything else is refused. */
+ * sequences per workgroup, one per CU: n = 64, 80, 96 in modes 1 / 2; 16, 32, 48, 64, 80, 96 in mode 3 -- 16 keeps the first weight pieces in registers, the form for a few
+ * utterances); anything else is refused. */
 int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                      int64_t t_stride, int ndir, int seq_tile, void* stream);

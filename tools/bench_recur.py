@@ -247,7 +247,7 @@ def main():
         print(f"gemm mode {a.gemm_mode} ({np_} products): seq_tile wgs/CU ms us/step TFLOP/s(fp32-equivalent) bf16-MFMA-floor-us/step@2.4GHz")
         forms = ((32, 2), (2064, 1), (2080, 1), (2096, 1))
         if a.gemm_mode == 3:    # f16 pieces: the eight-wave kernels only
-            forms = ((2032, 1), (2032, 2), (2048, 1), (2048, 2), (2064, 1), (2080, 1), (2096, 1))
+            forms = ((2016, 1), (2032, 1), (2032, 2), (2048, 1), (2048, 2), (2064, 1), (2080, 1), (2096, 1))
         for seq_tile, per_cu in forms:
             ms, tf = run(st, seq_tile, ncu * per_cu, a.T, iters=5)
             tiles = (abs(seq_tile) % 1000 + 15) // 16

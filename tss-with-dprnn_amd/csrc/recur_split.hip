@@ -328,8 +328,8 @@ int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, b
 #endif
     const int nsr = seq_tile % 1000;
     if (products == 2) {                                   // f16 form (gemm mode 3): the eight-wave kernels only
-        if (seq_tile < 2000 || (nsr != 32 && nsr != 48 && nsr != 64 && nsr != 80 && nsr != 96)) {
-            dprnn_set_error("dprnn_rnn_fwd: gemm mode 3 has seq_tile 2032, 2048, 2064, 2080, 2096 (got %d)", seq_tile);
+        if (seq_tile < 2000 || (nsr != 16 && nsr != 32 && nsr != 48 && nsr != 64 && nsr != 80 && nsr != 96)) {
+            dprnn_set_error("dprnn_rnn_fwd: gemm mode 3 has seq_tile 2016, 2032, 2048, 2064, 2080, 2096 (got %d)", seq_tile);
             return -1;
         }
         return launch_split8_f16(a, nsr, stag, fast, st);

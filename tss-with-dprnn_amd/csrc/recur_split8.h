@@ -36,7 +36,7 @@ template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, 
 __global__ __launch_bounds__(512, 2)
 void bilstm_split8_kernel(RecurArgs a) {
     static_assert(!SAVE || (NSR == 64 && !STAG), "the tape layout is written for 64-sequence tiles");
-    static_assert(NSR % 16 == 0 && NSR >= 32 && NSR <= 96, "whole 16-row tiles");
+    static_assert(NSR % 16 == 0 && NSR >= 16 && NSR <= 96, "whole 16-row tiles");
     static_assert(!F16 || NP == 3, "the f16 form has two pieces and three products");
     constexpr int NT = NSR / 16;
     constexpr int NPC = NP == 6 ? 3 : 2;
@@ -245,11 +245,23 @@ void bilstm_split8_kernel(RecurArgs a) {
     for (int e = 0; e < 4; ++e) hb[e] = (4 * q + e) * 256 + ((((w4 ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3) + 2 * wu;
     const unsigned hcol = (unsigned)(dir * HD + unit0) * 4u;
 
+    // WRES (f16 pieces, 16-sequence tile: the low-latency form for a few utterances): a step of a small tile is bound by the
+    // L2 -> CU stream of the direction's 512 KB of weight pieces, not by its 96 MFMAs per wave, so the FIRST pieces of this
+    // wave's weights (128 registers) stay resident for the whole kernel and only the second pieces are streamed: half the bytes
+    // per step.
+    constexpr bool WRES = F16 && NSR == 16 && !STAG;
+    u32x4 wres[WRES ? NSLAB : 1][4];
+    if constexpr (WRES) {
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wres[s][g] = wload(s, g, 0);
+    }
     u32x4 bw[4][NPC];                                  // B fragments of the k-slab in progress (single-buffered: a piece is
 #pragma unroll                                         // re-requested for the next slab when its last product is done)
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) bw[g][pc] = wload(STAG ? 0 : 0, g, pc);
+        for (int pc = WRES ? 1 : 0; pc < NPC; ++pc) bw[g][pc] = wload(0, g, pc);
     f32x4 acc[STAG ? 2 : 1][NT][4];
     u32x4 fa[NT], fb[NT];
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
@@ -261,8 +273,15 @@ void bilstm_split8_kernel(RecurArgs a) {
                                 : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
+        if (WRES && wpc == 0) return;                  // resident
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[g][wpc] = wload(sn, g, wpc);
+    };
+    auto pass_res = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int sc) __attribute__((always_inline)) {     // first pieces of slab sc
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ac[nt][g] = mfma_f16(af[nt], wres[WRES ? sc : 0][g], ac[nt][g]);
     };
     // k-slab s4 of region reg (weights of global slab `s` are in bw; those of slab `sn` are requested as pieces die)
     auto slab = [&](f32x4 (&ac)[NT][4], const char* reg, u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int sn, bool have_p, bool prefetch,
@@ -281,10 +300,13 @@ void bilstm_split8_kernel(RecurArgs a) {
             if (prefetch) aload(Q, reg, 0, s4 + 1);
             pass(ac, P, 0, false); wreload(sn, 0); fence();
         } else {
+            const int sc = (sn + NSLAB - 1) & (NSLAB - 1);      // the slab in progress
             pass(ac, P, 1, first); wreload(sn, 1); fence();
-            pass(ac, P, 0, false); fence();
+            if constexpr (WRES) pass_res(ac, P, sc); else pass(ac, P, 0, false);
+            fence();
             if (prefetch) aload(P, reg, 0, s4 + 1);
-            pass(ac, Q, 0, false); wreload(sn, 0); fence();
+            if constexpr (WRES) pass_res(ac, Q, sc); else pass(ac, Q, 0, false);
+            wreload(sn, 0); fence();
         }
     };
     // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end

@@ -8,6 +8,7 @@ int recur::launch_split8_f16(const RecurArgs& a, int nsr, bool stag, bool fast, 
 #endif
     (void)stag;
     switch (nsr) {
+        case 16: return launch_split8_form<16, false, true>(a, 2, fast, st);
         case 32: return launch_split8_form<32, false, true>(a, 2, fast, st);
         case 48: return launch_split8_form<48, false, true>(a, 2, fast, st);
         case 80: return launch_split8_form<80, false, true>(a, 2, fast, st);

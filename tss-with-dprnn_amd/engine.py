@@ -296,8 +296,8 @@ SPLIT_STEP_US = {32: 25.0, 2064: 18.6, 2080: 23.3}
 SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split modes: one group's launches rarely fill 256 CUs exactly
 
 
-# gate-GEMM mode 3 (f16 pieces), eight-wave kernels only (profiles/r02_f16_pieces.txt): 32 sequences two-per-CU, 64 / 80 one-per-CU
-SPLIT_STEP_US_F16 = {2032: 14.1, 2064: 12.2, 2080: 15.1}
+# gate-GEMM mode 3 (f16 pieces), eight-wave kernels only (profiles/r02_f16_pieces.txt): 16 and 64 / 80 sequences one-per-CU, 32 two-per-CU
+SPLIT_STEP_US_F16 = {2016: 4.4, 2032: 14.6, 2064: 11.6, 2080: 15.3}   # 2016: first weight pieces resident in registers (few utterances)
 
 
 def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1) -> int:
