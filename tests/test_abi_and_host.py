@@ -189,3 +189,48 @@ def test_dropout_is_the_no_op_it_is_in_the_reference():
         pkg.DPRNNTasNet(64, n_repeats=1, dropout=1.5)
     ref = torch.nn.LSTM(4, 4, num_layers=1, dropout=0)            # the same checks torch performs
     assert ref.dropout == 0
+
+
+def test_split_tile_returns_codes_the_library_accepts():
+    """engine.split_tile picks the recurrence tile of the split gate-GEMM modes from the launch geometry: whatever the batch,
+    the code must be one the dispatcher builds (recur_split.hip: 32 / 2064 / 2080 / 2096 for the bf16 modes; 2016 .. 2096 for
+    f16 pieces), a handful of utterances must get the low-latency 16-sequence tile and the headline launches the 64-sequence one."""
+    from tss_with_dprnn_amd import engine
+    for nseq in (1, 7, 194, 250, 1552, 3104, 6208, 8000, 12416, 50000):
+        for ndir in (1, 2):
+            for conc in (1, 2):
+                assert engine.split_tile(nseq, ndir, 256, conc, 3) in (2016, 2032, 2048, 2064, 2080, 2096)
+                assert engine.split_tile(nseq, ndir, 256, conc, 1) in (32, 2064, 2080, 2096)
+    assert engine.split_tile(194, 2, 256, 1, 3) == 2016            # B = 1, intra-chunk path
+    assert engine.split_tile(6208, 2, 256, 2, 3) == 2064           # B = 64 as two groups of 32, intra-chunk path
+    assert engine.split_tile(8000, 2, 256, 2, 3) == 2064           # ... inter-chunk path
+
+
+def test_forwards_hand_the_library_back_in_the_exact_mode():
+    """engine._leaves_exact_mode: whatever a forward does -- return or raise -- the process-wide gate-GEMM mode is 0 afterwards."""
+    from tss_with_dprnn_amd import engine
+
+    class FakeLib:
+        mode = 3
+        def dprnn_set_gemm_mode(self, m):
+            self.mode = m
+
+    class FakeStage:
+        lib = FakeLib()
+
+    @engine._leaves_exact_mode
+    def ok(st):
+        st.lib.dprnn_set_gemm_mode(3)
+        return 7
+
+    @engine._leaves_exact_mode
+    def boom(st):
+        st.lib.dprnn_set_gemm_mode(1)
+        raise ValueError("x")
+
+    st = FakeStage()
+    assert ok(st) == 7 and st.lib.mode == 0
+    st.lib.mode = 3
+    with pytest.raises(ValueError):
+        boom(st)
+    assert st.lib.mode == 0
