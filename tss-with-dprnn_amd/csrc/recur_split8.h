@@ -27,6 +27,9 @@ namespace rsplit {
 #ifndef DPRNN_SPLIT8_PRIO
 #define DPRNN_SPLIT8_PRIO 1
 #endif
+#ifndef DPRNN_SPLIT8_RES32
+#define DPRNN_SPLIT8_RES32 1
+#endif
 constexpr bool split8_double_buffered(int nsr, bool f16, bool stag) { return DPRNN_SPLIT8_DB && f16 && !stag && nsr <= 64; }
 
 // SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
@@ -249,11 +252,13 @@ void bilstm_split8_kernel(RecurArgs a) {
     // L2 -> CU stream of the direction's 512 KB of weight pieces, not by its 96 MFMAs per wave, so the FIRST pieces of this
     // wave's weights (128 registers) stay resident for the whole kernel and only the second pieces are streamed: half the bytes
     // per step.
-    constexpr bool WRES = F16 && NSR == 16 && !STAG;
-    u32x4 wres[WRES ? NSLAB : 1][4];
+    // The 32-sequence tile has registers for half of them (k-slabs 0 .. 3).
+    constexpr int RES = (F16 && !STAG) ? (NSR == 16 ? NSLAB : (NSR == 32 && DPRNN_SPLIT8_RES32) ? NSLAB / 2 : 0) : 0;   // resident k-slabs
+    constexpr bool WRES = RES > 0;
+    u32x4 wres[WRES ? RES : 1][4];
     if constexpr (WRES) {
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s)
+        for (int s = 0; s < RES; ++s)
 #pragma unroll
             for (int g = 0; g < 4; ++g) wres[s][g] = wload(s, g, 0);
     }
@@ -261,7 +266,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll                                         // re-requested for the next slab when its last product is done)
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int pc = WRES ? 1 : 0; pc < NPC; ++pc) bw[g][pc] = wload(0, g, pc);
+        for (int pc = WRES ? 1 : 0; pc < NPC; ++pc) bw[g][pc] = wload(0, g, pc);       // slab 0 is resident whenever any is
     f32x4 acc[STAG ? 2 : 1][NT][4];
     u32x4 fa[NT], fb[NT];
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
@@ -273,7 +278,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                                 : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
-        if (WRES && wpc == 0) return;                  // resident
+        if (WRES && wpc == 0 && sn < RES) return;      // resident
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[g][wpc] = wload(sn, g, wpc);
     };
@@ -281,7 +286,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ac[nt][g] = mfma_f16(af[nt], wres[WRES ? sc : 0][g], ac[nt][g]);
+            for (int nt = 0; nt < NT; ++nt) ac[nt][g] = mfma_f16(af[nt], wres[WRES && sc < RES ? sc : 0][g], ac[nt][g]);
     };
     // k-slab s4 of region reg (weights of global slab `s` are in bw; those of slab `sn` are requested as pieces die)
     auto slab = [&](f32x4 (&ac)[NT][4], const char* reg, u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int sn, bool have_p, bool prefetch,
@@ -302,10 +307,10 @@ void bilstm_split8_kernel(RecurArgs a) {
         } else {
             const int sc = (sn + NSLAB - 1) & (NSLAB - 1);      // the slab in progress
             pass(ac, P, 1, first); wreload(sn, 1); fence();
-            if constexpr (WRES) pass_res(ac, P, sc); else pass(ac, P, 0, false);
+            if (WRES && sc < RES) pass_res(ac, P, sc); else pass(ac, P, 0, false);
             fence();
             if (prefetch) aload(P, reg, 0, s4 + 1);
-            if constexpr (WRES) pass_res(ac, Q, sc); else pass(ac, Q, 0, false);
+            if (WRES && sc < RES) pass_res(ac, Q, sc); else pass(ac, Q, 0, false);
             wreload(sn, 0); fence();
         }
     };
