@@ -49,6 +49,8 @@ int64_t dprnn_rnn_pack_bwd_floats(int ndir);
  * makes the NEXT dprnn_wgrad call (only that one) run dG^T [x | h_prev] in f16 pieces (wgrad_f16_kernel: rows as the MFMA k
  * dimension through ds_read_b64_tr_b16), with P scaled by the power of two the BPTT launch took from max|dH| and Q by 2^4. */
 void dprnn_wgrad_use_f16_pieces(const float* grad_max);
+/* the same for the NEXT dprnn_dgrad call of shape 128 -> 256 (dH = dZ @ W of a bidirectional path's Linear); other shapes ignore it */
+void dprnn_dgrad_use_f16_pieces(const float* grad_max);
 /* max |x| over n floats (n % 4 == 0) into *out: the scale source for a P that no BPTT launch has measured (the Linears' dZ) */
 int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);

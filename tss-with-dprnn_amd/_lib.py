@@ -108,6 +108,7 @@ _VOID = {
     "dprnn_set_gemm_mode": [c_i],
     "dprnn_set_bwd_gemm_mode": [c_i],
     "dprnn_wgrad_use_f16_pieces": [c_fp],
+    "dprnn_dgrad_use_f16_pieces": [c_fp],
     "dprnn_debug_bwd_stamps": [c_fp],
 }
 _SPECIAL = {

@@ -687,10 +687,27 @@ struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 c
     }
 };
 
-template <int KD, int ND, int RT, bool XC, class AL, class EPT>
+// WT: out = A @ W with W [KD][ldw] row-major (W0: k < nd0, W1: the rest) -- the data gradients; amax (may be null): device pointer
+// to max|A|, which replaces the fixed 2^4 activation scale by the power of two that puts it at 2^6 (gradients have no natural scale).
+template <int RT, int NCT>
+struct EpTStore {               // out[row*pitch + col] = acc
+    float* out; int pitch;
+    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                *reinterpret_cast<f32x4*>(out + row * pitch + 16 * ct + 4 * q) = acc[rt][ct] * f32x4{inv, inv, inv, inv};
+        }
+    }
+};
+
+template <int KD, int ND, int RT, bool XC, class AL, class EPT, bool WT = false>
 __global__ __launch_bounds__(512, 1)
 void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
-                         long long M, AL al, EPT ep) {
+                         long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr) {
     constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8, NW = 8;
     constexpr int PF = XC ? (NS >= 4 ? 3 : NS - 1) : (NS >= 4 ? 2 : 1);
     static_assert(!XC || NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
@@ -700,11 +717,16 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
     const int c = lane & 15, q = lane >> 4;
 
     auto wrow = [&](int col) { return col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1; };
+    auto wt = [&](int k, int col) { return k < nd0 ? W0[(long long)k * ldw0 + col] : W1[(long long)(k - nd0) * ldw1 + col]; };   // WT
     float m = 0.f;
-    for (int idx = tid; idx < ND * KD / 4; idx += 64 * NW) {
-        const int col = idx / (KD / 4), k4 = idx % (KD / 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow(col) + 4 * k4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    if constexpr (WT) {
+        for (int idx = tid; idx < ND * KD; idx += 64 * NW) m = fmaxf(m, fabsf(wt(idx / ND, idx % ND)));
+    } else {
+        for (int idx = tid; idx < ND * KD / 4; idx += 64 * NW) {
+            const int col = idx / (KD / 4), k4 = idx % (KD / 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wrow(col) + 4 * k4);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -717,10 +739,16 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
     ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
     const float sw = ldexpf(1.f, 14 - ex);
     for (int idx = tid; idx < ND * K8; idx += 64 * NW) {               // slot (s, qq, i): k = 32 s + 4 qq + i (i < 4), 32 s + 16 + 4 qq + i - 4
-        const int col = idx / K8, k8 = idx % K8;
+        const int col = WT ? idx % ND : idx / K8, k8 = WT ? idx / ND : idx % K8;      // WT: consecutive threads read consecutive columns
         const int s = k8 >> 2, qq = k8 & 3;
-        const float* src = wrow(col) + 32 * s + 4 * qq;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+        f32x4 lo, hi;
+        if constexpr (WT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = wt(32 * s + 4 * qq + e, col); hi[e] = wt(32 * s + 16 + 4 * qq + e, col); }
+        } else {
+            const float* src = wrow(col) + 32 * s + 4 * qq;
+            lo = *reinterpret_cast<const f32x4*>(src); hi = *reinterpret_cast<const f32x4*>(src + 16);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lo[e] *= sw; hi[e] *= sw; }
         rg_u32x4 w1, w2;
@@ -730,7 +758,15 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
         wl16[((s * NCT + (col >> 4)) * 2 + 1) * 64 + ln] = w2;
     }
     __syncthreads();
-    const float inv = 1.f / (F16P_XS * sw);
+    float xs = F16P_XS;
+    if (amax) {
+        const float am = *amax;
+        int ea = 0;
+        if (am > 0.f && am < 3.0e38f) frexpf(am, &ea);
+        ea = ea < -100 ? -100 : ea > 100 ? 100 : ea;
+        xs = ldexpf(1.f, 6 - ea);
+    }
+    const float inv = 1.f / (xs * sw);
 
     constexpr int ROWS_IT = NW * RT * 16;
     const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
@@ -780,8 +816,8 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
                 f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
-                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * xs, -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * xs, -F16P_XMAX, F16P_XMAX);
                 }
                 f16_pieces8(lo, hi, h1[rt], h2[rt]);
             }
@@ -810,11 +846,11 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
     }
 }
 
-template <int KD, int ND, int RT, bool XC, class AL, class EPT>
+template <int KD, int ND, int RT, bool XC, bool WT = false, class AL, class EPT>
 int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
-                        const AL& al, const EPT& ep, hipStream_t st) {
+                        const AL& al, const EPT& ep, hipStream_t st, const float* amax = nullptr) {
     const size_t lds = (size_t)KD * ND * 4;
-    auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT>;
+    auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT, WT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -825,7 +861,7 @@ int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, co
     long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
     long long grid = nchunk < num_cus() ? nchunk : num_cus();
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax);
     return dprnn_check_launch(what);
 }
 

@@ -490,10 +490,22 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
 // (64,128), (256,128), (128,64)} -- intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out+gate convs (:157-158),
 // bottleneck conv (:135), speaker-encoder convs (dprnn_spe.py:18-19,27,117-122; 256 -> 256 as two 128-column halves:
 // offset W0 and dA by the column, lda = 256).
+// One-shot selector, like dprnn_wgrad_use_f16_pieces: the NEXT dprnn_dgrad call of shape (128 -> 256) multiplies in f16 pieces
+// with dOut scaled by the power of two that puts *grad_max (device pointer to max|dOut|, dprnn_absmax) at 2^6.
+static const float* g_dgrad_f16_amax = nullptr;
+extern "C" void dprnn_dgrad_use_f16_pieces(const float* grad_max) { g_dgrad_f16_amax = grad_max; }
+
 extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
                            float* dA, int lda, int nd, int64_t rows, void* stream) {
     if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1) || lda < nd) { dprnn_set_error("dprnn_dgrad: null pointer / rows / lda"); return -1; }
     hipStream_t st = (hipStream_t)stream;
+    const float* const amax = g_dgrad_f16_amax;
+    g_dgrad_f16_amax = nullptr;
+    if (amax && kd == 128 && nd == 256 && (lda % 4) == 0) {
+        PlainRows<1> al{dOut, kd};
+        EpTStore<1, 16> ep{dA, lda};
+        return launch_rowgemm_f16t<128, 256, 1, true, true>("dgrad128x256_f16", W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st, amax);
+    }
     // row tiles per wave: 4 x 16 rows while the accumulators fit (ND <= 128), 2 x 16 for the 256-wide outputs
 #define DG_CASE(KD, ND, RT)                                                                                          \
     if (kd == KD && nd == ND) {                                                                                      \

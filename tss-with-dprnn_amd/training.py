@@ -319,12 +319,16 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         # Linear (dprnn.py:88,96)
         hp = ndir * F_BUILT
         dH = torch.empty(rows, hp, **f32)
+        f16_lin = TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16      # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum
+        if f16_lin:
+            st.call("dprnn_absmax", _p(dZ), rows * F_BUILT, _p(zmax))
+            if ndir == 2:
+                lib.dprnn_dgrad_use_f16_pieces(zmax.data_ptr())
         st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
         Hp = H[p]
-        if TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16:      # dZ^T H in f16 pieces: dZ scaled by a power of two from its own maximum
-            st.call("dprnn_absmax", _p(dZ), rows * F_BUILT, _p(zmax))
+        if f16_lin:
             lib.dprnn_wgrad_use_f16_pieces(zmax.data_ptr())
         wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
               F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None)
