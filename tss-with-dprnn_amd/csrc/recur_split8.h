@@ -30,7 +30,12 @@ namespace rsplit {
 #ifndef DPRNN_SPLIT8_RES32
 #define DPRNN_SPLIT8_RES32 1
 #endif
-constexpr bool split8_double_buffered(int nsr, bool f16, bool stag) { return DPRNN_SPLIT8_DB && f16 && !stag && nsr <= 64; }
+#ifndef DPRNN_SPLIT8_LRES
+#define DPRNN_SPLIT8_LRES 3
+#endif
+constexpr bool split8_double_buffered(int nsr, bool f16, bool stag) { return DPRNN_SPLIT8_DB && f16 && !stag && nsr <= 64 && !(nsr == 16 && DPRNN_SPLIT8_LRES > 3); }
+// 16-sequence f16 tile: second weight pieces of the LAST `lres` k-slabs live in LDS (32 KB per slab and direction)
+constexpr int split8_lds_resident_slabs(int nsr, bool f16, bool stag) { return (f16 && !stag && nsr == 16) ? DPRNN_SPLIT8_LRES : 0; }
 
 // SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
 // state to a.tape in the layout of the fp32 training kernel (recur.hip: [dir][32-sequence workgroup][step][wave][nt][u][slot]
@@ -59,6 +64,8 @@ void bilstm_split8_kernel(RecurArgs a) {
     unsigned* const rowoff_h = rowoff_x + NSR;
     float* const musig = reinterpret_cast<float*>(rowoff_h + NSR);
     float* const gb = musig + 2 * NSR;
+    constexpr int LRES = split8_lds_resident_slabs(NSR, F16, STAG);       // second pieces of k-slabs NSLAB - LRES .. NSLAB - 1 in LDS
+    char* const wlds = reinterpret_cast<char*>(gb + 256);                 // [slab][w4][gate*2 + wu][lane] 16-byte fragments
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -124,6 +131,16 @@ void bilstm_split8_kernel(RecurArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffffu, 0x00020000);
     };
 
+    if constexpr (LRES > 0) {                              // whole workgroup: copy the direction's fragments once
+        const u32x4* const src = reinterpret_cast<const u32x4*>(a.Wp) + (size_t)dir * 4 * NSLAB * 8 * 3 * 64;
+        for (int i = tid; i < LRES * 4 * 8 * 64; i += 512) {
+            const int ln = i & 63, gu = (i >> 6) & 7, ww = (i >> 9) & 3, sl = i >> 11;
+            reinterpret_cast<u32x4*>(wlds)[i] = src[(((size_t)ww * NSLAB + (NSLAB - LRES + sl)) * 8 + gu) * 3 * 64 + 1 * 64 + ln];
+        }
+    }
+    auto wlds_load = [&](int slab, int g) __attribute__((always_inline)) {      // second piece of (slab, gate) of this wave
+        return *reinterpret_cast<const u32x4*>(wlds + ((((slab - (NSLAB - LRES)) * 4 + w4) * 8 + g * 2 + wu) * 64 + lane) * 16);
+    };
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     // x of one time step -> bf16 pieces in x buffer xb, one quad (4 floats of one row) per thread and m; XG quads are in
     // flight together (registers: the partner wave on the SIMD covers the rest of the latency)
@@ -279,6 +296,11 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
         if (WRES && wpc == 0 && sn < RES) return;      // resident
+        if (LRES > 0 && wpc == 1 && sn >= NSLAB - LRES) {      // from LDS
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bw[g][1] = wlds_load(sn, g);
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[g][wpc] = wload(sn, g, wpc);
     };
@@ -460,7 +482,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(STAG ? 3 : (split8_double_buffered(NSR, F16, STAG) ? 4 : 2)) * (NP == 6 ? 3 : 2) * NSR * 256 +
-                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4;
+                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4 + (size_t)split8_lds_resident_slabs(NSR, F16, STAG) * 32768;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>),

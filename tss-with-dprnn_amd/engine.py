@@ -297,7 +297,7 @@ SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split mode
 
 
 # gate-GEMM mode 3 (f16 pieces), eight-wave kernels only (profiles/r02_f16_pieces.txt): 16 and 64 / 80 sequences one-per-CU, 32 two-per-CU
-SPLIT_STEP_US_F16 = {2016: 4.4, 2032: 13.4, 2064: 11.6, 2080: 15.3}   # 2016: first weight pieces resident in registers (few utterances)
+SPLIT_STEP_US_F16 = {2016: 3.8, 2032: 13.2, 2064: 11.6, 2080: 15.3}   # 2016: first weight pieces resident in registers (few utterances)
 
 
 def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1) -> int:
