@@ -51,6 +51,9 @@ with torch.no_grad():
         dt = timed(lambda: inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True), reps=1)
         print(f"{kind} ragged, the rank's whole share ({len(order)} utterances sorted by length, {s_all:.0f} s of audio): {dt:.3f} s = "
               f"{len(order) / dt:6.1f} utt/s, {s_all / dt:5.0f}x real time", flush=True)
+        dt = timed(lambda: inference.separate_many(m, w_all, max_streams=48, extra_inputs=a_all, ragged=False), reps=1)
+        print(f"{kind} streams=48, the rank's whole share (one utterance per pipeline): {dt:.3f} s = {len(order) / dt:6.1f} utt/s, "
+              f"{s_all / dt:5.0f}x real time", flush=True)
         del w_all, a_all
     # the round-1 path: equal-length batches (here: single utterances) on streams, exact fp32 kernels at these sizes
     for ns in (16, 48):
