@@ -421,7 +421,7 @@ def test_head_conv_ola_matches_oracle(K, P, L, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 3])
-@pytest.mark.parametrize("ks,stride,T,relu", [(2, 1, 300, 0), (4, 2, 203, 1), (2, 1, 65, 1)])
+@pytest.mark.parametrize("ks,stride,T,relu", [(2, 1, 300, 0), (4, 2, 203, 1), (2, 1, 65, 1), (8, 4, 523, 0)])
 def test_encoder_bottleneck_and_decode_chain(ks, stride, T, relu, mode):
     """encoder stats -> bottleneck and mask/decode chain vs oracle with random V (stage inputs)."""
     B, N = 3, 64

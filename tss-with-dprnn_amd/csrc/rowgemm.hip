@@ -257,6 +257,12 @@ int launch_proj_f16(const char* what, const float* W, const float* bias, const f
 #ifndef HEAD_F16_NW
 #define HEAD_F16_NW 8
 #endif
+#ifndef HEAD_MD_RT
+#define HEAD_MD_RT 2                    // mask + decoder on transposed tiles: 16-row tiles per wave, and lookahead across tiles
+#endif
+#ifndef HEAD_MD_XC
+#define HEAD_MD_XC true
+#endif
 #ifndef HEAD_F16T_RT
 #define HEAD_F16T_RT 1                  // 16-row tiles per wave in the transposed-tile head kernels (256 output columns: 2 spill)
 #endif
@@ -400,7 +406,16 @@ static int head_mask_decode(const float* V, const float* Wend, const float* wav,
     const Geo geo{B, T, L, N, ks, stride};
     if (g_fast_head) {
         EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
-        if (dprnn_get_gemm_mode() == 3 && !mask_all)       // rows are tanh * sigmoid products, |v| < 1
+        if (dprnn_get_gemm_mode() == 3 && !mask_all && (long long)B * L * 2 < (1ll << 31)) {      // rows are tanh * sigmoid products, |v| < 1
+            PlainRows<HEAD_MD_RT> alt{V, 128};
+            if (ks <= 2) {                                   // the reference's configurations use kernel_size 2
+                EpTMaskDecode<HEAD_MD_RT, true, 2> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+                return launch_rowgemm_f16t<128, 64, HEAD_MD_RT, HEAD_MD_XC>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, alt, ept, (hipStream_t)stream);
+            }
+            EpTMaskDecode<HEAD_MD_RT, true, KSMAX> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+            return launch_rowgemm_f16t<128, 64, HEAD_MD_RT, false>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, alt, ept, (hipStream_t)stream);
+        }
+        if (dprnn_get_gemm_mode() == 3 && !mask_all)
             return launch_rowgemm_f16<128, 64, RT, HEAD_F16_NW, true>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
         return launch_rowgemm<128, 64, RT>("head_mask_decode", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
     }

@@ -647,6 +647,7 @@ int launch_rowgemm_f16(const char* what, const float* W0, int ldw0, int nd0, con
 template <int RT, bool FAST>
 struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigmoid(acc[128 + col] + bg[col])
     float* V; const float* bo; const float* bg;
+    __device__ void begin(int tid) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -668,6 +669,7 @@ struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigm
 template <int RT>
 struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 columns
     float* U; const float* bias; int L, K, P, S;
+    __device__ void begin(int tid) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -692,6 +694,7 @@ struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 c
 template <int RT, int NCT>
 struct EpTStore {               // out[row*pitch + col] = acc
     float* out; int pitch;
+    __device__ void begin(int tid) {}
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -700,6 +703,72 @@ struct EpTStore {               // out[row*pitch + col] = acc
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
                 *reinterpret_cast<f32x4*>(out + row * pitch + 16 * ct + 4 * q) = acc[rt][ct] * f32x4{inv, inv, inv, inv};
+        }
+    }
+};
+
+// Mask 1x1 conv + activation, times the encoder output (recomputed from the waveform), through the decoder basis: rows are
+// (b, l, spk), taps[b][spk][l][j] = sum_n Wd[n][j] * act(acc[n]) * relu(sum_i We[n][i] * wav[b][l*stride + i]).  In the transposed
+// layout a lane owns 16 channels of ONE row per tile, so the frame's samples are loaded once per row, the sum over channels is
+// lane-local down to the four q lanes (two shuffles per tap instead of four, one row per lane instead of sixteen) and the row's
+// (b, l) takes one 32-bit division.  We / Wd sit in LDS as [n][KS] (zero-padded to KS >= ks taps, KS = 2 or KSMAX): the lanes of
+// a q group read one address.
+template <int RT, bool FAST, int KS>
+struct EpTMaskDecode {
+    const float* wav; const float* We; const float* Wd; float* taps; float* masked; int relu_act; Geo geo;
+    __device__ static float* tab() {
+        __shared__ __attribute__((aligned(16))) float t[2 * 64 * KS];
+        return t;
+    }
+    __device__ void begin(int tid) {
+        float* t = tab();
+        for (int i = tid; i < 64 * KS; i += 512) {
+            const int n = i / KS, j = i % KS;
+            t[i] = j < geo.ks ? We[n * geo.ks + j] : 0.f;
+            t[64 * KS + i] = j < geo.ks ? Wd[n * geo.ks + j] : 0.f;
+        }
+    }
+    __device__ void operator()(f32x4 (&acc)[RT][4], long long row0, int c, int q, long long M, float inv) {
+        const int ks = geo.ks;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            int qo = 4 * q * KS;
+            asm volatile("" : "+v"(qo));                   // the table words are re-read per row, not kept in registers across tiles
+            const float* t = tab() + qo;
+            long long row = row0 + 16 * rt + c;
+            const bool ok = row < M;                       // every lane takes part in the shuffles below
+            if (!ok) row = M - 1;
+            const unsigned ur = (unsigned)row, spk = ur & 1u, bl = ur >> 1;        // M < 2^31 (host check)
+            const unsigned b = bl / (unsigned)geo.L, l = bl - b * (unsigned)geo.L;
+            const float* x = wav + (long long)b * geo.T + (long long)l * geo.stride;
+            float xv[KS], tp[KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) { xv[j] = j < ks ? x[j] : 0.f; tp[j] = 0.f; }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                f32x4 mev;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* te = t + (16 * ct + e) * KS;           // channel n = 16 ct + 4 q + e
+                    float en = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) en = fmaf(te[j], xv[j], en);
+                    en = fmaxf(en, 0.f);
+                    const float a = acc[rt][ct][e] * inv;
+                    const float me = (relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a)) * en;
+                    mev[e] = me;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) tp[j] = fmaf(te[64 * KS + j], me, tp[j]);
+                }
+                if (masked && ok && spk == 0) *reinterpret_cast<f32x4*>(masked + (long long)bl * geo.N + 16 * ct + 4 * q) = mev;
+            }
+            float* dst = taps + (((long long)b * 2 + spk) * geo.L + l) * ks;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                float v = tp[j];
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (ok && q == (j & 3) && j < ks) dst[j] = v;          // the four lanes of a row share its taps' stores
+            }
         }
     }
 };
@@ -757,6 +826,7 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
         wl16[((s * NCT + (col >> 4)) * 2 + 0) * 64 + ln] = w1;
         wl16[((s * NCT + (col >> 4)) * 2 + 1) * 64 + ln] = w2;
     }
+    ep.begin(tid);
     __syncthreads();
     float xs = F16P_XS;
     if (amax) {
