@@ -103,7 +103,8 @@ int dprnn_bottleneck_prep(const double* stats, const float* gamma, const float* 
 /* ---- bottleneck 1x1 conv on the normalised encoder output (dprnn.py:135-136,169; 'cat' fusion
  * dprnn_spe.py:186-192 enters as the per-utterance bias row_bias[B][F], may be NULL):
  *   Y[b][l][f] = sum_c Wb[f][c]*a[b,l,c] + bb[f] + row_bias[b][f]
- * Wb is [F][ldw] row-major (ldw >= N: the first N input channels are used). */
+ * Wb is [F][ldw] row-major (ldw >= N: the first N input channels are used).  In gate-GEMM mode 3 the product runs in f16
+ * pieces like the Linears and the mask head (a in fp32, then split; |a| clamped to 4062). */
 int dprnn_bottleneck_fwd(const float* wav, const float* enc_w, const float* sc, const float* sh,
                          const float* Wb, int ldw, const float* bb, const float* row_bias, float* Y,
                          int B, int T, int L, int N, int ks, int stride, void* stream);

@@ -4,6 +4,13 @@ using namespace rg;
 
 extern "C" int dprnn_num_cus(void) { return num_cus(); }
 
+#ifndef BOTTLENECK_T_RT
+#define BOTTLENECK_T_RT 2               // bottleneck on transposed f16 tiles: 16-row tiles per wave, lookahead across tiles
+#endif
+#ifndef BOTTLENECK_T_XC
+#define BOTTLENECK_T_XC true
+#endif
+extern "C" int dprnn_get_gemm_mode(void);
 static int g_fast_head = 1;
 extern "C" void dprnn_set_fast_head_activations(int on) { g_fast_head = on; }
 
@@ -14,6 +21,11 @@ static int bottleneck(const float* wav, const float* enc_w, const float* sc, con
     if (N != 64 || ks < 1 || ks > KSMAX || ldw < N || (ldw % 4) != 0 || L != (T - ks) / stride + 1) {
         dprnn_set_error("dprnn_bottleneck_fwd: unsupported N=%d ks=%d ldw=%d L=%d T=%d stride=%d (built for input_size 64, ks<=8)", N, ks, ldw, L, T, stride);
         return -1;
+    }
+    if (dprnn_get_gemm_mode() == 3) {          // f16 pieces on transposed tiles (16-byte stores); A = the normalised encoder output
+        GenBottleneck<BOTTLENECK_T_RT> alt{wav, enc_w, sc, sh, Geo{B, T, L, N, ks, stride}};
+        EpTBiasStore<BOTTLENECK_T_RT, 8> ept{Y, bb, row_bias, (long long)L, row_scale};
+        return launch_rowgemm_f16t<64, 128, BOTTLENECK_T_RT, BOTTLENECK_T_XC>("bottleneck_f16", Wb, ldw, 128, nullptr, 0, (long long)B * L, alt, ept, (hipStream_t)stream);
     }
     constexpr int RT = 4;
     GenBottleneck<RT> al{wav, enc_w, sc, sh, Geo{B, T, L, N, ks, stride}};
@@ -38,7 +50,6 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
 #define PROJ_NW 8
 #endif
 
-extern "C" int dprnn_get_gemm_mode(void);
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Linear 256|128 -> 128 + GroupNorm sums in f16 pieces (gate-GEMM mode 3): the one row GEMM that runs 24 times per forward,

@@ -707,6 +707,29 @@ struct EpTStore {               // out[row*pitch + col] = acc
     }
 };
 
+template <int RT, int NCT>
+struct EpTBiasStore {           // out[row][col] = acc*row_scale[row] + bias[col] (+ row_bias[row / rows_per_b][col]), 16 NCT columns
+    float* out; const float* bias; const float* row_bias; long long rows_per_b; const float* row_scale;
+    __device__ void begin(int tid) {}
+    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+            const float rs = row_scale ? inv * row_scale[row] : inv;
+            const float* rb = row_bias ? row_bias + (row / rows_per_b) * (16 * NCT) + 4 * q : nullptr;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(bias + 16 * ct + 4 * q);
+                if (rb) v = v + *reinterpret_cast<const f32x4*>(rb + 16 * ct);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[rt][ct][e], rs, v[e]);
+                *reinterpret_cast<f32x4*>(out + row * (16 * NCT) + 16 * ct + 4 * q) = v;
+            }
+        }
+    }
+};
+
 // Mask 1x1 conv + activation, times the encoder output (recomputed from the waveform), through the decoder basis: rows are
 // (b, l, spk), taps[b][spk][l][j] = sum_n Wd[n][j] * act(acc[n]) * relu(sum_i We[n][i] * wav[b][l*stride + i]).  In the transposed
 // layout a lane owns 16 channels of ONE row per tile, so the frame's samples are loaded once per row, the sum over channels is
