@@ -365,9 +365,9 @@ static int head_gate(const float* U, const float* Wo, const float* bo, const flo
     PlainRows<RT> al{U, 128};
     if (g_fast_head) {
         EpGate<RT, true> ep{V, bo, bg, TG};
-        if (dprnn_get_gemm_mode() == 3 && !TG) {
+        if (dprnn_get_gemm_mode() == 3) {
             PlainRows<HEAD_F16T_RT> alt{U, 128};
-            EpTGate<HEAD_F16T_RT, true> ept{V, bo, bg};
+            EpTGate<HEAD_F16T_RT, true> ept{V, bo, bg, TG};
             return launch_rowgemm_f16t<128, 256, HEAD_F16T_RT, true>("head_gate_f16", Wo, 128, 128, Wg, 128, rows, alt, ept, (hipStream_t)stream);
         }
         return launch_rowgemm<128, 256, RT>("head_gate", Wo, 128, 128, Wg, 128, rows, al, ep, (hipStream_t)stream);
@@ -417,13 +417,13 @@ static int head_mask_decode(const float* V, const float* Wend, const float* wav,
     const Geo geo{B, T, L, N, ks, stride};
     if (g_fast_head) {
         EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
-        if (dprnn_get_gemm_mode() == 3 && !mask_all && (long long)B * L * 2 < (1ll << 31)) {      // rows are tanh * sigmoid products, |v| < 1
+        if (dprnn_get_gemm_mode() == 3 && (long long)B * L * 2 < (1ll << 31)) {      // rows are tanh * sigmoid products, |v| < 1
             PlainRows<HEAD_MD_RT> alt{V, 128};
             if (ks <= 2) {                                   // the reference's configurations use kernel_size 2
-                EpTMaskDecode<HEAD_MD_RT, true, 2> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+                EpTMaskDecode<HEAD_MD_RT, true, 2> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
                 return launch_rowgemm_f16t<128, 64, HEAD_MD_RT, HEAD_MD_XC>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, alt, ept, (hipStream_t)stream);
             }
-            EpTMaskDecode<HEAD_MD_RT, true, KSMAX> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo};
+            EpTMaskDecode<HEAD_MD_RT, true, KSMAX> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
             return launch_rowgemm_f16t<128, 64, HEAD_MD_RT, false>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, alt, ept, (hipStream_t)stream);
         }
         if (dprnn_get_gemm_mode() == 3 && !mask_all)

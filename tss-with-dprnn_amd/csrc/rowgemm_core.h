@@ -647,6 +647,7 @@ int launch_rowgemm_f16(const char* what, const float* W0, int ldw0, int nd0, con
 template <int RT, bool FAST>
 struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigmoid(acc[128 + col] + bg[col])
     float* V; const float* bo; const float* bg;
+    float* TG = nullptr;        // training forward: also keeps [tanh | sigmoid] as [row][256]
     __device__ void begin(int tid) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
@@ -656,11 +657,18 @@ struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigm
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bo + 16 * ct + 4 * q), b2 = *reinterpret_cast<const f32x4*>(bg + 16 * ct + 4 * q);
-                f32x4 v;
+                f32x4 v, ta, sg;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = tanh_f<FAST>(fmaf(acc[rt][ct][e], inv, b1[e])) * sigmoid_f<FAST>(fmaf(acc[rt][ct + 8][e], inv, b2[e]));
+                for (int e = 0; e < 4; ++e) {
+                    ta[e] = tanh_f<FAST>(fmaf(acc[rt][ct][e], inv, b1[e]));
+                    sg[e] = sigmoid_f<FAST>(fmaf(acc[rt][ct + 8][e], inv, b2[e]));
+                    v[e] = ta[e] * sg[e];
+                }
                 *reinterpret_cast<f32x4*>(V + row * F + 16 * ct + 4 * q) = v;
+                if (TG) {
+                    *reinterpret_cast<f32x4*>(TG + row * 256 + 16 * ct + 4 * q) = ta;
+                    *reinterpret_cast<f32x4*>(TG + row * 256 + 128 + 16 * ct + 4 * q) = sg;
+                }
             }
         }
     }
@@ -739,6 +747,7 @@ struct EpTBiasStore {           // out[row][col] = acc*row_scale[row] + bias[col
 template <int RT, bool FAST, int KS>
 struct EpTMaskDecode {
     const float* wav; const float* We; const float* Wd; float* taps; float* masked; int relu_act; Geo geo;
+    float* mask_all = nullptr;  // training forward: also keeps the mask as [row][N]
     __device__ static float* tab() {
         __shared__ __attribute__((aligned(16))) float t[2 * 64 * KS];
         return t;
@@ -769,7 +778,7 @@ struct EpTMaskDecode {
             for (int j = 0; j < KS; ++j) { xv[j] = j < ks ? x[j] : 0.f; tp[j] = 0.f; }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                f32x4 mev;
+                f32x4 mev, mkv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float* te = t + (16 * ct + e) * KS;           // channel n = 16 ct + 4 q + e
@@ -778,12 +787,14 @@ struct EpTMaskDecode {
                     for (int j = 0; j < KS; ++j) en = fmaf(te[j], xv[j], en);
                     en = fmaxf(en, 0.f);
                     const float a = acc[rt][ct][e] * inv;
-                    const float me = (relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a)) * en;
-                    mev[e] = me;
+                    const float mk = relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a);
+                    const float me = mk * en;
+                    mev[e] = me; mkv[e] = mk;
 #pragma unroll
                     for (int j = 0; j < KS; ++j) tp[j] = fmaf(te[64 * KS + j], me, tp[j]);
                 }
                 if (masked && ok && spk == 0) *reinterpret_cast<f32x4*>(masked + (long long)bl * geo.N + 16 * ct + 4 * q) = mev;
+                if (mask_all && ok) *reinterpret_cast<f32x4*>(mask_all + row * geo.N + 16 * ct + 4 * q) = mkv;
             }
             float* dst = taps + (((long long)b * 2 + spk) * geo.L + l) * ks;
 #pragma unroll
