@@ -12,7 +12,7 @@ def klass(name):
         return "recurrence"
     if "proj_f16" in name or "EpProjStats" in name:
         return "projection"
-    if "EpHeadConv" in name or "EpGate" in name or "EpMaskDecode" in name or name.startswith("decoder"):
+    if "HeadConv" in name or "Gate" in name or "MaskDecode" in name or name.startswith("decoder"):
         return "mask head + decoder"
     return "other"
 

@@ -185,22 +185,30 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
     return sc, sh
 
 
-def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None):
+def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None, gemm_mode=None):
     """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias,
-    'att' fusion as row_scale)."""
+    'att' fusion as row_scale).  gemm_mode: arithmetic of the product (3: f16 pieces like the Linears and the mask head, else the
+    fp32 MFMA); default GEMM_MODE's.  This call comes before dprnn_process selects the forward's mode, so it selects its own and
+    puts the library's back."""
     dev = wav.device
     w = _param(conv.weight, "conv.weight", dev)
     if w.shape[0] != F_BUILT or w.shape[1] < geo.N:
         raise DprnnError(f"1x1 conv weight {tuple(w.shape)} does not fit the {geo.N}->{F_BUILT} kernel")
     Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
-    if row_scale is not None:
-        st.call("dprnn_bottleneck_att_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
-                _p(_param(conv.bias, "conv.bias", dev)), _p(row_scale), _p(Y),
-                geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
-        return Y
-    st.call("dprnn_bottleneck_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
-            _p(_param(conv.bias, "conv.bias", dev)), _p(row_bias), _p(Y),
-            geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+    mode = GEMM_MODE if gemm_mode is None else gemm_mode
+    prev = st.lib.dprnn_get_gemm_mode()
+    st.lib.dprnn_set_gemm_mode(3 if mode == 3 else 0)
+    try:
+        if row_scale is not None:
+            st.call("dprnn_bottleneck_att_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
+                    _p(_param(conv.bias, "conv.bias", dev)), _p(row_scale), _p(Y),
+                    geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+        else:
+            st.call("dprnn_bottleneck_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
+                    _p(_param(conv.bias, "conv.bias", dev)), _p(row_bias), _p(Y),
+                    geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+    finally:
+        st.lib.dprnn_set_gemm_mode(prev)
     return Y
 
 

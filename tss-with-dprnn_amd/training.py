@@ -110,7 +110,8 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     fwd_mode = 3 if (TRAIN_GEMM_MODE == 3 and lstm_only) else 0
     fusion = fusion or {}
     sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], fusion.get("mul"), fusion.get("add"))
-    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"), fusion.get("row_scale"))
+    Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"), fusion.get("row_scale"),
+                                 gemm_mode=fwd_mode)
     Y_keep = Y if (keep and fusion.get("row_scale") is not None) else None        # 'att': the backward needs W a' = (Y - b) / rs
     X = [torch.empty(rows, F_BUILT, **f32)]
     Z, H, tapes = [], [], []

@@ -153,7 +153,7 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
     stats_a = torch.zeros(B, 2, device=dev, dtype=torch.float64)
     sc_a, sh_a = engine.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats_a)
-    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
+    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a, gemm_mode=training.TRAIN_GEMM_MODE).view(B * geo_a.L, F_BUILT)
     v0, tail0 = _spk_tail_forward(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
     spk0 = dict(aux=aux, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, tail=tail0, emb=v0)
     out, saved = training.forward_train(model, wav, keep=True, fusion=_fusion_for(st, model, wav, v0, geo), want_d0=ira)
