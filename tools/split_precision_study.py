@@ -62,10 +62,40 @@ def mm_f16(x, w, sx=16.0, sw=None, ftz=False):
     return out * np.float32(1.0 / (sx * sw))
 
 
+def fp8(x):
+    """round to fp8 e4m3 (4 significant bits, normals from 2^-6, subnormal step 2^-9, largest 448) -- the operand type of
+    v_mfma_f32_16x16x128_f8f6f4, which runs at twice the f16 rate"""
+    x = np.clip(x.astype(np.float32), -448, 448)
+    e = np.floor(np.log2(np.maximum(np.abs(x), 2.0 ** -6)))
+    q = (2.0 ** (e - 3)).astype(np.float32)
+    return (np.round(x / q) * q).astype(np.float32)
+
+
+def p2_scale(a, top):
+    m = float(np.abs(a).max())
+    return 2.0 ** (top - np.frexp(m)[1]) if m > 0 else 1.0
+
+
+def mm_f16_fp8(x, w, sx=16.0, sw=None):
+    """a possible next step, NOT built: the leading product x1 w1 on the f16 MFMA as in mm_f16, the two cross terms x1 w2 + x2 w1 with all
+    four operands rounded to fp8 e4m3 (each under its own power-of-two scale, largest value in [2^7, 2^8)) -- 32 instead of 48 matrix
+    cycles per 16 x 16 x 32 tile.  The cross terms are 2^-11 of the product and keep 4 bits: error ~2^-15 of the product."""
+    sw = w_scale(w) if sw is None else sw
+    x1, x2 = split2_f16(np.clip(x.astype(np.float32) * np.float32(sx), -65000, 65000))
+    w1, w2 = split2_f16(w.astype(np.float32) * np.float32(sw))
+    out = x1 @ w1.T
+    for a_, b_ in ((x1, w2), (x2, w1)):
+        sa, sb = p2_scale(a_, 8), p2_scale(b_, 8)
+        out += (fp8(a_ * np.float32(sa)) @ fp8(b_ * np.float32(sb)).T) * np.float32(1.0 / (sa * sb))
+    return out * np.float32(1.0 / (sx * sw))
+
+
 def mm_split(x, w, terms):
     """x [.., K] @ w[N, K]^T with bf16-split operands, products exact in fp32, fp32 accumulate (terms = "f16": f16 pieces)."""
     if terms == "f16":
         return mm_f16(x, w)
+    if terms == "f16+fp8":
+        return mm_f16_fp8(x, w)
     xs, ws = split3(x.astype(np.float32)), split3(w.astype(np.float32))
     pairs = [(0, 0), (0, 1), (1, 0)] if terms == 3 else [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)]
     out = np.zeros(x.shape[:-1] + (w.shape[0],), dtype=np.float32)
@@ -82,9 +112,10 @@ def run(terms, sd, cfg, mix):
         b = sd_[f"{prefix}.rnn.bias_ih_l0{suf}"] + sd_[f"{prefix}.rnn.bias_hh_l0{suf}"]
         Bn, T, _ = x.shape; H = whh.shape[1]
         h = np.zeros((Bn, H), np.float32); c = np.zeros((Bn, H), np.float32); out = np.zeros((Bn, T, H), np.float32)
-        if terms == "f16":                  # one scale per LSTM (both matrices), as the kernel's pack does
+        if terms in ("f16", "f16+fp8"):     # one scale per LSTM (both matrices), as the kernel's pack does
             sw = min(w_scale(wih), w_scale(whh))
-            mm = lambda a_, w_, _t: mm_f16(a_, w_, 16.0, sw)
+            f_ = mm_f16 if terms == "f16" else mm_f16_fp8
+            mm = lambda a_, w_, _t: f_(a_, w_, 16.0, sw)
         else:
             mm = mm_split
         gi = mm(x, wih, terms) + b
@@ -110,11 +141,11 @@ tgt, mix = make_sources(2, 4000, seed=5)
 ref64 = onp.tasnet_forward(sd, cfg, mix, np.float64)
 ref32 = onp.tasnet_forward(sd, cfg, mix, np.float32)
 print(f"fp32 oracle vs fp64 oracle         rel-L2 {rel(ref32, ref64):.2e}")
-for terms in (6, 3, "f16"):
+for terms in (6, 3, "f16", "f16+fp8"):
     out = run(terms, sd, cfg, mix)
     d = np.abs(si_sdr(out, tgt) - si_sdr(ref32, tgt)).max()
-    label = "f16 pieces, 3 products" if terms == "f16" else f"bf16 split, {terms} products"
-    print(f"{label:24s} vs fp64  rel-L2 {rel(out, ref64):.2e}   vs fp32 {rel(out, ref32):.2e}   |dSI-SDR| {d:.2e} dB")
+    label = {"f16": "f16 pieces, 3 products", "f16+fp8": "f16 x1 + fp8 cross (not built)"}.get(terms, f"bf16 split, {terms} products")
+    print(f"{label:30s} vs fp64  rel-L2 {rel(out, ref64):.2e}   vs fp32 {rel(out, ref32):.2e}   |dSI-SDR| {d:.2e} dB")
 
 print()
 print("one contraction [4096 x 256] x [256 x 512], error against float64 (rel-L2 / max abs):")
@@ -135,3 +166,4 @@ for name, X in cases:
     print(f"    f16 x3, no scaling                            {e(mm_f16(X, W, 1.0, 1.0))}")
     print(f"    f16 x3, kernel scaling (x 2^4, W 2^e)         {e(mm_f16(X, W))}")
     print(f"    f16 x3, kernel scaling, subnormals FLUSHED    {e(mm_f16(X, W, ftz=True))}")
+    print(f"    f16 x1 + fp8 cross terms (not built)          {e(mm_f16_fp8(X, W))}")
