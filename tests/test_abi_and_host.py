@@ -234,3 +234,49 @@ def test_forwards_hand_the_library_back_in_the_exact_mode():
     with pytest.raises(ValueError):
         boom(st)
     assert st.lib.mode == 0
+
+
+def test_bottleneck_selects_its_arithmetic_and_puts_the_library_mode_back():
+    """engine.bottleneck_frames runs before dprnn_process selects the forward's gate-GEMM mode: it launches under its own
+    (3 = f16 pieces, anything else = fp32 MFMA) and restores whatever the library was in, also when the launch fails."""
+    from tss_with_dprnn_amd import engine
+
+    seen = []
+
+    class FakeLib:
+        mode = 1
+        def dprnn_set_gemm_mode(self, m):
+            self.mode = m
+        def dprnn_get_gemm_mode(self):
+            return self.mode
+
+    class FakeStage:
+        lib = FakeLib()
+        fail = False
+        def call(self, name, *args):
+            seen.append((name, self.lib.mode))
+            if self.fail:
+                raise engine.DprnnError("launch failed")
+
+    st = FakeStage()
+    conv = torch.nn.Conv1d(64, 128, 1)
+    geo = engine.make_geometry(2, 400, 64, 50, 25, 2, 1)
+    wav, enc_w, sc = torch.zeros(2, 400), torch.zeros(64, 1, 2), torch.zeros(2, 64)
+    args = (st, wav, enc_w, sc, sc, conv, geo)
+    engine.bottleneck_frames(*args, gemm_mode=3)
+    assert seen[-1] == ("dprnn_bottleneck_fwd", 3) and st.lib.mode == 1
+    engine.bottleneck_frames(*args, gemm_mode=1)                       # the bf16 modes have no row-GEMM form: fp32 MFMA
+    assert seen[-1] == ("dprnn_bottleneck_fwd", 0) and st.lib.mode == 1
+    engine.bottleneck_frames(*args, row_scale=torch.zeros(2 * geo.L), gemm_mode=3)
+    assert seen[-1] == ("dprnn_bottleneck_att_fwd", 3) and st.lib.mode == 1
+    old = engine.GEMM_MODE
+    try:
+        engine.GEMM_MODE = 0
+        engine.bottleneck_frames(*args)                                # default: the engine's mode
+        assert seen[-1] == ("dprnn_bottleneck_fwd", 0)
+    finally:
+        engine.GEMM_MODE = old
+    st.fail = True
+    with pytest.raises(engine.DprnnError):
+        engine.bottleneck_frames(*args, gemm_mode=3)
+    assert st.lib.mode == 1
