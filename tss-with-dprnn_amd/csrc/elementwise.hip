@@ -53,17 +53,22 @@ __global__ void bottleneck_prep_kernel(const double* __restrict__ stats, const f
     sh[idx] = (beta[c] - g * (float)mean) * m + a;
 }
 
-// ---- X[b][s][k][:] = Y[b][s*P + k - K][:] or 0 (dprnn.py:189-201); one thread per float4
+// ---- X[b][s][k][:] = Y[b][s*P + k - K][:] or 0 (dprnn.py:189-201): a chunk is K consecutive frames of one utterance, so a workgroup
+// copies whole chunks (K x 512 B, contiguous on both sides, zero outside [0, L)) and nothing in the loop divides
 __global__ __launch_bounds__(256) void segment_kernel(const f32x4* __restrict__ Y, f32x4* __restrict__ X,
-                                                      long long total4, int L, int K, int P, int S) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const long long row = i >> 5; const int c4 = (int)(i & 31);
-        const int k = (int)(row % K); const long long bs = row / K;
-        const int s = (int)(bs % S); const long long b = bs / S;
-        const int l = s * P + k - K;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (l >= 0 && l < L) v = Y[(b * L + l) * 32 + c4];
-        X[i] = v;
+                                                      int nchunk, int L, int K, int P, int S) {
+    const int c4 = threadIdx.x & 31, kr = threadIdx.x >> 5;
+    for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const int b = ch / S, s = ch - b * S;
+        const int l0 = s * P - K;
+        const f32x4* src = Y + (long long)b * L * 32 + c4;
+        f32x4* dst = X + (long long)ch * K * 32 + c4;
+        for (int k = kr; k < K; k += 8) {
+            const int l = l0 + k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (l >= 0 && l < L) v = src[(long long)l * 32];
+            dst[(long long)k * 32] = v;
+        }
     }
 }
 
@@ -142,9 +147,11 @@ extern "C" int dprnn_bottleneck_prep(const double* stats, const float* gamma, co
 extern "C" int dprnn_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int S, void* stream) {
     if (!Y || !X) { dprnn_set_error("dprnn_segment_fwd: null pointer"); return -1; }
     if (K < 1 || P < 1 || S != (L + K) / P + 1) { dprnn_set_error("dprnn_segment_fwd: bad geometry L=%d K=%d P=%d S=%d", L, K, P, S); return -1; }
-    const long long total4 = (long long)B * S * K * 32;
-    hipLaunchKernelGGL(segment_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(Y), reinterpret_cast<f32x4*>(X), total4, L, K, P, S);
+    const long long nchunk = (long long)B * S;
+    if (B < 1 || nchunk > 0x7fffffffLL) { dprnn_set_error("dprnn_segment_fwd: B=%d S=%d out of range", B, S); return -1; }
+    const long long grid = nchunk < 16 * 256 ? nchunk : 16 * 256;
+    hipLaunchKernelGGL(segment_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(Y), reinterpret_cast<f32x4*>(X), (int)nchunk, L, K, P, S);
     return dprnn_check_launch("segment_kernel");
 }
 
