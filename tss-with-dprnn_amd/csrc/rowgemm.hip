@@ -54,7 +54,7 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
 // ------------------------------------------------------------------------------------------------------------------------
 // Linear 256|128 -> 128 + GroupNorm sums in f16 pieces (gate-GEMM mode 3): the one row GEMM that runs 24 times per forward,
 // written for the HBM stream it is bound by (1 KB in, 512 B out per row):
-//  * the MFMA operands are SWAPPED against rowgemm_f16_kernel -- weights as the A operand (16 output columns), 16 rows of H
+//  * the MFMA operands are SWAPPED against rowgemm_kernel -- weights as the A operand (16 output columns), 16 rows of H
 //    as the B operand -- so a lane ends up with FOUR ADJACENT output columns of ONE row: 16-byte stores (a wave's store
 //    instruction writes 1 KB instead of 256 B), and one row, hence one utterance, per lane in the GroupNorm sums;
 //  * the rows of the NEXT 32-row tile are requested while the current one is still in the MFMAs (the rotating slab buffers
@@ -265,9 +265,6 @@ int launch_proj_f16(const char* what, const float* W, const float* bias, const f
 }  // namespace
 
 // gate-GEMM mode 3 (f16 pieces) covers the Linear that follows the recurrence too: its rows are RNN outputs, |h| < 1
-#ifndef HEAD_F16_NW
-#define HEAD_F16_NW 8
-#endif
 #ifndef HEAD_MD_RT
 #define HEAD_MD_RT 2                    // mask + decoder on transposed tiles: 16-row tiles per wave, and lookahead across tiles
 #endif
@@ -412,12 +409,13 @@ static int head_mask_decode(const float* V, const float* Wend, const float* wav,
         dprnn_set_error("dprnn_head_mask_decode_fwd: unsupported N=%d ks=%d (built for input_size 64, ks<=8)", N, ks);
         return -1;
     }
+    if ((long long)B * L * 2 >= (1ll << 31)) { dprnn_set_error("dprnn_head_mask_decode_fwd: B*L*2 = %lld rows do not fit 31 bits", (long long)B * L * 2); return -1; }
     constexpr int RT = 4;
     PlainRows<RT> al{V, 128};
     const Geo geo{B, T, L, N, ks, stride};
     if (g_fast_head) {
         EpMaskDecode<RT, 4, true> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
-        if (dprnn_get_gemm_mode() == 3 && (long long)B * L * 2 < (1ll << 31)) {      // rows are tanh * sigmoid products, |v| < 1
+        if (dprnn_get_gemm_mode() == 3) {      // rows are tanh * sigmoid products, |v| < 1
             PlainRows<HEAD_MD_RT> alt{V, 128};
             if (ks <= 2) {                                   // the reference's configurations use kernel_size 2
                 EpTMaskDecode<HEAD_MD_RT, true, 2> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
@@ -426,8 +424,6 @@ static int head_mask_decode(const float* V, const float* Wend, const float* wav,
             EpTMaskDecode<HEAD_MD_RT, true, KSMAX> ept{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};
             return launch_rowgemm_f16t<128, 64, HEAD_MD_RT, false>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, alt, ept, (hipStream_t)stream);
         }
-        if (dprnn_get_gemm_mode() == 3 && !mask_all)
-            return launch_rowgemm_f16<128, 64, RT, HEAD_F16_NW, true>("head_mask_decode_f16", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
         return launch_rowgemm<128, 64, RT>("head_mask_decode", Wend, 128, 64, nullptr, 0, (long long)B * L * 2, al, ep, (hipStream_t)stream);
     }
     EpMaskDecode<RT, 4, false> ep{wav, enc_w, dec_w, taps, masked_out, relu_act, geo, mask_all};

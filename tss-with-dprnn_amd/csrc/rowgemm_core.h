@@ -193,7 +193,6 @@ template <int RT, int NCT>
 struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in double
     float* Z; const float* bias; double* stats; long long rows_per_b;
     const long long* starts; int n_utt;        // ragged batches: first row of every utterance ([n_utt + 1]); nullptr = uniform
-    float acc_scale = 1.f;                     // f16-pieces kernel: the accumulators carry the operands' power-of-two scales
     double d1, d2; long long cur_b;
     __device__ void begin() { d1 = 0.0; d2 = 0.0; cur_b = -1; }
     __device__ void flush(int lane) {
@@ -231,7 +230,7 @@ struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in
                     float* zr = Z + (row0 + 16 * rt + 4 * q + e) * (16 * NCT) + r;
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) {
-                        const float v = fmaf(acc[rt][ct][e], acc_scale, bv[ct]);       // scale 1: exactly acc + bias
+                        const float v = acc[rt][ct][e] + bv[ct];
                         zr[16 * ct] = v;
                         p1 += v; p2 = fmaf(v, v, p2);
                     }
@@ -254,7 +253,7 @@ struct EpProjStats {            // Z = acc + bias; per-utterance (sum, sumsq) in
                     if (row < M && row >= lo && row < hi) {
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) {
-                            const float v = fmaf(acc[rt][ct][e], acc_scale, bv[ct]);
+                            const float v = acc[rt][ct][e] + bv[ct];
                             Z[row * (16 * NCT) + 16 * ct + r] = v;
                             p1 += v; p2 = fmaf(v, v, p2);
                         }
@@ -452,8 +451,7 @@ void rowgemm_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float
 // The same persistent row GEMM with every fp32 operand written as TWO f16 pieces of a power-of-two multiple of itself
 // (recur_split.hip explains the arithmetic: 22+ operand bits, three products on v_mfma_f32_16x16x32_f16, the dropped term
 // ~2^-24 |a||w|): the fp32 form above is bound by the fp32 MFMA (2048 matrix cycles per 16x16x256 tile; this one 384), which
-// leaves the kernel to the HBM stream.  Used for the Linear after each recurrence in gate-GEMM mode 3, where the rows are RNN
-// outputs (|h| < 1; rows are scaled by 2^4 and clamped to +-4062 like the recurrence's activations).  The weight scale 2^e
+// leaves the kernel to the HBM stream.  Rows are scaled by 2^4 and clamped to +-4062 like the recurrence's activations.  The weight scale 2^e
 // (max|W| into [2^13, 2^14)) is found by every workgroup while it stages W, so there is no packed copy and no extra launch.
 // LDS: [slab KD/32][col tile][piece 2][lane] 16-byte B fragments (lane (c, q): column 16 ct + c, k = 32 s + 8 q .. + 7).
 typedef _Float16 rg_f16x8 __attribute__((ext_vector_type(8)));
@@ -476,118 +474,9 @@ __device__ __forceinline__ f32x4 mfma_f16p(rg_u32x4 a, rg_u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, a), __builtin_bit_cast(rg_f16x8, b), c, 0, 0, 0);
 }
 
-// AL: any of the A loaders above (two of their 16-byte loads make one lane's eight k values of a 32-wide slab: k = 32 s + 4 q + i
-// and 32 s + 16 + 4 q + i -- the MFMA does not care which k a slot holds as long as the B fragments agree, and this keeps
-// every loader's fp32 fragment addressing).  PRESCALE: multiply the accumulators by 1 / (S_x S_w) before the epilogue (epilogues
-// without an acc_scale member).
-template <int KD, int ND, int RT, class AL, class EP, int NW, bool PRESCALE>
-__global__ __launch_bounds__(64 * NW, 1)
-void rowgemm_f16_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
-                        long long M, AL al, EP ep) {
-    constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8;
-    extern __shared__ __attribute__((aligned(16))) rg_u32x4 wl16[];     // [NS][NCT][2][64]
-    __shared__ float red[NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-
-    // k values of slot (slab s, lane-quarter qq, element i < 8): 32 s + 4 qq + i (i < 4), 32 s + 16 + 4 qq + (i - 4)
-    auto wrow = [&](int col) { return col < nd0 ? W0 + (long long)col * ldw0 : W1 + (long long)(col - nd0) * ldw1; };
-    float m = 0.f;
-    for (int idx = tid; idx < ND * KD / 4; idx += 64 * NW) {
-        const int col = idx / (KD / 4), k4 = idx % (KD / 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow(col) + 4 * k4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NW; ++i) m = fmaxf(m, red[i]);
-    int ex = 0;
-    if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
-    ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
-    const float sw = ldexpf(1.f, 14 - ex);
-    for (int idx = tid; idx < ND * K8; idx += 64 * NW) {
-        const int col = idx / K8, k8 = idx % K8;
-        const int s = k8 >> 2, qq = k8 & 3;
-        const float* src = wrow(col) + 32 * s + 4 * qq;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] *= sw; hi[e] *= sw; }
-        rg_u32x4 w1, w2;
-        f16_pieces8(lo, hi, w1, w2);
-        const int ln = qq * 16 + (col & 15);
-        wl16[((s * NCT + (col >> 4)) * 2 + 0) * 64 + ln] = w1;
-        wl16[((s * NCT + (col >> 4)) * 2 + 1) * 64 + ln] = w2;
-    }
-    __syncthreads();
-    const float inv = 1.f / (F16P_XS * sw);
-    if constexpr (!PRESCALE) ep.acc_scale = inv;
-
-    constexpr int ROWS_IT = NW * RT * 16;
-    const long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
-    const long long per = (nchunk + gridDim.x - 1) / gridDim.x;
-    long long c0 = per * blockIdx.x, c1 = c0 + per;
-    if (c1 > nchunk) c1 = nchunk;
-    ep.begin();
-    for (long long ch = c0; ch < c1; ++ch) {
-        const long long row0 = ch * ROWS_IT + wave * RT * 16;
-        if (row0 >= M) break;
-        al.init(row0, r, q, M);
-        f32x4 acc[RT][NCT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int PF = NS >= 8 ? 3 : (NS >= 4 ? 2 : 1);     // k-slabs of rows in flight ahead of the MFMAs
-        f32x4 a[PF + 1][RT][2];
-#pragma unroll
-        for (int s = 0; s < PF; ++s)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int cb = s % (PF + 1);
-            if (s + PF < NS) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    a[(s + PF) % (PF + 1)][rt][0] = al.load(rt, 2 * (s + PF));
-                    a[(s + PF) % (PF + 1)][rt][1] = al.load(rt, 2 * (s + PF) + 1);
-                }
-            }
-            rg_u32x4 a1[RT], a2[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
-                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
-                }
-                f16_pieces8(lo, hi, a1[rt], a2[rt]);
-            }
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const rg_u32x4 b1 = wl16[((s * NCT + ct) * 2 + 0) * 64 + lane], b2 = wl16[((s * NCT + ct) * 2 + 1) * 64 + lane];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][ct] = mfma_f16p(a2[rt], b1, acc[rt][ct]);
-                    acc[rt][ct] = mfma_f16p(a1[rt], b2, acc[rt][ct]);
-                    acc[rt][ct] = mfma_f16p(a1[rt], b1, acc[rt][ct]);
-                }
-            }
-        }
-        if constexpr (PRESCALE) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = acc[rt][ct] * f32x4{inv, inv, inv, inv};
-        }
-        ep(acc, row0, r, q, lane, M);
-    }
-    ep.end(lane);
-}
+// A loaders and f16 slabs: two of a loader's 16-byte loads make one lane's eight k values of a 32-wide slab (k = 32 s + 4 q + i and
+// 32 s + 16 + 4 q + i) -- the MFMA does not care which k a slot holds as long as the weight fragments agree, and this keeps every
+// loader's fp32 fragment addressing.
 
 inline int num_cus() {
     static int g_num_cus = 0;
@@ -619,27 +508,8 @@ int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const f
 }
 
 
-template <int KD, int ND, int RT, int NW, bool PRESCALE, class AL, class EP>
-int launch_rowgemm_f16(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
-                       const AL& al, const EP& ep, hipStream_t st) {
-    const size_t lds = (size_t)KD * ND * 4;               // two f16 pieces per weight
-    auto kern = &rowgemm_f16_kernel<KD, ND, RT, AL, EP, NW, PRESCALE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
-        attr_set = true;
-    }
-    constexpr int ROWS_IT = NW * RT * 16;
-    long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
-    long long grid = nchunk < num_cus() ? nchunk : num_cus();
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep);
-    return dprnn_check_launch(what);
-}
-
 // ------------------------------------------------------------------------------------------------ f16 pieces, transposed tiles
-// rowgemm_f16_kernel with the MFMA operands swapped (weights as the A operand, 16 rows of the input as the B operand), as in
+// The f16-pieces row GEMM: MFMA operands swapped against rowgemm_kernel (weights as the A operand, 16 rows of the input as the B operand), as in
 // proj_f16_kernel (rowgemm.hip): acc[rt][ct][e] is row row0 + 16 rt + c, column 16 ct + 4 q + e (c = lane & 15, q = lane >> 4), so
 // an epilogue stores 16 bytes per lane and a wave's store instruction writes 1 KB instead of 256 B -- the 4-byte stores of the
 // plain layout, not HBM, bound the mask-head kernels (1.2-1.5 TB/s).  XC: the loader is cheap enough to keep a second copy
