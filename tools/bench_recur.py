@@ -36,6 +36,43 @@ def run(st, seq_tile, nwg, T, ndir=2, iters=3):
     return ms, flops / ms / 1e9
 
 
+def run_forward_shapes(st, B=32, S=194, K=250, iters=5):
+    """The forward's own launches alone on the chip: one 32-utterance group's intra-chunk (B S sequences of K steps) and inter-chunk
+    (B K sequences of S steps) recurrences, 64-sequence tiles, without and with the pending norm + residual folded into the x loads."""
+    rows = B * S * K
+    X = torch.randn(rows, 128, device="cuda") * 0.5
+    X2 = torch.empty_like(X)
+    Z = torch.randn(rows, 128, device="cuda")
+    H = torch.empty(rows, 256, device="cuda")
+    stats = torch.zeros(B, 2, device="cuda", dtype=torch.float64)
+    stats[:, 1] = S * K * 128
+    gamma, beta = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device="cuda")
+    bsum = torch.empty(2 * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    for name, addr, T, per in (("intra-chunk", (B * S, K, B * S, 0, K, 1), K, S), ("inter-chunk", (B * K, S, K, S * K, 1, K), S, K)):
+        for fuse in (0, 1):
+            if fuse:
+                args = (0, X.data_ptr(), Z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-8, per, S * K, X2.data_ptr(),
+                        packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, 2064)
+            else:
+                args = (0, X.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, 2064)
+            st.call("dprnn_rnn_fwd", *args)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                st.call("dprnn_rnn_fwd", *args)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            wgs = 2 * -(-addr[0] // 64)
+            print(f"{name} of {B} utterances ({addr[0]} sequences x {T} steps, {wgs} workgroups), pending norm {'folded in' if fuse else 'none'}: "
+                  f"{ms:.3f} ms = {ms / T * 1e3:.2f} us per step, {addr[0] * T * 2 * 2 * 256 * 512 / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+
 def run_train(st, nwg, T, ndir=2, iters=3):
     """dprnn_rnn_fwd_train (forward + gate tape) and dprnn_rnn_bwd (BPTT) on a grid of nwg 32-sequence workgroups."""
     lib = st.lib
@@ -207,6 +244,7 @@ def main():
     ap.add_argument("--stamps", type=int, default=0)
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3, 3 f16 pieces x3")
     ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
+    ap.add_argument("--forward-shapes", type=int, default=0, help="1: the forward's own launches of one 32-utterance group, alone on the chip")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
@@ -215,6 +253,9 @@ def main():
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
+    if a.forward_shapes:
+        run_forward_shapes(st)
+        return
     if a.stamps and a.gemm_mode in (1, 3):
         for seq_tile in (2064,):
             stamps_split(st, seq_tile, a.T)
