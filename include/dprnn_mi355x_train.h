@@ -40,7 +40,7 @@ int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, flo
 
 /* Arithmetic of the step GEMM of the LSTM backward (process-wide; pack and launch under the same setting): 0 = exact fp32 MFMA,
  * 3 = two f16 pieces / three products (train_recur_f16.hip: da scaled by a power of two taken from max|dH| of the launch, which
- * dprnn_rnn_bwd finds with one extra pass over dH; weights by a per-LSTM 2^e).  GRU / Elman cells always use the fp32 kernel.
+ * dprnn_rnn_bwd finds with one extra pass over dH unless dprnn_rnn_bwd_use_gradmax hands it over; weights by a per-LSTM 2^e).  GRU / Elman cells always use the fp32 kernel.
  * packedT must hold dprnn_rnn_pack_bwd_floats(ndir) floats in either mode (ndir * 131072 fragments + 128 of scales). */
 void dprnn_set_bwd_gemm_mode(int mode);
 int dprnn_get_bwd_gemm_mode(void);
@@ -54,6 +54,16 @@ void dprnn_dgrad_use_f16_pieces(const float* grad_max);
 /* max |x| over n floats (n % 4 == 0) into *out: the scale source for a P that no BPTT launch has measured (the Linears' dZ) */
 int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);
+/* The same maxima without the extra passes -- one-shot selectors like the two above, each consumed by the NEXT call of its entry point:
+ *   dprnn_gn_bwd_dz_store_absmax(slot)   dprnn_gn_bwd_dz also leaves max|dZ| in *slot (what dprnn_absmax(dZ) would write);
+ *   dprnn_dgrad_store_absmax(slot)       dprnn_dgrad also leaves max|dA| in *slot (in the epilogue of its f16 form; its fp32 forms run
+ *                                        dprnn_absmax on a dense dA afterwards);
+ *   dprnn_rnn_bwd_use_gradmax(slot)      dprnn_rnn_bwd in mode 3 takes max|dH| from *slot instead of passing over dH (the fp32 kernel
+ *                                        ignores it).
+ * slot: one device float, written / read on the stream of the call it applies to. */
+void dprnn_gn_bwd_dz_store_absmax(float* slot);
+void dprnn_dgrad_store_absmax(float* slot);
+void dprnn_rnn_bwd_use_gradmax(const float* slot);
 
 /* ---- the same three entry points for every rnn_type the reference accepts (getattr(nn, rnn_type), dprnn.py:23):
  * cell 0 = LSTM, 1 = GRU, 2 = RNN (tanh), packing as dprnn_rnn_pack.  dG per row and direction: LSTM [i,f,g,o] (512),

@@ -209,3 +209,60 @@ def test_mask_decode_backward_with_encoder_domain_gradient():
     want_dE = E.grad.permute(0, 3, 1, 2).reshape(B * L * 2, N).numpy()
     assert rel_l2(dE.cpu().numpy(), want_dE) < 2e-6
     assert rel_l2(dWd.cpu().numpy().reshape(N, ks), Wd.grad.numpy()[:, 0]) < 2e-6
+
+
+@pytest.mark.parametrize("kd,nd,f16", [(128, 256, True), (128, 256, False), (128, 128, False)])
+def test_dgrad_leaves_the_maximum_of_its_output(kd, nd, f16):
+    """dprnn_dgrad_store_absmax: the next dprnn_dgrad also writes max|dA| (epilogue of the f16 form, a pass after the fp32 forms);
+    the selector is consumed by that call only."""
+    rng = np.random.default_rng(7)
+    rows = 1256
+    dOut = (rng.standard_normal((rows, kd)) * 3e-4).astype(np.float32)
+    W0 = rng.standard_normal((kd, nd)).astype(np.float32)
+    st = _st()
+    dA = torch.full((rows, nd), float("nan"), device=DEV)
+    slot = torch.full((1,), 123.0, device=DEV)
+    d = _t(dOut)
+    if f16:
+        amax = torch.zeros(1, device=DEV)
+        st.call("dprnn_absmax", _p(d), rows * kd, _p(amax))
+        st.lib.dprnn_dgrad_use_f16_pieces(amax.data_ptr())
+    st.lib.dprnn_dgrad_store_absmax(slot.data_ptr())
+    st.call("dprnn_dgrad", _p(d), kd, _p(_t(W0)), nd, kd, 0, nd, _p(dA), nd, nd, rows)
+    torch.cuda.synchronize()
+    want = dOut.astype(np.float64) @ W0.astype(np.float64)
+    assert rel_l2(dA.cpu().numpy(), want) < 1e-6
+    assert float(slot) == float(dA.abs().max())
+    slot.fill_(123.0)
+    st.call("dprnn_dgrad", _p(d), kd, _p(_t(W0)), nd, kd, 0, nd, _p(dA), nd, nd, rows)     # selector already consumed
+    torch.cuda.synchronize()
+    assert float(slot) == 123.0
+
+
+def test_groupnorm_backward_leaves_the_maximum_of_dz():
+    """dprnn_gn_bwd_dz_store_absmax: same dZ as without it, and max|dZ| in the slot (what dprnn_absmax(dZ) gives)."""
+    rng = np.random.default_rng(3)
+    B, rpu = 3, 517
+    Z = _t(rng.standard_normal((B * rpu, 128)).astype(np.float32))
+    dY = _t((rng.standard_normal((B * rpu, 128)) * 1e-3).astype(np.float32))
+    gamma = _t(rng.uniform(0.5, 1.5, 128).astype(np.float32))
+    zz = Z.view(B, -1).double()
+    stats = torch.stack([zz.sum(1), (zz * zz).sum(1)], 1).contiguous()
+    red = _t(rng.standard_normal(2 * B)).double().contiguous()
+    st = _st()
+    outs = []
+    slot = torch.full((1,), 123.0, device=DEV)
+    for use in (False, True):
+        dZ = torch.full((B * rpu, 128), float("nan"), device=DEV)
+        if use:
+            st.lib.dprnn_gn_bwd_dz_store_absmax(slot.data_ptr())
+        st.call("dprnn_gn_bwd_dz", _p(dY), _p(Z), _p(stats), _p(red), _p(gamma), 1e-8, B, rpu, _p(dZ))
+        torch.cuda.synchronize()
+        outs.append(dZ)
+        if not use:
+            assert float(slot) == 123.0
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(1, device=DEV)
+    st.call("dprnn_absmax", _p(outs[1]), B * rpu * 128, _p(ref))
+    torch.cuda.synchronize()
+    assert float(slot) == float(ref) == float(outs[1].abs().max())

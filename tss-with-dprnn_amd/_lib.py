@@ -109,6 +109,9 @@ _VOID = {
     "dprnn_set_bwd_gemm_mode": [c_i],
     "dprnn_wgrad_use_f16_pieces": [c_fp],
     "dprnn_dgrad_use_f16_pieces": [c_fp],
+    "dprnn_gn_bwd_dz_store_absmax": [c_fp],
+    "dprnn_dgrad_store_absmax": [c_fp],
+    "dprnn_rnn_bwd_use_gradmax": [c_fp],
     "dprnn_debug_bwd_stamps": [c_fp],
 }
 _SPECIAL = {

@@ -519,6 +519,7 @@ struct EpTGate {                // V[row][col] = tanh(acc[col] + bo[col]) * sigm
     float* V; const float* bo; const float* bg;
     float* TG = nullptr;        // training forward: also keeps [tanh | sigmoid] as [row][256]
     __device__ void begin(int tid) {}
+    __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -548,6 +549,7 @@ template <int RT>
 struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 columns
     float* U; const float* bias; int L, K, P, S;
     __device__ void begin(int tid) {}
+    __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -570,17 +572,28 @@ struct EpTHeadConv {            // U[(b,l)][col] = acc + cnt(l)*bias[col], 256 c
 // WT: out = A @ W with W [KD][ldw] row-major (W0: k < nd0, W1: the rest) -- the data gradients; amax (may be null): device pointer
 // to max|A|, which replaces the fixed 2^4 activation scale by the power of two that puts it at 2^6 (gradients have no natural scale).
 template <int RT, int NCT>
-struct EpTStore {               // out[row*pitch + col] = acc
+struct EpTStore {               // out[row*pitch + col] = acc; amax_out (may be null): max |out| of the launch, as float bits (zeroed by the caller)
     float* out; int pitch;
+    unsigned* amax_out = nullptr;
+    float mx = 0.f;
     __device__ void begin(int tid) {}
+    __device__ void end(int lane) {
+        if (!amax_out) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
+    }
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const long long row = row0 + 16 * rt + c;
             if (row >= M) continue;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                *reinterpret_cast<f32x4*>(out + row * pitch + 16 * ct + 4 * q) = acc[rt][ct] * f32x4{inv, inv, inv, inv};
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x4 v = acc[rt][ct] * f32x4{inv, inv, inv, inv};
+                *reinterpret_cast<f32x4*>(out + row * pitch + 16 * ct + 4 * q) = v;
+                if (amax_out) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
         }
     }
 };
@@ -589,6 +602,7 @@ template <int RT, int NCT>
 struct EpTBiasStore {           // out[row][col] = acc*row_scale[row] + bias[col] (+ row_bias[row / rows_per_b][col]), 16 NCT columns
     float* out; const float* bias; const float* row_bias; long long rows_per_b; const float* row_scale;
     __device__ void begin(int tid) {}
+    __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -630,6 +644,7 @@ struct EpTMaskDecode {
             t[64 * KS + i] = j < geo.ks ? Wd[n * geo.ks + j] : 0.f;
         }
     }
+    __device__ void end(int lane) {}
     __device__ void operator()(f32x4 (&acc)[RT][4], long long row0, int c, int q, long long M, float inv) {
         const int ks = geo.ks;
 #pragma unroll
@@ -818,6 +833,7 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
                 for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
         }
     }
+    ep.end(lane);
 }
 
 template <int KD, int ND, int RT, bool XC, bool WT = false, class AL, class EPT>

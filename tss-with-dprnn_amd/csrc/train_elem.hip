@@ -90,9 +90,10 @@ void gn_bwd_stats_kernel(const float* __restrict__ dXn, const float* __restrict_
 __global__ __launch_bounds__(256)
 void gn_bwd_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Z, const double* __restrict__ stats,
                       const double* __restrict__ red, const float* __restrict__ gamma, float eps, long long rows_per_utt,
-                      long long rows, float* __restrict__ dZ) {
+                      long long rows, float* __restrict__ dZ, unsigned* __restrict__ amax) {
     const int c4 = threadIdx.x & 31;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+    float mx = 0.f;
     for (long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (long long)gridDim.x * 8) {
         const int b = (int)(row / rows_per_utt);
         const double cnt = (double)rows_per_utt * 128.0;
@@ -108,6 +109,12 @@ void gn_bwd_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
             o[e] = rs * (gm[e] * dy[e] - m1 - xh * m2);
         }
         *reinterpret_cast<f32x4*>(dZ + row * 128 + 4 * c4) = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if (amax) {                                          // max |dZ| of the launch as float bits (dprnn_gn_bwd_dz_store_absmax)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax, __float_as_uint(mx));
     }
 }
 
@@ -458,12 +465,23 @@ extern "C" int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const floa
     return dprnn_check_launch("gn_bwd_stats_kernel");
 }
 
+// One-shot selector: the NEXT dprnn_gn_bwd_dz call also leaves max|dZ| in *slot (device float) -- the scale source of the Linear's
+// f16-pieces gradients (dprnn_dgrad_use_f16_pieces, dprnn_wgrad_use_f16_pieces), measured while dZ is written instead of by dprnn_absmax.
+static float* g_gn_dz_absmax_out = nullptr;
+extern "C" void dprnn_gn_bwd_dz_store_absmax(float* slot) { g_gn_dz_absmax_out = slot; }
+
 extern "C" int dprnn_gn_bwd_dz(const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
                                float eps, int B, int64_t rows_per_utt, float* dZ, void* stream) {
+    float* const max_out = g_gn_dz_absmax_out;           // one-shot: consumed by this call whatever it returns
+    g_gn_dz_absmax_out = nullptr;
     if (!dY || !Z || !stats || !red || !gamma || !dZ || B < 1 || rows_per_utt < 1) { dprnn_set_error("dprnn_gn_bwd_dz: null pointer / sizes"); return -1; }
     const long long rows = (long long)B * rows_per_utt;
+    if (max_out) {
+        hipError_t e = hipMemsetAsync(max_out, 0, sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { dprnn_set_error("dprnn_gn_bwd_dz: %s", hipGetErrorString(e)); return -2; }
+    }
     hipLaunchKernelGGL(gn_bwd_dz_kernel, dim3(grid_for((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
-                       dY, Z, stats, red, gamma, eps, (long long)rows_per_utt, rows, dZ);
+                       dY, Z, stats, red, gamma, eps, (long long)rows_per_utt, rows, dZ, reinterpret_cast<unsigned*>(max_out));
     return dprnn_check_launch("gn_bwd_dz_kernel");
 }
 

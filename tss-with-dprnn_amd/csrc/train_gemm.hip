@@ -494,17 +494,34 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
 // with dOut scaled by the power of two that puts *grad_max (device pointer to max|dOut|, dprnn_absmax) at 2^6.
 static const float* g_dgrad_f16_amax = nullptr;
 extern "C" void dprnn_dgrad_use_f16_pieces(const float* grad_max) { g_dgrad_f16_amax = grad_max; }
+// One-shot as well: the NEXT dprnn_dgrad call also leaves max|dA| in *slot (device float) -- what dprnn_rnn_bwd's f16 form needs of
+// its dH (dprnn_rnn_bwd_use_gradmax), measured in the epilogue that writes dH instead of by a pass over it.  The f16 form does it
+// in its epilogue; the fp32 forms run dprnn_absmax afterwards (dA must then be dense: lda == nd).
+static float* g_dgrad_absmax_out = nullptr;
+extern "C" void dprnn_dgrad_store_absmax(float* slot) { g_dgrad_absmax_out = slot; }
+extern "C" int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 
 extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
                            float* dA, int lda, int nd, int64_t rows, void* stream) {
+    const float* const amax = g_dgrad_f16_amax;         // one-shot selectors: consumed by this call whatever it returns
+    g_dgrad_f16_amax = nullptr;
+    float* const max_out = g_dgrad_absmax_out;
+    g_dgrad_absmax_out = nullptr;
     if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1) || lda < nd) { dprnn_set_error("dprnn_dgrad: null pointer / rows / lda"); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    const float* const amax = g_dgrad_f16_amax;
-    g_dgrad_f16_amax = nullptr;
     if (amax && kd == 128 && nd == 256 && (lda % 4) == 0) {
+        if (max_out) {
+            hipError_t e = hipMemsetAsync(max_out, 0, sizeof(float), st);
+            if (e != hipSuccess) { dprnn_set_error("dprnn_dgrad: %s", hipGetErrorString(e)); return -2; }
+        }
         PlainRows<1> al{dOut, kd};
-        EpTStore<1, 16> ep{dA, lda};
+        EpTStore<1, 16> ep{dA, lda, reinterpret_cast<unsigned*>(max_out)};
         return launch_rowgemm_f16t<128, 256, 1, true, true>("dgrad128x256_f16", W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st, amax);
+    }
+    if (max_out) {
+        if (lda != nd) { dprnn_set_error("dprnn_dgrad: dprnn_dgrad_store_absmax needs a dense dA (lda == nd) outside the f16 form"); return -1; }
+        const int rc = dprnn_dgrad(dOut, kd, W0, ldw0, k0, W1, ldw1, dA, lda, nd, rows, stream);
+        return rc ? rc : dprnn_absmax(dA, rows * nd, max_out, stream);
     }
     // row tiles per wave: 4 x 16 rows while the accumulators fit (ND <= 128), 2 x 16 for the 256-wide outputs
 #define DG_CASE(KD, ND, RT)                                                                                          \

@@ -324,7 +324,11 @@ extern "C" int dprnn_get_bwd_gemm_mode(void) { return g_bwd_gemm_mode; }
 int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, float* packedT, hipStream_t st);
 int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packedT, float* dX, float* dG, long long rows_total,
                          int nseq, int T, int inner_n, long long outer_stride, long long inner_stride, long long t_stride, int ndir,
-                         bool fast, hipStream_t st);
+                         bool fast, const float* dhmax, hipStream_t st);
+// One-shot selector: the NEXT dprnn_rnn_bwd launch in mode 3 takes max|dH| from *slot (device float, e.g. written by the dprnn_dgrad
+// call that produced dH: dprnn_dgrad_store_absmax) instead of measuring it with a pass over dH.  Ignored by the fp32 kernel.
+static const float* g_bwd_dhmax = nullptr;
+extern "C" void dprnn_rnn_bwd_use_gradmax(const float* slot) { g_bwd_dhmax = slot; }
 
 extern "C" int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
                                   float* packedT, void* stream) {
@@ -375,6 +379,8 @@ extern "C" void dprnn_debug_bwd_stamps(unsigned long long* buf) { g_bwd_stamps =
 extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
                              int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                              int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    const float* const dhmax = g_bwd_dhmax;              // one-shot: consumed by this call whatever it returns
+    g_bwd_dhmax = nullptr;
     if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_rnn_bwd: null pointer"); return -1; }
     if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2) || rows_total < (int64_t)nseq * T) {
         dprnn_set_error("dprnn_rnn_bwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d rows_total=%lld", nseq, T, inner_n, ndir,
@@ -390,7 +396,7 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
     if (cell == 0 && g_bwd_gemm_mode == 3 && !g_bwd_stamps)
         return recur_bwd_f16_launch(dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, (long long)outer_stride,
                                     (long long)inner_stride, (long long)t_stride, ndir, dprnn_fast_activations_enabled() != 0,
-                                    (hipStream_t)stream);
+                                    dhmax, (hipStream_t)stream);
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride, g_bwd_stamps};
     if (g_bwd_stamps && cell == 0) {            // diagnostic twin: same kernel with cycle stamps of wave 0 per workgroup

@@ -343,10 +343,15 @@ int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r
 
 int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packedT, float* dX, float* dG, long long rows_total,
                          int nseq, int T, int inner_n, long long outer_stride, long long inner_stride, long long t_stride, int ndir,
-                         bool fast, hipStream_t st) {
+                         bool fast, const float* dhmax, hipStream_t st) {
     float* extra = const_cast<float*>(packedT) + (size_t)ndir * BWD_PACK_WORDS_PER_DIR;
     const long long n4 = rows_total * ndir * HD / 4;
-    hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra + EX_DHMAX);
+    if (dhmax) {                                         // measured by dH's producer (dprnn_rnn_bwd_use_gradmax): 4 bytes instead of a pass
+        hipError_t e = hipMemcpyAsync(extra + EX_DHMAX, dhmax, sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { dprnn_set_error("dprnn_rnn_bwd: %s", hipGetErrorString(e)); return -2; }
+    } else {
+        hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra + EX_DHMAX);
+    }
     Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, rows_total, nseq, T, inner_n, ndir,
                 outer_stride, inner_stride, t_stride};
     const size_t lds = (size_t)2 * 64 * 512 * 2 + 3 * 64 * 4;

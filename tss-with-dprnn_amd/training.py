@@ -303,6 +303,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     dZ = torch.empty(rows, F_BUILT, **f32)
     packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), **f32)
     zmax = torch.zeros(1, **f32)
+    hmax = torch.zeros(1, **f32)
     have_dx = False
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
     for p in range(npth - 1, -1, -1):
@@ -313,6 +314,9 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         a_red, a_dgb = scr.slot(f"red{p}", 2 * B), scr.slot(f"dgb{p}", 2 * F_BUILT)
         st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
                 _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
+        f16_lin = TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16      # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum,
+        if f16_lin:                                                 # which the kernel that writes dZ measures
+            lib.dprnn_gn_bwd_dz_store_absmax(zmax.data_ptr())
         st.call("dprnn_gn_bwd_dz", _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
         gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
         grads[f"{blk}_norm.{gname}"] = to_grad(a_dgb, gamma)
@@ -320,11 +324,12 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         # Linear (dprnn.py:88,96)
         hp = ndir * F_BUILT
         dH = torch.empty(rows, hp, **f32)
-        f16_lin = TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16      # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum
-        if f16_lin:
-            st.call("dprnn_absmax", _p(dZ), rows * F_BUILT, _p(zmax))
-            if ndir == 2:
-                lib.dprnn_dgrad_use_f16_pieces(zmax.data_ptr())
+        cell = engine.CELL_ID[rnn.rnn.mode]
+        bptt_f16 = TRAIN_BWD_GEMM_MODE == 3 and cell == 0
+        if f16_lin and ndir == 2:
+            lib.dprnn_dgrad_use_f16_pieces(zmax.data_ptr())
+        if bptt_f16:                                                # the f16 BPTT scales by max|dH|: measured where dH is written
+            lib.dprnn_dgrad_store_absmax(hmax.data_ptr())
         st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
@@ -336,12 +341,13 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
         # recurrence (dprnn.py:86,95)
         addr = _addr(geo, intra)
-        cell = engine.CELL_ID[rnn.rnn.mode]
         kg = F_BUILT if cell == 2 else 4 * F_BUILT          # gate-gradient columns per direction: LSTM i,f,g,o; GRU r,z,n_x,n_h; RNN a
         dG = torch.empty(rows, ndir * kg, **f32)
-        lib.dprnn_set_bwd_gemm_mode(3 if (TRAIN_BWD_GEMM_MODE == 3 and cell == 0) else 0)     # layout of the pack = kernel of the launch
+        lib.dprnn_set_bwd_gemm_mode(3 if bptt_f16 else 0)     # layout of the pack = kernel of the launch
         try:
             st.call("dprnn_rnn_pack_bwd", cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
+            if bptt_f16:
+                lib.dprnn_rnn_bwd_use_gradmax(hmax.data_ptr())
             st.call("dprnn_rnn_bwd", cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
         finally:
             lib.dprnn_set_bwd_gemm_mode(0)
