@@ -266,3 +266,46 @@ def test_groupnorm_backward_leaves_the_maximum_of_dz():
     st.call("dprnn_absmax", _p(outs[1]), B * rpu * 128, _p(ref))
     torch.cuda.synchronize()
     assert float(slot) == float(ref) == float(outs[1].abs().max())
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("ks,stride,T,relu", [(2, 1, 300, 0), (4, 2, 203, 1)])
+def test_training_forward_of_the_mask_head_keeps_what_the_backward_needs(ks, stride, T, relu, mode):
+    """dprnn_head_gate_fwd_train / dprnn_head_mask_decode_fwd_train in both arithmetics: the same V, taps and mask * enc as the
+    inference entry points, plus [tanh | sigmoid] and the mask themselves (float64 numpy as the reference)."""
+    rng = np.random.default_rng(T + mode)
+    B, N = 3, 64
+    L = (T - ks) // stride + 1
+    R = B * L * 2
+    U = rng.standard_normal((R, 128)).astype(np.float32)
+    Wo = (rng.standard_normal((128, 128)) / 11).astype(np.float32); bo = rng.standard_normal(128).astype(np.float32)
+    Wg = (rng.standard_normal((128, 128)) / 11).astype(np.float32); bg = rng.standard_normal(128).astype(np.float32)
+    Wend = (rng.standard_normal((N, 128)) / 11).astype(np.float32)
+    wav = (0.1 * rng.standard_normal((B, T))).astype(np.float32)
+    We = (rng.standard_normal((N, 1, ks)) / np.sqrt(ks)).astype(np.float32)
+    Wd = (rng.standard_normal((N, 1, ks)) / 8).astype(np.float32)
+    u = U.astype(np.float64)
+    ta, sg = np.tanh(u @ Wo.T + bo), 1 / (1 + np.exp(-(u @ Wg.T + bg)))
+    mk = (ta * sg) @ Wend.T.astype(np.float64)
+    mk = np.maximum(mk, 0) if relu else 1 / (1 + np.exp(-mk))
+    st = _st()
+    st.lib.dprnn_set_gemm_mode(mode)
+    try:
+        d = {k: _t(v) for k, v in dict(U=U, Wo=Wo, bo=bo, Wg=Wg, bg=bg, Wend=Wend, wav=wav, We=We, Wd=Wd).items()}
+        V0, V1 = torch.empty(R, 128, device=DEV), torch.empty(R, 128, device=DEV)
+        TG = torch.full((R, 256), float("nan"), device=DEV)
+        st.call("dprnn_head_gate_fwd", _p(d["U"]), _p(d["Wo"]), _p(d["bo"]), _p(d["Wg"]), _p(d["bg"]), _p(V0), R)
+        st.call("dprnn_head_gate_fwd_train", _p(d["U"]), _p(d["Wo"]), _p(d["bo"]), _p(d["Wg"]), _p(d["bg"]), _p(V1), _p(TG), R)
+        taps0, taps1 = torch.empty(B, 2, L, ks, device=DEV), torch.empty(B, 2, L, ks, device=DEV)
+        m0, m1 = torch.empty(B, L, N, device=DEV), torch.empty(B, L, N, device=DEV)
+        mask = torch.full((R, N), float("nan"), device=DEV)
+        st.call("dprnn_head_mask_decode_fwd", _p(V0), _p(d["Wend"]), _p(d["wav"]), _p(d["We"]), _p(d["Wd"]), _p(taps0), _p(m0), relu,
+                B, T, L, N, ks, stride)
+        st.call("dprnn_head_mask_decode_fwd_train", _p(V1), _p(d["Wend"]), _p(d["wav"]), _p(d["We"]), _p(d["Wd"]), _p(taps1), _p(mask),
+                _p(m1), relu, B, T, L, N, ks, stride)
+        torch.cuda.synchronize()
+    finally:
+        st.lib.dprnn_set_gemm_mode(0)
+    assert torch.equal(V0, V1) and torch.equal(taps0, taps1) and torch.equal(m0, m1)
+    assert rel_l2(TG.cpu().numpy(), np.concatenate([ta, sg], 1)) < 2e-6
+    assert rel_l2(mask.cpu().numpy(), mk) < 2e-6

@@ -173,15 +173,19 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     mask = torch.empty(R, geo.N, **f32)
     taps = torch.empty(B, 2, L, geo.ks, **f32)
     d0 = torch.empty(B * L, geo.N, **f32) if want_d0 else None            # mask_0 * enc (DPRNN-Spe-IRA)
-    st.call("dprnn_head_conv_ola_fwd", _p(X[npth]), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
-            _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
-            _p(U), B, L, K, P, S)
-    st.call("dprnn_head_gate_fwd_train", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
-            _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
-            _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), _p(TG), R)
-    st.call("dprnn_head_mask_decode_fwd_train", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
-            _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(mask), _p(d0), 1 if cfg["activation_type"] == "relu" else 0,
-            B, geo.T, L, geo.N, geo.ks, geo.stride)
+    lib.dprnn_set_gemm_mode(fwd_mode)       # the mask head in the forward's arithmetic too (the same kernels as inference)
+    try:
+        st.call("dprnn_head_conv_ola_fwd", _p(X[npth]), _p(_param(sep.prelu.weight, "prelu.weight", dev)),
+                _p(_param(sep.conv2d.weight, "conv2d.weight", dev)), _p(_param(sep.conv2d.bias, "conv2d.bias", dev)),
+                _p(U), B, L, K, P, S)
+        st.call("dprnn_head_gate_fwd_train", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
+                _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
+                _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), _p(TG), R)
+        st.call("dprnn_head_mask_decode_fwd_train", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
+                _p(wav), _p(enc_w), _p(dec_w), _p(taps), _p(mask), _p(d0), 1 if cfg["activation_type"] == "relu" else 0,
+                B, geo.T, L, geo.N, geo.ks, geo.stride)
+    finally:
+        lib.dprnn_set_gemm_mode(0)
     out = engine.decode(st, taps, geo, 2)
     if not keep:
         return out, None
