@@ -200,14 +200,31 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     dist_info = dict(world_size=1, backend=None, devices=[torch.cuda.get_device_name(dev)])
-    if world > 1:
+    # under torch.distributed.run the process group is formed for ONE rank too: the driver's launch form then exercises the same
+    # RCCL init / barrier / max-over-ranks calls at every N
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        import ctypes
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
-        else:
-            dist.init_process_group(backend=backend)
-        names = [None] * world
-        dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}")
+        # RCCL prints a version banner on the C stdout when its first communicator comes up; stdout carries ONE JSON line, so the
+        # file descriptor points at stderr while the group forms
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+            else:
+                dist.init_process_group(backend=backend)
+            names = [None] * world
+            dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}")
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), devices=names)
 
     import tss_with_dprnn_amd as pkg
@@ -239,7 +256,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -248,11 +265,11 @@ def main():
     lstm_flop_per_step = geo.rows * 2 * (2 * 256 * 512) * 2 * cfg["n_repeats"]      # rows * 2 dirs * (2*256*512) per path
 
     if args.mode == "train":
-        line = bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, make_sources)
+        line = bench_train(args, model, dev, world, rank, dist if world > 1 else None, sync, lstm_flop_per_step, make_sources)
         if rank == 0:
             line["distributed"] = dist_info
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -271,7 +288,12 @@ def main():
         elapsed = time.perf_counter() - t0
         prof, engine.PROFILE = engine.PROFILE, None
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
-    elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
+    if use_dist and world == 1:         # one rank under torch.distributed.run: the same collective the N > 1 runs use
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+    else:
+        elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
 
     kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get("dprnn_rnn_fwd", []), t_ref)
     n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
@@ -371,7 +393,7 @@ def main():
             line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, model, dev)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
