@@ -17,6 +17,7 @@ no data-path collective (weak scaling: 64 utterances per GPU).  Rank 0 prints ON
   distributed  : what torch.distributed actually saw (world size, backend, one device name per rank).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -38,8 +39,8 @@ CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_siz
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd = the headline forward (configs[1]); train = fwd + PIT SI-SDR loss + bwd + gradient all-reduce "
                          "+ clip + Adam (configs[3], 64 utterances per GPU)")
@@ -279,6 +280,8 @@ def main():
             out = model(x)
         sync()
         engine.PROFILE = {"names": {"dprnn_rnn_fwd"}, "events": {}}
+        gc.collect()
+        gc.disable()                    # the host enqueues ~300 launches per step: no collector pauses inside the timed region
         t_ref = torch.cuda.Event(enable_timing=True)
         t_ref.record()
         t0 = time.perf_counter()
@@ -286,6 +289,7 @@ def main():
             out = model(x)
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         prof, engine.PROFILE = engine.PROFILE, None
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
     if use_dist and world == 1:         # one rank under torch.distributed.run: the same collective the N > 1 runs use
