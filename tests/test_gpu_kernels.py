@@ -387,9 +387,9 @@ def test_proj_stats_ragged(kdim, mode):
         assert abs(got[u, 1] - (zu ** 2).sum()) <= 1e-6 * (zu ** 2).sum()
 
 
-@pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (8, 8, 40), (250, 125, 700)])
-def test_segment_matches_unfold(K, P, L):
-    B = 2
+@pytest.mark.parametrize("K,P,L,B", [(10, 5, 101, 2), (16, 5, 77, 2), (8, 8, 40, 2), (250, 125, 700, 2), (7, 3, 5, 3), (3, 2, 50, 1),
+                                     (10, 5, 2000, 11)])       # the last one: more chunks than workgroups (grid-stride loop)
+def test_segment_matches_unfold(K, P, L, B):
     Y = np.random.default_rng(K).standard_normal((B, L, 128)).astype(np.float32)
     S = onp.n_chunks(L, K, P)
     want = onp.segmentation(Y.transpose(0, 2, 1), K, P).transpose(0, 3, 2, 1)      # [B,S,K,F]
@@ -399,7 +399,7 @@ def test_segment_matches_unfold(K, P, L):
     assert np.array_equal(X.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("mode", [0, 3])        # 3: the f16-pieces row GEMM takes over the mask head (rowgemm_f16_kernel)
+@pytest.mark.parametrize("mode", [0, 3])        # 3: the f16-pieces row GEMM takes over the mask head (rowgemm_f16t_kernel)
 @pytest.mark.parametrize("K,P,L", [(10, 5, 101), (16, 5, 77), (250, 125, 700)])
 def test_head_conv_ola_matches_oracle(K, P, L, mode):
     B = 2
