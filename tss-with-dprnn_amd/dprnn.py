@@ -168,7 +168,7 @@ class DPRNNTasNet(nn.Module):
     def forward(self, input, debug=None):
         # As in torch, what decides whether activations are kept for a backward is grad mode, not model.training: eval() without
         # torch.no_grad() keeps the tape (about 4 GB per 3-s utterance) -- evaluate under no_grad / inference_mode, as the
-        # reference's inferencer does (src/inferencers/inferencer.py:48).
+        # reference's inferencer does (src/inferencers/inferencer.py:53).
         if debug is None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training          # differentiable forward: autograd.Function over the HIP kernels
             return training.tasnet_forward_autograd(self, input)
