@@ -8,10 +8,10 @@
 // dW and a contiguous range of rows; chunks of 16 rows of P (256 columns) and Q (128 columns) go HBM -> registers ->
 // LDS (double-buffered, one barrier per chunk) and every wave multiplies its 64 x 64 sub-block out of LDS with
 // v_mfma_f32_16x16x4_f32: a lane's 16-byte LDS read of four consecutive columns feeds four different 16x16 tiles (tile j
-// owns columns 4c + j), so one ds_read_b128 of P and one of Q feed 16 MFMAs.  Row ranges are split over blockIdx.z;
+// owns columns 4c + j), so one ds_read_b128 of P and one of Q feed 16 MFMAs.  Row ranges are split over the grid (wgrad_block: XCD-aware order);
 // the partial blocks are written to a workspace and summed by wgrad_reduce_kernel in a fixed order, so the result
 // does not depend on scheduling (no floating-point atomics).  The column sums of P (bias gradients) ride along in the
-// staging registers of the workgroups with blockIdx.y == 0.
+// staging registers of the workgroups with nb == 0.
 #include "rowgemm_core.h"
 using namespace rg;
 
@@ -32,7 +32,22 @@ struct WgradArgs {
     float* part;                           // [splits][Mpad][Npad]
     float* part_b;                         // [splits][Mpad] or null
     int Mpad, Npad;
+    int mblocks, nblocks, splits;          // grid: mblocks * nblocks * (splits rounded up to 8) workgroups in one dimension
 };
+
+// XCD-aware block order.  The (mb, nb) blocks of one row range read the same rows of P (the same mb) or of Q (the same nb); workgroups go to
+// the 8 XCDs round-robin by linear id, so with (mb, nb) fastest the siblings of a row range sat on different XCDs, behind different L2s, and
+// every row came from HBM once per sibling (PMC: 7.4 GB per launch against 3.9 GB of P and Q).  Here workgroup id = 8 j + xcd takes sibling
+// j % nblk of row range (j / nblk) * 8 + xcd: the siblings share an XCD and leave the dispatcher back to back.
+__device__ __forceinline__ bool wgrad_block(const WgradArgs& a, int& mb, int& nb, int& ks) {
+    const int nblk = a.mblocks * a.nblocks;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int sib = j % nblk;
+    ks = (j / nblk) * 8 + xcd;
+    mb = sib % a.mblocks;
+    nb = sib / a.mblocks;
+    return ks < a.splits;
+}
 
 __global__ __launch_bounds__(WG_THREADS)
 void wgrad_kernel(WgradArgs a) {
@@ -41,7 +56,8 @@ void wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int mb = blockIdx.x, nb = blockIdx.y, ks = blockIdx.z;
+    int mb, nb, ks;
+    if (!wgrad_block(a, mb, nb, ks)) return;        // padding of the last group of 8 row ranges (uniform per workgroup)
     const QDesc qd = a.q[nb];
     const long long r0 = (long long)ks * a.rows_per_split;
     long long r1 = r0 + a.rows_per_split;
@@ -182,7 +198,8 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax) {
     extern __shared__ __attribute__((aligned(16))) char wimg[];           // [buf 2][P piece 0 | P piece 1 | Q piece 0 | Q piece 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int mb = blockIdx.x, nb = blockIdx.y, ks = blockIdx.z;
+    int mb, nb, ks;
+    if (!wgrad_block(a, mb, nb, ks)) return;        // padding of the last group of 8 row ranges (uniform per workgroup)
     const QDesc qd = a.q[nb];
     const long long r0 = (long long)ks * a.rows_per_split;
     long long r1 = r0 + a.rows_per_split;
@@ -459,6 +476,8 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     int mblocks, nblocks; long long splits, per;
     wgrad_plan(M, N, rows, mblocks, nblocks, splits, per);
     a.Mpad = mblocks * WG_MB; a.Npad = nblocks * WG_NB;
+    a.mblocks = mblocks; a.nblocks = nblocks; a.splits = (int)splits;
+    const unsigned grid = (unsigned)(mblocks * nblocks * ((splits + 7) / 8 * 8));
     a.rows_per_split = per;
     a.part = workspace;
     a.part_b = (db0 || db1) ? workspace + splits * (long long)a.Mpad * a.Npad : nullptr;
@@ -472,10 +491,10 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
             if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(wgrad_f16): %s", hipGetErrorString(e)); return -2; }
             attr_set = true;
         }
-        hipLaunchKernelGGL(wgrad_f16_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, pmax);
+        hipLaunchKernelGGL(wgrad_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, pmax);
         rc = dprnn_check_launch("wgrad_f16_kernel");
     } else {
-        hipLaunchKernelGGL(wgrad_kernel, dim3(mblocks, nblocks, (unsigned)splits), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
         rc = dprnn_check_launch("wgrad_kernel");
     }
     if (rc) return rc;
