@@ -25,9 +25,12 @@
 extern "C" {
 #endif
 
+#define DPRNN_ABI_VERSION   2   /* dprnn_abi_version(): 2 since dprnn_adam_multi takes its betas as double and the *_ex,
+                                 * saturation and pack-format entry points exist; hosts compare it when they load the library */
 #define DPRNN_OK            0
 #define DPRNN_EINVAL       -1   /* unsupported size / null pointer */
 #define DPRNN_ELAUNCH      -2   /* HIP launch error */
+#define DPRNN_EFORMAT      -3   /* packed weights of another mode / cell / layout than the launch reads (or never packed) */
 
 #define DPRNN_F   128           /* feature_size the kernels are built for (config_bss.yaml:19) */
 #define DPRNN_HD  128           /* hidden_size  (config_bss.yaml:20) */
@@ -40,18 +43,40 @@ int dprnn_num_cus(void);
  * 2e-7 rel-L2 against the reference output end to end, tests/test_gpu_parity.py), 0 = libm expf/tanhf */
 void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
 void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
-/* OPTIONAL arithmetic mode of the LSTM gate GEMM (process-wide, read by dprnn_rnn_pack / dprnn_lstm_pack and by the
- * recurrence entry points, so set it before packing): 0 = exact fp32 operands on the fp32 MFMA (default, what every
- * parity claim and the bench headline refer to); 1 = operands split into three bf16 pieces, the six cross products of
- * order <= 2^-16 on the bf16 MFMA with fp32 accumulation (product error ~2^-24: end-to-end deviation identical to the
- * fp32 path's own rounding noise); 2 = two bf16 pieces / three products (product error ~2^-16); 3 = two f16 pieces of
- * power-of-two-scaled operands (activations x 2^4, weights x a per-LSTM 2^e), three products on the f16 MFMA: 22+ operand
- * bits, product error ~2^-24 like mode 1 at half its MFMA work (eight-wave kernels, seq_tile 2032 .. 2096 and the ragged
- * entry; |x| is clamped to 4062 in the piece conversion) -- recur_split.hip.  The mode is a property of the PACKED weights
- * as much as of the launch: pack and launch under the same mode, and hand the library back in mode 0 (the Python host's
- * forwards do: engine._leaves_exact_mode). */
+/* Arithmetic mode of the contractions (gate GEMM of the LSTM recurrence; in mode 3 also the Linear after it, the bottleneck and
+ * the mask head):
+ *   0 = exact fp32 operands on the fp32 MFMA: bit-for-bit an fma chain (the library's own default; what GRU / Elman cells
+ *       always run);
+ *   1 = operands split into three bf16 pieces, the six cross products of order <= 2^-16 on the bf16 MFMA with fp32 accumulation
+ *       (product error ~2^-24, fp32's exponent range: NO assumption about magnitudes) -- the fallback when mode 3 saturates;
+ *   3 = two f16 pieces of power-of-two-scaled operands (activations x 2^4, weights x a per-matrix 2^e), three products on the
+ *       f16 MFMA: 22+ operand bits, product error ~2^-24 at half the MFMA work of mode 1 (eight-wave kernels, seq_tile 2016 ..
+ *       2096 and the ragged entry).  Values with |2^4 x| > 65000 do not fit f16: the conversion clamps them AND raises a
+ *       saturation flag (below) -- a host must check the flags and re-run in mode 1 or 0, as the Python host does
+ *       (engine.py: the default mode of its forwards, what the bench headline is measured in).
+ *   (Mode 2, two bf16 pieces / three products at ~2^-16, existed in ABI 1 and is gone.)
+ * The mode is a property of the PACKED weights as much as of the launch.  dprnn_set_gemm_mode sets the calling THREAD's default,
+ * read by the entry points without an explicit mode (dprnn_rnn_pack, dprnn_rnn_fwd, ..., and the row GEMMs, whose operands are
+ * the plain torch parameters); the *_ex forms take the mode as an argument.  Either way every pack call records the format it
+ * wrote with the buffer's device address and every recurrence launch checks it: a mismatch returns DPRNN_EFORMAT. */
 void dprnn_set_gemm_mode(int mode);
 int dprnn_get_gemm_mode(void);
+/* forget the recorded format of a packed buffer (NULL: of all) -- for hosts that recycle device memory outside the library */
+void dprnn_pack_forget(const void* packed);
+
+/* ---- saturation flags of the f16-pieces arithmetic (mode 3, and the f16 forms of the backward).  A thread registers a
+ * device buffer of DPRNN_SAT_SLOTS int32 (zeroed by the call, on `stream`); every f16-pieces kernel launched by that thread
+ * afterwards ORs 1 into slot s when a value it converted exceeded the f16 range (Inf / NaN inputs included):
+ *   0 recurrence input rows, 1 rows of the Linear after a recurrence, 2 rows of the other row GEMMs (bottleneck, mask head,
+ *   data gradients), 3 gate gradients of the BPTT, 4 operands of the weight-gradient GEMM.
+ * dprnn_saturation_flags copies them to `host_out` (DPRNN_SAT_SLOTS int32 of host memory) after synchronising `stream`, and
+ * returns 1 if any is set, 0 if none, < 0 on error.  flags == NULL unregisters (detection off; the clamp stays).  The Python host
+ * brackets every forward / backward with the pair and re-runs a saturated call in mode 1 (forward) / the exact fp32 kernels
+ * (backward): clamped results are never returned. */
+#define DPRNN_SAT_SLOTS 8
+int dprnn_saturation_begin(void* flags, void* stream);
+int dprnn_saturation_flags(void* host_out, void* stream);
+
 /* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order; the f16 form uses
  * two planes and keeps its scale 2^e, and 1 / (2^4 2^e), in words 512 and 513 of the third) */
 int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
@@ -66,7 +91,7 @@ int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih,
  * `parts` is not NULL -- the size of each buffer the entry points below take, indexed by DPRNN_WS_*.  The host allocates
  * them (tss-with-dprnn_amd/engine.py does with torch.empty; an utterance group on its own stream is one such set for its
  * share of B) and passes the pointers; the library itself never allocates.  split_gemm != 0 sizes the packed weights for
- * dprnn_set_gemm_mode(1|2).  DPRNN-Spe / IRA add B*(La+L)*128 floats of speaker-encoder rows at most. */
+ * dprnn_set_gemm_mode(1|3).  DPRNN-Spe / IRA add B*(La+L)*128 floats of speaker-encoder rows at most. */
 enum {
     DPRNN_WS_Y = 0,      /* frames      [B][L][F]                 (dprnn_bottleneck_fwd -> dprnn_segment_fwd) */
     DPRNN_WS_X,          /* slab        [B][S][K][F]              residual stream */
@@ -141,8 +166,8 @@ int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
  * inter path (dprnn.py:94-95): nseq=B*K, T=S, inner_n=K, outer_stride=S*K, inner_stride=1, t_stride=K
  * seq_tile: sequences per workgroup (16, 32, 48 or 64; 0 = choose).  16 runs on eight waves of 16 hidden units each
  * (the small-batch latency form); -16 selects the four-wave form of the same tile (for A/B measurements).  In the split
- * gate-GEMM modes the codes are: 32 (modes 1 / 2: two 32-sequence workgroups per CU), 2000 + n (the eight-wave kernel with n
- * sequences per workgroup, one per CU: n = 64, 80, 96 in modes 1 / 2; 16, 32, 48, 64, 80, 96 in mode 3 -- 16 keeps the first weight pieces in registers, the form for a few
+ * gate-GEMM modes the codes are: 32 (mode 1: two 32-sequence workgroups per CU), 2000 + n (the eight-wave kernel with n
+ * sequences per workgroup, one per CU: n = 64, 80, 96 in mode 1; 16, 32, 48, 64, 80, 96 in mode 3 -- 16 keeps the first weight pieces in registers, the form for a few
  * utterances); anything else is refused. */
 int dprnn_bilstm_fwd(const float* X, const float* packed, const float* bsum, float* H,
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
@@ -171,6 +196,16 @@ int dprnn_rnn_fwd(int cell, const float* X, const float* Z, const double* stats,
                   const float* packed, const float* bsum, float* H,
                   int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                   int64_t t_stride, int ndir, int seq_tile, void* stream);
+/* the same with the gate-GEMM mode (0, 1 or 3) as an argument instead of the thread's default: what a host that runs several
+ * models / threads should call (the Python host does) */
+int dprnn_rnn_pack_ex(int gemm_mode, int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                      float* packed, float* bsum, void* stream);
+int dprnn_rnn_fwd_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                     const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                     const float* packed, const float* bsum, float* H,
+                     int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                     int64_t t_stride, int ndir, int seq_tile, void* stream);
 
 /* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
  * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; used by tools/bench_recur.py only. */
@@ -207,7 +242,7 @@ int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* s
  * test utterances one at a time, src/inferencers/inferencer.py:54-58, inferencer_spe.py:27-32, because zero-padding would
  * change the per-utterance GroupNorm statistics).  The slab is the concatenation of the utterances' [S_u][K][F] slabs; per
  * utterance tables replace the uniform (B, S) arithmetic:
- *   dprnn_rnn_fwd_ragged: SingleRNN.forward (dprnn.py:33-37) for one path, bf16-split gate GEMM (dprnn_set_gemm_mode 1|2), LSTM.
+ *   dprnn_rnn_fwd_ragged: SingleRNN.forward (dprnn.py:33-37) for one path, split gate GEMM (gemm mode 1 or 3), LSTM.
  *     intra-chunk: wg_desc NULL, n_items = total chunks, T = K, seq_utt[chunk] = its utterance;
  *     inter-chunk: wg_desc[n_items][8] = {row0 lo, row0 hi, T = S_u, sequences <= 64, u, 0, 0, 0} per 64-sequence workgroup
  *       (tiles never straddle utterances), seq_utt NULL.
@@ -217,6 +252,10 @@ int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* s
 int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
                          float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
                          float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir, void* stream);
+int dprnn_rnn_fwd_ragged_ex(int gemm_mode, const float* X, const float* Z, const double* stats, const float* gamma,
+                            const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                            int n_items, float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
+                            void* stream);
 int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
                                 int64_t M, const int64_t* utt_starts, int n_utt, int kdim, void* stream);
 

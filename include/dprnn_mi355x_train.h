@@ -38,7 +38,8 @@ int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, flo
                    int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                    int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
 
-/* Arithmetic of the step GEMM of the LSTM backward (process-wide; pack and launch under the same setting): 0 = exact fp32 MFMA,
+/* Arithmetic of the step GEMM of the LSTM backward (the calling thread's default for dprnn_rnn_pack_bwd / dprnn_rnn_bwd; their _ex forms
+ * take it as an argument; the pack records the layout with the buffer and the launch checks it, DPRNN_EFORMAT): 0 = exact fp32 MFMA,
  * 3 = two f16 pieces / three products (train_recur_f16.hip: da scaled by a power of two taken from max|dH| of the launch, which
  * dprnn_rnn_bwd finds with one extra pass over dH unless dprnn_rnn_bwd_use_gradmax hands it over; weights by a per-LSTM 2^e).  GRU / Elman cells always use the fp32 kernel.
  * packedT must hold dprnn_rnn_pack_bwd_floats(ndir) floats in either mode (ndir * 131072 fragments + 128 of scales). */
@@ -54,7 +55,8 @@ void dprnn_dgrad_use_f16_pieces(const float* grad_max);
 /* max |x| over n floats (n % 4 == 0) into *out: the scale source for a P that no BPTT launch has measured (the Linears' dZ) */
 int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);
-/* The same maxima without the extra passes -- one-shot selectors like the two above, each consumed by the NEXT call of its entry point:
+/* The same maxima without the extra passes -- one-shot selectors like the two above (per THREAD: they apply to the next call the
+ * same host thread makes; the *_ex forms of the entry points take them as arguments instead), each consumed by the NEXT call of its entry point:
  *   dprnn_gn_bwd_dz_store_absmax(slot)   dprnn_gn_bwd_dz also leaves max|dZ| in *slot (what dprnn_absmax(dZ) would write);
  *   dprnn_dgrad_store_absmax(slot)       dprnn_dgrad also leaves max|dA| in *slot (in the epilogue of its f16 form; its fp32 forms run
  *                                        dprnn_absmax on a dense dA afterwards);
@@ -80,6 +82,18 @@ int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const flo
 int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
                   int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                   int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
+/* the same with every selector as an argument (no per-thread state involved): gemm modes as in dprnn_mi355x.h / above;
+ * dh_absmax = device float holding max|dH| (NULL: dprnn_rnn_bwd measures it with a pass over dH; mode 3 only) */
+int dprnn_rnn_fwd_train_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                           const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                           const float* packed, const float* bsum, float* H, float* tape,
+                           int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                           int64_t t_stride, int ndir, void* stream);
+int dprnn_rnn_pack_bwd_ex(int bwd_gemm_mode, int cell, const float* w_ih, const float* w_hh, const float* w_ih_r,
+                          const float* w_hh_r, float* packedT, void* stream);
+int dprnn_rnn_bwd_ex(int bwd_gemm_mode, const float* dh_absmax, int cell, const float* dH, const float* tape,
+                     const float* packedT, float* dX, float* dG, int64_t rows_total, int nseq, int T, int inner_n,
+                     int64_t outer_stride, int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
 
 /* diagnostic: while a device buffer of [workgroups][8] u64 is registered (NULL clears it), dprnn_rnn_bwd with the LSTM
  * cell runs its stamped twin and wave 0 of every workgroup writes: cycles of the whole step loop, then the cycles spent
@@ -99,6 +113,11 @@ int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n
                 const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
                 float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
                 float* workspace, void* stream);
+/* f16_grad_max != NULL: in f16 pieces, P scaled from *f16_grad_max (what dprnn_wgrad_use_f16_pieces selects for the next call) */
+int dprnn_wgrad_ex(const float* f16_grad_max, const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
+                   const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
+                   float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
+                   float* workspace, void* stream);
 
 /* ---- data gradient of a Linear / 1x1 conv: dA[row*lda + 0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1 (kd-k0 rows)]
  * row-major torch weights [kd][ldw] read transposed; (kd, nd) in {(128,256), (128,128), (64,128), (256,128), (128,64)}:
@@ -107,6 +126,9 @@ int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n
  * the column, lda = 256). */
 int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
                 float* dA, int lda, int nd, int64_t rows, void* stream);
+/* f16_grad_max / absmax_out as arguments (dprnn_dgrad_use_f16_pieces / dprnn_dgrad_store_absmax select them for the next call) */
+int dprnn_dgrad_ex(const float* f16_grad_max, float* absmax_out, const float* dOut, int kd, const float* W0, int ldw0, int k0,
+                   const float* W1, int ldw1, float* dA, int lda, int nd, int64_t rows, void* stream);
 
 /* ---- training variants of the mask-head forward (dprnn_mi355x.h) that keep what the backward needs:
  * TG [rows][256] = [tanh(out conv) | sigmoid(gate conv)] (dprnn.py:157-158), mask [B*L*2][N] rows (b,l,spk) (:161-164);
@@ -153,6 +175,9 @@ int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const float* dXb, flo
                        double* red, double* dgb, void* stream);
 int dprnn_gn_bwd_dz(const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
                     float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
+/* absmax_out as an argument (dprnn_gn_bwd_dz_store_absmax selects it for the next call) */
+int dprnn_gn_bwd_dz_ex(float* absmax_out, const float* dY, const float* Z, const double* stats, const double* red,
+                       const float* gamma, float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
 
 /* ---- DPRNN._segmentation backward (dprnn.py:189-201): dY[(b,l)] = sum over chunks covering l of (dXn + dXa + dXb) */
 int dprnn_segment_bwd(const float* dXn, const float* dXa, const float* dXb, float* dY,

@@ -59,7 +59,7 @@ def test_binding_table_has_one_argtype_per_header_parameter():
 
 def test_library_loads_and_reports_abi(lib_path):
     lib = pkg.load_library()
-    assert lib.dprnn_abi_version() == 1
+    assert lib.dprnn_abi_version() == 2
     assert lib.dprnn_last_error() is not None
 
 

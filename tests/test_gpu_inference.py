@@ -148,6 +148,32 @@ def test_ragged_batch_equals_one_by_one(kind, split_gate_gemm):
                 assert torch.allclose(v, bn_ragged[k], rtol=1e-5, atol=1e-7), k
 
 
+@pytest.mark.parametrize("hop", [40, 30, 27])
+def test_ragged_batch_with_hops_above_half_a_chunk(hop, split_gate_gemm):
+    """hop_length > chunk_length / 2 (the reference's hop_length is a free constructor argument, dprnn.py:128): an utterance's
+    slab then has fewer than 2 L rows, so its mask-head scratch (U [L][2F] + V [2L][F]) no longer fits the share of H its S K rows
+    own -- every utterance gets max(S K 2F, 4 L F) floats at its own offset.  Ten utterances whose heads run concurrently on the
+    side streams, against the one-by-one loop."""
+    from tss_with_dprnn_amd import inference
+    from conftest import build_model
+    from oracle.weights import make_mixture
+    model, _, cfg = build_model("bss", dict(chunk_length=40, hop_length=hop, n_repeats=2), 83, DEV)
+    lens = [901, 377, 640, 233, 901, 512, 777, 300, 845, 1203]
+    for n in lens:      # the point of the test: the slab is smaller than the head's scratch
+        L = n - 1
+        S = (L + 40) // hop + 1
+        assert S * 40 < 2 * L or n < 400
+    wavs = [torch.from_numpy(make_mixture(1, n, seed=700 + i)[0]).to(DEV) for i, n in enumerate(lens)]
+    got = inference.separate_many(model, wavs, ragged=True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i, w in enumerate(wavs):
+            want = model(w[None])[0]
+            assert got[i].shape == want.shape == (2, lens[i])
+            r = float(((got[i].double() - want.double()).norm() / want.double().norm()).item())
+            assert r <= 2e-6, (hop, i, r)
+
+
 def test_ragged_full_config_against_cpu_oracle(split_gate_gemm):
     """Shipped depth / chunk geometry (6 blocks, K 250 / P 125), four lengths between 1.2 and 3.6 s in one ragged batch,
     against the torch-CPU oracle of each utterance."""

@@ -107,6 +107,72 @@ def test_lstm_backward_matches_autograd(path, B, S, K):
         assert max(e1, e2, e3, e4) < 1e-5
 
 
+def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
+    """The f16-pieces BPTT multiplies da by 2^(6 - e), e = exponent of max|dH| (handed over by dH's producer); a gate gradient more
+    than 2^10 above that does not fit f16: the conversion clamps AND raises saturation flag 3 (the weight-gradient GEMM under the
+    same scale: flag 4).  With the true maximum nothing is flagged and dX matches autograd; with a maximum 2^13 too small (what an
+    exploding recurrence amounts to) the flags are up -- training.backward then repeats the step in the exact kernels.  Also: the
+    backward pack carries its format like the forward's (DPRNN_EFORMAT on a mismatch)."""
+    import ctypes
+    B, S, K = 2, 9, 23
+    rng = np.random.default_rng(11)
+    lstm = _cpu_lstm(7)
+    X = torch.from_numpy(rng.standard_normal((B, S, K, 128)).astype(np.float32))
+    dH = torch.from_numpy(rng.standard_normal((B, S, K, 256)).astype(np.float32))
+    Xr = X.clone().requires_grad_(True)
+    out = lstm(Xr.reshape(B * S, K, 128))[0].reshape(B, S, K, 256)
+    out.backward(dH)
+    st = _st()
+    lib = st.lib
+    w = [_t(getattr(lstm, n).detach()) for n in NAMES] + [_t(getattr(lstm, n + "_reverse").detach()) for n in NAMES]
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), device=DEV)
+    rows = B * S * K
+    addr = (B * S, K, B * S, 0, K, 1)
+    tape = torch.empty(lib.dprnn_lstm_tape_floats(addr[0], addr[1], 2), device=DEV)
+    Xd, dHd = _t(X), _t(dH)
+    H = torch.empty(rows, 256, device=DEV)
+    dXd = torch.empty(2, rows, 128, device=DEV)
+    dG = torch.empty(rows, 1024, device=DEV)
+    st.call("dprnn_rnn_pack_ex", 0, 0, *[_p(t) for t in w], _p(packed), _p(bsum))
+    st.call("dprnn_rnn_fwd_train_ex", 0, 0, _p(Xd), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), _p(tape), *addr, 2)
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(512, 256, rows), device=DEV)
+    dW = torch.empty(512, 256, device=DEV)
+
+    def run(hmax_value):
+        hmax = torch.full((1,), hmax_value, device=DEV)
+        flags = torch.empty(8, dtype=torch.int32, device=DEV)
+        host = (ctypes.c_int32 * 8)()
+        assert lib.dprnn_saturation_begin(flags.data_ptr(), st.stream) == 0
+        try:
+            st.call("dprnn_rnn_pack_bwd_ex", 3, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
+            st.call("dprnn_rnn_bwd_ex", 3, _p(hmax), 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2)
+            st.call("dprnn_wgrad_ex", packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2), dG.data_ptr(), 1024, 512,
+                    _p(Xd), 128, 128, 0, H.data_ptr(), 256, 128, 1, rows, 1, K, _p(dW), 256, 1, 0, 0, 0, _p(ws))
+            rc = lib.dprnn_saturation_flags(ctypes.addressof(host), st.stream)
+        finally:
+            lib.dprnn_saturation_begin(0, 0)
+        return rc, list(host)
+    true_max = float(dH.abs().max())
+    rc, flags = run(true_max)
+    assert rc == 0 and not any(flags), flags
+    dX = (dXd[0] + dXd[1]).cpu().numpy().reshape(B, S, K, 128)
+    assert rel_l2(dX, Xr.grad.numpy()) < 5e-6
+    g = np.concatenate([lstm.weight_ih_l0.grad.numpy(), lstm.weight_hh_l0.grad.numpy()], axis=1)
+    assert rel_l2(dW.cpu().numpy(), g) < 1e-5
+    rc, flags = run(true_max / 8192.0)
+    assert rc == 1 and flags[3] == 1 and flags[4] == 1 and not any(flags[:3]), flags
+    # pack / launch mismatch in either direction, and a forward pack handed to the backward
+    st.call("dprnn_rnn_pack_bwd_ex", 0, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
+    assert lib.dprnn_rnn_bwd_ex(3, 0, 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2, st.stream) == -3
+    assert b"pack and launch under the same mode" in lib.dprnn_last_error()
+    st.call("dprnn_rnn_pack_bwd_ex", 3, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
+    assert lib.dprnn_rnn_bwd_ex(0, 0, 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2, st.stream) == -3
+    assert lib.dprnn_rnn_bwd_ex(0, 0, 0, _p(dHd), _p(tape), _p(packed), _p(dXd), _p(dG), rows, *addr, 2, st.stream) == -3
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rows", [1256, 198, 22, 1])
 @pytest.mark.parametrize("kd,nd", [(128, 256), (128, 128), (64, 128), (256, 128), (128, 64)])
 def test_dgrad_matches_matmul(kd, nd, rows):

@@ -37,12 +37,18 @@ SIGNATURES = {
     "dprnn_rnn_pack": [c_i] + [c_fp] * 10 + [c_fp],
     "dprnn_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
                       c_i64, c_i, c_i, c_fp],
+    "dprnn_rnn_pack_ex": [c_i, c_i] + [c_fp] * 10 + [c_fp],
+    "dprnn_rnn_fwd_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
+                         c_i64, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
     "dprnn_lstm_pack_f16": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],
     "dprnn_proj_stats_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i, c_fp],
     "dprnn_proj_stats_ragged_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_i, c_i, c_fp],
     "dprnn_rnn_fwd_ragged": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_rnn_fwd_ragged_ex": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "dprnn_saturation_begin": [c_fp, c_fp],
+    "dprnn_saturation_flags": [c_fp, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_head_conv_ola_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -64,6 +70,14 @@ SIGNATURES = {
     "dprnn_rnn_fwd_train": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
                             c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_rnn_pack_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_rnn_fwd_train_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i,
+                               c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_rnn_pack_bwd_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_rnn_bwd_ex": [c_i, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_wgrad_ex": [c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
+                       c_fp, c_fp, c_i, c_fp, c_fp],
+    "dprnn_dgrad_ex": [c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i64, c_fp],
+    "dprnn_gn_bwd_dz_ex": [c_fp] * 6 + [c_f, c_i, c_i64, c_fp, c_fp],
     "dprnn_absmax": [c_fp, c_i64, c_fp, c_fp],
     "dprnn_rnn_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
@@ -113,6 +127,7 @@ _VOID = {
     "dprnn_dgrad_store_absmax": [c_fp],
     "dprnn_rnn_bwd_use_gradmax": [c_fp],
     "dprnn_debug_bwd_stamps": [c_fp],
+    "dprnn_pack_forget": [c_fp],
 }
 _SPECIAL = {
     "dprnn_last_error": ([], ctypes.c_char_p),
@@ -128,6 +143,10 @@ _SPECIAL = {
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
+ABI_VERSION = 2             # DPRNN_ABI_VERSION of include/dprnn_mi355x.h this binding is written against
+SAT_SLOTS = 8               # DPRNN_SAT_SLOTS
+SAT_NAMES = ("recurrence input rows", "rows of the Linear after a recurrence", "rows of a row GEMM (bottleneck / mask head / data gradient)",
+             "BPTT gate gradients", "weight-gradient operands", "", "", "")
 
 
 class DprnnError(RuntimeError):
@@ -175,6 +194,14 @@ def load_library() -> ctypes.CDLL:
             lib = ctypes.CDLL(path)
         except OSError as e:
             raise DprnnError(f"cannot load {path}: {e}") from e
+        try:
+            lib.dprnn_abi_version.restype = c_i
+            have = int(lib.dprnn_abi_version())
+        except AttributeError as e:
+            raise DprnnError(f"{path} does not export dprnn_abi_version: not a libdprnn_mi355x build") from e
+        if have != ABI_VERSION:
+            raise DprnnError(f"{path} has ABI version {have}, this host code is written against {ABI_VERSION}: rebuild the library "
+                             f"(`make -C {os.path.join(_HERE, 'csrc')}`) or point DPRNN_LIB at a matching build")
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args

@@ -3,6 +3,8 @@
 #include "dprnn_mi355x.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
 
@@ -23,7 +25,76 @@ int dprnn_check_launch(const char* what) {
 }
 
 extern "C" const char* dprnn_last_error(void) { return g_err; }
-extern "C" int dprnn_abi_version(void) { return 1; }
+extern "C" int dprnn_abi_version(void) { return DPRNN_ABI_VERSION; }
+
+// ---- saturation flags: the calling thread's device buffer (common.h: sat_track / sat_commit)
+static thread_local int* g_sat_flags = nullptr;
+int* dprnn_sat_ptr() { return g_sat_flags; }
+
+extern "C" int dprnn_saturation_begin(void* flags, void* stream) {
+    g_sat_flags = static_cast<int*>(flags);
+    if (!flags) return 0;
+    hipError_t e = hipMemsetAsync(flags, 0, DPRNN_SAT_SLOTS * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) { dprnn_set_error("dprnn_saturation_begin: %s", hipGetErrorString(e)); g_sat_flags = nullptr; return -2; }
+    return 0;
+}
+
+extern "C" int dprnn_saturation_flags(void* host_out, void* stream) {
+    if (!host_out) { dprnn_set_error("dprnn_saturation_flags: null pointer"); return -1; }
+    int* out = static_cast<int*>(host_out);
+    for (int i = 0; i < DPRNN_SAT_SLOTS; ++i) out[i] = 0;
+    if (!g_sat_flags) return 0;
+    hipError_t e = hipMemcpyAsync(out, g_sat_flags, DPRNN_SAT_SLOTS * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { dprnn_set_error("dprnn_saturation_flags: %s", hipGetErrorString(e)); return -2; }
+    int any = 0;
+    for (int i = 0; i < DPRNN_SAT_SLOTS; ++i) any |= out[i] != 0;
+    return any;
+}
+
+// ---- packed-weight formats, keyed by device address (common.h)
+static std::mutex g_pack_mu;
+static std::unordered_map<const void*, unsigned> g_pack_fmt;
+static unsigned pack_word(int kind, int cell, int mode, int ndir) {
+    return ((unsigned)DPRNN_ABI_VERSION << 24) | ((unsigned)kind << 16) | ((unsigned)cell << 12) | ((unsigned)mode << 8) | (unsigned)ndir;
+}
+static const char* pack_mode_name(int kind, int mode) {
+    if (kind == DPRNN_PACK_BWD) return mode == 3 ? "bwd mode 3 (f16 pieces)" : "bwd mode 0 (fp32 fragments)";
+    switch (mode) {
+        case 0: return "mode 0 (fp32 fragments)";
+        case 1: return "mode 1 (bf16 pieces)";
+        case 3: return "mode 3 (f16 pieces)";
+        default: return "an unknown mode";
+    }
+}
+void dprnn_pack_note(const void* packed, int kind, int cell, int mode, int ndir) {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    g_pack_fmt[packed] = pack_word(kind, cell, mode, ndir);
+}
+int dprnn_pack_expect(const void* packed, int kind, int cell, int mode, int ndir, const char* what) {
+    unsigned have = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pack_mu);
+        auto it = g_pack_fmt.find(packed);
+        if (it != g_pack_fmt.end()) have = it->second;
+    }
+    if (!have) {
+        dprnn_set_error("%s: the weight buffer at %p was not filled by a dprnn_*_pack* call of this library", what, packed);
+        return DPRNN_EFORMAT;
+    }
+    const int h_kind = (have >> 16) & 0xff, h_cell = (have >> 12) & 0xf, h_mode = (have >> 8) & 0xf, h_ndir = have & 0xff;
+    if ((have >> 24) != (unsigned)DPRNN_ABI_VERSION || h_kind != kind || h_cell != cell || h_mode != mode || h_ndir < ndir) {
+        dprnn_set_error("%s: packed weights at %p hold %s of cell %d, %d direction(s), %s; this launch reads cell %d, %d direction(s), %s "
+                        "-- pack and launch under the same mode", what, packed, h_kind == DPRNN_PACK_BWD ? "the backward layout" : "the forward layout",
+                        h_cell, h_ndir, pack_mode_name(h_kind, h_mode), cell, ndir, pack_mode_name(kind, mode));
+        return DPRNN_EFORMAT;
+    }
+    return 0;
+}
+extern "C" void dprnn_pack_forget(const void* packed) {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    if (packed) g_pack_fmt.erase(packed); else g_pack_fmt.clear();
+}
 
 // ---- buffer sizes of one forward (what a C host must allocate; tss-with-dprnn_amd/engine.py sizes its arenas with it)
 extern "C" int64_t dprnn_workspace_bytes(int B, int T, int N, int K, int P, int ks, int stride, int n_blocks,

@@ -99,3 +99,39 @@ __device__ __forceinline__ float wave_sum(float v) {
 // host-side error plumbing (api.hip)
 void dprnn_set_error(const char* fmt, ...);
 int dprnn_check_launch(const char* what);
+
+// ---- saturation flags (api.hip: dprnn_saturation_begin / dprnn_saturation_flags).  The f16-pieces kernels multiply their fp32
+// operands by a power of two and convert to f16; a value beyond the f16 range would be clamped.  Every such site tracks the
+// largest |scaled value| it converts (as float bits: Inf and NaN patterns order above every finite value) and, at kernel end,
+// raises flag `slot` of the calling thread's registered device buffer when the limit was crossed -- one ballot per wave, one
+// atomic per wave that saw it.  The host checks the flags once per forward / backward and re-runs in a range-free arithmetic.
+enum { DPRNN_SAT_RECUR_X = 0, DPRNN_SAT_PROJ_ROWS = 1, DPRNN_SAT_GEMM_ROWS = 2, DPRNN_SAT_BPTT_DA = 3, DPRNN_SAT_WGRAD = 4,
+       DPRNN_SAT_SLOTS = 8 };
+int* dprnn_sat_ptr();        // device int32[DPRNN_SAT_SLOTS] registered by the calling thread, or nullptr (detection off)
+__device__ __forceinline__ void sat_track(unsigned& m, float a, float b) {
+    const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu;
+    m = ua > m ? ua : m;
+    m = ub > m ? ub : m;
+}
+__device__ __forceinline__ void sat_track(unsigned& m, const f32x4& v) { sat_track(m, v[0], v[1]); sat_track(m, v[2], v[3]); }
+__device__ __forceinline__ void sat_commit(int* flags, int slot, unsigned m, float limit) {
+    if (!flags) return;
+    const bool over = m > __float_as_uint(limit);
+    if (__builtin_amdgcn_ballot_w64(over) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + slot, 1);
+}
+
+// ---- packed-weight formats (api.hip).  The recurrence kernels read weights in a layout that depends on the cell and on the
+// arithmetic mode the pack call ran under; every pack entry point records the format of the buffer it filled (keyed by the
+// device address) and every launcher checks it: a mismatch is an error (rc DPRNN_EFORMAT), never numbers.
+enum { DPRNN_PACK_FWD = 1, DPRNN_PACK_BWD = 2 };
+void dprnn_pack_note(const void* packed, int kind, int cell, int mode, int ndir);
+int dprnn_pack_expect(const void* packed, int kind, int cell, int mode, int ndir, const char* what);   // 0 or -3
+
+// hipFuncSetAttribute is per device: launchers keep one bit per device ordinal
+#include <atomic>
+inline bool dprnn_attr_needed(std::atomic<unsigned long long>& mask, int* dev_out) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    *dev_out = dev;
+    return !(mask.load(std::memory_order_relaxed) & (1ull << (dev & 63)));
+}
+inline void dprnn_attr_done(std::atomic<unsigned long long>& mask, int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_relaxed); }

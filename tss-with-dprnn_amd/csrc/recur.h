@@ -34,6 +34,7 @@ struct RecurArgs {
                                                       // its sequences are rows row0 + j * inner_stride, it runs T steps (inter-chunk path)
     const int* seq_utt;                               // utterance of every sequence (intra-chunk path; wg_desc == nullptr)
     const long long* utt_rows;                        // rows of every utterance (count of its pending norm); nullptr: rows_per_utt
+    int* sat;                                         // f16-pieces kernels: saturation flags of the calling thread (common.h), may be null
 };
 
 // The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's
@@ -48,9 +49,9 @@ inline bool tile_offsets_fit(int inner_n, long long outer_stride, long long inne
     return span_rows * pitch_floats * 4 < 0x7fffffffLL;
 }
 
-// split gate GEMMs (recur_split.hip): products = 6 or 3 (bf16 pieces), 2 = two f16 pieces / three products
-int launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st);
-int launch_split8_bf16(const RecurArgs& a, int products, int nsr, bool stag, bool fast, hipStream_t st);   // recur_split8_bf16.hip
-int launch_split8_f16(const RecurArgs& a, int nsr, bool stag, bool fast, hipStream_t st);                  // recur_split8_f16.hip
+// split gate GEMMs (recur_split.hip): gemm_mode 1 = three bf16 pieces / six products, 3 = two f16 pieces / three products
+int launch_bilstm_split(const RecurArgs& a, int gemm_mode, int seq_tile, bool fast, hipStream_t st);
+int launch_split8_bf16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                            // recur_split8_bf16.hip
+int launch_split8_f16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                             // recur_split8_f16.hip
 int launch_split8_f16_train(const RecurArgs& a, bool fast, hipStream_t st);                                // ... with the gate tape (a.tape)
 }  // namespace recur

@@ -488,12 +488,13 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
     // between the MFMAs (measured +6 % at NT = 4); with two co-resident workgroups (NT <= 2) the plain loop is as fast
     constexpr int SCHED = (NT >= 3 && CELL == 0) ? 1 : 0;
     const size_t lds = (size_t)2 * NS * XS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm): %s", hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
     hipLaunchKernelGGL((bilstm_kernel<NT, FAST, false, 0, SCHED, CELL, SAVE, NW>), grid, dim3(64 * NW), lds, st, a);
@@ -502,31 +503,47 @@ int launch_bilstm(const RecurArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// 0 exact fp32 MFMA (default); bf16-split: 1 = 6 products, 2 = 3 products (recur_split.hip)
-static int g_gemm_mode = 0;
-static int split_products() { return g_gemm_mode == 1 ? 6 : g_gemm_mode == 2 ? 3 : 2; }   // 2 = the f16 form's code (three products of two f16 pieces)
-extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = (mode >= 1 && mode <= 3) ? mode : 0; }
+// Arithmetic of the LSTM gate GEMM: 0 exact fp32 MFMA, 1 = three bf16 pieces / six products, 3 = two f16 pieces / three products
+// (recur_split.h).  The *_ex entry points take it as an argument; the plain ones read this per-THREAD default (two host threads
+// driving two models never see each other's setting).  Whatever selects it, the format a pack call wrote is recorded with the
+// buffer (dprnn_pack_note) and checked by every launch that reads it.
+static thread_local int g_gemm_mode = 0;
+static bool mode_ok(int m) { return m == 0 || m == 1 || m == 3; }
+extern "C" void dprnn_set_gemm_mode(int mode) { g_gemm_mode = mode_ok(mode) ? mode : 0; }
 extern "C" int dprnn_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" int dprnn_lstm_pack_split(const float*, const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, void*, float*, void*);
 extern "C" int dprnn_lstm_pack_f16(const float*, const float*, const float*, const float*, const float*, const float*,
                                    const float*, const float*, void*, float*, void*);
 
-extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                              const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
-                              float* packed, float* bsum, void* stream) {
+static int rnn_pack(int mode, int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                    const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                    float* packed, float* bsum, void* stream) {
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_rnn_pack: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (cell == 0 && g_gemm_mode == 3)       // f16 form: two f16 piece planes of 2^e * W
+    if (!mode_ok(mode)) { dprnn_set_error("dprnn_rnn_pack: gemm mode must be 0, 1 or 3 (got %d)", mode); return -1; }
+    if (cell == 0 && mode == 3)              // f16 form: two f16 piece planes of 2^e * W
         return dprnn_lstm_pack_f16(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
-    if (cell == 0 && g_gemm_mode != 0)       // bf16 split modes: bf16 piece planes instead of fp32 fragments
+    if (cell == 0 && mode == 1)              // three bf16 piece planes instead of fp32 fragments
         return dprnn_lstm_pack_split(w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_rnn_pack: incomplete reverse direction"); return -1; }
     const int n = ndir * PACK_PER_DIR;
     hipLaunchKernelGGL(rnn_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, ndir, cell);
+    dprnn_pack_note(packed, DPRNN_PACK_FWD, cell, 0, ndir);
     return dprnn_check_launch("rnn_pack_kernel");
+}
+
+extern "C" int dprnn_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                              const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                              float* packed, float* bsum, void* stream) {
+    return rnn_pack(g_gemm_mode, cell, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
+}
+extern "C" int dprnn_rnn_pack_ex(int gemm_mode, int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                 const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                                 float* packed, float* bsum, void* stream) {
+    return rnn_pack(gemm_mode, cell, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, packed, bsum, stream);
 }
 
 extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
@@ -539,12 +556,15 @@ static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
 int dprnn_fast_activations_enabled(void) { return g_fast_act; }      // train_recur.hip
 
-static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
+static int bilstm_dispatch(RecurArgs a, int mode, int seq_tile, hipStream_t st) {
     if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_bilstm_fwd: null pointer"); return -1; }
     if (a.nseq <= 0 || a.T <= 0 || a.inner_n <= 0 || (a.ndir != 1 && a.ndir != 2)) {
         dprnn_set_error("dprnn_bilstm_fwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d", a.nseq, a.T, a.inner_n, a.ndir);
         return -1;
     }
+    if (a.cell < 0 || a.cell > 2) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    if (!mode_ok(mode)) { dprnn_set_error("dprnn_rnn_fwd: gemm mode must be 0, 1 or 3 (got %d)", mode); return -1; }
+    if (a.cell != 0) mode = 0;                // GRU / Elman cells have the exact fp32 kernels only (and dprnn_rnn_pack packs them so)
     if (a.Z && (!a.stats || !a.gamma || !a.beta || !a.Xout || a.Xout == a.X || a.seqs_per_utt <= 0 || a.rows_per_utt <= 0)) {
         dprnn_set_error("dprnn_bilstm_norm_fwd: the pending norm needs stats, gamma, beta, sizes and an Xout different from X");
         return -1;
@@ -554,7 +574,9 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
                         a.outer_stride);
         return -1;
     }
-    if (seq_tile == 0) seq_tile = a.nseq <= 16 ? 16 : 32;
+    if (int rc = dprnn_pack_expect(a.Wp, DPRNN_PACK_FWD, a.cell, mode, a.ndir, "dprnn_rnn_fwd")) return rc;
+    a.sat = dprnn_sat_ptr();
+    if (seq_tile == 0) seq_tile = mode != 0 ? 2064 : (a.nseq <= 16 ? 16 : 32);
     const bool fast = g_fast_act != 0;
     // 16-sequence tiles run on eight waves (half the MFMA chain per wave and step: the small-batch latency form);
     // -16 selects the four-wave form of the same tile (kept for A/B measurements: tools/latency.py)
@@ -567,8 +589,7 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         if (small) return fast ? launch_bilstm<1, true, 2, false, 8>(a, st) : launch_bilstm<1, false, 2, false, 8>(a, st);
         return fast ? launch_bilstm<2, true, 2>(a, st) : launch_bilstm<2, false, 2>(a, st);
     }
-    if (a.cell != 0) { dprnn_set_error("dprnn_rnn_fwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (g_gemm_mode != 0) return launch_bilstm_split(a, split_products(), seq_tile, fast, st);
+    if (mode != 0) return launch_bilstm_split(a, mode, seq_tile, fast, st);
     switch (seq_tile) {
         case 16: return fast ? launch_bilstm<1, true, 0, false, 8>(a, st) : launch_bilstm<1, false, 0, false, 8>(a, st);
         case -16: return fast ? launch_bilstm<1, true>(a, st) : launch_bilstm<1, false>(a, st);
@@ -576,7 +597,7 @@ static int bilstm_dispatch(RecurArgs a, int seq_tile, hipStream_t st) {
         case 48: return fast ? launch_bilstm<3, true>(a, st) : launch_bilstm<3, false>(a, st);
         case 64:
             return fast ? launch_bilstm<4, true>(a, st) : launch_bilstm<4, false>(a, st);
-        default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,-16,32,48,64 (got %d; the bf16-split modes also take 80, 96, 104, 1048, 1064)", seq_tile); return -1;
+        default: dprnn_set_error("dprnn_bilstm_fwd: seq_tile must be 0,16,-16,32,48,64 in gemm mode 0 (got %d)", seq_tile); return -1;
     }
 }
 
@@ -586,7 +607,19 @@ extern "C" int dprnn_bilstm_fwd(const float* X, const float* packed, const float
     RecurArgs a{};
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
-    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+    return bilstm_dispatch(a, g_gemm_mode, seq_tile, (hipStream_t)stream);
+}
+
+static RecurArgs rnn_args(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                          const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                          const float* packed, const float* bsum, float* H,
+                          int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride, int ndir) {
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
+    a.rows_per_utt = rows_per_utt; a.Xout = Xout;
+    return a;
 }
 
 extern "C" int dprnn_rnn_fwd(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
@@ -594,12 +627,16 @@ extern "C" int dprnn_rnn_fwd(int cell, const float* X, const float* Z, const dou
                              const float* packed, const float* bsum, float* H,
                              int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                              int64_t t_stride, int ndir, int seq_tile, void* stream) {
-    RecurArgs a{};
-    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
-    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
-    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
-    a.rows_per_utt = rows_per_utt; a.Xout = Xout;
-    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+    return bilstm_dispatch(rnn_args(cell, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, nseq, T,
+                                    inner_n, outer_stride, inner_stride, t_stride, ndir), g_gemm_mode, seq_tile, (hipStream_t)stream);
+}
+extern "C" int dprnn_rnn_fwd_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                                const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                const float* packed, const float* bsum, float* H,
+                                int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                int64_t t_stride, int ndir, int seq_tile, void* stream) {
+    return bilstm_dispatch(rnn_args(cell, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, nseq, T,
+                                    inner_n, outer_stride, inner_stride, t_stride, ndir), gemm_mode, seq_tile, (hipStream_t)stream);
 }
 
 extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
@@ -608,28 +645,27 @@ extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const doubl
                                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                                      int64_t t_stride, int ndir, int seq_tile, void* stream) {
     if (!Z) { dprnn_set_error("dprnn_bilstm_norm_fwd: Z is null (use dprnn_bilstm_fwd)"); return -1; }
-    RecurArgs a{};
-    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
-    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
-    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
-    a.rows_per_utt = rows_per_utt; a.Xout = Xout;
-    return bilstm_dispatch(a, seq_tile, (hipStream_t)stream);
+    return bilstm_dispatch(rnn_args(0, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, nseq, T,
+                                    inner_n, outer_stride, inner_stride, t_stride, ndir), g_gemm_mode, seq_tile, (hipStream_t)stream);
 }
 
-// ---- ragged batches: one recurrence launch over utterances of DIFFERENT lengths (bf16-split modes, LSTM cell, 64-sequence
-// eight-wave kernel).  The slab is the concatenation of the utterances' [S_u][K][F] slabs.
+// ---- ragged batches: one recurrence launch over utterances of DIFFERENT lengths (split gate-GEMM modes 1 / 3, LSTM cell,
+// 64-sequence eight-wave kernel).  The slab is the concatenation of the utterances' [S_u][K][F] slabs.
 //   intra-chunk (wg_desc == NULL): n_items = total number of chunks, T = K; sequence q is rows q*K .. q*K + K-1; seq_utt[q]
 //       names its utterance (needed only with a pending norm).
 //   inter-chunk (wg_desc != NULL): n_items = workgroups per direction; workgroup w runs the sequences row0 + j (j < count)
 //       for T steps of stride K rows: wg_desc[w] = {row0 lo, row0 hi, T = S_u, count <= 64, u, 0, 0, 0}; tiles never
 //       straddle utterances (sort them by T, longest first: they end at different times).
 // utt_rows[u] = S_u * K (the count of the pending norm; stats[u] as everywhere).
-extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
-                                    float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
-                                    float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
-                                    void* stream) {
+static int rnn_fwd_ragged(int mode, const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                          float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
+                          float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
+                          void* stream) {
     if (!X || !packed || !bsum || !H) { dprnn_set_error("dprnn_rnn_fwd_ragged: null pointer"); return -1; }
-    if (g_gemm_mode == 0) { dprnn_set_error("dprnn_rnn_fwd_ragged: needs a bf16-split gemm mode (dprnn_set_gemm_mode 1 or 2)"); return -1; }
+    if (mode != 1 && mode != 3) {
+        dprnn_set_error("dprnn_rnn_fwd_ragged: needs a split gate-GEMM mode, 1 (bf16 pieces) or 3 (f16 pieces); got %d", mode);
+        return -1;
+    }
     if (n_items <= 0 || K <= 0 || (ndir != 1 && ndir != 2) || (!wg_desc && T <= 0)) {
         dprnn_set_error("dprnn_rnn_fwd_ragged: bad sizes n_items=%d T=%d K=%d ndir=%d", n_items, T, K, ndir);
         return -1;
@@ -646,7 +682,21 @@ extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double
     if (wg_desc) { a.inner_n = 1 << 30; a.outer_stride = 0; a.inner_stride = 1; a.t_stride = K; }
     else { a.inner_n = n_items; a.outer_stride = 0; a.inner_stride = K; a.t_stride = 1; }
     if ((long long)64 * K * ndir * HD * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_fwd_ragged: chunk_length too large"); return -1; }
-    return launch_bilstm_split(a, split_products(), 2064, g_fast_act != 0, (hipStream_t)stream);
+    if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, mode, ndir, "dprnn_rnn_fwd_ragged")) return rc;
+    a.sat = dprnn_sat_ptr();
+    return launch_bilstm_split(a, mode, 2064, g_fast_act != 0, (hipStream_t)stream);
+}
+extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                                    float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
+                                    float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
+                                    void* stream) {
+    return rnn_fwd_ragged(g_gemm_mode, X, Z, stats, gamma, beta, eps, utt_rows, seq_utt, wg_desc, n_items, Xout, packed, bsum, H, T, K, ndir, stream);
+}
+extern "C" int dprnn_rnn_fwd_ragged_ex(int gemm_mode, const float* X, const float* Z, const double* stats, const float* gamma,
+                                       const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                                       int n_items, float* Xout, const float* packed, const float* bsum, float* H, int T, int K,
+                                       int ndir, void* stream) {
+    return rnn_fwd_ragged(gemm_mode, X, Z, stats, gamma, beta, eps, utt_rows, seq_utt, wg_desc, n_items, Xout, packed, bsum, H, T, K, ndir, stream);
 }
 
 // ---- training forward: dprnn_rnn_fwd for the LSTM cell on 32-sequence tiles, plus the gate tape for dprnn_lstm_bwd
@@ -655,15 +705,15 @@ extern "C" int64_t dprnn_rnn_tape_floats(int cell, int nseq, int T, int ndir) {
 }
 extern "C" int64_t dprnn_lstm_tape_floats(int nseq, int T, int ndir) { return dprnn_rnn_tape_floats(0, nseq, T, ndir); }
 
-extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+static int rnn_fwd_train(int mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
                                    const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
                                    const float* packed, const float* bsum, float* H, float* tape,
                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                                    int64_t t_stride, int ndir, void* stream) {
     if (!tape) { dprnn_set_error("dprnn_lstm_fwd_train: tape is null"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_fwd_train: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
-    if (g_gemm_mode != 0 && !(g_gemm_mode == 3 && cell == 0)) {
-        dprnn_set_error("dprnn_rnn_fwd_train: the training forward runs in gate-GEMM mode 0 (any cell) or 3 (LSTM), not %d", g_gemm_mode);
+    if (mode != 0 && !(mode == 3 && cell == 0)) {
+        dprnn_set_error("dprnn_rnn_fwd_train: the training forward runs in gate-GEMM mode 0 (any cell) or 3 (LSTM), not %d", mode);
         return -1;
     }
     RecurArgs a{};
@@ -685,11 +735,30 @@ extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, con
         dprnn_set_error("dprnn_rnn_fwd_train: a sequence tile spans more than 2 GiB (outer_stride=%lld rows, T=%d)", a.outer_stride, a.T);
         return -1;
     }
+    if (int rc = dprnn_pack_expect(a.Wp, DPRNN_PACK_FWD, cell, mode, ndir, "dprnn_rnn_fwd_train")) return rc;
+    a.sat = dprnn_sat_ptr();
     hipStream_t st = (hipStream_t)stream;
-    if (g_gemm_mode == 3) return launch_split8_f16_train(a, g_fast_act != 0, st);      // f16 pieces, same tape
+    if (mode == 3) return launch_split8_f16_train(a, g_fast_act != 0, st);      // f16 pieces, same tape
     if (cell == 1) return g_fast_act ? launch_bilstm<2, true, 1, true>(a, st) : launch_bilstm<2, false, 1, true>(a, st);
     if (cell == 2) return g_fast_act ? launch_bilstm<2, true, 2, true>(a, st) : launch_bilstm<2, false, 2, true>(a, st);
     return g_fast_act ? launch_bilstm<2, true, 0, true>(a, st) : launch_bilstm<2, false, 0, true>(a, st);
+}
+
+extern "C" int dprnn_rnn_fwd_train(int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                                   const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                   const float* packed, const float* bsum, float* H, float* tape,
+                                   int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                   int64_t t_stride, int ndir, void* stream) {
+    return rnn_fwd_train(g_gemm_mode, cell, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, tape,
+                         nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
+}
+extern "C" int dprnn_rnn_fwd_train_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                                      const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                      const float* packed, const float* bsum, float* H, float* tape,
+                                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                      int64_t t_stride, int ndir, void* stream) {
+    return rnn_fwd_train(gemm_mode, cell, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, tape,
+                         nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
 }
 
 extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double* stats, const float* gamma,
@@ -711,9 +780,10 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.stamps = stamps;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, g_gemm_mode, ndir, "dprnn_bilstm_fwd_stamped")) return rc;
     if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // eight-wave split kernel with stamps (packed by dprnn_rnn_pack in the same mode)
         if (seq_tile != 2064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064"); return -1; }
-        return launch_bilstm_split(a, split_products(), seq_tile, true, st);
+        return launch_bilstm_split(a, g_gemm_mode, seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {
         const size_t lds = (size_t)2 * NS * XS * sizeof(float);

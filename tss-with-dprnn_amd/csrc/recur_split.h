@@ -1,4 +1,4 @@
-// Split gate-GEMM forms of the BiLSTM recurrence (dprnn_set_gemm_mode 1 / 2 / 3): what the kernels share -- operand splitting,
+// Split gate-GEMM forms of the BiLSTM recurrence (dprnn_set_gemm_mode 1 / 3): what the kernels share -- operand splitting,
 // MFMA wrappers, constants.
 //
 // The exact path (recur.hip) multiplies fp32 operands on v_mfma_f32_16x16x4_f32, which runs at the fp32 *vector* rate and --
@@ -6,7 +6,7 @@
 // faster per FLOP and leave the vector ALU free, so these kernels write every fp32 operand as a sum of 16-bit pieces and sum
 // cross products with fp32 accumulation inside the MFMA:
 //     mode 1: three bf16 pieces, 6 products (v1w1, v1w2, v2w1, v1w3, v2w2, v3w1): product error ~2^-24, fp32's exponent range;
-//     mode 2: two bf16 pieces, 3 products: product error ~2^-16 (opt-in only);
+//     (mode 2, two bf16 pieces / 3 products with product error ~2^-16, was opt-in only and left the tree in round 3;)
 //     mode 3: two f16 pieces of power-of-two-scaled operands, 3 products: product error ~2^-24 at half the work of mode 1 (below).
 // Everything else (cell arithmetic, state, addressing, pending-norm loader) is the fp32 code of recur.hip.
 //

@@ -1,5 +1,5 @@
 // Split gate-GEMM forms of the BiLSTM recurrence (recur_split.h): weight packing, the two-workgroups-per-CU 32-sequence kernel
-// (bf16 pieces, small launches of modes 1 / 2) and the dispatcher over the tile codes of dprnn_rnn_fwd's seq_tile argument.
+// (bf16 pieces, small launches of mode 1) and the dispatcher over the tile codes of dprnn_rnn_fwd's seq_tile argument.
 #include "recur_split.h"
 using namespace recur;
 using namespace rsplit;
@@ -303,12 +303,13 @@ template <int NT, int NP, bool FAST>
 int launch_split(const RecurArgs& a, hipStream_t st) {
     constexpr int NS = 16 * NT;
     const size_t lds = (size_t)3 * NS * PITCH;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split_kernel<NT, NP, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split): %s", hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     dim3 grid((a.nseq + NS - 1) / NS, a.ndir);
     hipLaunchKernelGGL((bilstm_split_kernel<NT, NP, FAST>), grid, dim3(256), lds, st, a);
@@ -319,29 +320,24 @@ int launch_split(const RecurArgs& a, hipStream_t st) {
 }  // namespace
 
 // seq_tile codes of the split modes: 32 = two 32-sequence workgroups per CU (bf16 pieces only; the L2 weight stream bounds it);
-// 2000 + n = the eight-wave kernel with n sequences per workgroup, one workgroup per CU (bf16: 64 / 80 / 96; f16: 32 .. 96);
-// 3000 + n = its staggered form (-DDPRNN_STAG_FORMS builds only).  products: 6 / 3 = bf16 pieces, 2 = the f16 form.
-int recur::launch_bilstm_split(const RecurArgs& a, int products, int seq_tile, bool fast, hipStream_t st) {
-    const bool stag = seq_tile >= 3000;
-#ifndef DPRNN_STAG_FORMS
-    if (stag) { dprnn_set_error("dprnn_rnn_fwd: staggered split forms (seq_tile %d) are not built (-DDPRNN_STAG_FORMS)", seq_tile); return -1; }
-#endif
+// 2000 + n = the eight-wave kernel with n sequences per workgroup, one workgroup per CU (bf16: 64 / 80 / 96; f16: 16 .. 96).
+int recur::launch_bilstm_split(const RecurArgs& a, int gemm_mode, int seq_tile, bool fast, hipStream_t st) {
     const int nsr = seq_tile % 1000;
-    if (products == 2) {                                   // f16 form (gemm mode 3): the eight-wave kernels only
-        if (seq_tile < 2000 || (nsr != 16 && nsr != 32 && nsr != 48 && nsr != 64 && nsr != 80 && nsr != 96)) {
+    if (gemm_mode == 3) {                                  // f16 pieces: the eight-wave kernels only
+        if (seq_tile < 2000 || seq_tile >= 3000 || (nsr != 16 && nsr != 32 && nsr != 48 && nsr != 64 && nsr != 80 && nsr != 96)) {
             dprnn_set_error("dprnn_rnn_fwd: gemm mode 3 has seq_tile 2016, 2032, 2048, 2064, 2080, 2096 (got %d)", seq_tile);
             return -1;
         }
-        return launch_split8_f16(a, nsr, stag, fast, st);
+        return launch_split8_f16(a, nsr, fast, st);
     }
+    if (gemm_mode != 1) { dprnn_set_error("dprnn_rnn_fwd: no split kernels for gemm mode %d", gemm_mode); return -1; }
     if (seq_tile >= 2000) {
-        if (nsr != 64 && nsr != 80 && nsr != 96) { dprnn_set_error("dprnn_rnn_fwd: bf16 split modes have seq_tile 32, 2064, 2080, 2096 (got %d)", seq_tile); return -1; }
-        return launch_split8_bf16(a, products, nsr, stag, fast, st);
+        if (seq_tile >= 3000 || (nsr != 64 && nsr != 80 && nsr != 96)) { dprnn_set_error("dprnn_rnn_fwd: gemm mode 1 has seq_tile 32, 2064, 2080, 2096 (got %d)", seq_tile); return -1; }
+        return launch_split8_bf16(a, nsr, fast, st);
     }
-    if (seq_tile != 32) { dprnn_set_error("dprnn_rnn_fwd: bf16 split modes have seq_tile 32, 2064, 2080, 2096 (got %d)", seq_tile); return -1; }
+    if (seq_tile != 32) { dprnn_set_error("dprnn_rnn_fwd: gemm mode 1 has seq_tile 32, 2064, 2080, 2096 (got %d)", seq_tile); return -1; }
     if (a.wg_desc || a.seq_utt) { dprnn_set_error("dprnn_rnn_fwd: ragged batches need an eight-wave tile (seq_tile 2064)"); return -1; }
-    if (products == 6) return fast ? launch_split<2, 6, true>(a, st) : launch_split<2, 6, false>(a, st);
-    return fast ? launch_split<2, 3, true>(a, st) : launch_split<2, 3, false>(a, st);
+    return fast ? launch_split<2, 6, true>(a, st) : launch_split<2, 6, false>(a, st);
 }
 
 extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
@@ -354,6 +350,7 @@ extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const f
     const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
     hipLaunchKernelGGL(lstm_pack_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
+    dprnn_pack_note(packed, DPRNN_PACK_FWD, 0, 3, ndir);
     return dprnn_check_launch("lstm_pack_f16_kernel");
 }
 
@@ -366,5 +363,6 @@ extern "C" int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const
     const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
     hipLaunchKernelGGL(lstm_pack_split_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
+    dprnn_pack_note(packed, DPRNN_PACK_FWD, 0, 1, ndir);
     return dprnn_check_launch("lstm_pack_split_kernel");
 }

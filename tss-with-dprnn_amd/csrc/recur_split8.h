@@ -1,5 +1,5 @@
 // Eight-wave split recurrence kernel (template) and its launcher; instantiated by recur_split8_bf16.hip (three bf16 pieces,
-// gate-GEMM modes 1 / 2) and recur_split8_f16.hip (two f16 pieces, mode 3) so that the two sets build in parallel.
+// gate-GEMM mode 1) and recur_split8_f16.hip (two f16 pieces, mode 3) so that the two sets build in parallel.
 #pragma once
 #include "recur_split.h"
 
@@ -10,17 +10,10 @@ namespace rsplit {
 // fragment column tile (w >> 1, w & 1) for all four gates).  Why: profiles/r02_split_wide.txt -- with ONE wave per SIMD
 // every weight request (buffer_load_dwordx4, ~33 cycles of issue) stops that SIMD's MFMA stream, 27 % of the MFMA phase
 // at 64 sequences; with two waves per SIMD one wave's memory and vector instructions issue under the other's MFMAs.
-//   STAG = false: [gate GEMM (8 k-slabs)] barrier [cell update + staging of x_{t+1}] barrier        (as the wide form)
-//   STAG = true : the x half of the gate GEMM does not depend on h, so between the two barriers that the recurrence needs
-//       all waves     : h half of step t                                  (MFMA)
-//       barrier A       (h_{t-1} no longer read)
-//       waves 0..3    : cell(t), stage x_{t+2}   then   x half of step t+1
-//       waves 4..7    : x half of step t+1       then   cell(t), stage x_{t+2}
-//       barrier B       (h_t in place)
-//   each SIMD holds one wave of either group (waves w and w + 4 share a SIMD), so its vector pipe works on one group's
-//   cell update while its matrix pipe works on the other's x half.  Costs: a second accumulator set, x double-buffered
-//   in LDS (NSR <= 64).
-// Image: regions h | x0 (| x1), each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
+//   per step: [gate GEMM (8 k-slabs: x half, then h half)] [cell update + staging of x_{t+1}] barrier
+// (A staggered form -- cell update of one wave group beside the x half of the other's next step -- was measured in round 2
+// and removed in round 3: two accumulator sets spill at 64 sequences, 15.1 against 11.6 us per step; profiles/r02_split_wide.txt.)
+// Image: regions h (x 2) | x (x 2) when double-buffered, each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
 #ifndef DPRNN_SPLIT8_DB
 #define DPRNN_SPLIT8_DB 1
 #endif
@@ -33,19 +26,19 @@ namespace rsplit {
 #ifndef DPRNN_SPLIT8_LRES
 #define DPRNN_SPLIT8_LRES 3
 #endif
-constexpr bool split8_double_buffered(int nsr, bool f16, bool stag) { return DPRNN_SPLIT8_DB && f16 && !stag && nsr <= 64 && !(nsr == 16 && DPRNN_SPLIT8_LRES > 3); }
+constexpr bool split8_double_buffered(int nsr, bool f16) { return DPRNN_SPLIT8_DB && f16 && nsr <= 64 && !(nsr == 16 && DPRNN_SPLIT8_LRES > 3); }
 // 16-sequence f16 tile: second weight pieces of the LAST `lres` k-slabs live in LDS (32 KB per slab and direction)
-constexpr int split8_lds_resident_slabs(int nsr, bool f16, bool stag) { return (f16 && !stag && nsr == 16) ? DPRNN_SPLIT8_LRES : 0; }
+constexpr int split8_lds_resident_slabs(int nsr, bool f16) { return (f16 && nsr == 16) ? DPRNN_SPLIT8_LRES : 0; }
 
 // SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
 // state to a.tape in the layout of the fp32 training kernel (recur.hip: [dir][32-sequence workgroup][step][wave][nt][u][slot]
 // [lane] float4 over four sequences), which is what the backward kernels read: a 64-sequence tile is two of those workgroups.
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false>
 __global__ __launch_bounds__(512, 2)
 void bilstm_split8_kernel(RecurArgs a) {
-    static_assert(!SAVE || (NSR == 64 && !STAG), "the tape layout is written for 64-sequence tiles");
+    static_assert(!SAVE || NSR == 64, "the tape layout is written for 64-sequence tiles");
     static_assert(NSR % 16 == 0 && NSR >= 16 && NSR <= 96, "whole 16-row tiles");
-    static_assert(!F16 || NP == 3, "the f16 form has two pieces and three products");
+    static_assert(NP == 6 || (F16 && NP == 3), "three bf16 pieces / six products, or two f16 pieces / three products");
     constexpr int NT = NSR / 16;
     constexpr int NPC = NP == 6 ? 3 : 2;
     constexpr int PL = NSR * 256;                      // bytes of one piece plane of one region
@@ -54,9 +47,9 @@ void bilstm_split8_kernel(RecurArgs a) {
     // between the gate GEMM and the cell update -- a wave that is through its MFMAs starts its cell update while its SIMD
     // partner still multiplies (they share the matrix pipe, so one of them always finishes first), instead of both waiting
     // and then both doing vector work with the matrix pipe idle.
-    constexpr bool DB = split8_double_buffered(NSR, F16, STAG);
+    constexpr bool DB = split8_double_buffered(NSR, F16);
     constexpr int NHB = DB ? 2 : 1;                    // h buffers
-    constexpr int NXB = (STAG || DB) ? 2 : 1;          // x buffers
+    constexpr int NXB = DB ? 2 : 1;                    // x buffers
     extern __shared__ __attribute__((aligned(16))) char img[];
     char* const hreg = img;                            // + hb * REG
     char* const xreg = img + NHB * REG;                // + xb * REG
@@ -64,7 +57,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     unsigned* const rowoff_h = rowoff_x + NSR;
     float* const musig = reinterpret_cast<float*>(rowoff_h + NSR);
     float* const gb = musig + 2 * NSR;
-    constexpr int LRES = split8_lds_resident_slabs(NSR, F16, STAG);       // second pieces of k-slabs NSLAB - LRES .. NSLAB - 1 in LDS
+    constexpr int LRES = split8_lds_resident_slabs(NSR, F16);       // second pieces of k-slabs NSLAB - LRES .. NSLAB - 1 in LDS
     char* const wlds = reinterpret_cast<char*>(gb + 256);                 // [slab][w4][gate*2 + wu][lane] 16-byte fragments
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +66,6 @@ void bilstm_split8_kernel(RecurArgs a) {
 #if DPRNN_SPLIT8_PRIO
     if (DB && wave < 4) __builtin_amdgcn_s_setprio(DPRNN_SPLIT8_PRIO);     // one wave of every SIMD pair runs ahead through the MFMAs
 #endif
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * NSR;
     constexpr unsigned OOB = 0x80000000u;
@@ -142,13 +134,14 @@ void bilstm_split8_kernel(RecurArgs a) {
         return *reinterpret_cast<const u32x4*>(wlds + ((((slab - (NSLAB - LRES)) * 4 + w4) * 8 + g * 2 + wu) * 64 + lane) * 16);
     };
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    unsigned satm = 0u;                                    // f16 pieces: bits of the largest |2^4 x| this lane converted (common.h: sat_track)
     // x of one time step -> bf16 pieces in x buffer xb, one quad (4 floats of one row) per thread and m; XG quads are in
     // flight together (registers: the partner wave on the SIMD covers the rest of the latency)
     auto x_stage = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
         const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
         const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
-        constexpr int XG = STAG ? 1 : 2;
+        constexpr int XG = 2;
 #pragma unroll
         for (int m0 = 0; m0 < NT; m0 += XG) {
             f32x4 xv[XG], zv[XG];
@@ -175,8 +168,10 @@ void bilstm_split8_kernel(RecurArgs a) {
                 }
                 unsigned pa[3], pb[3];
                 if constexpr (F16) {
+                    v = v * f32x4{F16_XS, F16_XS, F16_XS, F16_XS};
+                    sat_track(satm, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -F16_XMAX, F16_XMAX);
                     split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                     split2_pair_f16(v[2], v[3], pb[0], pb[1]);
                 } else {
@@ -195,7 +190,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     // issued at the start of the LAST k-slab of step t and land under its MFMAs, barrier A and the cell update, instead of
     // being waited for right after they are issued.  (vmcnt retires in order: loads issued earlier in the step would sit in
     // front of every weight wait; from the last slab on, the only younger loads are next step's slab-0 weights.)
-    constexpr bool XPF = !STAG && NT <= 4;
+    constexpr bool XPF = NT <= 4;
     f32x4 xq[XPF ? NT : 1], zq[XPF ? NT : 1];
     auto x_issue = [&](long long t) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
@@ -225,8 +220,10 @@ void bilstm_split8_kernel(RecurArgs a) {
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
+                v = v * f32x4{F16_XS, F16_XS, F16_XS, F16_XS};
+                sat_track(satm, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -F16_XMAX, F16_XMAX);
                 split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                 split2_pair_f16(v[2], v[3], pb[0], pb[1]);
             } else {
@@ -241,10 +238,9 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
 
     __syncthreads();                                   // row tables are in place
-    const long long tfirst = dir ? (T - 1) : 0, tsecond = T > 1 ? (dir ? (T - 2) : 1) : tfirst;
+    const long long tfirst = dir ? (T - 1) : 0;
     if constexpr (XPF) { x_issue(tfirst); x_finish(tfirst, 0, true); }
     else x_stage(tfirst, 0, true);
-    if (STAG) x_stage(tsecond, 1, T > 1);
     for (int i = tid; i < REG / 4; i += 512) reinterpret_cast<unsigned*>(hreg)[i] = 0u;
     f32x4 c[NT];
 #pragma unroll
@@ -270,7 +266,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     // wave's weights (128 registers) stay resident for the whole kernel and only the second pieces are streamed: half the bytes
     // per step.
     // The 32-sequence tile has registers for half of them (k-slabs 0 .. 3).
-    constexpr int RES = (F16 && !STAG) ? (NSR == 16 ? NSLAB : (NSR == 32 && DPRNN_SPLIT8_RES32) ? NSLAB / 2 : 0) : 0;   // resident k-slabs
+    constexpr int RES = F16 ? (NSR == 16 ? NSLAB : (NSR == 32 && DPRNN_SPLIT8_RES32) ? NSLAB / 2 : 0) : 0;   // resident k-slabs
     constexpr bool WRES = RES > 0;
     u32x4 wres[WRES ? RES : 1][4];
     if constexpr (WRES) {
@@ -284,7 +280,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int pc = WRES ? 1 : 0; pc < NPC; ++pc) bw[g][pc] = wload(0, g, pc);       // slab 0 is resident whenever any is
-    f32x4 acc[STAG ? 2 : 1][NT][4];
+    f32x4 acc[NT][4];
     u32x4 fa[NT], fb[NT];
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
 #pragma unroll
@@ -421,7 +417,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
 
     unsigned long long st_t0 = 0, st_r0 = 0, st_p1 = 0, st_p2 = 0;
-    if constexpr (!STAG) {
+    {
         __syncthreads();
         if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
         for (int step = 0; step < T; ++step) {
@@ -431,95 +427,60 @@ void bilstm_split8_kernel(RecurArgs a) {
             const bool more = step + 1 < T;
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
-            half(acc[0], xreg + rb * REG, 0, true);
-            half(acc[0], hreg + rb * REG, 4, false, XPF, tn);
+            half(acc, xreg + rb * REG, 0, true);
+            half(acc, hreg + rb * REG, 4, false, XPF, tn);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             if constexpr (!DB) __syncthreads();        // single-buffered: every wave is done reading the image of this step
-            cell(acc[0], t, step, hreg + wb * REG);
+            cell(acc, t, step, hreg + wb * REG);
             if constexpr (XPF) x_finish(tn, wb, more);
             else x_stage(tn, wb, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
             __syncthreads();
         }
-    } else {
-        __syncthreads();
-        half(acc[0], xreg, 0, true);                   // x half of the first step
-        if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-        auto one_step = [&](f32x4 (&acur)[NT][4], f32x4 (&anxt)[NT][4], int step) __attribute__((always_inline)) {
-            unsigned long long st_a = 0, st_b = 0;
-            if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
-            const long long t = dir ? (T - 1 - step) : step;
-            // x_{t+1} sits in buffer (step + 1) & 1; x_{t+2} goes to buffer step & 1 (last read by the x half of step t)
-            const long long t2 = step + 2 < T ? (dir ? (t - 2) : (t + 2)) : t;
-            const char* const xnext = xreg + ((step + 1) & 1) * REG;
-            half(acur, hreg, 4, false);
-            if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
-            __syncthreads();                           // barrier A: h_{t-1} is no longer read
-            // one copy of the MFMA code, the (much shorter) vector code before it for waves 0..3 and after it for waves 4..7
-            if (grp == 0) { cell(acur, t); x_stage(t2, step & 1, step + 2 < T); }
-            half(anxt, xnext, 0, true);
-            if (grp != 0) { cell(acur, t); x_stage(t2, step & 1, step + 2 < T); }
-            if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
-            __syncthreads();                           // barrier B: h_t and x_{t+2} are in place
-        };
-        for (int step = 0; step < T; step += 2) {
-            one_step(acc[0], acc[STAG ? 1 : 0], step);
-            if (step + 1 < T) one_step(acc[STAG ? 1 : 0], acc[0], step + 1);
-        }
     }
+    if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX);
     if constexpr (STAMP) {
         if (tid == 0 && a.stamps) {
             unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
             o[0] = __builtin_amdgcn_s_memtime() - st_t0;
             o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
-            o[2] = st_p1;                                         // MFMA phase (STAG: h half)
-            o[3] = st_p2;                                         // cell + staging (STAG: cell + staging + x half)
+            o[2] = st_p1;                                         // MFMA phase
+            o[3] = st_p2;                                         // cell + staging
             o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = 0; o[7] = 0;
         }
     }
 }
 
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAG, bool STAMP = false, bool F16 = false, bool SAVE = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(STAG ? 3 : (split8_double_buffered(NSR, F16, STAG) ? 4 : 2)) * (NP == 6 ? 3 : 2) * NSR * 256 +
-                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4 + (size_t)split8_lds_resident_slabs(NSR, F16, STAG) * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>),
+    const size_t lds = (size_t)(split8_double_buffered(NSR, F16) ? 4 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 +
+                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4 + (size_t)split8_lds_resident_slabs(NSR, F16) * 32768;
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
-    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAG, STAMP, F16, SAVE>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE>), grid, dim3(512), lds, st, a);
     return dprnn_check_launch("bilstm_split8_kernel");
 }
 
 // One tile size of one piece format: FAST / FUSE / STAMP variants.  The libm-activation variants (dprnn_set_fast_activations(0))
 // are built for the 64-sequence tile only; other tile sizes fall back to it (any tile size serves any launch).
-template <int NSR, bool STAG, bool F16>
-int launch_split8_form(const RecurArgs& a, int products, bool fast, hipStream_t st) {
-    constexpr int NPF = 3;
+template <int NSR, bool F16>
+int launch_split8_form(const RecurArgs& a, bool fast, hipStream_t st) {
+    constexpr int NP = F16 ? 3 : 6;
     const bool fuse = a.Z != nullptr;
-    if constexpr (NSR == 64 && !STAG) {
-        if (a.stamps) {                                    // in-kernel stamps (tools/bench_recur.py --stamps): fast, no pending norm
-            if constexpr (F16) return launch_split8<64, NPF, true, false, false, true, true>(a, st);
-            else if (products == 6) return launch_split8<64, 6, true, false, false, true, false>(a, st);
-        }
-    }
-    if (!fast) {
-        if constexpr (NSR != 64 || STAG) return launch_split8_form<64, false, F16>(a, products, false, st);
-        else if constexpr (F16) return fuse ? launch_split8<64, NPF, false, true, false, false, true>(a, st)
-                                            : launch_split8<64, NPF, false, false, false, false, true>(a, st);
-        else if (products == 6) return fuse ? launch_split8<64, 6, false, true, false>(a, st) : launch_split8<64, 6, false, false, false>(a, st);
-        else return fuse ? launch_split8<64, 3, false, true, false>(a, st) : launch_split8<64, 3, false, false, false>(a, st);
-    }
-    if constexpr (F16) {
-        return fuse ? launch_split8<NSR, NPF, true, true, STAG, false, true>(a, st) : launch_split8<NSR, NPF, true, false, STAG, false, true>(a, st);
+    if constexpr (NSR == 64) {
+        if (a.stamps) return launch_split8<64, NP, true, false, true, F16>(a, st);    // in-kernel stamps (tools/bench_recur.py --stamps): fast, no pending norm
+        if (!fast) return fuse ? launch_split8<64, NP, false, true, false, F16>(a, st) : launch_split8<64, NP, false, false, false, F16>(a, st);
     } else {
-        if (products == 6) return fuse ? launch_split8<NSR, 6, true, true, STAG>(a, st) : launch_split8<NSR, 6, true, false, STAG>(a, st);
-        return fuse ? launch_split8<NSR, 3, true, true, STAG>(a, st) : launch_split8<NSR, 3, true, false, STAG>(a, st);
+        if (!fast) return launch_split8_form<64, F16>(a, false, st);
     }
+    return fuse ? launch_split8<NSR, NP, true, true, false, F16>(a, st) : launch_split8<NSR, NP, true, false, false, F16>(a, st);
 }
 
 }  // namespace rsplit

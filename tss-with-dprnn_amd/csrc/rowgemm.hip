@@ -66,8 +66,9 @@ template <int KD>
 __global__ __launch_bounds__(512, 1)
 void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ H,
                      float* __restrict__ Z, double* __restrict__ stats, long long M, long long rows_per_b,
-                     const long long* __restrict__ starts, int n_utt) {
+                     const long long* __restrict__ starts, int n_utt, int* sat) {
     constexpr int ND = 128, NCT = 8, NS = KD / 32, K8 = KD / 8, RT = 2, NW = 8, PF = 3;
+    unsigned satm = 0u;                                                 // bits of the largest |2^4 h| converted (|h| < 1 for RNN outputs)
     static_assert(NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
     extern __shared__ __attribute__((aligned(16))) u32x4_t wl16[];      // [NS][NCT][2][64] + bias
     __shared__ float red[NW];
@@ -172,10 +173,12 @@ void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
+                lo = lo * f32x4{F16P_XS, F16P_XS, F16P_XS, F16P_XS}; hi = hi * f32x4{F16P_XS, F16P_XS, F16P_XS, F16P_XS};
+                sat_track(satm, lo); sat_track(satm, hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
-                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * F16P_XS, -F16P_XMAX, F16P_XMAX);
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e], -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e], -F16P_XMAX, F16P_XMAX);
                 }
                 f16_pieces8(lo, hi, h1[rt], h2[rt]);
             }
@@ -243,6 +246,7 @@ void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias
         (void)o1; (void)o2;
     }
     flush();
+    sat_commit(sat, DPRNN_SAT_PROJ_ROWS, satm, F16P_XMAX);
 }
 
 template <int KD>
@@ -250,16 +254,17 @@ int launch_proj_f16(const char* what, const float* W, const float* bias, const f
                     long long rows_per_b, const long long* starts, int n_utt, hipStream_t st) {
     const size_t lds = (size_t)KD * 128 * 4 + 128 * 4;
     auto kern = &proj_f16_kernel<KD>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     const long long nchunk = (M + 255) / 256;
     long long grid = nchunk < num_cus() ? nchunk : num_cus();
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, H, Z, stats, M, rows_per_b, starts, n_utt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, H, Z, stats, M, rows_per_b, starts, n_utt, dprnn_sat_ptr());
     return dprnn_check_launch(what);
 }
 }  // namespace

@@ -493,11 +493,12 @@ int launch_rowgemm(const char* what, const float* W0, int ldw0, int nd0, const f
                    const AL& al, const EP& ep, hipStream_t st) {
     const size_t lds = (size_t)KD * ND * sizeof(float);
     auto kern = &rowgemm_kernel<KD, ND, RT, AL, EP, WT, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     constexpr int ROWS_IT = NW * RT * 16;
     long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
@@ -695,8 +696,9 @@ struct EpTMaskDecode {
 template <int KD, int ND, int RT, bool XC, class AL, class EPT, bool WT = false>
 __global__ __launch_bounds__(512, 1)
 void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
-                         long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr) {
+                         long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr, int* sat = nullptr) {
     constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8, NW = 8;
+    unsigned satm = 0u;                                                // bits of the largest |scaled row element| converted to f16 pieces
     constexpr int PF = XC ? (NS >= 4 ? 3 : NS - 1) : (NS >= 4 ? 2 : 1);
     static_assert(!XC || NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
     extern __shared__ __attribute__((aligned(16))) rg_u32x4 wl16[];     // [NS][NCT][2][64]
@@ -803,10 +805,12 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
+                lo = lo * f32x4{xs, xs, xs, xs}; hi = hi * f32x4{xs, xs, xs, xs};
+                sat_track(satm, lo); sat_track(satm, hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * xs, -F16P_XMAX, F16P_XMAX);
-                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * xs, -F16P_XMAX, F16P_XMAX);
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e], -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e], -F16P_XMAX, F16P_XMAX);
                 }
                 f16_pieces8(lo, hi, h1[rt], h2[rt]);
             }
@@ -833,6 +837,7 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
                 for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
         }
     }
+    sat_commit(sat, DPRNN_SAT_GEMM_ROWS, satm, F16P_XMAX);
     ep.end(lane);
 }
 
@@ -841,17 +846,18 @@ int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, co
                         const AL& al, const EPT& ep, hipStream_t st, const float* amax = nullptr) {
     const size_t lds = (size_t)KD * ND * 4;
     auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT, WT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return -2; }
-        attr_set = true;
+        dprnn_attr_done(attr_mask, attr_dev);
     }
     constexpr int ROWS_IT = 8 * RT * 16;
     long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
     long long grid = nchunk < num_cus() ? nchunk : num_cus();
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax, dprnn_sat_ptr());
     return dprnn_check_launch(what);
 }
 

@@ -467,13 +467,24 @@ extern "C" int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const floa
 
 // One-shot selector: the NEXT dprnn_gn_bwd_dz call also leaves max|dZ| in *slot (device float) -- the scale source of the Linear's
 // f16-pieces gradients (dprnn_dgrad_use_f16_pieces, dprnn_wgrad_use_f16_pieces), measured while dZ is written instead of by dprnn_absmax.
-static float* g_gn_dz_absmax_out = nullptr;
+static thread_local float* g_gn_dz_absmax_out = nullptr;
 extern "C" void dprnn_gn_bwd_dz_store_absmax(float* slot) { g_gn_dz_absmax_out = slot; }
 
+static int gn_bwd_dz_impl(float* max_out, const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
+                          float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
 extern "C" int dprnn_gn_bwd_dz(const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
                                float eps, int B, int64_t rows_per_utt, float* dZ, void* stream) {
     float* const max_out = g_gn_dz_absmax_out;           // one-shot: consumed by this call whatever it returns
     g_gn_dz_absmax_out = nullptr;
+    return gn_bwd_dz_impl(max_out, dY, Z, stats, red, gamma, eps, B, rows_per_utt, dZ, stream);
+}
+// the same with the selector as an argument: absmax_out != NULL = also leave max|dZ| there (device float)
+extern "C" int dprnn_gn_bwd_dz_ex(float* absmax_out, const float* dY, const float* Z, const double* stats, const double* red,
+                                  const float* gamma, float eps, int B, int64_t rows_per_utt, float* dZ, void* stream) {
+    return gn_bwd_dz_impl(absmax_out, dY, Z, stats, red, gamma, eps, B, rows_per_utt, dZ, stream);
+}
+static int gn_bwd_dz_impl(float* max_out, const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
+                          float eps, int B, int64_t rows_per_utt, float* dZ, void* stream) {
     if (!dY || !Z || !stats || !red || !gamma || !dZ || B < 1 || rows_per_utt < 1) { dprnn_set_error("dprnn_gn_bwd_dz: null pointer / sizes"); return -1; }
     const long long rows = (long long)B * rows_per_utt;
     if (max_out) {

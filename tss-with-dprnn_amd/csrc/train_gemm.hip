@@ -194,7 +194,7 @@ typedef short wf_s4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned wf_swz(int row) { return (unsigned)(((row & 3) << 2) ^ (((row >> 3) & 1) << 4)); }
 
 __global__ __launch_bounds__(WG_THREADS, 2)
-void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax) {
+void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax, int* sat) {
     extern __shared__ __attribute__((aligned(16))) char wimg[];           // [buf 2][P piece 0 | P piece 1 | Q piece 0 | Q piece 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -262,11 +262,14 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax) {
             }
         }
     };
+    unsigned satm = 0u;                                  // bits of the largest |scaled dG / x element| converted (common.h)
     // element unit (row, 8-byte unit u) of a plane with `pitch` bytes per row: row*pitch + ((u ^ swz(row)) << 3)
     auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
+        const f32x4 sv = v * f32x4{s, s, s, s};
+        sat_track(satm, sv);
         float c[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(sv[e], -F16P_XMAX, F16P_XMAX);
         unsigned a1, a2, b1, b2;
         f16_pieces2(c[0], c[1], a1, a2);
         f16_pieces2(c[2], c[3], b1, b2);
@@ -351,6 +354,7 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax) {
             __syncthreads();
         }
     }
+    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX);
     // acc[jm][jn][e] = dW[m][n], m = 256 mb + 64 wm + 16 jm + 4 g + e, n = 128 nb + 64 wn + 16 jn + l
     float* const out = a.part + (long long)ks * a.Mpad * a.Npad;
 #pragma unroll
@@ -453,13 +457,13 @@ extern "C" int64_t dprnn_wgrad_workspace_floats(int M, int N, int64_t rows) {
 
 // One-shot selector: the NEXT dprnn_wgrad call on this thread of control multiplies in f16 pieces, scaling P by the power of two
 // that the BPTT launch derived from *grad_max (device pointer to max|dH|, dprnn_rnn_bwd_gradmax_offset); cleared by that call.
-static const float* g_wgrad_f16_pmax = nullptr;
+static thread_local const float* g_wgrad_f16_pmax = nullptr;
 extern "C" void dprnn_wgrad_use_f16_pieces(const float* grad_max) { g_wgrad_f16_pmax = grad_max; }
 
-extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
-                           const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
-                           float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
-                           float* workspace, void* stream) {
+static int wgrad_impl(const float* pmax, const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
+                      const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
+                      float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
+                      float* workspace, void* stream) {
     if (!P || !Q0 || !dW || !workspace) { dprnn_set_error("dprnn_wgrad: null pointer"); return -1; }
     const int N = n0 + (Q1 ? n1 : 0);
     if (rows <= 0 || M <= 0 || (M % 4) || n0 <= 0 || n0 > WG_NB || (n0 % 4) || (Q1 && (n1 <= 0 || n1 > WG_NB || (n1 % 4) || n0 != WG_NB)) ||
@@ -481,17 +485,16 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     a.rows_per_split = per;
     a.part = workspace;
     a.part_b = (db0 || db1) ? workspace + splits * (long long)a.Mpad * a.Npad : nullptr;
-    const float* const pmax = g_wgrad_f16_pmax;
-    g_wgrad_f16_pmax = nullptr;
     int rc;
     if (pmax) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_mask{0};
+        int attr_dev;
+        if (dprnn_attr_needed(attr_mask, &attr_dev)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WF_BUF);
             if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(wgrad_f16): %s", hipGetErrorString(e)); return -2; }
-            attr_set = true;
+            dprnn_attr_done(attr_mask, attr_dev);
         }
-        hipLaunchKernelGGL(wgrad_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, pmax);
+        hipLaunchKernelGGL(wgrad_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, pmax, dprnn_sat_ptr());
         rc = dprnn_check_launch("wgrad_f16_kernel");
     } else {
         hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
@@ -504,6 +507,22 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
     return dprnn_check_launch("wgrad_reduce_kernel");
 }
 
+extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
+                           const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
+                           float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
+                           float* workspace, void* stream) {
+    const float* const pmax = g_wgrad_f16_pmax;          // one-shot selector: consumed by this call whatever it returns
+    g_wgrad_f16_pmax = nullptr;
+    return wgrad_impl(pmax, P, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, rows, t_stride, T, dW, ldm, ldn, db0, db1, accumulate, workspace, stream);
+}
+// the same with the selector as an argument: f16_grad_max != NULL = f16 pieces with P scaled from *f16_grad_max (device float)
+extern "C" int dprnn_wgrad_ex(const float* f16_grad_max, const float* P, int ldp, int M, const float* Q0, int ldq0, int n0, int dt0,
+                              const float* Q1, int ldq1, int n1, int dt1, int64_t rows, int64_t t_stride, int T,
+                              float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
+                              float* workspace, void* stream) {
+    return wgrad_impl(f16_grad_max, P, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, rows, t_stride, T, dW, ldm, ldn, db0, db1, accumulate, workspace, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ data gradients
 // dA[row*lda + 0:nd] = dOut[row][0:kd] @ W, W = [W0 (k0 rows); W1] row-major [kd][ldw]: (kd, nd) in {(128,256), (128,128),
 // (64,128), (256,128), (128,64)} -- intra/inter Linear (dprnn.py:88,96), end_conv1x1 (:160), out+gate convs (:157-158),
@@ -511,21 +530,33 @@ extern "C" int dprnn_wgrad(const float* P, int ldp, int M, const float* Q0, int 
 // offset W0 and dA by the column, lda = 256).
 // One-shot selector, like dprnn_wgrad_use_f16_pieces: the NEXT dprnn_dgrad call of shape (128 -> 256) multiplies in f16 pieces
 // with dOut scaled by the power of two that puts *grad_max (device pointer to max|dOut|, dprnn_absmax) at 2^6.
-static const float* g_dgrad_f16_amax = nullptr;
+static thread_local const float* g_dgrad_f16_amax = nullptr;
 extern "C" void dprnn_dgrad_use_f16_pieces(const float* grad_max) { g_dgrad_f16_amax = grad_max; }
 // One-shot as well: the NEXT dprnn_dgrad call also leaves max|dA| in *slot (device float) -- what dprnn_rnn_bwd's f16 form needs of
 // its dH (dprnn_rnn_bwd_use_gradmax), measured in the epilogue that writes dH instead of by a pass over it.  The f16 form does it
 // in its epilogue; the fp32 forms run dprnn_absmax afterwards (dA must then be dense: lda == nd).
-static float* g_dgrad_absmax_out = nullptr;
+static thread_local float* g_dgrad_absmax_out = nullptr;
 extern "C" void dprnn_dgrad_store_absmax(float* slot) { g_dgrad_absmax_out = slot; }
 extern "C" int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 
+static int dgrad_impl(const float* amax, float* max_out, const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
+                      float* dA, int lda, int nd, int64_t rows, void* stream);
 extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
                            float* dA, int lda, int nd, int64_t rows, void* stream) {
     const float* const amax = g_dgrad_f16_amax;         // one-shot selectors: consumed by this call whatever it returns
     g_dgrad_f16_amax = nullptr;
     float* const max_out = g_dgrad_absmax_out;
     g_dgrad_absmax_out = nullptr;
+    return dgrad_impl(amax, max_out, dOut, kd, W0, ldw0, k0, W1, ldw1, dA, lda, nd, rows, stream);
+}
+// the same with the selectors as arguments: f16_grad_max != NULL = the (128 -> 256) product in f16 pieces with dOut scaled from
+// *f16_grad_max; absmax_out != NULL = also leave max|dA| there
+extern "C" int dprnn_dgrad_ex(const float* f16_grad_max, float* absmax_out, const float* dOut, int kd, const float* W0, int ldw0, int k0,
+                              const float* W1, int ldw1, float* dA, int lda, int nd, int64_t rows, void* stream) {
+    return dgrad_impl(f16_grad_max, absmax_out, dOut, kd, W0, ldw0, k0, W1, ldw1, dA, lda, nd, rows, stream);
+}
+static int dgrad_impl(const float* amax, float* max_out, const float* dOut, int kd, const float* W0, int ldw0, int k0, const float* W1, int ldw1,
+                      float* dA, int lda, int nd, int64_t rows, void* stream) {
     if (!dOut || !W0 || !dA || rows <= 0 || (k0 < kd && !W1) || lda < nd) { dprnn_set_error("dprnn_dgrad: null pointer / rows / lda"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     if (amax && kd == 128 && nd == 256 && (lda % 4) == 0) {
@@ -539,7 +570,7 @@ extern "C" int dprnn_dgrad(const float* dOut, int kd, const float* W0, int ldw0,
     }
     if (max_out) {
         if (lda != nd) { dprnn_set_error("dprnn_dgrad: dprnn_dgrad_store_absmax needs a dense dA (lda == nd) outside the f16 form"); return -1; }
-        const int rc = dprnn_dgrad(dOut, kd, W0, ldw0, k0, W1, ldw1, dA, lda, nd, rows, stream);
+        const int rc = dgrad_impl(nullptr, nullptr, dOut, kd, W0, ldw0, k0, W1, ldw1, dA, lda, nd, rows, stream);
         return rc ? rc : dprnn_absmax(dA, rows * nd, max_out, stream);
     }
     // row tiles per wave: 4 x 16 rows while the accumulators fit (ND <= 128), 2 x 16 for the 256-wide outputs

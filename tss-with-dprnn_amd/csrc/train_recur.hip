@@ -316,9 +316,10 @@ void lstm_bwd_kernel(BwdArgs a) {
 }  // namespace
 
 // Arithmetic of the step GEMM of the LSTM backward: 0 = exact fp32 MFMA (lstm_bwd_kernel), 3 = two f16 pieces / three products
-// (train_recur_f16.hip).  Process-wide like dprnn_set_gemm_mode; it decides the layout dprnn_rnn_pack_bwd writes and the kernel
-// dprnn_rnn_bwd launches, so pack and launch under the same setting.  GRU / Elman cells always use the fp32 kernel.
-static int g_bwd_gemm_mode = 0;
+// (train_recur_f16.hip).  The *_ex entry points take it as an argument, the plain ones read this per-thread default; either way
+// dprnn_rnn_pack_bwd records the layout it wrote with the buffer and dprnn_rnn_bwd refuses a buffer of the other layout.
+// GRU / Elman cells always use the fp32 kernel.
+static thread_local int g_bwd_gemm_mode = 0;
 extern "C" void dprnn_set_bwd_gemm_mode(int mode) { g_bwd_gemm_mode = mode == 3 ? 3 : 0; }
 extern "C" int dprnn_get_bwd_gemm_mode(void) { return g_bwd_gemm_mode; }
 int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, float* packedT, hipStream_t st);
@@ -327,20 +328,34 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
                          bool fast, const float* dhmax, hipStream_t st);
 // One-shot selector: the NEXT dprnn_rnn_bwd launch in mode 3 takes max|dH| from *slot (device float, e.g. written by the dprnn_dgrad
 // call that produced dH: dprnn_dgrad_store_absmax) instead of measuring it with a pass over dH.  Ignored by the fp32 kernel.
-static const float* g_bwd_dhmax = nullptr;
+// (dprnn_rnn_bwd_ex takes it as an argument.)
+static thread_local const float* g_bwd_dhmax = nullptr;
 extern "C" void dprnn_rnn_bwd_use_gradmax(const float* slot) { g_bwd_dhmax = slot; }
 
-extern "C" int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
-                                  float* packedT, void* stream) {
+static int rnn_pack_bwd(int mode, int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                        float* packedT, void* stream) {
     if (!w_ih || !w_hh || !packedT) { dprnn_set_error("dprnn_rnn_pack_bwd: null pointer"); return -1; }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_pack_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    if (mode != 0 && mode != 3) { dprnn_set_error("dprnn_rnn_pack_bwd: backward gemm mode must be 0 or 3 (got %d)", mode); return -1; }
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && !w_hh_r) { dprnn_set_error("dprnn_rnn_pack_bwd: incomplete reverse direction"); return -1; }
-    if (cell == 0 && g_bwd_gemm_mode == 3) return recur_bwd_f16_pack(w_ih, w_hh, w_ih_r, w_hh_r, packedT, (hipStream_t)stream);
+    if (cell == 0 && mode == 3) {
+        dprnn_pack_note(packedT, DPRNN_PACK_BWD, 0, 3, ndir);
+        return recur_bwd_f16_pack(w_ih, w_hh, w_ih_r, w_hh_r, packedT, (hipStream_t)stream);
+    }
     const int n = ndir * PACKT_PER_DIR;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, w_ih_r, w_hh_r, packedT, ndir, cell);
+    dprnn_pack_note(packedT, DPRNN_PACK_BWD, cell, 0, ndir);
     return dprnn_check_launch("lstm_pack_bwd_kernel");
+}
+extern "C" int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
+                                  float* packedT, void* stream) {
+    return rnn_pack_bwd(g_bwd_gemm_mode, cell, w_ih, w_hh, w_ih_r, w_hh_r, packedT, stream);
+}
+extern "C" int dprnn_rnn_pack_bwd_ex(int bwd_gemm_mode, int cell, const float* w_ih, const float* w_hh, const float* w_ih_r,
+                                     const float* w_hh_r, float* packedT, void* stream) {
+    return rnn_pack_bwd(bwd_gemm_mode, cell, w_ih, w_hh, w_ih_r, w_hh_r, packedT, stream);
 }
 
 extern "C" int dprnn_lstm_pack_bwd(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r,
@@ -360,11 +375,12 @@ int launch_bwd(const BwdArgs& a, hipStream_t st) {
     static const bool nts = !(getenv("DPRNN_BWD_NT") && atoi(getenv("DPRNN_BWD_NT")) == 0);      // A/B knob: DPRNN_BWD_NT=0 = default policy
     auto kern = fast ? (nts ? &lstm_bwd_kernel<NT, true, CELL> : &lstm_bwd_kernel<NT, true, CELL, false, false>)
                      : (nts ? &lstm_bwd_kernel<NT, false, CELL> : &lstm_bwd_kernel<NT, false, CELL, false, false>);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fast]) {
+    static std::atomic<unsigned long long> attr_mask[2];
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask[fast], &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(rnn_bwd): %s", hipGetErrorString(e)); return -2; }
-        attr_set[fast] = true;
+        dprnn_attr_done(attr_mask[fast], attr_dev);
     }
     hipLaunchKernelGGL(kern, dim3((a.nseq + 16 * NT - 1) / (16 * NT), a.ndir), dim3(256), lds, st, a);
     return dprnn_check_launch("lstm_bwd_kernel");
@@ -373,14 +389,15 @@ int launch_bwd(const BwdArgs& a, hipStream_t st) {
 
 // diagnostic: when set, dprnn_rnn_bwd (LSTM) runs the stamped twin and writes [workgroup][8] u64: total cycles of the
 // step loop, then the cycles wave 0 spent in gates / barrier 1 / GEMM / barrier 2 / tail (tools/bench_recur.py --train 2)
-static unsigned long long* g_bwd_stamps = nullptr;
+static thread_local unsigned long long* g_bwd_stamps = nullptr;
 extern "C" void dprnn_debug_bwd_stamps(unsigned long long* buf) { g_bwd_stamps = buf; }
 
-extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
-                             int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
-                             int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
-    const float* const dhmax = g_bwd_dhmax;              // one-shot: consumed by this call whatever it returns
-    g_bwd_dhmax = nullptr;
+static int rnn_bwd(int mode, const float* dhmax, int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                   int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                   int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    if (mode != 0 && mode != 3) { dprnn_set_error("dprnn_rnn_bwd: backward gemm mode must be 0 or 3 (got %d)", mode); return -1; }
+    if (cell != 0) mode = 0;
     if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_rnn_bwd: null pointer"); return -1; }
     if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2) || rows_total < (int64_t)nseq * T) {
         dprnn_set_error("dprnn_rnn_bwd: bad sizes nseq=%d T=%d inner_n=%d ndir=%d rows_total=%lld", nseq, T, inner_n, ndir,
@@ -393,7 +410,8 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
                         (long long)outer_stride, T);
         return -1;
     }
-    if (cell == 0 && g_bwd_gemm_mode == 3 && !g_bwd_stamps)
+    if (int rc = dprnn_pack_expect(packedT, DPRNN_PACK_BWD, cell, mode, ndir, "dprnn_rnn_bwd")) return rc;
+    if (cell == 0 && mode == 3 && !g_bwd_stamps)
         return recur_bwd_f16_launch(dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, (long long)outer_stride,
                                     (long long)inner_stride, (long long)t_stride, ndir, dprnn_fast_activations_enabled() != 0,
                                     dhmax, (hipStream_t)stream);
@@ -412,6 +430,20 @@ extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const
         case 2: return launch_bwd<2>(a, (hipStream_t)stream);
         default: dprnn_set_error("dprnn_rnn_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1;
     }
+}
+
+extern "C" int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
+                             int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
+                             int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    const float* const dhmax = g_bwd_dhmax;              // one-shot: consumed by this call whatever it returns
+    g_bwd_dhmax = nullptr;
+    return rnn_bwd(g_bwd_gemm_mode, dhmax, cell, dH, tape, packedT, dX, dG, rows_total, nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
+}
+// the same with the mode and max|dH| (device float written by dH's producer; NULL = measure it with a pass over dH) as arguments
+extern "C" int dprnn_rnn_bwd_ex(int bwd_gemm_mode, const float* dh_absmax, int cell, const float* dH, const float* tape,
+                                const float* packedT, float* dX, float* dG, int64_t rows_total, int nseq, int T, int inner_n,
+                                int64_t outer_stride, int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
+    return rnn_bwd(bwd_gemm_mode, dh_absmax, cell, dH, tape, packedT, dX, dG, rows_total, nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
 }
 
 extern "C" int dprnn_lstm_bwd(const float* dH, const float* tape, const float* packedT, float* dX, float* dG,

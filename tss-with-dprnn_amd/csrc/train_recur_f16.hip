@@ -106,6 +106,7 @@ void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restr
 struct Bwd16Args {
     const float* dH; const float* tape; const unsigned* Wp; const float* extra;
     float* dX; float* dG;
+    int* sat;
     long long rows_total;
     int nseq, T, inner_n, ndir;
     long long outer_stride, inner_stride, t_stride;
@@ -232,6 +233,7 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) bw[ct][pc] = wload(0, ct, pc);
 
+    unsigned satm = 0u;                                  // bits of the largest |S_g da| converted to f16 pieces (common.h: sat_track)
     for (int fs = T - 1; fs >= 0; --fs) {
         const long long trow = row0 + t_of(fs) * a.t_stride;
 #pragma unroll
@@ -259,8 +261,10 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
-                    const float s0 = __builtin_amdgcn_fmed3f(da[g][2 * p2] * sg, -F16_XMAX, F16_XMAX);
-                    const float s1 = __builtin_amdgcn_fmed3f(da[g][2 * p2 + 1] * sg, -F16_XMAX, F16_XMAX);
+                    const float u0 = da[g][2 * p2] * sg, u1 = da[g][2 * p2 + 1] * sg;
+                    sat_track(satm, u0, u1);
+                    const float s0 = __builtin_amdgcn_fmed3f(u0, -F16_XMAX, F16_XMAX);
+                    const float s1 = __builtin_amdgcn_fmed3f(u1, -F16_XMAX, F16_XMAX);
                     unsigned w1, w2;
                     split2_pair_f16(s0, s1, w1, w2);
                     char* const d0 = img + nt * 16384 + g * 256, *const d1 = d0;
@@ -326,6 +330,7 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             }
         }
     }
+    sat_commit(a.sat, DPRNN_SAT_BPTT_DA, satm, F16_XMAX);
 }
 
 }  // namespace
@@ -352,15 +357,16 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
     } else {
         hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra + EX_DHMAX);
     }
-    Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, rows_total, nseq, T, inner_n, ndir,
+    Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, dprnn_sat_ptr(), rows_total, nseq, T, inner_n, ndir,
                 outer_stride, inner_stride, t_stride};
     const size_t lds = (size_t)2 * 64 * 512 * 2 + 3 * 64 * 4;
     auto kern = fast ? &lstm_bwd8_f16_kernel<true> : &lstm_bwd8_f16_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fast]) {
+    static std::atomic<unsigned long long> attr_mask[2];
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask[fast], &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lstm_bwd8_f16): %s", hipGetErrorString(e)); return -2; }
-        attr_set[fast] = true;
+        dprnn_attr_done(attr_mask[fast], attr_dev);
     }
     hipLaunchKernelGGL(kern, dim3((nseq + 63) / 64, ndir), dim3(512), lds, st, a);
     return dprnn_check_launch("lstm_bwd8_f16_kernel");

@@ -9,20 +9,24 @@ those kernels.  Stage order follows the reference forward:
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import functools
 import os
+import threading
+import warnings
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 
-from ._lib import DprnnError, check, load_library
+from ._lib import SAT_NAMES, SAT_SLOTS, DprnnError, check, load_library
 
 F_BUILT = 128      # feature_size / hidden_size the kernels are built for (config_bss.yaml:19-20)
 N_BUILT = 64       # input_size (config_bss.yaml:18)
 KS_MAX = 8
 PACK_PER_DIR = 4 * 16 * 8 * 256            # fp32 fragments of one direction (floats)
-PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4   # the optional bf16-split modes need three piece planes (u32 words)
+PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4   # the split modes' piece planes (u32 words; three planes of bf16 pieces, two of f16)
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
@@ -39,22 +43,109 @@ MIN_GROUP_BATCH = 16         # utterances per group, about (much smaller groups 
 # mask head for the last one) instead of a separate pass over the slab.  Off => explicit dprnn_norm_residual_fwd.
 FUSE_NORM = True
 
-# Arithmetic mode of the LSTM gate GEMM (include/dprnn_mi355x.h: dprnn_set_gemm_mode).
+# Arithmetic mode of the contractions (include/dprnn_mi355x.h: dprnn_set_gemm_mode / the *_ex entry points).
 #   3 (default) = every fp32 operand as a sum of TWO f16 pieces of a power-of-two multiple of it (activations x 2^4, weights x
-#                 a per-LSTM 2^e that puts max|W| in [2^13, 2^14)): 22+ operand bits, three cross products on the f16 MFMA
+#                 a per-matrix 2^e that puts max|W| in [2^13, 2^14)): 22+ operand bits, three cross products on the f16 MFMA
 #                 with fp32 accumulation, the dropped product v2 w2 ~ 2^-24 |v||w| -- one fp32 product rounding
-#                 (recur_split.hip; tools/split_precision_study.py).  End to end the same 1.4e-7 rel-L2 between this, mode 1
-#                 and the exact path as each has against float64; every golden (BSS, Spe, IRA; the B = 64 headline batch)
-#                 passes at the same tolerances with every batch size on these kernels.  Faster than the exact kernels at
-#                 EVERY batch size (B = 1: 16 vs 24 ms; B = 64: 97 vs 188 ms; profiles/r02_f16_pieces.txt);
+#                 (recur_split.h; tools/split_precision_study.py) -- in the recurrence, the Linear after it, the bottleneck and the
+#                 mask head.  f16 has 5 exponent bits: |x| > 4062 does not fit 2^4 x.  Every conversion site raises a device flag
+#                 when that happens (dprnn_saturation_begin / _flags); every forward checks the flags before it returns and, if
+#                 one is set, runs again in mode 1 (_guarded below) -- a clamped value never reaches the caller;
 #   1           = three bf16 pieces, the six cross products of order <= 2^-16 on the bf16 MFMA (product error ~2^-24, no
-#                 range assumption at all: bf16 has fp32's exponent); from SPLIT_MIN_BATCH utterances up;
-#   0           = exact fp32 operands on the fp32 MFMA (recur.hip): bit-for-bit an fma chain; DPRNN_GEMM_MODE=0 selects it;
-#   2           = two bf16 pieces / three products (product error ~2^-16): opt-in only, never a default.
+#                 range assumption at all: bf16 has fp32's exponent); from SPLIT_MIN_BATCH utterances up (below: mode 0);
+#   0           = exact fp32 operands on the fp32 MFMA (recur.hip): bit-for-bit an fma chain; DPRNN_GEMM_MODE=0 selects it.
 # GRU / Elman cells always run the exact fp32 kernels (training: training.TRAIN_GEMM_MODE / TRAIN_BWD_GEMM_MODE).
+GEMM_MODES = (0, 1, 3)
 DEFAULT_GEMM_MODE = int(os.environ.get("DPRNN_GEMM_MODE", "3"))
+if DEFAULT_GEMM_MODE not in GEMM_MODES:
+    raise DprnnError(f"DPRNN_GEMM_MODE={DEFAULT_GEMM_MODE}: the gate-GEMM modes are 0 (exact fp32 MFMA), 1 (three bf16 pieces) "
+                     "and 3 (two f16 pieces, the default)")
 GEMM_MODE = DEFAULT_GEMM_MODE
-SPLIT_ONE_GROUP = True      # bf16-split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
+SPLIT_ONE_GROUP = True      # split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
+
+# What a forward does when the f16-pieces arithmetic met a value beyond its range: "fallback" = run the call again in mode 1
+# (default), "raise" = DprnnError.  SATURATION counts the checks, the fall-backs and keeps the flags of the last one.
+ON_SATURATION = os.environ.get("DPRNN_ON_SATURATION", "fallback")
+SATURATION = {"checks": 0, "fallbacks": 0, "last_flags": None, "last_what": None}
+_TLS = threading.local()
+
+
+def current_mode() -> int:
+    """The mode this thread's forwards run in: engine.GEMM_MODE unless a `use_gemm_mode` block is active on the thread."""
+    m = getattr(_TLS, "mode", None)
+    return GEMM_MODE if m is None else m
+
+
+@contextlib.contextmanager
+def use_gemm_mode(mode: int):
+    """Run the forwards of this block, on this thread, in gate-GEMM mode `mode` (other threads keep theirs: the C library's mode
+    is per thread too, and the packed weights carry their format)."""
+    if mode not in GEMM_MODES:
+        raise DprnnError(f"gate-GEMM mode {mode}: choose one of {GEMM_MODES}")
+    prev = getattr(_TLS, "mode", None)
+    _TLS.mode = mode
+    try:
+        yield
+    finally:
+        _TLS.mode = prev
+
+
+def _bn_buffers(module):
+    if module is None:
+        return []
+    return [b for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
+            for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
+
+
+def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None):
+    """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
+    f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
+    fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
+    flags come back with a 32-byte copy).  Nested calls are covered by the outermost guard.
+    active: whether detection is needed at all (default: the thread's mode is 3)."""
+    if active is None:
+        active = current_mode() == 3
+    if not active or getattr(_TLS, "guard", 0) > 0:
+        return primary()
+    lib = load_library()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
+        bufs = _bn_buffers(module)
+        keep = [b.clone() for b in bufs]
+        check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
+        _TLS.guard = 1
+        host = (ctypes.c_int32 * SAT_SLOTS)()
+        try:
+            out = primary()
+            rc = lib.dprnn_saturation_flags(ctypes.addressof(host), stream.cuda_stream)
+        finally:
+            _TLS.guard = 0
+            lib.dprnn_saturation_begin(0, 0)
+        if rc < 0:
+            check(lib, rc, "dprnn_saturation_flags")
+        SATURATION["checks"] += 1
+        if rc == 0:
+            return out
+        hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
+        SATURATION["fallbacks"] += 1
+        SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
+        msg = (f"{what}: the f16-pieces arithmetic met values beyond its range ({', '.join(hit)}: |x| > 4062 after scaling, or "
+               "Inf / NaN)")
+        if ON_SATURATION == "raise":
+            raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
+        if SATURATION["fallbacks"] == 1:
+            warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
+                          "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=3)
+        del out
+        for b, k in zip(bufs, keep):
+            b.copy_(k)
+        _TLS.guard = 1                 # the fall-back arithmetic has no range assumption: nothing to detect
+        try:
+            return fallback()
+        finally:
+            _TLS.guard = 0
+
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
 # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
@@ -195,7 +286,7 @@ def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bi
     if w.shape[0] != F_BUILT or w.shape[1] < geo.N:
         raise DprnnError(f"1x1 conv weight {tuple(w.shape)} does not fit the {geo.N}->{F_BUILT} kernel")
     Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
-    mode = GEMM_MODE if gemm_mode is None else gemm_mode
+    mode = current_mode() if gemm_mode is None else gemm_mode
     prev = st.lib.dprnn_get_gemm_mode()
     st.lib.dprnn_set_gemm_mode(3 if mode == 3 else 0)
     try:
@@ -246,6 +337,7 @@ class _Group:
         self.H = self.arena[3 * n:]
         self.pending = None           # (stats_slot, gamma, beta, eps) of a norm not yet applied to X
         self.n_concurrent = 1         # utterance groups in flight together (set by dprnn_process)
+        self.mode = 0                 # gate-GEMM mode of this forward (set by dprnn_process; the packed weights are in it)
 
 
 def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool):
@@ -271,14 +363,13 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     cell = CELL_ID[rnn.rnn.mode]
     if cell != 0 and tile > 32:
         tile = 32
-    if cell == 0 and st.lib.dprnn_get_gemm_mode() != 0:
-        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent,
-                                                                     st.lib.dprnn_get_gemm_mode())
+    if cell == 0 and g.mode != 0:
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
     if g.pending is None:
-        st.call("dprnn_rnn_fwd", cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
+        st.call("dprnn_rnn_fwd_ex", g.mode, cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
         pstats, pg, pb, peps = g.pending
-        st.call("dprnn_rnn_fwd", cell, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
+        st.call("dprnn_rnn_fwd_ex", g.mode, cell, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
                 _p(g.X2), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
         g.X, g.X2 = g.X2, g.X
         g.pending = None
@@ -328,23 +419,25 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 
 GROUP_SIZES = None        # experiment knob: explicit utterance-group sizes (must sum to the batch), else an even split
 
 
-SPLIT_MIN_BATCH = int(os.environ.get("DPRNN_SPLIT_MIN_BATCH", "20"))    # bf16 modes 1 / 2: below this the exact fp32 kernels' small tiles are faster (profiles/r02_split_wide.txt: B = 16 62 vs 54 ms)
+SPLIT_MIN_BATCH = int(os.environ.get("DPRNN_SPLIT_MIN_BATCH", "20"))    # mode 1: below this the exact fp32 kernels' small tiles are faster (profiles/r02_split_wide.txt: B = 16 62 vs 54 ms)
 
 
 def effective_gemm_mode(B: int, blocks=None) -> int:
     """GEMM_MODE as it applies to a batch of B: the bf16-split kernels need launches that fill the chip, and only the
     LSTM cell has them; everything else runs the exact fp32 kernels (which are never less accurate)."""
-    if GEMM_MODE == 0 or (GEMM_MODE != 3 and B < SPLIT_MIN_BATCH):      # the f16 form wins at every size, down to one utterance
+    mode = current_mode()
+    if mode == 0 or (mode != 3 and B < SPLIT_MIN_BATCH):      # the f16 form wins at every size, down to one utterance
         return 0
     if blocks is not None and not all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in blocks):
         return 0
-    return GEMM_MODE
+    return mode
 
 
 def _leaves_exact_mode(fn):
-    """The gate-GEMM mode is process-wide library state (dprnn_set_gemm_mode) that decides both how dprnn_rnn_pack lays the
-    weights out and which recurrence kernels read them.  A forward selects its mode and, whatever happens, hands the library
-    back in the exact fp32 mode, so that no later caller of the C ABI packs or launches under a mode it did not ask for."""
+    """The library's default gate-GEMM mode is per-thread state (dprnn_set_gemm_mode); the recurrences get their mode as an
+    argument (dprnn_rnn_pack_ex / dprnn_rnn_fwd_ex) and the packed weights carry their format, the row GEMMs (projection,
+    bottleneck, mask head) read the thread's default.  A forward sets it and, whatever happens, hands the thread back in the
+    exact fp32 mode, so that no later caller of the C ABI on this thread runs under a mode it did not ask for."""
     @functools.wraps(fn)
     def run(st, *args, **kwargs):
         try:
@@ -393,14 +486,15 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
     blocks = list(sep.dprnn_blocks)
 
-    st.lib.dprnn_set_gemm_mode(effective_gemm_mode(B, blocks))
+    mode = effective_gemm_mode(B, blocks)
+    st.lib.dprnn_set_gemm_mode(mode)            # the row GEMMs of this forward (this thread's default)
     # pack every LSTM once, on the caller's stream, before the groups fork
     packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
     bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
             _, fw, bw = _rnn_tensors(rnn, dev)
-            st.call("dprnn_rnn_pack", CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
+            st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
                     _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
@@ -408,7 +502,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
     parts = _split(B) if debug is None else [(0, B)]
-    if st.lib.dprnn_get_gemm_mode() != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
+    if mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
         parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
@@ -423,6 +517,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     for g in groups:
         g.n_concurrent = len(groups)
+        g.mode = mode
         g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
         debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()
@@ -494,7 +589,7 @@ def check_input(x: torch.Tensor, what: str = "input") -> torch.Tensor:
     return x.contiguous()
 
 
-def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
+def _tasnet_forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
     """DPRNNTasNet.forward (dprnn.py:271-283): [B, T] -> [B, 2, T_out]."""
     cfg = model.cfg
     check_supported(cfg)
@@ -645,7 +740,7 @@ def _att_row_scale(st: Stage, sep, cfg, wav, enc_w, geo: Geometry, stats_slot, a
     return row_scale
 
 
-def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
+def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
     """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) / DPRNNSpeIRATasNet.forward (dprnn_spe_ira.py:179-190):
     (mix [B,T], aux [B,Ta], aux_len) -> (estimate [B,T_out], speaker logits [B,num_spks])."""
     cfg = model.cfg
@@ -740,7 +835,7 @@ def _check_frames(x: torch.Tensor, channels: int, what: str) -> torch.Tensor:
     return x
 
 
-def separator_masks(sep, frames: torch.Tensor) -> torch.Tensor:
+def _separator_masks_impl(sep, frames: torch.Tensor) -> torch.Tensor:
     """DPRNN._dprnn_process (dprnn.py:171-186 == dprnn_spe.py:231-248): bottleneck output [B, F, L] -> masks [B, 2, N, L]."""
     cfg = dict(input_size=sep.input_size, feature_size=sep.feature_size, hidden_size=sep.dprnn_blocks[0].intra_rnn.hidden_size,
                rnn_type=sep.dprnn_blocks[0].intra_rnn.rnn.mode, kernel_size=1, norm_type=sep.norm_type,
@@ -778,7 +873,7 @@ def _rows_affine(st: Stage, x_cl, norm, B: int, L: int, N: int):
     return sc, sh
 
 
-def separator_forward(sep, enc: torch.Tensor) -> torch.Tensor:
+def _separator_forward_impl(sep, enc: torch.Tensor) -> torch.Tensor:
     """DPRNN.forward (dprnn.py:166-187) on a materialised encoder output [B, N, L] -> masks [B, 2, N, L]."""
     enc = _check_frames(enc, sep.input_size, "separator input")
     _no_grad_only("DPRNN.forward", enc, module=sep)
@@ -796,7 +891,7 @@ def separator_forward(sep, enc: torch.Tensor) -> torch.Tensor:
     return separator_masks(sep, Y.view(B, L, F_BUILT).transpose(1, 2))
 
 
-def auxiliary_embedding(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
+def _auxiliary_embedding_impl(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
     """DPRNNSpe._auxiliary (dprnn_spe.py:156-163): encoder output of the reference utterance [B, N, La] -> [B, E]."""
     aux = _check_frames(aux, sep.input_size, "aux")
     _no_grad_only("_auxiliary", aux, module=sep.spk_encoder)
@@ -879,7 +974,7 @@ def _bn_training(module) -> bool:
 
 
 def ragged_supported(sep) -> bool:
-    return GEMM_MODE != 0 and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
+    return current_mode() in (1, 3) and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
 
 
 @_leaves_exact_mode
@@ -892,8 +987,9 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     K, P, ks, N = geos[0].K, geos[0].P, geos[0].ks, geos[0].N
     blocks = list(sep.dprnn_blocks)
     if not ragged_supported(sep):
-        raise DprnnError("ragged batches need engine.GEMM_MODE 1, 2 or 3 and LSTM cells")
-    st.lib.dprnn_set_gemm_mode(GEMM_MODE)
+        raise DprnnError("ragged batches need gate-GEMM mode 1 or 3 and LSTM cells")
+    mode = current_mode()
+    st.lib.dprnn_set_gemm_mode(mode)
     rows = np.array([g.S * K for g in geos], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
     total = int(starts[-1])
@@ -918,10 +1014,16 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
             _, fw, bw = _rnn_tensors(rnn, dev)
-            st.call("dprnn_rnn_pack", 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
+            st.call("dprnn_rnn_pack_ex", mode, 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
     m = total * F_BUILT
-    arena = torch.empty(5 * m, device=dev, dtype=torch.float32)
+    # H [total][2F] is dead once the last projection has read it; the mask head of utterance u then takes its U [L_u][2F] and
+    # V [2 L_u][F] from the same region.  S_u K rows of 2F floats cover them when hop <= K / 2 (S K >= 2 L); a larger hop needs
+    # more, so every utterance gets max(S_u K 2F, 4 L_u F) floats at its own offset (the non-ragged arena does the same through
+    # dprnn_workspace_bytes).
+    head_need = np.array([max(g.S * K * 2 * F_BUILT, 4 * g.L * F_BUILT) for g in geos], dtype=np.int64)
+    head_off = np.concatenate([[0], np.cumsum(head_need)]).astype(np.int64)
+    arena = torch.empty(3 * m + int(head_off[-1]), device=dev, dtype=torch.float32)
     X, X2, Z, H = arena[:m], arena[m: 2 * m], arena[2 * m: 3 * m], arena[3 * m:]
     stats = torch.zeros(2 * len(blocks), n, 2, device=dev, dtype=torch.float64)
     fan = _Fan(st, n)
@@ -937,7 +1039,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             slot = 2 * i + (0 if intra else 1)
             ndir = 2 if rnn.rnn.bidirectional else 1
             pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
-            st.call("dprnn_rnn_fwd_ragged", _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
+            st.call("dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
                     int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
                     K if intra else 0, K, ndir)
             if pending is not None:
@@ -956,8 +1058,9 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     def head(sg, u):
         g = geos[u]
         r0 = int(starts[u])
-        Hu = H[r0 * 2 * F_BUILT: (r0 + int(rows[u])) * 2 * F_BUILT]          # this utterance's share of H: U | V scratch
+        Hu = H[int(head_off[u]): int(head_off[u + 1])]                        # this utterance's U | V scratch
         U, V = Hu[: g.L * 2 * F_BUILT], Hu[g.L * 2 * F_BUILT: 2 * g.L * 2 * F_BUILT]
+        assert V.numel() == g.L * 2 * F_BUILT
         if pending is None:
             sg.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
         else:
@@ -980,7 +1083,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     return taps, (masked if want_masked else None)
 
 
-def tasnet_forward_ragged(model, wavs):
+def _tasnet_forward_ragged_impl(model, wavs):
     """DPRNNTasNet.forward for a list of 1-D waveforms of different lengths -> list of [2, T_out_u] (each equal to the
     batch-of-one forward of that utterance)."""
     cfg = model.cfg
@@ -1006,7 +1109,7 @@ def tasnet_forward_ragged(model, wavs):
         return [o[0] for o in outs]
 
 
-def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
+def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
     """DPRNNSpeTasNet / DPRNNSpeIRATasNet forward for lists of mixtures and reference utterances of different lengths ->
     list of (estimate [T_out_u], logits [num_spks]); every utterance keeps batch-of-one semantics (BatchNorm statistics of
     the speaker branch included, as the reference's one-at-a-time loop has them)."""
@@ -1086,3 +1189,58 @@ def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
         r3 = [fan.run(u, lambda sg, u=u: last(sg, u)) for u in range(n)]
         fan.join()
         return [(est[0, 0, :], logits[0]) for est, logits in r3]
+
+
+# ------------------------------------------------------------------------------------------------ guarded entry points
+# What the model classes call.  Each runs its forward with saturation detection (see _guarded) and, should the f16-pieces
+# arithmetic have met a value beyond its range, again in mode 1 (three bf16 pieces: no range assumption).
+def _in_mode(mode: int, fn):
+    def run():
+        with use_gemm_mode(mode):
+            return fn()
+    return run
+
+
+def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
+    wav = check_input(wav)
+    run = lambda: _tasnet_forward_impl(model, wav, debug)
+    return _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None)
+
+
+def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
+    wav = check_input(wav)
+    run = lambda: _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
+    return _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation)
+
+
+def separator_masks(sep, frames: torch.Tensor):
+    frames = _check_frames(frames, F_BUILT, "bottleneck output")
+    run = lambda: _separator_masks_impl(sep, frames)
+    return _guarded(frames.device, run, _in_mode(1, run), "DPRNN._dprnn_process", None)
+
+
+def separator_forward(sep, enc: torch.Tensor):
+    enc = _check_frames(enc, sep.input_size, "separator input")
+    run = lambda: _separator_forward_impl(sep, enc)
+    return _guarded(enc.device, run, _in_mode(1, run), "DPRNN.forward", None)
+
+
+def auxiliary_embedding(sep, aux: torch.Tensor, aux_len):
+    aux = _check_frames(aux, sep.input_size, "aux")
+    run = lambda: _auxiliary_embedding_impl(sep, aux, aux_len)
+    return _guarded(aux.device, run, _in_mode(1, run), "DPRNNSpe._auxiliary", sep.spk_encoder)
+
+
+def tasnet_forward_ragged(model, wavs):
+    for w in wavs:
+        check_input(w.reshape(1, -1))
+    run = lambda: _tasnet_forward_ragged_impl(model, wavs)
+    return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNTasNet ragged forward", None)
+
+
+def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
+    for w in wavs:
+        check_input(w.reshape(1, -1))
+    run = lambda: _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira)
+    return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNSpeTasNet ragged forward", model.separation)
+

@@ -62,13 +62,22 @@ def separate_many(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, ext
 
     wavs: 1-D float32 device tensors.  For DPRNN-Spe / IRA models pass extra_inputs = [(aux 1-D tensor, aux_len)]
     and each output is (estimate, logits).  ragged: None = one ragged launch per path when the model and the gate-GEMM mode
-    support it and there are at least RAGGED_MIN_UTTS utterances, else equal-length batches on streams; True / False force."""
+    support it and there are at least RAGGED_MIN_UTTS utterances, else equal-length batches on streams; True / False force.
+    The whole call is ONE saturation-guarded unit (engine._guarded): the forwards inside enqueue without synchronising, the
+    flags of all of them are read once at the end, and a saturated call is repeated in gate-GEMM mode 1."""
     if len(wavs) == 0:
         return []
     dev = wavs[0].device
     if not all(w.is_cuda and w.dim() == 1 and w.dtype == torch.float32 for w in wavs):
         raise DprnnError("separate_many expects 1-D float32 tensors on a HIP device")
     from . import engine
+    run = lambda: _separate_many(model, wavs, max_streams, extra_inputs, ragged)
+    return engine._guarded(dev, run, engine._in_mode(1, run), "separate_many", getattr(model, "separation", None))
+
+
+def _separate_many(model, wavs, max_streams, extra_inputs, ragged) -> List:
+    from . import engine
+    dev = wavs[0].device
     if ragged is None:
         ragged = len(wavs) >= RAGGED_MIN_UTTS and engine.ragged_supported(model.separation)
     if ragged:

@@ -16,7 +16,9 @@ backward (forward recomputation, +1 forward per step), smaller batches keep ever
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from typing import Dict, List, Optional
 
 import torch
@@ -48,6 +50,34 @@ TRAIN_BWD_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_BWD_GEMM_MODE", "3"))
 # ... and, with it, the LSTM weight-gradient GEMMs dG^T [x | h_prev] in f16 pieces with the same gradient scale (wgrad_f16_kernel)
 TRAIN_WGRAD_F16 = os.environ.get("DPRNN_TRAIN_WGRAD_F16", "1") != "0"
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
+_TLS = threading.local()
+
+
+def train_modes():
+    """(forward gate-GEMM mode, BPTT mode, f16 weight gradients) of this thread's training calls: the module settings unless a
+    `use_train_modes` block is active on the thread (the saturation fall-back runs one)."""
+    o = getattr(_TLS, "modes", None)
+    fwd = TRAIN_GEMM_MODE if o is None or o[0] is None else o[0]
+    bwd = TRAIN_BWD_GEMM_MODE if o is None or o[1] is None else o[1]
+    return (3 if fwd == 3 else 0), (3 if bwd == 3 else 0), (TRAIN_WGRAD_F16 and bwd == 3)
+
+
+@contextlib.contextmanager
+def use_train_modes(fwd: Optional[int] = None, bwd: Optional[int] = None):
+    prev = getattr(_TLS, "modes", None)
+    _TLS.modes = (fwd if fwd is not None else (prev[0] if prev else None), bwd if bwd is not None else (prev[1] if prev else None))
+    try:
+        yield
+    finally:
+        _TLS.modes = prev
+
+
+def _exact(fn, fwd: bool = True, bwd: bool = True):
+    """fn under the exact fp32 kernels (the range-free arithmetic a saturated f16-pieces training call is repeated in)."""
+    def run():
+        with use_train_modes(0 if fwd else None, 0 if bwd else None):
+            return fn()
+    return run
 
 
 def check_supported_train(cfg: dict) -> None:
@@ -107,7 +137,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     stats = torch.zeros(1 + npth, B, 2, device=dev, dtype=torch.float64)
     lib.dprnn_set_gemm_mode(0)
     lstm_only = all(rnn.rnn.mode == "LSTM" for rnn, _, _, _ in paths)
-    fwd_mode = 3 if (TRAIN_GEMM_MODE == 3 and lstm_only) else 0
+    fwd_mode = 3 if (train_modes()[0] == 3 and lstm_only) else 0
     fusion = fusion or {}
     sc, sh = engine.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], fusion.get("mul"), fusion.get("add"))
     Y = engine.bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, fusion.get("row_bias"), fusion.get("row_scale"),
@@ -131,16 +161,16 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
         for p, (rnn, lin, norm, intra) in enumerate(paths):
             ndir, fw, bw = _rnn_tensors(rnn, dev)
             cell = engine.CELL_ID[rnn.rnn.mode]
-            st.call("dprnn_rnn_pack", cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+            st.call("dprnn_rnn_pack_ex", fwd_mode, cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
             addr = _addr(geo, intra)
             Hp = torch.empty(rows, ndir * F_BUILT, **f32)
             tape = torch.empty(lib.dprnn_rnn_tape_floats(cell, addr[0], addr[1], ndir), **f32)
             if pending is None:
-                st.call("dprnn_rnn_fwd_train", cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+                st.call("dprnn_rnn_fwd_train_ex", fwd_mode, cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
             else:               # X[p] = X[p-1] + norm(Z[p-1]) on the fly
                 Zq, sq, gq, bq, eq = pending
                 Xn = torch.empty(rows, F_BUILT, **f32)
-                st.call("dprnn_rnn_fwd_train", cell, _p(X[p - 1]), _p(Zq), _p(sq), _p(gq), _p(bq), eq, S if intra else K, S * K, _p(Xn),
+                st.call("dprnn_rnn_fwd_train_ex", fwd_mode, cell, _p(X[p - 1]), _p(Zq), _p(sq), _p(gq), _p(bq), eq, S if intra else K, S * K, _p(Xn),
                         _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
                 X.append(Xn)
                 if not keep:
@@ -253,8 +283,11 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
               (4 * F_BUILT, 2 * F_BUILT, rows), (F_BUILT, N, B * L)]
     ws = torch.empty(max(lib.dprnn_wgrad_workspace_floats(m_, n_, r_) for m_, n_, r_ in shapes), **f32)
 
-    def wgrad(Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, dW, ldm, ldn, db0, db1):
-        st.call("dprnn_wgrad", Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, _p(dW), ldm, ldn,
+    _, bwd_mode, wgrad_f16 = train_modes()
+
+    def wgrad(Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, dW, ldm, ldn, db0, db1, f16_max=0):
+        # f16_max: device float with the maximum the f16-pieces form scales P from (0 = the fp32 MFMA kernel)
+        st.call("dprnn_wgrad_ex", f16_max, Pp, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, nrows, t_stride, T, _p(dW), ldm, ldn,
                 _p(db0), _p(db1), 0, _p(ws))
 
     # ---- decoder, masking, mask activation (encoder_decoder.py:40-42, dprnn.py:277, :161-164)
@@ -318,10 +351,9 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         a_red, a_dgb = scr.slot(f"red{p}", 2 * B), scr.slot(f"dgb{p}", 2 * F_BUILT)
         st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
                 _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
-        f16_lin = TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16      # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum,
-        if f16_lin:                                                 # which the kernel that writes dZ measures
-            lib.dprnn_gn_bwd_dz_store_absmax(zmax.data_ptr())
-        st.call("dprnn_gn_bwd_dz", _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
+        f16_lin = wgrad_f16                                         # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum,
+        st.call("dprnn_gn_bwd_dz_ex", zmax.data_ptr() if f16_lin else 0,      # which the kernel that writes dZ measures
+                _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
         gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
         grads[f"{blk}_norm.{gname}"] = to_grad(a_dgb, gamma)
         grads[f"{blk}_norm.{bname}"] = to_grad(a_dgb + 8 * F_BUILT, beta)
@@ -329,32 +361,24 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         hp = ndir * F_BUILT
         dH = torch.empty(rows, hp, **f32)
         cell = engine.CELL_ID[rnn.rnn.mode]
-        bptt_f16 = TRAIN_BWD_GEMM_MODE == 3 and cell == 0
-        if f16_lin and ndir == 2:
-            lib.dprnn_dgrad_use_f16_pieces(zmax.data_ptr())
-        if bptt_f16:                                                # the f16 BPTT scales by max|dH|: measured where dH is written
-            lib.dprnn_dgrad_store_absmax(hmax.data_ptr())
-        st.call("dprnn_dgrad", _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
+        bptt_f16 = bwd_mode == 3 and cell == 0
+        # the f16 BPTT scales by max|dH|: measured where dH is written
+        st.call("dprnn_dgrad_ex", zmax.data_ptr() if (f16_lin and ndir == 2) else 0, hmax.data_ptr() if bptt_f16 else 0,
+                _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
         Hp = H[p]
-        if f16_lin:
-            lib.dprnn_wgrad_use_f16_pieces(zmax.data_ptr())
         wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
-              F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None)
+              F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None, f16_max=zmax.data_ptr() if f16_lin else 0)
         grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
         # recurrence (dprnn.py:86,95)
         addr = _addr(geo, intra)
         kg = F_BUILT if cell == 2 else 4 * F_BUILT          # gate-gradient columns per direction: LSTM i,f,g,o; GRU r,z,n_x,n_h; RNN a
         dG = torch.empty(rows, ndir * kg, **f32)
-        lib.dprnn_set_bwd_gemm_mode(3 if bptt_f16 else 0)     # layout of the pack = kernel of the launch
-        try:
-            st.call("dprnn_rnn_pack_bwd", cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
-            if bptt_f16:
-                lib.dprnn_rnn_bwd_use_gradmax(hmax.data_ptr())
-            st.call("dprnn_rnn_bwd", cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG), rows, *addr, ndir)
-        finally:
-            lib.dprnn_set_bwd_gemm_mode(0)
+        bm = 3 if bptt_f16 else 0                               # layout of the pack = kernel of the launch (checked by the library)
+        st.call("dprnn_rnn_pack_bwd_ex", bm, cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
+        st.call("dprnn_rnn_bwd_ex", bm, hmax.data_ptr() if bptt_f16 else 0, cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG),
+                rows, *addr, ndir)
         del dH
         pre = f"{blk}_rnn.rnn."
         for d in range(ndir):
@@ -364,10 +388,10 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
             if cell == 0:         # one GEMM: dG^T [x | h_prev] -> [W_ih | W_hh] (torch rows i,f,g,o)
                 gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
                 gbias = torch.empty(4 * F_BUILT, **f32)
-                if TRAIN_BWD_GEMM_MODE == 3 and TRAIN_WGRAD_F16:      # dG^T [x | h_prev] in f16 pieces, dG scaled like the BPTT's da
-                    lib.dprnn_wgrad_use_f16_pieces(packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir))
+                # with the f16 BPTT: dG^T [x | h_prev] in f16 pieces, dG scaled like the BPTT's da
                 wgrad(gbase, ndir * kg, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, *hprev, rows, addr[5], addr[1],
-                      gcat, 2 * F_BUILT, 1, gbias, None)
+                      gcat, 2 * F_BUILT, 1, gbias, None,
+                      f16_max=(packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir)) if (bptt_f16 and wgrad_f16) else 0)
                 g_ih, g_hh = gcat[:, :F_BUILT].contiguous(), gcat[:, F_BUILT:].contiguous()
                 b_ih, b_hh = gbias, gbias.clone()
             elif cell == 1:       # torch rows r,z,n: W_ih pairs with (r, z, n_x), W_hh with (r, z, n_h)
@@ -551,10 +575,13 @@ class _TasNetFunction(torch.autograd.Function):
         per_utt = saved_bytes_per_utt(geo, len(ndirs), ndirs)
         mb_max = max(1, save_budget_bytes(wav.device) // per_utt)
         ctx.done = False
-        if mb_max >= B:
-            out, saved = _forward_groups(model, wav)
-            ctx.saved, ctx.wav, ctx.mb = saved, None, B
-        else:
+        ctx.wav_all = wav               # 4 bytes per sample: what a saturated backward needs to run again from the waveform
+        ctx.fwd_exact = False
+
+        def run():
+            if mb_max >= B:
+                out, saved = _forward_groups(model, wav)
+                return out, saved, None, B
             # too large to keep: micro-batches.  The first one runs the training forward and keeps its activations; the
             # rest run the SAME training kernels now without keeping anything (forward_train(keep=False): the outputs the
             # loss sees and the gradients the backward recomputes come from one arithmetic, whatever engine.GEMM_MODE
@@ -565,24 +592,37 @@ class _TasNetFunction(torch.autograd.Function):
             outs = [out0]
             for b0 in range(mb, B, mb):
                 outs.append(_forward_groups(model, wav[b0:b0 + mb], keep=False)[0])
-            out = torch.cat(outs)
-            ctx.saved, ctx.wav, ctx.mb = saved, wav, mb
+            return torch.cat(outs), saved, wav, mb
+
+        def run_exact():                # the f16-pieces forward met a value beyond its range: the exact fp32 kernels, and the
+            ctx.fwd_exact = True        # backward recomputes in them too
+            return _exact(run, fwd=True, bwd=False)()
+
+        out, ctx.saved, ctx.wav, ctx.mb = engine._guarded(wav.device, run, run_exact, "DPRNNTasNet training forward",
+                                                          active=train_modes()[0] == 3)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         with torch.cuda.device(d_out.device):
-            return _TasNetFunction._backward(ctx, d_out)
+            if ctx.done:
+                raise DprnnError("DPRNN MI355X training path: backward() was called a second time on the same forward; the "
+                                 "saved activations (tape) are released by the first backward (retain_graph is not supported "
+                                 "-- run the forward again)")
+            ctx.done = True
+            d_out = d_out.contiguous()
+            fwd_only = (lambda fn: _exact(fn, fwd=True, bwd=False)) if ctx.fwd_exact else (lambda fn: fn)
+            first = fwd_only(lambda: _TasNetFunction._backward(ctx, d_out))
+            # a BPTT / weight-gradient launch in f16 pieces met a gradient beyond its scale's range (more than 2^10 above the
+            # largest incoming one, or Inf / NaN): everything again from the waveform with the exact fp32 backward kernels
+            again = _exact(lambda: _TasNetFunction._recompute(ctx, d_out), fwd=ctx.fwd_exact, bwd=True)
+            grads = engine._guarded(d_out.device, first, again, "DPRNNTasNet training backward", active=train_modes()[1] == 3)
+            ctx.saved = ctx.wav = ctx.wav_all = None
+            return (None, None, None) + tuple(grads[n] for n in ctx.names)
 
     @staticmethod
     def _backward(ctx, d_out):
-        model, names = ctx.model, ctx.names
-        if ctx.done:
-            raise DprnnError("DPRNN MI355X training path: backward() was called a second time on the same forward; the "
-                             "saved activations (tape) are released by the first backward (retain_graph is not supported "
-                             "-- run the forward again)")
-        ctx.done = True
-        d_out = d_out.contiguous()
+        model = ctx.model
         mb = ctx.mb
         grads = _backward_groups(model, ctx.saved, d_out[:mb])
         ctx.saved = None
@@ -594,7 +634,23 @@ class _TasNetFunction(torch.autograd.Function):
                 del saved
                 for k in g:
                     grads[k] += g[k]
-        return (None, None, None) + tuple(grads[n] for n in names)
+        return grads
+
+    @staticmethod
+    def _recompute(ctx, d_out):
+        model, wav, mb = ctx.model, ctx.wav_all, ctx.mb
+        ctx.saved = None
+        grads = None
+        for b0 in range(0, wav.shape[0], mb):
+            _, saved = _forward_groups(model, wav[b0:b0 + mb])
+            g = _backward_groups(model, saved, d_out[b0:b0 + mb])
+            del saved
+            if grads is None:
+                grads = g
+            else:
+                for k in g:
+                    grads[k] += g[k]
+        return grads
 
 
 def tasnet_forward_autograd(model, wav: torch.Tensor) -> torch.Tensor:

@@ -153,7 +153,7 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     aux_len_dev = engine._aux_len_tensor(aux_len, B, dev)
     stats_a = torch.zeros(B, 2, device=dev, dtype=torch.float64)
     sc_a, sh_a = engine.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats_a)
-    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a, gemm_mode=training.TRAIN_GEMM_MODE).view(B * geo_a.L, F_BUILT)
+    A0 = engine.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a, gemm_mode=training.train_modes()[0]).view(B * geo_a.L, F_BUILT)
     v0, tail0 = _spk_tail_forward(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
     spk0 = dict(aux=aux, geo_a=geo_a, stats_a=stats_a, sc_a=sc_a, sh_a=sh_a, tail=tail0, emb=v0)
     out, saved = training.forward_train(model, wav, keep=True, fusion=_fusion_for(st, model, wav, v0, geo), want_d0=ira)
@@ -434,15 +434,38 @@ class _SpeFunction(torch.autograd.Function):
     def forward(ctx, model, wav, aux, aux_len, names, *params):
         ctx.model, ctx.names = model, names
         ctx.ira = bool(getattr(model, "_ira", False))
-        est, logits, saved = spe_forward_train(model, wav, aux, aux_len, ctx.ira)
+        ctx.inputs = (wav, aux, aux_len)        # what a saturated backward needs to run again from the waveforms
+        ctx.fwd_exact = False
+        run = lambda: spe_forward_train(model, wav, aux, aux_len, ctx.ira)
+
+        def run_exact():
+            ctx.fwd_exact = True
+            return training._exact(run, fwd=True, bwd=False)()
+        est, logits, saved = engine._guarded(wav.device, run, run_exact, "DPRNNSpeTasNet training forward", model.separation,
+                                             active=training.train_modes()[0] == 3)
         ctx.saved = saved
         return est, logits
 
     @staticmethod
     def backward(ctx, d_est, d_logits):
+        model = ctx.model
         with torch.cuda.device(d_est.device):
-            grads = spe_backward(ctx.model, ctx.saved, d_est.contiguous().float(), d_logits, ctx.ira)
-        ctx.saved = None
+            d_est = d_est.contiguous().float()
+            first = lambda: spe_backward(model, ctx.saved, d_est, d_logits, ctx.ira)
+            if ctx.fwd_exact:
+                first = training._exact(first, fwd=True, bwd=False)
+
+            def again():                 # f16-pieces backward saturated: forward again (BatchNorm running buffers put back
+                ctx.saved = None         # afterwards: the step has already updated them once), backward in the exact kernels
+                bufs = engine._bn_buffers(model.separation)
+                keep = [b.clone() for b in bufs]
+                _, _, saved = spe_forward_train(model, *ctx.inputs, ctx.ira)
+                for b, k in zip(bufs, keep):
+                    b.copy_(k)
+                return spe_backward(model, saved, d_est, d_logits, ctx.ira)
+            grads = engine._guarded(d_est.device, first, training._exact(again, fwd=ctx.fwd_exact, bwd=True),
+                                    "DPRNNSpeTasNet training backward", active=training.train_modes()[1] == 3)
+        ctx.saved = ctx.inputs = None
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
