@@ -9,9 +9,17 @@
 A "step" is one forward of the HIP path over one batch of 64 synthetic 3-second mixtures already
 resident in HBM (BASELINE.json configs[1]).  Utterances are independent, so ranks shard the batch with
 no data-path collective (weak scaling: 64 utterances per GPU).  Rank 0 prints ONE JSON line with
-  roofline     : the dominant kernel (fused BiLSTM recurrence, dprnn_rnn_fwd) timed with HIP events
-                 on its launch stream inside the timed region; achieved = algorithmic FLOPs per launch
-                 (rows * 2 dirs * 2*256*512) / mean launch time; peak = 157.3 TFLOP/s fp32 MFMA.
+  value        : utterances/s in the engine's default arithmetic (`dtype` names it: fp32 operands as two f16 pieces,
+                 three products on the f16 MFMA, fp32 accumulate; every forward checks the saturation flags of that
+                 arithmetic before it returns -- the check is inside the timed region);
+  exact_fp32   : the SAME batch, steps and warm-up under DPRNN_GEMM_MODE=0 (fp32 operands on the fp32 MFMA, the
+                 reference's own precision), timed right after the headline region, with its own roofline (peak 157.3);
+  roofline     : the dominant kernel (fused BiLSTM recurrence, dprnn_rnn_fwd_ex) timed with HIP events
+                 on its launch streams inside the timed region; achieved = algorithmic FLOPs per launch
+                 (rows * 2 dirs * 2*256*512) / MEAN LAUNCH DURATION (what rocprofv3 --stats reports per kernel);
+                 peak = the ceiling of the arithmetic that runs (2500 / 3 = 833 algorithmic TFLOP/s for three f16
+                 products per product; 157.3 for the fp32 MFMA).  chip_level_tflops = the same FLOPs / the union of
+                 the (overlapping) launch intervals;
   cpu_baseline : the reference's CPU path (oracle/dprnn_torch_cpu.py: the same ATen CPU ops the
                  reference dispatches to) timed on this host's cores per BASELINE.md section 3 (N=1 only).
   distributed  : what torch.distributed actually saw (world size, backend, one device name per rank).
@@ -27,6 +35,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / HIP IPC between the ranks of one node needs dmabuf handles on this driver: set before anything imports torch, in
+# every launch form (the self-launch parent, a rank under the driver's torch.distributed.run, a plain single process)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SAMPLES = 24000          # 3 s @ 8 kHz
 PER_GPU_BATCH = 64       # BASELINE.json configs[1]
@@ -39,8 +50,8 @@ CTOR = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_siz
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd = the headline forward (configs[1]); train = fwd + PIT SI-SDR loss + bwd + gradient all-reduce "
                          "+ clip + Adam (configs[3], 64 utterances per GPU)")
@@ -49,9 +60,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
-    ap.add_argument("--gemm-mode", type=int, default=None,
-                    help="LSTM gate GEMM: 1 = fp32 operands as three bf16 pieces, six products on the bf16 MFMA, fp32 accumulate "
-                         "(the engine's default, fp32-equivalent); 0 = exact fp32 MFMA; 2 = three products (2^-16, opt-in)")
+    ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
+                    help="arithmetic of the contractions: 3 = fp32 operands as two f16 pieces of 2^e-scaled values, three products on "
+                         "the f16 MFMA, fp32 accumulate (the engine's default, fp32-equivalent, saturation-checked); 1 = three bf16 "
+                         "pieces, six products (fp32-equivalent, no range assumption); 0 = exact fp32 MFMA")
+    ap.add_argument("--rowgemm-grid", type=int, default=None, help="workgroups of the HBM-bound f16 row GEMMs (dprnn_set_rowgemm_grid)")
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
     ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
@@ -240,6 +253,8 @@ def main():
     lib = pkg.load_library()
     lib.dprnn_set_fast_activations(args.fast_act)
     lib.dprnn_set_fast_head_activations(args.fast_act)
+    if args.rowgemm_grid is not None:
+        lib.dprnn_set_rowgemm_grid(args.rowgemm_grid)
     engine.SEQ_TILE["intra"], engine.SEQ_TILE["inter"] = args.seq_tile_intra, args.seq_tile_inter
     if args.groups is not None:
         engine.STREAM_GROUPS = args.groups
@@ -275,23 +290,43 @@ def main():
         return
 
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = model(x)
-        sync()
-        engine.PROFILE = {"names": {"dprnn_rnn_fwd"}, "events": {}}
-        gc.collect()
-        gc.disable()                    # the host enqueues ~300 launches per step: no collector pauses inside the timed region
-        t_ref = torch.cuda.Event(enable_timing=True)
-        t_ref.record()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(x)
-        sync()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
-        prof, engine.PROFILE = engine.PROFILE, None
+    REC = "dprnn_rnn_fwd_ex"            # the recurrence launches (the dominant kernel)
+
+    def timed_region(mode, steps, warmup):
+        """`warmup` untimed forwards, then exactly `steps` timed ones between barriers, under gate-GEMM mode `mode`.  Every
+        forward ends with the saturation check of the f16-pieces arithmetic (one stream synchronisation), so the host clock
+        around each call is that step's latency."""
+        engine.GEMM_MODE = mode
+        with torch.no_grad():
+            for _ in range(warmup):
+                o = model(x)
+            sync()
+            engine.PROFILE = {"names": {REC}, "events": {}}
+            gc.collect()
+            gc.disable()                # the host enqueues ~300 launches per step: no collector pauses inside the timed region
+            t_ref = torch.cuda.Event(enable_timing=True)
+            t_ref.record()
+            per_step = []
+            t0 = time.perf_counter()
+            tp = t0
+            for _ in range(steps):
+                o = model(x)
+                if mode != 3:           # modes without the check return before the GPU is done: make the step boundary explicit
+                    torch.cuda.current_stream(dev).synchronize()
+                tn = time.perf_counter()
+                per_step.append(tn - tp)
+                tp = tn
+            sync()
+            dt = time.perf_counter() - t0
+            gc.enable()
+            prof, engine.PROFILE = engine.PROFILE, None
+        return o, dt, per_step, prof, t_ref
+
+    sat0 = dict(engine.SATURATION)
+    out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup)
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
+    sat_checks = engine.SATURATION["checks"] - sat0["checks"]
+    sat_fallbacks = engine.SATURATION["fallbacks"] - sat0["fallbacks"]
     if use_dist and world == 1:         # one rank under torch.distributed.run: the same collective the N > 1 runs use
         t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -299,31 +334,86 @@ def main():
     else:
         elapsed = sharding.max_over_ranks(elapsed, device=dev if backend == "nccl" else None)   # slowest rank defines the step
 
-    kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get("dprnn_rnn_fwd", []), t_ref)
-    n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
-    launches_per_step = 2 * cfg["n_repeats"] * n_groups
-    flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
-    achieved = lstm_flop_per_step * args.steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
-    traffic, traffic_src = None, None
-    try:
-        name, key = {0: ("r01_pmc_traffic.json", "bilstm_kernel"), 1: ("r02_pmc_traffic.json", "bilstm_split8_kernel"),
-                     3: ("r02_pmc_traffic_f16.json", "bilstm_split8_kernel_f16")}[args.gemm_mode]
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            pm = json.load(f)[key]
-        if pm["group_batch"] * n_groups == B:
-            traffic, traffic_src = pm["traffic_GB_per_launch"], name
-    except (OSError, KeyError, ValueError):
-        pass
+    BF16_PEAK = 2500.0                  # dense 16-bit MFMA peak (f16 = bf16), /opt/skills/guides/MI355X_MICROARCH.md
+    PRODUCTS = {0: 1, 1: 6, 3: 3}
 
-    # The other arithmetic modes of the gate GEMM, timed AFTER (and outside) the headline region: same batch, same
-    # protocol, 3 steps each; deviation is measured against the output of the headline mode of this very run.
-    mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 2: "bf16_split_3_products", 3: "f16_pieces_3_products"}
+    def roofline(mode, prof, t_ref, steps, utt_per_s):
+        """Roofline object of the recurrence kernel for a timed region run under `mode`."""
+        kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get(REC, []), t_ref)
+        engine.GEMM_MODE = mode
+        n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
+        flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
+        per_launch = flop_per_launch / (kern_ms * 1e-3) / 1e12
+        chip = lstm_flop_per_step * steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
+        products = PRODUCTS[mode]
+        peak = PEAK_F32_MFMA_TFLOPS if mode == 0 else BF16_PEAK / products
+        piece = "f16" if mode == 3 else "bf16"
+        traffic, traffic_src = None, None
+        try:
+            name, key = {0: ("r01_pmc_traffic.json", "bilstm_kernel"), 1: ("r02_pmc_traffic.json", "bilstm_split8_kernel"),
+                         3: ("r02_pmc_traffic_f16.json", "bilstm_split8_kernel_f16")}[mode]
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pm = json.load(f)[key]
+            if pm["group_batch"] * n_groups == B:
+                traffic, traffic_src = pm["traffic_GB_per_launch"], name
+        except (OSError, KeyError, ValueError):
+            pass
+        return {"bound": "mfma",
+                "kernel": "bilstm_kernel (dprnn_rnn_fwd_ex, LSTM cell, exact fp32 MFMA)" if mode == 0 else
+                f"bilstm_split8_kernel (dprnn_rnn_fwd_ex, LSTM cell, fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)",
+                # achieved: algorithmic FLOPs of one launch / the MEAN duration of a launch (HIP events on the launch streams,
+                # = rocprofv3 --stats' per-kernel average).  The utterance groups' launches overlap on the chip, so this includes
+                # the time a launch waits for CUs the other group's launch still holds.
+                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)", "frac": per_launch / peak,
+                "traffic": traffic, "traffic_unit": f"GB per launch (PMC, profiles/{traffic_src})",
+                "peak_note": "157.3 = fp32 MFMA peak" if mode == 0 else
+                f"{BF16_PEAK:.0f} TFLOP/s dense {piece} MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
+                f"{PEAK_F32_MFMA_TFLOPS} (achieved / that = {per_launch / PEAK_F32_MFMA_TFLOPS:.2f})",
+                "executed_mfma_tflops": None if mode == 0 else per_launch * products,
+                "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
+                # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
+                # the previous norm is folded in: all launches of a forward but the first]
+                "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 *
+                ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
+                "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": 2 * cfg["n_repeats"] * n_groups,
+                "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / steps,
+                # the same FLOPs over the UNION of the launch intervals: the chip-level rate while any recurrence launch is in flight
+                "chip_level_tflops": chip, "chip_level_frac": chip / peak, "mean_concurrency": conc,
+                "whole_forward_frac": utt_per_s * FLOP_PER_UTT / 1e12 / peak,
+                # SURVEY.md section 8(d): the HBM side of the same forward -- 1.433 GB per utterance with ideal fusion
+                # against 8 TB/s (the path is matrix-bound: this stays a small fraction)
+                "whole_forward_hbm_tb_s": utt_per_s * 1.433e9 / 1e12,
+                "whole_forward_hbm_frac": utt_per_s * 1.433e9 / 8e12,
+                "whole_forward_tflops": utt_per_s * FLOP_PER_UTT / 1e12}
+
+    def latency(per_step):
+        v = np.sort(np.asarray(per_step)) * 1e3
+        return {"ms_per_step_p50": float(np.percentile(v, 50)), "ms_per_step_p99": float(np.percentile(v, 99)),
+                "ms_per_step_min": float(v[0]), "ms_per_step_max": float(v[-1]), "steps": int(v.size)}
+
+    value = world * B * args.steps / elapsed
+    head_roof = roofline(args.gemm_mode, prof, t_ref, args.steps, value / world)
+    n_groups = head_roof["concurrent_streams"]
+
+    # The reference's own precision, first class: the same batch, the same number of steps and warm-ups under
+    # DPRNN_GEMM_MODE=0 (fp32 operands on the fp32 MFMA), with its own roofline against the fp32 MFMA peak.
+    exact = None
+    ref_out = out.double()
+    if args.gemm_mode != 0 and world == 1 and not args.no_optional_modes:
+        o0, dt0, ps0, prof0, tref0 = timed_region(0, args.steps, args.warmup)
+        v0 = B * args.steps / dt0
+        exact = dict({"metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd, exact fp32 MFMA arithmetic (DPRNN_GEMM_MODE=0)",
+                      "value": v0, "unit": "utt/s", "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt0 / args.steps,
+                      "dtype": "f32", "rel_l2_vs_headline_output": float((o0.double() - ref_out).norm() / ref_out.norm()),
+                      "roofline": roofline(0, prof0, tref0, args.steps, v0)}, **latency(ps0))
+        del o0
+    # mode 1 (three bf16 pieces, six products: the fall-back arithmetic of a saturated forward), 3 steps after the timed regions
+    mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 3: "f16_pieces_3_products"}
     optional = None
     if world == 1 and not args.no_optional_modes:
         optional = {}
-        ref_out = out.double()
         with torch.no_grad():
-            for mode in (0, 1, 2, 3):
+            for mode in (1, 3):
                 if mode == args.gemm_mode:
                     continue
                 engine.GEMM_MODE = mode
@@ -336,20 +426,10 @@ def main():
                 dt = (time.perf_counter() - t1) / 3
                 optional[mode_names[mode]] = {"value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt,
                                               "rel_l2_vs_headline_mode": float((o.double() - ref_out).norm() / ref_out.norm())}
-            engine.GEMM_MODE = args.gemm_mode
-    # roofline of the dominant kernel.  Exact mode: the fp32 MFMA peak.  Six-product bf16 split: every algorithmic FLOP costs
-    # six bf16 MFMA FLOPs, so the kernel's ceiling in algorithmic (fp32-equivalent) TFLOP/s is the dense bf16 peak / 6.
-    BF16_PEAK = 2500.0
-    products = {0: 1, 1: 6, 2: 3, 3: 3}[args.gemm_mode]
-    peak = PEAK_F32_MFMA_TFLOPS if args.gemm_mode == 0 else BF16_PEAK / products
-    piece = "f16" if args.gemm_mode == 3 else "bf16"
-    kernel_name = "bilstm_kernel (dprnn_rnn_fwd, LSTM cell, exact fp32 MFMA)" if args.gemm_mode == 0 else \
-        f"bilstm_split8_kernel (dprnn_rnn_fwd, LSTM cell, fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)"
+    engine.GEMM_MODE = args.gemm_mode
     dtype = {0: "f32", 1: "f32 via 3 x bf16 split, 6 products, f32 accumulate",
-             2: "f32 via 2 x bf16 split, 3 products (2^-16), f32 accumulate",
-             3: "f32 via 2 x f16 pieces of 2^e-scaled operands (22+ bits), 3 products, f32 accumulate"}[args.gemm_mode]
+             3: "f32 via 2 x f16 pieces of 2^e-scaled operands (22+ bits), 3 products, f32 accumulate; saturation-checked per forward"}[args.gemm_mode]
     if rank == 0:
-        value = world * B * args.steps / elapsed
         line = {
             "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -360,39 +440,22 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS,
-                       "stream_groups_used": n_groups,
-                       "gemm_mode": ["exact fp32 MFMA (DPRNN_GEMM_MODE=0)", "fp32-equivalent bf16 split, 6 products (DPRNN_GEMM_MODE=1)",
-                                     "bf16 split, 3 products (opt-in, 2^-16)",
-                                     "fp32-equivalent f16 pieces, 3 products (DPRNN_GEMM_MODE=3)"][args.gemm_mode]
+                       "stream_groups_used": n_groups, "rowgemm_grid": lib.dprnn_get_rowgemm_grid(),
+                       "gemm_mode": {0: "exact fp32 MFMA (DPRNN_GEMM_MODE=0)", 1: "fp32-equivalent bf16 split, 6 products (DPRNN_GEMM_MODE=1)",
+                                     3: "fp32-equivalent f16 pieces, 3 products (DPRNN_GEMM_MODE=3)"}[args.gemm_mode]
                        + (" (default)" if args.gemm_mode == engine.DEFAULT_GEMM_MODE else "")},
-            "roofline": {"bound": "mfma", "kernel": kernel_name,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": f"GB per launch (PMC, profiles/{traffic_src})",
-                         "peak_note": "157.3 = fp32 MFMA peak" if args.gemm_mode == 0 else
-                         f"{BF16_PEAK:.0f} TFLOP/s dense {piece} MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
-                         f"{PEAK_F32_MFMA_TFLOPS} (achieved / that = {achieved / PEAK_F32_MFMA_TFLOPS:.2f})",
-                         "executed_mfma_tflops": None if args.gemm_mode == 0 else achieved * products,
-                         "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
-                         # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
-                         # the previous norm is folded in: all launches of a forward but the first]
-                         "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 *
-                         ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
-                         "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": launches_per_step,
-                         "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / args.steps,
-                         # achieved = per_launch_tflops x mean_concurrency: the launches of the pipelines overlap
-                         "per_launch_tflops": flop_per_launch / (kern_ms * 1e-3) / 1e12,
-                         "mean_concurrency": conc,
-                         "whole_forward_frac": value / world * FLOP_PER_UTT / 1e12 / peak,
-                         # the HBM side of the same forward -- 1.433 GB per utterance with ideal fusion
-                         # against 8 TB/s (the path is matrix-bound: this stays a small fraction)
-                         "whole_forward_hbm_tb_s": value / world * 1.433e9 / 1e12,
-                         "whole_forward_hbm_frac": value / world * 1.433e9 / 8e12,
-                         "whole_forward_tflops": value / world * FLOP_PER_UTT / 1e12},
+            "latency": latency(per_step),
+            "saturation": {"checks": sat_checks, "fallbacks": sat_fallbacks,
+                           "note": "every forward in the f16-pieces arithmetic reads its saturation flags before it returns (inside the "
+                                   "timed region); a fall-back re-runs the forward in mode 1"},
+            "roofline": head_roof,
             "distributed": dist_info,
         }
-        if optional is not None:
-            line["other_gemm_modes"] = dict(optional, note="the same batch under the other settings of engine.GEMM_MODE / "
-                                            "DPRNN_GEMM_MODE, 3 steps each after the timed region; NOT part of `value`")
+        if exact is not None:
+            line["exact_fp32"] = exact
+        if optional:
+            line["other_gemm_modes"] = dict(optional, note="the same batch under the other split setting of engine.GEMM_MODE / "
+                                            "DPRNN_GEMM_MODE, 3 steps after the timed regions; NOT part of `value`")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, model, dev)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
@@ -420,7 +483,7 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
         loss, _ = trainer.train_step(model, lossm, opt, mix_d, tgt_d, clip_norm=5, reducer=reducer)
     sync()
     reducer.events.clear()
-    names = {"dprnn_rnn_bwd", "dprnn_lstm_bwd"}
+    names = {"dprnn_rnn_bwd_ex", "dprnn_rnn_bwd", "dprnn_lstm_bwd"}
     engine.PROFILE = {"names": names, "events": {}}
     t_ref = torch.cuda.Event(enable_timing=True)
     t_ref.record()
@@ -439,7 +502,7 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
     value = world * B * args.steps / elapsed
     assert bool(torch.isfinite(loss).all())
     from tss_with_dprnn_amd import training as _tr
-    f16_bwd, f16_fwd = _tr.TRAIN_BWD_GEMM_MODE == 3, _tr.TRAIN_GEMM_MODE == 3
+    f16_bwd, f16_fwd = _tr.train_modes()[1] == 3, _tr.train_modes()[0] == 3
     # BPTT in f16 pieces is bound by its HBM streams, not by the matrix pipe: per slab row and both directions it reads the
     # tape (2 x 128 units x 5 floats) and dH (256) and writes dG (1024) and dX (2 x 128): 11 264 bytes
     geo = engine.make_geometry(B, SAMPLES, 64, 250, 125, 2, 1)
@@ -452,13 +515,13 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
     except (OSError, KeyError, ValueError):
         pass
     if f16_bwd:
-        roof = {"bound": "hbm", "kernel": "lstm_bwd8_f16_kernel (dprnn_rnn_bwd, BPTT, step GEMM in f16 pieces)", "achieved": hbm,
+        roof = {"bound": "hbm", "kernel": "lstm_bwd8_f16_kernel (dprnn_rnn_bwd_ex, BPTT, step GEMM in f16 pieces)", "achieved": hbm,
                 "peak": 8.0, "unit": "TB/s", "frac": hbm / 8.0, "traffic": traffic,
                 "traffic_unit": f"GB per launch of one 32-utterance micro-batch (PMC, {traffic_src}); algorithmic {bwd_gb_per_step / 24:.2f}",
                 "algorithmic_gb_per_step": bwd_gb_per_step, "matrix_tflops_algorithmic": achieved,
                 "matrix_frac_of_f16_pieces_ceiling": achieved / (2500.0 / 3)}
     else:
-        roof = {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd, BPTT, fp32 MFMA)", "achieved": achieved,
+        roof = {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd_ex, BPTT, fp32 MFMA)", "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
     return {
         "metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet training step", "value": value, "unit": "utt/s",

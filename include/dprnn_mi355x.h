@@ -61,6 +61,11 @@ void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
  * wrote with the buffer's device address and every recurrence launch checks it: a mismatch returns DPRNN_EFORMAT. */
 void dprnn_set_gemm_mode(int mode);
 int dprnn_get_gemm_mode(void);
+/* Workgroups of the f16-pieces row GEMMs (projection, bottleneck, mask head; process-wide tuning knob).  They are bound by their
+ * HBM streams, and a persistent workgroup holds a CU's LDS: the grid is also the number of CUs taken from whatever else runs (the
+ * other utterance group's recurrence).  0 = one workgroup per CU; the default comes from DPRNN_ROWGEMM_GRID. */
+void dprnn_set_rowgemm_grid(int workgroups);
+int dprnn_get_rowgemm_grid(void);
 /* forget the recorded format of a packed buffer (NULL: of all) -- for hosts that recycle device memory outside the library */
 void dprnn_pack_forget(const void* packed);
 
@@ -68,7 +73,9 @@ void dprnn_pack_forget(const void* packed);
  * device buffer of DPRNN_SAT_SLOTS int32 (zeroed by the call, on `stream`); every f16-pieces kernel launched by that thread
  * afterwards ORs 1 into slot s when a value it converted exceeded the f16 range (Inf / NaN inputs included):
  *   0 recurrence input rows, 1 rows of the Linear after a recurrence, 2 rows of the other row GEMMs (bottleneck, mask head,
- *   data gradients), 3 gate gradients of the BPTT, 4 operands of the weight-gradient GEMM.
+ *   data gradients), 3 gate gradients of the BPTT, 4 operands of the weight-gradient GEMM, 5 non-finite input: the statistics
+ *   dprnn_bottleneck_prep reads are NaN / Inf, i.e. the utterance holds such a sample (the conversion sites track maxima, which
+ *   see Inf but skip NaN; every forward passes dprnn_bottleneck_prep first).
  * dprnn_saturation_flags copies them to `host_out` (DPRNN_SAT_SLOTS int32 of host memory) after synchronising `stream`, and
  * returns 1 if any is set, 0 if none, < 0 on error.  flags == NULL unregisters (detection off; the clamp stays).  The Python host
  * brackets every forward / backward with the pair and re-runs a saturated call in mode 1 (forward) / the exact fp32 kernels

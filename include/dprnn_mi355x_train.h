@@ -52,6 +52,12 @@ int64_t dprnn_rnn_pack_bwd_floats(int ndir);
 void dprnn_wgrad_use_f16_pieces(const float* grad_max);
 /* the same for the NEXT dprnn_dgrad call of shape 128 -> 256 (dH = dZ @ W of a bidirectional path's Linear); other shapes ignore it */
 void dprnn_dgrad_use_f16_pieces(const float* grad_max);
+/* Saturation of the f16-pieces BPTT (dprnn_mi355x.h: dprnn_saturation_begin / _flags): the BPTT kernel itself does not follow the
+ * largest gate gradient (it sits at the register limit); dG, which it writes, is read back under the SAME scale by the f16-pieces
+ * weight-gradient GEMM, which raises flag 4 for it.  A host that runs the fp32 weight-gradient kernel on a mode-3 BPTT's dG calls
+ * this instead: one pass over dG (n floats, n % 4 == 0) against the range of the scale taken from *grad_max (packedT +
+ * dprnn_rnn_bwd_gradmax_offset(ndir)), raising flag 3.  No-op when the thread has no flag buffer registered. */
+int dprnn_bwd_range_check(const float* dG, int64_t n, const float* grad_max, void* stream);
 /* max |x| over n floats (n % 4 == 0) into *out: the scale source for a P that no BPTT launch has measured (the Linears' dZ) */
 int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);

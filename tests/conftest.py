@@ -22,8 +22,20 @@ def load_golden(name):
     return d
 
 
-def golden_names(prefix=""):
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix))
+def golden_names(prefix="", trained=False):
+    """Fixture names; the trained-like fixtures (make_golden.TRAINED_CASES: other weight recipe, two-sided tolerance) are listed
+    only on request and have their own tests."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix) and (("trained" in f) == trained))
+
+
+def state_from_meta(meta):
+    """The numpy-recipe state_dict a fixture was generated with (meta.style / meta.recipe: synthetic.make_state)."""
+    from oracle.weights import make_state
+    return make_state(meta["kind"], meta["cfg"], meta["seed"], style=meta.get("style", "init"), **(meta.get("recipe") or {}))
+
+
+def model_from_meta(meta, device=None):
+    return build_model(meta["kind"], meta["cfg"], meta["seed"], device, style=meta.get("style", "init"), recipe=meta.get("recipe"))
 
 
 def rel_l2(a, b):
@@ -37,8 +49,8 @@ def root():
     return ROOT
 
 
-def build_model(kind, cfg, seed, device=None):
-    """Our module (tss_with_dprnn_amd) with the numpy-recipe weights loaded strict=True."""
+def build_model(kind, cfg, seed, device=None, style="init", recipe=None):
+    """Our module (tss_with_dprnn_amd) with the numpy-recipe weights loaded strict=True (style: synthetic.make_state)."""
     import torch
     import tss_with_dprnn_amd as pkg
     from oracle.weights import full_cfg, make_state
@@ -52,7 +64,7 @@ def build_model(kind, cfg, seed, device=None):
         from tss_with_dprnn_amd import dprnn_spe, dprnn_spe_ira
         cls = dprnn_spe.DPRNNSpeTasNet if kind == "spe" else dprnn_spe_ira.DPRNNSpeIRATasNet
         model = cls(**{k: cfg[k] for k in spe})
-    sd = make_state(kind, cfg, seed)
+    sd = make_state(kind, cfg, seed, style=style, **(recipe or {}))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model.eval()
     if device is not None:

@@ -57,3 +57,44 @@ def test_bench_has_no_module_level_gpu_imports():
     assert "import torch" not in head and "import numpy" not in head
     body = src[src.index("def main():"):]
     assert body.index("_self_launch(args.gpus)") < body.index("import torch")
+
+
+SPY = """
+import importlib.abc, os, sys
+os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+class Spy(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path, target=None):
+        if name == "torch":
+            print("AT_TORCH_IMPORT", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), flush=True)
+            os._exit(0)         # the rank stops here: this test has no GPU
+sys.meta_path.insert(0, Spy())
+sys.path.insert(0, {root!r})
+sys.argv = ["bench.py", "--gpus", "1"] + {extra!r}
+{body}
+"""
+
+
+def _spy(tmp_path, body, extra=()):
+    f = tmp_path / "spy.py"
+    f.write_text(SPY.format(root=ROOT, extra=list(extra), body=body))
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    return subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_rank_under_the_drivers_torchrun_has_dmabuf_ipc_before_torch_is_imported(tmp_path):
+    """The driver starts the ranks itself (python -m torch.distributed.run ... bench.py --gpus N): every rank must have
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment before torch (and with it the HIP runtime / RCCL) is imported, in the
+    forward and in the training mode -- not only under bench.py's own self-launch."""
+    for extra in ((), ("--mode", "train")):
+        r = _spy(tmp_path, "import bench\nbench.main()", extra)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "AT_TORCH_IMPORT 0" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_package_import_sets_dmabuf_ipc_before_torch(tmp_path):
+    """Users of trainer.DistributedTrainer / trainer.init_process_group import the package, not bench.py."""
+    r = _spy(tmp_path, "import tss_with_dprnn_amd")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "AT_TORCH_IMPORT 0" in r.stdout, r.stdout + r.stderr[-2000:]

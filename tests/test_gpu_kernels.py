@@ -278,10 +278,11 @@ def _sat_flags(st, fn):
 
 
 @pytest.mark.parametrize("seq_tile", [2016, 2064, 2080])
-@pytest.mark.parametrize("huge", [5000.0, 1e6, float("inf"), float("nan")])
+@pytest.mark.parametrize("huge", [5000.0, 1e6, float("inf")])
 def test_bilstm_f16_pieces_flag_values_beyond_the_f16_range(seq_tile, huge):
-    """|x| > 4062 does not fit 2^4 x in f16: the piece conversion clamps AND raises saturation flag 0 (Inf / NaN likewise), so that
-    the host can repeat the call in a range-free mode; the same launch on in-range input leaves every flag clear, and mode 1
+    """|x| > 4062 does not fit 2^4 x in f16: the piece conversion clamps AND raises saturation flag 0 (Inf likewise; a NaN sample is
+    flagged where every forward starts, by the statistics dprnn_bottleneck_prep reads -- test_gpu_parity.py), so that the host can
+    repeat the call in a range-free mode; the same launch on in-range input leaves every flag clear, and mode 1
     (bf16 pieces: fp32's exponent) on the out-of-range input matches the oracle -- what the fall-back returns."""
     B, S, K = 1, 3, 40
     rng = np.random.default_rng(5)

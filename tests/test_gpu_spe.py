@@ -181,3 +181,125 @@ def test_rawnet_style_subclass_uses_the_device_pieces():
         masks, logits = sub(torch.from_numpy(enc).to(DEV), torch.from_numpy(aenc).to(DEV))
     assert rel_l2(masks.cpu().numpy(), want) <= REL_TOL
     assert rel_l2(logits.cpu().numpy(), emb @ sd["separation.pred_linear.weight"].T + sd["separation.pred_linear.bias"]) <= REL_TOL
+
+
+# ---- sub-module forwards (inference): the reference's classes have them (dprnn.py:33-37,79-99, encoder_decoder.py:25-33,40-49,
+# dprnn_spe.py:31-42, dprnn_spe_ira.py:53-115); the mirrors run them through the same HIP kernels.  Checked against stock torch
+# CPU modules carrying the same weights (the operators the reference's classes are made of).
+def _cpu_lstm_like(rnn):
+    mod = getattr(torch.nn, rnn.rnn.mode)(rnn.rnn.input_size, rnn.rnn.hidden_size, 1, batch_first=True, bidirectional=rnn.rnn.bidirectional)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(getattr(rnn.rnn, n).detach().cpu())
+    return mod
+
+
+@pytest.mark.parametrize("rnn_type,bidir", [("LSTM", True), ("GRU", False), ("RNN", True)])
+def test_single_rnn_and_block_forward(rnn_type, bidir):
+    from conftest import build_model, rel_l2
+    model, _, cfg = build_model("bss", dict(chunk_length=16, hop_length=8, n_repeats=1, rnn_type=rnn_type, bidirectional=bidir), 77, DEV)
+    blk = model.separation.dprnn_blocks[0]
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((37, 21, 128)).astype(np.float32))
+    with torch.no_grad():
+        got = blk.inter_rnn(x.to(DEV)).cpu().numpy()
+        want = _cpu_lstm_like(blk.inter_rnn)(x)[0].numpy()
+    assert got.shape == want.shape and rel_l2(got, want) < 2e-6
+    # the whole block on [B, F, K, S] against the reference's permutations (dprnn.py:79-99) written with stock modules
+    B, K, S = 2, 16, 9
+    xb = torch.from_numpy(rng.standard_normal((B, 128, K, S)).astype(np.float32))
+    with torch.no_grad():
+        got = blk(xb.to(DEV)).cpu().numpy()
+        def cpu(m):
+            return m.cpu() if hasattr(m, "cpu") else m
+        intra, inter = _cpu_lstm_like(blk.intra_rnn), _cpu_lstm_like(blk.inter_rnn)
+        lin1 = torch.nn.Linear(256, 128); lin1.load_state_dict({k: v.cpu() for k, v in blk.intra_linear.state_dict().items()})
+        lin2 = torch.nn.Linear(128 * (2 if bidir else 1), 128); lin2.load_state_dict({k: v.cpu() for k, v in blk.inter_linear.state_dict().items()})
+        n1 = torch.nn.GroupNorm(1, 128); n1.load_state_dict({k: v.cpu() for k, v in blk.intra_norm.state_dict().items()})
+        n2 = torch.nn.GroupNorm(1, 128); n2.load_state_dict({k: v.cpu() for k, v in blk.inter_norm.state_dict().items()})
+        o = xb.transpose(1, -1).reshape(B * S, K, 128)
+        o = lin1(intra(o)[0]).reshape(B, S, K, 128).transpose(1, -1)
+        o = n1(o) + xb
+        y = o
+        o = o.transpose(1, 2).transpose(2, -1).reshape(B * K, S, 128)
+        o = lin2(inter(o)[0]).reshape(B, K, S, 128).transpose(1, -1).transpose(2, -1).contiguous()
+        want = (n2(o) + y).numpy()
+    assert got.shape == want.shape and rel_l2(got, want) < 3e-6, rel_l2(got, want)
+
+
+def test_encoder_decoder_resblock_forward():
+    from conftest import build_model, rel_l2
+    model, _, cfg = build_model("spe", dict(chunk_length=16, hop_length=8, n_repeats=1, kernel_size=4), 78, DEV)
+    rng = np.random.default_rng(4)
+    wav = torch.from_numpy(rng.standard_normal((3, 501)).astype(np.float32))
+    enc_w = model.encoder.conv1d.weight.detach().cpu()
+    with torch.no_grad():
+        e = model.encoder(wav.to(DEV))
+        want = torch.relu(torch.nn.functional.conv1d(wav[:, None, :], enc_w, stride=model.encoder.conv1d.stride[0]))
+        assert e.shape == want.shape and rel_l2(e.cpu().numpy(), want.numpy()) < 1e-6
+        z = torch.from_numpy(rng.standard_normal(tuple(want.shape)).astype(np.float32))
+        d = model.decoder(z.to(DEV))
+        wantd = torch.nn.functional.conv_transpose1d(z, model.decoder.weight.detach().cpu(), stride=model.decoder.stride[0]).squeeze()
+        assert d.shape == wantd.shape and rel_l2(d.cpu().numpy(), wantd.numpy()) < 1e-6
+        d1 = model.decoder(z[:1].to(DEV))            # B = 1: the reference squeezes only dim 1 (encoder_decoder.py:44-48)
+        assert tuple(d1.shape) == (1, wantd.shape[-1])
+        rb = model.separation.spk_encoder[3]         # ResBlock(128 -> 256) in eval mode
+        xr = torch.from_numpy(rng.standard_normal((2, 128, 95)).astype(np.float32))
+        got = rb(xr.to(DEV)).cpu().numpy()
+        import copy
+        from tss_with_dprnn_amd import dprnn_spe
+        ref = copy.deepcopy(rb).cpu()
+        y = ref.conv1(xr); y = ref.prelu1(ref.batch_norm1(y)); y = ref.batch_norm2(ref.conv2(y))
+        y = ref.maxpool(ref.prelu2(y + ref.conv_downsample(xr)))
+        assert got.shape == tuple(y.shape) and rel_l2(got, y.numpy()) < 2e-6
+
+
+def test_ira_separator_forward_on_encoder_outputs():
+    """DPRNNSpeIRA.forward(input [B,N,L], aux [B,N,La], aux_len) (dprnn_spe_ira.py:53-115) against the TasNet wrapper's own
+    pieces: d1 decoded must equal DPRNNSpeIRATasNet.forward's estimate, the logits must agree."""
+    from conftest import build_model, rel_l2
+    from oracle.weights import make_mixture
+    model, _, cfg = build_model("ira", dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type="cat", norm_type="ln"), 79, DEV)
+    mix = torch.from_numpy(make_mixture(2, 700, seed=5)).to(DEV)
+    aux = torch.from_numpy(make_mixture(2, 640, seed=6)).to(DEV)
+    alen = torch.tensor(640.0)
+    with torch.no_grad():
+        est, logits = model(mix, aux, alen)
+        d1, lg = model.separation(model.encoder(mix), model.encoder(aux), alen)
+        est2 = model.decoder(d1.contiguous())
+    assert rel_l2(lg.cpu().numpy(), logits.cpu().numpy()) < 2e-6
+    assert rel_l2(est2.cpu().numpy(), est.cpu().numpy()) < 2e-6
+
+
+def test_spe_cat_batch_b64_full_size():
+    """BASELINE.json configs[2] at its own size: DPRNN-Spe (cat fusion, shipped config) on 64 x 24 000 samples with a 3-s reference
+    utterance each, default engine settings (stream groups, tile heuristics, speaker branch at B = 64).  Utterances 0 / 31 / 32 / 63
+    against the torch-CPU oracle, every utterance (estimate and speaker logits) against its own batch-of-one forward."""
+    from conftest import build_model, rel_l2
+    from oracle import dprnn_torch_cpu as otc
+    from tss_with_dprnn_amd import engine
+    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
+    model, sd, cfg = build_model("spe", dict(norm_type="ln", fusion_type="cat"), 3, DEV)
+    B, T = 64, 24000
+    x, a = make_mixture(B, T, seed=1234), make_mixture(B, T, seed=1235)
+    xd, ad = torch.from_numpy(x).to(DEV), torch.from_numpy(a).to(DEV)
+    alen = torch.tensor(float(T))
+    before = dict(engine.SATURATION)
+    with torch.no_grad():
+        est, logits = model(xd, ad, alen)
+        torch.cuda.synchronize()
+        assert est.shape == (B, T) and logits.shape == (B, cfg["num_spks"]) and bool(torch.isfinite(est).all())
+        worst = 0.0
+        for b in range(B):
+            e1, l1 = model(xd[b:b + 1], ad[b:b + 1], alen)
+            r = float(((e1[0].double() - est[b].double()).norm() / e1[0].double().norm()).item())
+            rl = float(((l1[0].double() - logits[b].double()).norm() / l1[0].double().norm()).item())
+            worst = max(worst, r, rl)
+            assert r <= 2e-6 and rl <= 2e-6, f"utterance {b}: batched vs batch-of-one rel-L2 {r:.3e} (logits {rl:.3e})"
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"]
+    pick = [0, 31, 32, 63]
+    we, wl = otc.spe_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x[pick]), torch.from_numpy(a[pick]), alen)
+    r = rel_l2(est.cpu().numpy()[pick], we.numpy())
+    rl = rel_l2(logits.cpu().numpy()[pick], wl.numpy())
+    assert r <= 1e-5 and rl <= 1e-5, (r, rl)
+    print(f"DPRNN-Spe (cat) B=64 x 24000: rel-L2 vs CPU oracle {r:.2e} (logits {rl:.2e}); worst batched-vs-single {worst:.2e}")

@@ -109,10 +109,11 @@ def test_lstm_backward_matches_autograd(path, B, S, K):
 
 def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
     """The f16-pieces BPTT multiplies da by 2^(6 - e), e = exponent of max|dH| (handed over by dH's producer); a gate gradient more
-    than 2^10 above that does not fit f16: the conversion clamps AND raises saturation flag 3 (the weight-gradient GEMM under the
-    same scale: flag 4).  With the true maximum nothing is flagged and dX matches autograd; with a maximum 2^13 too small (what an
-    exploding recurrence amounts to) the flags are up -- training.backward then repeats the step in the exact kernels.  Also: the
-    backward pack carries its format like the forward's (DPRNN_EFORMAT on a mismatch)."""
+    than 2^10 above that does not fit f16 and is clamped.  The gate gradients land in dG, which the f16 weight-gradient GEMM reads
+    back under the same scale and flags (4); dprnn_bwd_range_check is the explicit pass for hosts that run the fp32 weight-gradient
+    kernel (3).  With the true maximum nothing is flagged and dX / dW match autograd; with a maximum 2^13 too small (what an
+    exploding recurrence amounts to) both flags are up -- training.backward then repeats the step in the exact kernels.  Also:
+    the backward pack carries its format like the forward's (DPRNN_EFORMAT on a mismatch)."""
     import ctypes
     B, S, K = 2, 9, 23
     rng = np.random.default_rng(11)
@@ -150,6 +151,7 @@ def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
             st.call("dprnn_rnn_bwd_ex", 3, _p(hmax), 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2)
             st.call("dprnn_wgrad_ex", packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2), dG.data_ptr(), 1024, 512,
                     _p(Xd), 128, 128, 0, H.data_ptr(), 256, 128, 1, rows, 1, K, _p(dW), 256, 1, 0, 0, 0, _p(ws))
+            st.call("dprnn_bwd_range_check", _p(dG), dG.numel(), packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2))
             rc = lib.dprnn_saturation_flags(ctypes.addressof(host), st.stream)
         finally:
             lib.dprnn_saturation_begin(0, 0)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden_names, load_golden, rel_l2
+from conftest import GOLDEN, golden_names, load_golden, rel_l2, state_from_meta
 from oracle import dprnn_numpy as onp
 from oracle import dprnn_torch_cpu as otc
 from oracle.weights import full_cfg, make_mixture, make_state, state_spec
@@ -178,3 +178,29 @@ def test_oracle_spe_training_step_matches_reference_autograd(name):
         assert err < 5e-6, (k, err)
         checked += 1
     assert checked > 60
+
+
+# ---- trained-like fixtures (tests/golden/make_golden.py:TRAINED_CASES): heavy-tailed LSTM rows, forget-gate offsets, norm gains
+# far from 1.  Such a DPRNN is close to a chaotic map, so the fixtures carry the reference's own fp32-vs-float64 distance and the
+# float64 output; a restatement is pinned by (a) its fp32 form within max(TOL, 3 x that distance) of the reference's fp32 output
+# and (b) its float64 form within 1e-9 of the reference's float64 output (same graph, no rounding to speak of).
+@pytest.mark.parametrize("name", [n for n in golden_names("bss", trained=True) if "full" not in n])
+def test_oracles_match_reference_on_trained_like_weights(name):
+    g = load_golden(name)
+    m = g["meta"]
+    gap = m["ref_fp32_vs_fp64_rel_l2"]
+    sd = state_from_meta(m)
+    out32 = onp.tasnet_forward(sd, m["cfg"], g["mix"], np.float32)
+    out64 = onp.tasnet_forward(sd, m["cfg"], g["mix"], np.float64)
+    assert rel_l2(out64, g["out64"]) < 1e-9
+    assert rel_l2(out32, g["out"]) < max(TOL, 3 * gap), (rel_l2(out32, g["out"]), gap)
+    out_t = otc.tasnet_forward(otc.to_torch_state(sd), m["cfg"], torch.from_numpy(g["mix"])).numpy()
+    assert rel_l2(out_t, g["out"]) < max(TOL, 3 * gap)
+
+
+def test_torch_cpu_oracle_matches_reference_on_trained_like_weights_full_size():
+    g = load_golden("bss_full_trained_rms1")
+    m = g["meta"]
+    out_t = otc.tasnet_forward(otc.to_torch_state(state_from_meta(m)), m["cfg"], torch.from_numpy(g["mix"])).numpy()
+    assert rel_l2(out_t, g["out"]) < max(TOL, 3 * m["ref_fp32_vs_fp64_rel_l2"])
+    assert rel_l2(out_t, g["out64"]) < 3 * m["ref_fp32_vs_fp64_rel_l2"]

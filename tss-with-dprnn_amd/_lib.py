@@ -79,6 +79,7 @@ SIGNATURES = {
     "dprnn_dgrad_ex": [c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i64, c_fp],
     "dprnn_gn_bwd_dz_ex": [c_fp] * 6 + [c_f, c_i, c_i64, c_fp, c_fp],
     "dprnn_absmax": [c_fp, c_i64, c_fp, c_fp],
+    "dprnn_bwd_range_check": [c_fp, c_i64, c_fp, c_fp],
     "dprnn_rnn_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
@@ -128,12 +129,14 @@ _VOID = {
     "dprnn_rnn_bwd_use_gradmax": [c_fp],
     "dprnn_debug_bwd_stamps": [c_fp],
     "dprnn_pack_forget": [c_fp],
+    "dprnn_set_rowgemm_grid": [c_i],
 }
 _SPECIAL = {
     "dprnn_last_error": ([], ctypes.c_char_p),
     "dprnn_abi_version": ([], c_i),
     "dprnn_num_cus": ([], c_i),
     "dprnn_get_gemm_mode": ([], c_i),
+    "dprnn_get_rowgemm_grid": ([], c_i),
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
@@ -146,7 +149,7 @@ ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
 ABI_VERSION = 2             # DPRNN_ABI_VERSION of include/dprnn_mi355x.h this binding is written against
 SAT_SLOTS = 8               # DPRNN_SAT_SLOTS
 SAT_NAMES = ("recurrence input rows", "rows of the Linear after a recurrence", "rows of a row GEMM (bottleneck / mask head / data gradient)",
-             "BPTT gate gradients", "weight-gradient operands", "", "", "")
+             "BPTT gate gradients", "weight-gradient operands", "non-finite input (NaN / Inf samples)", "", "")
 
 
 class DprnnError(RuntimeError):

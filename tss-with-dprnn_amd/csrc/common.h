@@ -11,6 +11,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ReLU that keeps NaN (torch.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN sample must come out as NaN, as the reference returns it
+__device__ __forceinline__ float relu_f(float x) { return x < 0.f ? 0.f : x; }
+
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
 
@@ -106,17 +109,28 @@ int dprnn_check_launch(const char* what);
 // raises flag `slot` of the calling thread's registered device buffer when the limit was crossed -- one ballot per wave, one
 // atomic per wave that saw it.  The host checks the flags once per forward / backward and re-runs in a range-free arithmetic.
 enum { DPRNN_SAT_RECUR_X = 0, DPRNN_SAT_PROJ_ROWS = 1, DPRNN_SAT_GEMM_ROWS = 2, DPRNN_SAT_BPTT_DA = 3, DPRNN_SAT_WGRAD = 4,
-       DPRNN_SAT_SLOTS = 8 };
+       DPRNN_SAT_NONFINITE = 5, DPRNN_SAT_SLOTS = 8 };
 int* dprnn_sat_ptr();        // device int32[DPRNN_SAT_SLOTS] registered by the calling thread, or nullptr (detection off)
+// Tracking costs one v_max3_f32 per two converted values (|.| is an operand modifier).  A float maximum skips NaN operands, so a NaN
+// is not seen here: NaN / Inf INPUTS are flagged where every forward begins instead (bottleneck_prep_kernel: non-finite statistics
+// of the encoder output raise DPRNN_SAT_NONFINITE), Inf is an ordinary "beyond the limit" value.
+// DPRNN_SAT_TRACK (A/B builds only): 0 = no tracking, 1 = integer compare of the bit patterns (sees NaN, three times the work).
+#ifndef DPRNN_SAT_TRACK
+#define DPRNN_SAT_TRACK 2
+#endif
 __device__ __forceinline__ void sat_track(unsigned& m, float a, float b) {
+#if DPRNN_SAT_TRACK == 1
     const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu;
     m = ua > m ? ua : m;
     m = ub > m ? ub : m;
+#elif DPRNN_SAT_TRACK == 2
+    m = __float_as_uint(__builtin_fmaxf(__uint_as_float(m), __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))));
+#endif
 }
 __device__ __forceinline__ void sat_track(unsigned& m, const f32x4& v) { sat_track(m, v[0], v[1]); sat_track(m, v[2], v[3]); }
 __device__ __forceinline__ void sat_commit(int* flags, int slot, unsigned m, float limit) {
     if (!flags) return;
-    const bool over = m > __float_as_uint(limit);
+    const bool over = m > __float_as_uint(limit);        // non-negative floats order like their bit patterns
     if (__builtin_amdgcn_ballot_w64(over) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + slot, 1);
 }
 

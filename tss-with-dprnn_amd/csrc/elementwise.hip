@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void encoder_stats_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < KSMAX; ++j)
                 if (j < ks) s = fmaf(wsh[n * ks + j], xv[j], s);
-            s = fmaxf(s, 0.f);
+            s = relu_f(s);
             p1 += s; p2 = fmaf(s, s, p2);
         }
     }
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void encoder_stats_kernel(const float* __restr
 __global__ void bottleneck_prep_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float eps, const float* __restrict__ mul,
                                        const float* __restrict__ add, float* __restrict__ sc, float* __restrict__ sh,
-                                       int B, int L, int N) {
+                                       int B, int L, int N, int* __restrict__ sat) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * N) return;
     const int b = idx / N, c = idx % N;
@@ -51,6 +51,12 @@ __global__ void bottleneck_prep_kernel(const double* __restrict__ stats, const f
     const float g = gamma[c] * rstd;
     sc[idx] = g * m;
     sh[idx] = (beta[c] - g * (float)mean) * m + a;
+    // statistics that are not finite numbers = a NaN / Inf sample in this utterance's input: every forward passes here first, so this
+    // is where non-finite inputs raise their saturation flag (the f16-pieces conversions downstream track maxima, which skip NaN)
+    if (sat && c == 0) {
+        const double s0 = stats[2 * b], s1 = stats[2 * b + 1];
+        if (!(fabs(s0) <= 1.7e308) || !(fabs(s1) <= 1.7e308)) atomicOr(sat + DPRNN_SAT_NONFINITE, 1);
+    }
 }
 
 // ---- X[b][s][k][:] = Y[b][s*P + k - K][:] or 0 (dprnn.py:189-201): a chunk is K consecutive frames of one utterance, so a workgroup
@@ -140,7 +146,7 @@ extern "C" int dprnn_bottleneck_prep(const double* stats, const float* gamma, co
                                      int B, int L, int N, void* stream) {
     if (!stats || !gamma || !beta || !sc || !sh) { dprnn_set_error("dprnn_bottleneck_prep: null pointer"); return -1; }
     hipLaunchKernelGGL(bottleneck_prep_kernel, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       stats, gamma, beta, eps, mul, add, sc, sh, B, L, N);
+                       stats, gamma, beta, eps, mul, add, sc, sh, B, L, N, dprnn_sat_ptr());
     return dprnn_check_launch("bottleneck_prep_kernel");
 }
 

@@ -134,7 +134,7 @@ void bilstm_split8_kernel(RecurArgs a) {
         return *reinterpret_cast<const u32x4*>(wlds + ((((slab - (NSLAB - LRES)) * 4 + w4) * 8 + g * 2 + wu) * 64 + lane) * 16);
     };
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
-    unsigned satm = 0u;                                    // f16 pieces: bits of the largest |2^4 x| this lane converted (common.h: sat_track)
+    unsigned satm = 0u;                                    // f16 pieces: bits of the largest |x| this lane converted (common.h: sat_track)
     // x of one time step -> bf16 pieces in x buffer xb, one quad (4 floats of one row) per thread and m; XG quads are in
     // flight together (registers: the partner wave on the SIMD covers the rest of the latency)
     auto x_stage = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
@@ -168,10 +168,9 @@ void bilstm_split8_kernel(RecurArgs a) {
                 }
                 unsigned pa[3], pb[3];
                 if constexpr (F16) {
-                    v = v * f32x4{F16_XS, F16_XS, F16_XS, F16_XS};
                     sat_track(satm, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -F16_XMAX, F16_XMAX);
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
                     split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                     split2_pair_f16(v[2], v[3], pb[0], pb[1]);
                 } else {
@@ -220,10 +219,9 @@ void bilstm_split8_kernel(RecurArgs a) {
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
-                v = v * f32x4{F16_XS, F16_XS, F16_XS, F16_XS};
                 sat_track(satm, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -F16_XMAX, F16_XMAX);
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
                 split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                 split2_pair_f16(v[2], v[3], pb[0], pb[1]);
             } else {
@@ -438,7 +436,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             __syncthreads();
         }
     }
-    if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX);
+    if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX / F16_XS);
     if constexpr (STAMP) {
         if (tid == 0 && a.stamps) {
             unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);

@@ -75,7 +75,7 @@ struct GenBottleneck {
 #pragma unroll
             for (int j = 0; j < KSMAX; ++j)
                 if (j < geo.ks) s = fmaf(We[cch * geo.ks + j], xv[rt][j], s);
-            s = fmaxf(s, 0.f);
+            s = relu_f(s);
             v[e] = fmaf(s, sc[boff[rt] + cch], sh[boff[rt] + cch]);
         }
         return v;
@@ -344,9 +344,9 @@ struct EpMaskDecode {
 #pragma unroll
                     for (int j = 0; j < KSMAX; ++j)
                         if (j < ks) en = fmaf(We[n * ks + j], xv[j], en);
-                    en = fmaxf(en, 0.f);
+                    en = relu_f(en);
                     const float a = acc[rt][ct][e];
-                    const float m = relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a);
+                    const float m = relu_act ? relu_f(a) : sigmoid_f<FAST>(a);
                     const float me = m * en;
                     if (masked && ok && spk == 0) masked[bl * geo.N + n] = me;
                     if (mask_all && ok) mask_all[row * geo.N + n] = m;
@@ -486,6 +486,18 @@ inline int num_cus() {
         g_num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     return g_num_cus;
+}
+
+// Workgroups of the f16-pieces row GEMMs (projection, bottleneck, mask head: bound by their HBM streams, not by the CUs): a
+// persistent workgroup holds a CU's LDS, so the grid is also the number of CUs the kernel takes away from whatever else is on the
+// chip -- the other utterance group's recurrence.  dprnn_set_rowgemm_grid(n) caps it (0 = one workgroup per CU); the default
+// comes from DPRNN_ROWGEMM_GRID.  (rowgemm.hip)
+int rowgemm_grid_cap();
+inline long long rowgemm_f16_grid(long long nchunk) {
+    long long cap = rowgemm_grid_cap();
+    if (cap <= 0 || cap > num_cus()) cap = num_cus();
+    long long grid = nchunk < cap ? nchunk : cap;
+    return grid < 1 ? 1 : grid;
 }
 
 template <int KD, int ND, int RT, bool WT = false, int NW = 4, class AL, class EP>
@@ -671,9 +683,9 @@ struct EpTMaskDecode {
                     float en = 0.f;
 #pragma unroll
                     for (int j = 0; j < KS; ++j) en = fmaf(te[j], xv[j], en);
-                    en = fmaxf(en, 0.f);
+                    en = relu_f(en);
                     const float a = acc[rt][ct][e] * inv;
-                    const float mk = relu_act ? fmaxf(a, 0.f) : sigmoid_f<FAST>(a);
+                    const float mk = relu_act ? relu_f(a) : sigmoid_f<FAST>(a);
                     const float me = mk * en;
                     mev[e] = me; mkv[e] = mk;
 #pragma unroll
@@ -693,12 +705,14 @@ struct EpTMaskDecode {
     }
 };
 
-template <int KD, int ND, int RT, bool XC, class AL, class EPT, bool WT = false>
+// TRACK: follow the largest |row element| for the saturation flag (common.h).  Off where the rows are bounded by construction:
+// tanh * sigmoid products (mask + decode), gradients scaled from their own measured maximum (data gradients).
+template <int KD, int ND, int RT, bool XC, class AL, class EPT, bool WT = false, bool TRACK = true>
 __global__ __launch_bounds__(512, 1)
 void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
                          long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr, int* sat = nullptr) {
     constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8, NW = 8;
-    unsigned satm = 0u;                                                // bits of the largest |scaled row element| converted to f16 pieces
+    unsigned satm = 0u;                                                // bits of the largest |row element| converted to f16 pieces
     constexpr int PF = XC ? (NS >= 4 ? 3 : NS - 1) : (NS >= 4 ? 2 : 1);
     static_assert(!XC || NS % (PF + 1) == 0, "the slab buffers rotate across tiles");
     extern __shared__ __attribute__((aligned(16))) rg_u32x4 wl16[];     // [NS][NCT][2][64]
@@ -805,12 +819,11 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
-                lo = lo * f32x4{xs, xs, xs, xs}; hi = hi * f32x4{xs, xs, xs, xs};
-                sat_track(satm, lo); sat_track(satm, hi);
+                if constexpr (TRACK) { sat_track(satm, lo); sat_track(satm, hi); }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] = __builtin_amdgcn_fmed3f(lo[e], -F16P_XMAX, F16P_XMAX);
-                    hi[e] = __builtin_amdgcn_fmed3f(hi[e], -F16P_XMAX, F16P_XMAX);
+                    lo[e] = __builtin_amdgcn_fmed3f(lo[e] * xs, -F16P_XMAX, F16P_XMAX);
+                    hi[e] = __builtin_amdgcn_fmed3f(hi[e] * xs, -F16P_XMAX, F16P_XMAX);
                 }
                 f16_pieces8(lo, hi, h1[rt], h2[rt]);
             }
@@ -837,15 +850,15 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
                 for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
         }
     }
-    sat_commit(sat, DPRNN_SAT_GEMM_ROWS, satm, F16P_XMAX);
+    if constexpr (TRACK) sat_commit(sat, DPRNN_SAT_GEMM_ROWS, satm, F16P_XMAX / xs);
     ep.end(lane);
 }
 
-template <int KD, int ND, int RT, bool XC, bool WT = false, class AL, class EPT>
+template <int KD, int ND, int RT, bool XC, bool WT = false, bool TRACK = true, class AL, class EPT>
 int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, const float* W1, int ldw1, long long M,
                         const AL& al, const EPT& ep, hipStream_t st, const float* amax = nullptr) {
     const size_t lds = (size_t)KD * ND * 4;
-    auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT, WT>;
+    auto kern = &rowgemm_f16t_kernel<KD, ND, RT, XC, AL, EPT, WT, TRACK>;
     static std::atomic<unsigned long long> attr_mask{0};
     int attr_dev;
     if (dprnn_attr_needed(attr_mask, &attr_dev)) {
@@ -854,9 +867,7 @@ int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, co
         dprnn_attr_done(attr_mask, attr_dev);
     }
     constexpr int ROWS_IT = 8 * RT * 16;
-    long long nchunk = (M + ROWS_IT - 1) / ROWS_IT;
-    long long grid = nchunk < num_cus() ? nchunk : num_cus();
-    if (grid < 1) grid = 1;
+    const long long grid = rowgemm_f16_grid((M + ROWS_IT - 1) / ROWS_IT);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax, dprnn_sat_ptr());
     return dprnn_check_launch(what);
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(const float* __restrict
             const float* x = wav + (long long)b * T + (long long)(t * ks_a + j) * stride;
             float e = 0.f;
             for (int jj = 0; jj < ks; ++jj) e = fmaf(We[c * ks + jj], x[jj], e);
-            e = fmaxf(e, 0.f);
+            e = relu_f(e);
             av = fmaf(avg_w[c * ks_a + j], fmaf(e, sc0[b * N + c], sh0[b * N + c]), av);
         }
         s = fmaf(av, a[b * N + c], s);

@@ -164,7 +164,7 @@ void mask_decode_bwd_kernel(const float* __restrict__ dOut, const float* __restr
 #pragma unroll
         for (int j = 0; j < KSMAX; ++j)
             if (j < ks) en = fmaf(we[j], x[j], en);
-        en = fmaxf(en, 0.f);
+        en = relu_f(en);
         float denc = 0.f;
 #pragma unroll
         for (int spk = 0; spk < 2; ++spk) {
@@ -296,7 +296,7 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
 #pragma unroll
             for (int j = 0; j < KSMAX; ++j)
                 if (j < ks) en = fmaf(we[j], x[j], en);
-            en = fmaxf(en, 0.f);
+            en = relu_f(en);
         }
         if (MODE == 0) {
             A[row * 64 + n] = fmaf(en, scn, shn);

@@ -265,11 +265,9 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax, int* sat) {
     unsigned satm = 0u;                                  // bits of the largest |scaled dG / x element| converted (common.h)
     // element unit (row, 8-byte unit u) of a plane with `pitch` bytes per row: row*pitch + ((u ^ swz(row)) << 3)
     auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
-        const f32x4 sv = v * f32x4{s, s, s, s};
-        sat_track(satm, sv);
         float c[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(sv[e], -F16P_XMAX, F16P_XMAX);
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
         unsigned a1, a2, b1, b2;
         f16_pieces2(c[0], c[1], a1, a2);
         f16_pieces2(c[2], c[3], b1, b2);
@@ -283,6 +281,7 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax, int* sat) {
         for (int j = 0; j < 4; ++j) {
             const int row = prow + 8 * j;
             unsigned long long lo, hi;
+            sat_track(satm, pv[j]);                  // dG under the BPTT's gradient scale; x / h rows (Q) are tracked where the forward reads them
             pieces4(pv[j], sg, lo, hi);
             char* d = pb + row * (WG_MB * 2) + (((unsigned)pc4 ^ wf_swz(row)) << 3);
             *reinterpret_cast<unsigned long long*>(d) = lo;
@@ -354,7 +353,7 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax, int* sat) {
             __syncthreads();
         }
     }
-    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX);
+    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX / sg);
     // acc[jm][jn][e] = dW[m][n], m = 256 mb + 64 wm + 16 jm + 4 g + e, n = 128 nb + 64 wn + 16 jn + l
     float* const out = a.part + (long long)ks * a.Mpad * a.Npad;
 #pragma unroll
@@ -566,7 +565,7 @@ static int dgrad_impl(const float* amax, float* max_out, const float* dOut, int 
         }
         PlainRows<1> al{dOut, kd};
         EpTStore<1, 16> ep{dA, lda, reinterpret_cast<unsigned*>(max_out)};
-        return launch_rowgemm_f16t<128, 256, 1, true, true>("dgrad128x256_f16", W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st, amax);
+        return launch_rowgemm_f16t<128, 256, 1, true, true, false>("dgrad128x256_f16", W0, ldw0, k0, W1, ldw1, (long long)rows, al, ep, st, amax);
     }
     if (max_out) {
         if (lda != nd) { dprnn_set_error("dprnn_dgrad: dprnn_dgrad_store_absmax needs a dense dA (lda == nd) outside the f16 form"); return -1; }

@@ -12,6 +12,10 @@
 // 16-byte coalesced loads: a 64-sequence tile is two of those workgroups.  da_t goes to LDS as two piece planes
 // [piece][seq][512] (1 KB rows, 16-byte chunks XOR-ed with seq & 15) and, unscaled, to HBM for the weight-gradient GEMM.
 //
+// Saturation: da S_g beyond the f16 range is clamped in the piece conversion.  The kernel itself does not track it (it sits at the
+// register limit: following the maximum cost 84 bytes of scratch per lane and 14 % of its time); the gate gradients it writes to dG
+// are read back under the SAME scale by the weight-gradient GEMM (wgrad_f16_kernel tracks its P operand: flag DPRNN_SAT_WGRAD), and a
+// host that runs the fp32 weight-gradient kernel instead calls dprnn_bwd_range_check(dG, ...) after the launch (flag DPRNN_SAT_BPTT_DA).
 // Range: gradients have no natural scale, so da is multiplied by S_g = 2^(6 - e), e = exponent of max|dH| over the launch
 // (dh_absmax_kernel, one pass over dH before the launch): the largest incoming gradient sits at 2^6, a factor 2^10 below the
 // f16 limit for what the recurrence adds (beyond that the piece conversion clamps), and everything above 2^-20 of it keeps a
@@ -106,7 +110,6 @@ void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restr
 struct Bwd16Args {
     const float* dH; const float* tape; const unsigned* Wp; const float* extra;
     float* dX; float* dG;
-    int* sat;
     long long rows_total;
     int nseq, T, inner_n, ndir;
     long long outer_stride, inner_stride, t_stride;
@@ -233,7 +236,6 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) bw[ct][pc] = wload(0, ct, pc);
 
-    unsigned satm = 0u;                                  // bits of the largest |S_g da| converted to f16 pieces (common.h: sat_track)
     for (int fs = T - 1; fs >= 0; --fs) {
         const long long trow = row0 + t_of(fs) * a.t_stride;
 #pragma unroll
@@ -261,10 +263,8 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
-                    const float u0 = da[g][2 * p2] * sg, u1 = da[g][2 * p2 + 1] * sg;
-                    sat_track(satm, u0, u1);
-                    const float s0 = __builtin_amdgcn_fmed3f(u0, -F16_XMAX, F16_XMAX);
-                    const float s1 = __builtin_amdgcn_fmed3f(u1, -F16_XMAX, F16_XMAX);
+                    const float s0 = __builtin_amdgcn_fmed3f(da[g][2 * p2] * sg, -F16_XMAX, F16_XMAX);
+                    const float s1 = __builtin_amdgcn_fmed3f(da[g][2 * p2 + 1] * sg, -F16_XMAX, F16_XMAX);
                     unsigned w1, w2;
                     split2_pair_f16(s0, s1, w1, w2);
                     char* const d0 = img + nt * 16384 + g * 256, *const d1 = d0;
@@ -330,7 +330,6 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             }
         }
     }
-    sat_commit(a.sat, DPRNN_SAT_BPTT_DA, satm, F16_XMAX);
 }
 
 }  // namespace
@@ -357,7 +356,7 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
     } else {
         hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, st, dH, n4, extra + EX_DHMAX);
     }
-    Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, dprnn_sat_ptr(), rows_total, nseq, T, inner_n, ndir,
+    Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, rows_total, nseq, T, inner_n, ndir,
                 outer_stride, inner_stride, t_stride};
     const size_t lds = (size_t)2 * 64 * 512 * 2 + 3 * 64 * 4;
     auto kern = fast ? &lstm_bwd8_f16_kernel<true> : &lstm_bwd8_f16_kernel<false>;
@@ -379,6 +378,24 @@ extern "C" int dprnn_absmax(const float* x, int64_t n, float* out, void* stream)
     if (e != hipSuccess) { dprnn_set_error("dprnn_absmax: %s", hipGetErrorString(e)); return -2; }
     hipLaunchKernelGGL(dh_absmax_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, x, (long long)(n / 4), out);
     return dprnn_check_launch("dh_absmax_kernel");
+}
+
+// max|x| * S_g against the f16 range, S_g from *grad_max as the BPTT launch derived it: raises DPRNN_SAT_BPTT_DA (see the header comment)
+namespace {
+__global__ __launch_bounds__(256)
+void grad_range_check_kernel(const float* __restrict__ x, long long n4, const float* __restrict__ grad_max, int* __restrict__ sat) {
+    unsigned m = 0u;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) sat_track(m, p[i]);
+    sat_commit(sat, DPRNN_SAT_BPTT_DA, m, F16_XMAX / pow2_scale_to(*grad_max, 6));
+}
+}  // namespace
+extern "C" int dprnn_bwd_range_check(const float* dG, int64_t n, const float* grad_max, void* stream) {
+    if (!dG || !grad_max || n <= 0 || (n % 4)) { dprnn_set_error("dprnn_bwd_range_check: null pointer or n not a multiple of 4"); return -1; }
+    int* sat = dprnn_sat_ptr();
+    if (!sat) return 0;                                  // no flag buffer registered on this thread: nothing to report to
+    hipLaunchKernelGGL(grad_range_check_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, dG, (long long)(n / 4), grad_max, sat);
+    return dprnn_check_launch("grad_range_check_kernel");
 }
 
 extern "C" int64_t dprnn_rnn_pack_bwd_floats(int ndir) { return (int64_t)ndir * BWD_PACK_WORDS_PER_DIR + BWD_EXTRA; }

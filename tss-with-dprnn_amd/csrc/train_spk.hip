@@ -286,7 +286,7 @@ void fusion_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < KSMAX; ++j)
             if (j < ks) en = fmaf(we[j], x[j], en);
-        en = fmaxf(en, 0.f);
+        en = relu_f(en);
         const long long row = (long long)b * geo.L + l;
         const float g = dAp[row * 64 + n];
         const float an = fmaf(en, s0, t0);

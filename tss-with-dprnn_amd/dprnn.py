@@ -74,7 +74,8 @@ class SingleRNN(nn.Module):
         return self.hidden_size * (2 if self.bidirectional else 1)
 
     def forward(self, input):
-        raise DprnnError("SingleRNN is evaluated by dprnn_bilstm_fwd inside the TasNet wrapper forward")
+        """dprnn.py:33-37: [sequences, steps, input_size] -> [sequences, steps, output_size()] (inference only; HIP recurrence)."""
+        return engine.single_rnn_forward(self, input)
 
 
 def _make_norm(norm_type, channels):
@@ -99,7 +100,8 @@ class DPRNNBlock(nn.Module):
             self.intra_norm, self.inter_norm = n1, n2
 
     def forward(self, input):
-        raise DprnnError("DPRNNBlock is evaluated by the fused kernels inside the TasNet wrapper forward")
+        """dprnn.py:79-99: [B, F, K, S] -> [B, F, K, S] (inference only; the TasNet wrappers run the fused form of this)."""
+        return engine.block_forward(self, input)
 
 
 class DPRNN(nn.Module):

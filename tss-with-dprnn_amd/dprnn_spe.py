@@ -34,7 +34,8 @@ class ResBlock(nn.Module):
             self.conv_downsample = nn.Conv1d(in_dims, out_dims, kernel_size=1, bias=False)
 
     def forward(self, x):
-        raise DprnnError("ResBlock is evaluated by the fused MI355X kernels; call the TasNet wrapper")
+        """dprnn_spe.py:31-42: [B, C_in, T] -> [B, C_out, T // 3] (inference only; BatchNorm follows module.training)."""
+        return engine.resblock_forward(self, x)
 
 
 class DPRNNSpe(DPRNN):

@@ -1,6 +1,7 @@
 """DPRNN-Spe-IRA on the MI355X path: API mirror of the reference's src/models/dprnn_spe_ira.py
 (two separation passes; the second speaker embedding is Linear(cat(v0, spk_enc(mask0 * enc))),
 dprnn_spe_ira.py:53-115)."""
+import torch
 from torch import nn
 
 from ._lib import DprnnError
@@ -19,7 +20,19 @@ class DPRNNSpeIRA(DPRNNSpe):
         self.aux_linear = nn.Linear(2 * embeddings_size, embeddings_size)
 
     def forward(self, input, aux, aux_len):
-        raise DprnnError("DPRNNSpeIRA consumes raw waveforms on the MI355X path; call DPRNNSpeIRATasNet")
+        """dprnn_spe_ira.py:53-115 on encoder outputs: (mixture encoding [B,N,L], reference encoding [B,N,La], aux_len) ->
+        (d1 = mask_0 * input of the second pass [B,N,L], speaker logits [B,num_spks]).  Built from the same device pieces as
+        DPRNNSpe.forward (speaker encoder and DPRNN stack in HIP kernels, the per-frame glue as torch device ops); inference
+        only.  Note the reference normalises the embedding of d0 with the REFERENCE utterance's aux_len (:84): kept."""
+        B, _, L = input.size()
+        v0 = self._auxiliary(aux, aux_len)
+        output_norm = self.bottleneck[0](input)                              # cached for the second pass (:62,:96)
+        masks = self._dprnn_process(self.bottleneck[1](self._fusion(v0, output_norm, L)), B, L)
+        d0 = (masks * input.unsqueeze(1))[:, 0, :, :].contiguous()
+        v1 = self.aux_linear(torch.cat((v0, self._auxiliary(d0, aux_len)), dim=1))
+        masks = self._dprnn_process(self.bottleneck[1](self._fusion(v1, output_norm, L)), B, L)
+        d1 = (masks * input.unsqueeze(1))[:, 0, :, :]
+        return d1, self.pred_linear(v1)
 
 
 class DPRNNSpeIRATasNet(DPRNNSpeTasNet):

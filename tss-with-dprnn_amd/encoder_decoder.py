@@ -23,7 +23,9 @@ class Encoder(nn.Module):
                                 stride=stride, groups=1, bias=bias)
 
     def forward(self, input):
-        raise DprnnError("Encoder is fused into the MI355X separator kernels; call the TasNet wrapper")
+        """encoder_decoder.py:25-33: [B, T] -> [B, N, L] (inference only; the TasNet wrappers never materialise this)."""
+        from . import engine
+        return engine.encoder_forward(self, input)
 
 
 class Decoder(nn.ConvTranspose1d):
@@ -35,7 +37,9 @@ class Decoder(nn.ConvTranspose1d):
             raise NotImplementedError("Decoder(bias=True): the reference wrappers always pass bias=False (dprnn.py:263-269)")
 
     def forward(self, input):
-        raise DprnnError("Decoder is fused into the MI355X mask-head kernels; call the TasNet wrapper")
+        """encoder_decoder.py:40-49: [B, N, L] -> [B, T] (inference only; the TasNet wrappers fuse this behind the mask head)."""
+        from . import engine
+        return engine.decoder_forward(self, input)
 
 
 def squeeze_like_reference(y):

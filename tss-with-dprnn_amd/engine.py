@@ -66,6 +66,9 @@ SPLIT_ONE_GROUP = True      # split modes: SPLIT_GROUPS pipelines instead of STR
 # What a forward does when the f16-pieces arithmetic met a value beyond its range: "fallback" = run the call again in mode 1
 # (default), "raise" = DprnnError.  SATURATION counts the checks, the fall-backs and keeps the flags of the last one.
 ON_SATURATION = os.environ.get("DPRNN_ON_SATURATION", "fallback")
+# Diagnostics only (A/B timing of the check itself): DPRNN_SATURATION_CHECK=0 turns the detection off -- values beyond the range
+# would then be clamped silently, so no product path sets it.
+SATURATION_CHECK = os.environ.get("DPRNN_SATURATION_CHECK", "1") != "0"
 SATURATION = {"checks": 0, "fallbacks": 0, "last_flags": None, "last_what": None}
 _TLS = threading.local()
 
@@ -105,7 +108,7 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
     active: whether detection is needed at all (default: the thread's mode is 3)."""
     if active is None:
         active = current_mode() == 3
-    if not active or getattr(_TLS, "guard", 0) > 0:
+    if not active or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
         return primary()
     lib = load_library()
     with torch.cuda.device(dev):
@@ -907,6 +910,151 @@ def _auxiliary_embedding_impl(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
         A0 = _pointwise(st, x_cl, B * La, N, se[1].weight, se[1].bias, 128, in_scale=sc, in_shift=sh, aff_stride=N,
                         rows_per_utt=La)
         return speaker_embedding(st, sep, A0, B, La, _aux_len_tensor(aux_len, B, dev), sep.kernel_size)
+
+
+# ---- sub-module forwards (inference only).  No shipped caller uses them -- the TasNet wrappers fuse everything from the
+# waveform -- but the reference's classes have them (dprnn.py:33-37,79-99, encoder_decoder.py:25-33,40-49, dprnn_spe.py:31-42), so
+# code that drives a single block / RNN / encoder / decoder / ResBlock on [B, C, ...] tensors gets the same HIP kernels.  Layout
+# changes between the reference's channels-first tensors and the kernels' channels-last rows are torch copies (plumbing).
+def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
+    """SingleRNN.forward (dprnn.py:33-37): [n, T, F] batch-first -> [n, T, ndir*H], zero initial state."""
+    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[2] != F_BUILT or rnn.hidden_size != F_BUILT:
+        raise DprnnError(f"SingleRNN input must be [sequences, steps, {F_BUILT}] with hidden_size {F_BUILT}")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("SingleRNN runs on float32 HIP tensors only (no CPU fallback)")
+    _no_grad_only("SingleRNN.forward", x, module=rnn)
+    dev = x.device
+    n, T, _ = x.shape
+    if rnn.rnn.mode not in CELL_ID:
+        raise NotImplementedError(f"rnn_type {rnn.rnn.mode!r}")
+
+    def run():
+        with torch.cuda.device(dev):
+            st = Stage(dev)
+            xc = x.contiguous()
+            ndir, fw, bw = _rnn_tensors(rnn, dev)
+            cell = CELL_ID[rnn.rnn.mode]
+            mode = current_mode() if cell == 0 else 0
+            if mode == 1 and n < 64:
+                mode = 0
+            packed = torch.empty(2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
+            bsum = torch.empty(2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+            st.call("dprnn_rnn_pack_ex", mode, cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
+            H = torch.empty(n, T, ndir * F_BUILT, device=dev, dtype=torch.float32)
+            tile = 0 if mode == 0 else split_tile(n, ndir, st.lib.dprnn_num_cus(), 1, mode)
+            if cell != 0 and tile > 32:
+                tile = 32
+            st.call("dprnn_rnn_fwd_ex", mode, cell, _p(xc), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), n, T, n, 0, T, 1, ndir, tile)
+            return H
+    return _guarded(dev, run, _in_mode(1, run), "SingleRNN.forward")
+
+
+def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
+    """DPRNNBlock.forward (dprnn.py:79-99): [B, F, K, S] -> [B, F, K, S]."""
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != F_BUILT:
+        raise DprnnError(f"DPRNNBlock input must be [batch, {F_BUILT}, chunk_length, chunks]")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("DPRNNBlock runs on float32 HIP tensors only (no CPU fallback)")
+    if not hasattr(blk, "intra_norm"):
+        raise DprnnError("DPRNNBlock without norms (norm_type neither 'ln' nor 'gLN'): the reference's forward fails too")
+    _no_grad_only("DPRNNBlock.forward", x, module=blk)
+    dev = x.device
+    B, _, K, S = x.shape
+
+    def run():
+        with torch.cuda.device(dev):
+            st = Stage(dev)
+            import types
+            geo = Geometry(B, 0, 0, K, 1, S, 1, 1, N_BUILT)
+            rows = B * S * K
+            g = types.SimpleNamespace(st=st, geo=geo, b0=0, b1=B, pending=None, n_concurrent=1, mode=0,
+                                      X=torch.empty(rows * F_BUILT, device=dev, dtype=torch.float32), X2=None,
+                                      Z=torch.empty(rows * F_BUILT, device=dev, dtype=torch.float32),
+                                      H=torch.empty(rows * 2 * F_BUILT, device=dev, dtype=torch.float32))
+            g.X.view(B, S, K, F_BUILT).copy_(x.permute(0, 3, 2, 1))          # slab rows (b, s, k)
+            mode = effective_gemm_mode(B, [blk])
+            prev = st.lib.dprnn_get_gemm_mode()
+            st.lib.dprnn_set_gemm_mode(mode)
+            g.mode = mode
+            try:
+                stats = torch.zeros(2, B, 2, device=dev, dtype=torch.float64)
+                packed = torch.empty(2, 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
+                bsum = torch.empty(2, 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+                for j, (rnn, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
+                                                             (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
+                    _, fw, bw = _rnn_tensors(rnn, dev)
+                    st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
+                            _p(packed[j]), _p(bsum[j]))
+                    _run_path(g, rnn, lin, norm, stats[j], packed[j], bsum[j], intra, None, False)
+            finally:
+                st.lib.dprnn_set_gemm_mode(prev)
+            return g.X.view(B, S, K, F_BUILT).permute(0, 3, 2, 1).contiguous()
+    return _guarded(dev, run, _in_mode(1, run), "DPRNNBlock.forward")
+
+
+def encoder_forward(enc, wav: torch.Tensor) -> torch.Tensor:
+    """Encoder.forward (encoder_decoder.py:25-33): [B, T] -> relu(conv1d) [B, N, L]."""
+    wav = check_input(wav)
+    dev = wav.device
+    w = _param(enc.conv1d.weight, "encoder.conv1d.weight", dev)
+    N, _, ks = w.shape
+    stride = enc.conv1d.stride[0]
+    if N != N_BUILT or ks > KS_MAX:
+        raise NotImplementedError(f"Encoder MI355X path: output_size must be {N_BUILT}, kernel_size <= {KS_MAX}")
+    _no_grad_only("Encoder.forward", wav, module=enc)
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        geo = make_geometry(wav.shape[0], wav.shape[1], N, 1, 1, ks, stride)
+        one = torch.ones(geo.B, N, device=dev, dtype=torch.float32)
+        zero = torch.zeros_like(one)
+        A = torch.empty(geo.B, geo.L, N, device=dev, dtype=torch.float32)
+        st.call("dprnn_encoder_norm_rows", _p(wav), _p(w), _p(one), _p(zero), _p(A), geo.B, geo.T, geo.L, N, ks, stride)
+        return A.transpose(1, 2).contiguous()
+
+
+def decoder_forward(dec, x: torch.Tensor) -> torch.Tensor:
+    """Decoder.forward (encoder_decoder.py:40-49): [B, N, L] -> [B, T] with the reference's squeeze rule."""
+    if not isinstance(x, torch.Tensor) or x.dim() != 3:
+        raise DprnnError("Decoder input must be [batch, channels, frames]")   # (the reference also accepts 2-D; its wrappers never pass it)
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("Decoder runs on float32 HIP tensors only (no CPU fallback)")
+    _no_grad_only("Decoder.forward", x, module=dec)
+    dev = x.device
+    w = _param(dec.weight, "decoder.weight", dev)
+    N, oc, ks = w.shape
+    stride = dec.stride[0]
+    B, C, L = x.shape
+    if C != N or oc != 1:
+        raise DprnnError(f"Decoder expects {N} channels and one output channel")
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        rows = x.transpose(1, 2).contiguous().view(B * L, N)
+        wt = w[:, 0, :].t().contiguous()                                     # [ks][N]: taps[row][j] = sum_n Wd[n][j] x[row][n]
+        taps = torch.zeros(B, 2, L, ks, device=dev, dtype=torch.float32)     # dprnn_decoder_fwd reads [B][2 speakers][L][ks]
+        taps[:, 0] = _linear_small(st, wt, None, rows).view(B, L, ks)
+        geo = Geometry(B, 0, L, 1, 1, 1, ks, stride, N)
+        out = decode(st, taps, geo, 1)[:, 0, :]
+    from .encoder_decoder import squeeze_like_reference
+    return squeeze_like_reference(out)
+
+
+def resblock_forward(blk, x: torch.Tensor) -> torch.Tensor:
+    """ResBlock.forward (dprnn_spe.py:31-42): [B, C_in, T] -> [B, C_out, T // 3]."""
+    if not isinstance(x, torch.Tensor) or x.dim() != 3:
+        raise DprnnError("ResBlock input must be [batch, channels, frames]")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("ResBlock runs on float32 HIP tensors only (no CPU fallback)")
+    _no_grad_only("ResBlock.forward", x, module=blk)
+    dev = x.device
+    B, cin, T = x.shape
+    cout = blk.conv1.out_channels
+    if blk.conv1.in_channels != cin or cin not in (128, 256) or cout not in (128, 256):
+        raise NotImplementedError("ResBlock MI355X path: 128 or 256 channels (the reference's speaker encoder: O=128, P=256)")
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        rows = x.transpose(1, 2).contiguous().view(B * T, cin)
+        out, _ = _resblock(st, blk, rows, B, T, cin, cout)
+        return out.transpose(1, 2).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------ ragged batches

@@ -179,7 +179,17 @@ def make_tensor(key: str, shape: tuple, seed: int) -> np.ndarray:
     raise RuntimeError(f"bias tensors are generated in make_state: {key}")
 
 
-def make_state(kind: str, cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
+def make_state(kind: str, cfg: dict, seed: int = 0, style: str = "init", **recipe) -> Dict[str, np.ndarray]:
+    """style "init": ranges of torch's default initialisers (above).  style "trained": the same tensors reshaped towards
+    the statistics of a trained separator, where an arithmetic that leans on benign magnitudes would show it --
+      * every LSTM weight row times its own factor, log-uniform in [1, 30] (heavy-tailed rows: a few units dominate a gate);
+      * forget-gate biases (rows H .. 2H of bias_ih: gate order i, f, g, o) + U(1, 3) (the usual remember-by-default offset);
+      * norm gains log-uniform in [0.2, 8] (intra / inter GroupNorm, bottleneck norm), shifts U(-0.5, 0.5): the residual stream
+        grows over the 12 residual additions instead of staying O(1)."""
+    if style == "trained":
+        return _trained_like(kind, cfg, seed, **recipe)
+    if style != "init":
+        raise ValueError(f"unknown weight style {style!r}")
     cfg = full_cfg(**cfg)
     spec = state_spec(kind, cfg)
     shapes = dict(spec)
@@ -199,6 +209,32 @@ def make_state(kind: str, cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
             out[key] = ((2 * _rng(seed, key).random(shape) - 1) * a).astype(np.float32)
             continue
         out[key] = make_tensor(key, shape, seed)
+    return out
+
+
+TRAINED = dict(r_ih=30.0, r_hh=30.0, g_lo=0.2, g_hi=8.0, f_lo=1.0, f_hi=3.0)
+
+
+def _trained_like(kind: str, cfg: dict, seed: int, **recipe) -> Dict[str, np.ndarray]:
+    rc = dict(TRAINED, **recipe)
+    cfg = full_cfg(**cfg)
+    H = cfg["hidden_size"]
+    out = make_state(kind, cfg, seed, style="init")
+    for key in list(out):
+        g = _rng(seed + 7919, key)
+        v = out[key]
+        leaf = key.rsplit(".", 1)[-1]
+        if ".rnn.weight_" in key:
+            rows = np.exp(g.uniform(0.0, np.log(rc["r_ih"] if "weight_ih" in key else rc["r_hh"]), size=(v.shape[0], 1))).astype(np.float32)
+            out[key] = (v * rows).astype(np.float32)
+        elif ".rnn.bias_ih" in key and cfg["rnn_type"] == "LSTM":
+            v = v.copy()
+            v[H: 2 * H] += g.uniform(rc["f_lo"], rc["f_hi"], size=H).astype(np.float32)
+            out[key] = v
+        elif ("_norm." in key or "bottleneck.0." in key) and leaf in ("weight", "gamma"):
+            out[key] = np.exp(g.uniform(np.log(rc["g_lo"]), np.log(rc["g_hi"]), size=v.shape)).astype(np.float32)
+        elif ("_norm." in key or "bottleneck.0." in key) and leaf in ("bias", "beta"):
+            out[key] = g.uniform(-0.5, 0.5, size=v.shape).astype(np.float32)
     return out
 
 

@@ -17,14 +17,34 @@ import time
 from collections import deque
 from typing import Iterable, Optional
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC for RCCL on this driver: must be in the environment before the HIP runtime comes up (see tss_with_dprnn_amd.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from .training import FusedAdam, PITSiSdrLoss
 
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def init_process_group(backend: str = "nccl", device: Optional[torch.device] = None, **kwargs) -> None:
+    """``torch.distributed.init_process_group`` for one process per GPU (RANK / WORLD_SIZE / MASTER_* from the launcher, use
+    127.0.0.1 as the rendezvous address on one node).  backend "nccl" is RCCL over xGMI; it needs HSA_ENABLE_IPC_MODE_LEGACY=0
+    in the environment before the HIP runtime starts, which importing this package arranges -- a process that initialised the
+    GPU earlier with another value is told so here instead of failing inside RCCL with `hipIpcGetMemHandle: invalid argument`."""
+    if backend == "nccl":
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            raise RuntimeError("RCCL on this platform needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC); the environment has "
+                               f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}")
+        if device is None:
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=device, **kwargs)
+    else:
+        dist.init_process_group(backend=backend, **kwargs)
 
 
 class FlatGradAllReducer:

@@ -380,6 +380,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         st.call("dprnn_rnn_bwd_ex", bm, hmax.data_ptr() if bptt_f16 else 0, cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG),
                 rows, *addr, ndir)
         del dH
+        if bptt_f16 and not wgrad_f16:      # nobody will read dG under the BPTT's scale: check its range here (flag 3)
+            st.call("dprnn_bwd_range_check", _p(dG), dG.numel(), packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir))
         pre = f"{blk}_rnn.rnn."
         for d in range(ndir):
             suf = "_reverse" if d == 1 else ""
@@ -577,6 +579,7 @@ class _TasNetFunction(torch.autograd.Function):
         ctx.done = False
         ctx.wav_all = wav               # 4 bytes per sample: what a saturated backward needs to run again from the waveform
         ctx.fwd_exact = False
+        ctx.modes = train_modes()[:2]   # autograd runs backward() on another thread: the modes of THIS forward travel with it
 
         def run():
             if mb_max >= B:
@@ -604,7 +607,7 @@ class _TasNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        with torch.cuda.device(d_out.device):
+        with torch.cuda.device(d_out.device), use_train_modes(*ctx.modes):
             if ctx.done:
                 raise DprnnError("DPRNN MI355X training path: backward() was called a second time on the same forward; the "
                                  "saved activations (tape) are released by the first backward (retain_graph is not supported "

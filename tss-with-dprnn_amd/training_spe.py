@@ -436,6 +436,7 @@ class _SpeFunction(torch.autograd.Function):
         ctx.ira = bool(getattr(model, "_ira", False))
         ctx.inputs = (wav, aux, aux_len)        # what a saturated backward needs to run again from the waveforms
         ctx.fwd_exact = False
+        ctx.modes = training.train_modes()[:2]  # autograd runs backward() on another thread: this forward's modes travel with it
         run = lambda: spe_forward_train(model, wav, aux, aux_len, ctx.ira)
 
         def run_exact():
@@ -449,7 +450,7 @@ class _SpeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_est, d_logits):
         model = ctx.model
-        with torch.cuda.device(d_est.device):
+        with torch.cuda.device(d_est.device), training.use_train_modes(*ctx.modes):
             d_est = d_est.contiguous().float()
             first = lambda: spe_backward(model, ctx.saved, d_est, d_logits, ctx.ira)
             if ctx.fwd_exact:

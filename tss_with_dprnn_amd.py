@@ -6,6 +6,11 @@ directly; this module turns itself into that package by pointing ``__path__`` at
 """
 import os as _os
 
+# The host driver of this pool supports dmabuf IPC only: RCCL (torch.distributed backend "nccl") and device tensors shared between
+# the ranks of one node need HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the HIP runtime comes up (without it:
+# `hipIpcGetMemHandle: invalid argument`).  Importing this package is early enough in every launch form (python, torchrun,
+# a trainer script): nothing below touches the GPU.  An explicit setting in the environment wins.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 __path__ = [_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tss-with-dprnn_amd")]
 __version__ = "0.1.0"
