@@ -11,6 +11,8 @@ namespace rsplit {
 // every weight request (buffer_load_dwordx4, ~33 cycles of issue) stops that SIMD's MFMA stream, 27 % of the MFMA phase
 // at 64 sequences; with two waves per SIMD one wave's memory and vector instructions issue under the other's MFMAs.
 //   per step: [gate GEMM (8 k-slabs: x half, then h half)] [cell update + staging of x_{t+1}] barrier
+// (Round 3 also measured a skewed loop -- the x half of step t+1 before the barrier, so that one wave's cell update runs under its
+// SIMD partner's MFMAs: correct, 2 % slower; the per-phase stamps and the reasons are in profiles/r03_recur_skew.txt.)
 // (A staggered form -- cell update of one wave group beside the x half of the other's next step -- was measured in round 2
 // and removed in round 3: two accumulator sets spill at 64 sequences, 15.1 against 11.6 us per step; profiles/r02_split_wide.txt.)
 // Image: regions h (x 2) | x (x 2) when double-buffered, each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
@@ -19,12 +21,6 @@ namespace rsplit {
 #endif
 #ifndef DPRNN_SPLIT8_PRIO
 #define DPRNN_SPLIT8_PRIO 1
-#endif
-#ifndef DPRNN_SPLIT8_RES32
-#define DPRNN_SPLIT8_RES32 1
-#endif
-#ifndef DPRNN_SPLIT8_LRES
-#define DPRNN_SPLIT8_LRES 3
 #endif
 constexpr bool split8_double_buffered(int nsr, bool f16) { return DPRNN_SPLIT8_DB && f16 && nsr <= 64 && !(nsr == 16 && DPRNN_SPLIT8_LRES > 3); }
 // 16-sequence f16 tile: second weight pieces of the LAST `lres` k-slabs live in LDS (32 KB per slab and direction)
