@@ -22,6 +22,12 @@ namespace rsplit {
 #ifndef DPRNN_SPLIT8_PRIO
 #define DPRNN_SPLIT8_PRIO 1
 #endif
+#ifndef DPRNN_SPLIT8_RES32
+#define DPRNN_SPLIT8_RES32 1
+#endif
+#ifndef DPRNN_SPLIT8_LRES
+#define DPRNN_SPLIT8_LRES 3
+#endif
 constexpr bool split8_double_buffered(int nsr, bool f16) { return DPRNN_SPLIT8_DB && f16 && nsr <= 64 && !(nsr == 16 && DPRNN_SPLIT8_LRES > 3); }
 // 16-sequence f16 tile: second weight pieces of the LAST `lres` k-slabs live in LDS (32 KB per slab and direction)
 constexpr int split8_lds_resident_slabs(int nsr, bool f16) { return (f16 && nsr == 16) ? DPRNN_SPLIT8_LRES : 0; }
