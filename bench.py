@@ -292,21 +292,36 @@ def main():
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
     REC = "dprnn_rnn_fwd_ex"            # the recurrence launches (the dominant kernel)
 
-    def timed_region(mode, steps, warmup):
+    def host_state():
+        """What can stall the enqueueing host: the caching allocator going back to the driver (segments allocated / freed, retries) and
+        the cgroup throttling this process (periods in which the box's CPU quota ran out)."""
+        ms = torch.cuda.memory_stats(dev)
+        out = {k: int(ms.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
+        out["reserved_GiB"] = ms.get("reserved_bytes.all.current", 0) / 2**30
+        for p_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+            if os.path.exists(p_):
+                d_ = dict(ln.split() for ln in open(p_).read().strip().splitlines())
+                out.update({k: int(d_[k]) for k in ("nr_throttled", "throttled_usec") if k in d_})
+                break
+        return out
+
+    def timed_region(mode, steps, warmup, profile=False):
         """`warmup` untimed forwards, then exactly `steps` timed ones between barriers, under gate-GEMM mode `mode`.  Every
         forward ends with the saturation check of the f16-pieces arithmetic (one stream synchronisation), so the host clock
-        around each call is that step's latency."""
+        around each call is that step's latency.  profile: HIP events around every recurrence launch (engine.PROFILE) -- this
+        forces the eager launch sequence, a replayed HIP graph has no place for them."""
         engine.GEMM_MODE = mode
         with torch.no_grad():
             for _ in range(warmup):
                 o = model(x)
             sync()
-            engine.PROFILE = {"names": {REC}, "events": {}}
+            engine.PROFILE = {"names": {REC}, "events": {}} if profile else None
             gc.collect()
             gc.disable()                # the host enqueues ~300 launches per step: no collector pauses inside the timed region
             t_ref = torch.cuda.Event(enable_timing=True)
             t_ref.record()
             per_step = []
+            h0 = host_state()
             t0 = time.perf_counter()
             tp = t0
             for _ in range(steps):
@@ -318,12 +333,25 @@ def main():
                 tp = tn
             sync()
             dt = time.perf_counter() - t0
+            h1 = host_state()
             gc.enable()
             prof, engine.PROFILE = engine.PROFILE, None
+        host_delta[mode] = {k: (h1[k] - h0[k] if k != "reserved_GiB" else h1[k]) for k in h1}
         return o, dt, per_step, prof, t_ref
 
+    host_delta = {}
+
     sat0 = dict(engine.SATURATION)
-    out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup)
+    graphs0 = dict(engine.GRAPH_STATS)
+    # With HIP graphs on (the engine's default) the timed region replays the captured forward; the per-launch kernel timing of the
+    # roofline then comes from a second, eager pass of the same batch (PROF_STEPS steps).  DPRNN_GRAPHS=0: one region serves both.
+    PROF_STEPS = min(args.steps, 10)
+    out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup, profile=not engine.GRAPHS)
+    graph_replays = engine.GRAPH_STATS["replays"] - graphs0["replays"]
+    prof_steps = args.steps
+    if engine.GRAPHS:
+        _, _, _, prof, t_ref = timed_region(args.gemm_mode, PROF_STEPS, 1, profile=True)
+        prof_steps = PROF_STEPS
     assert out.shape == (B, 2, SAMPLES) and bool(torch.isfinite(out).all())
     sat_checks = engine.SATURATION["checks"] - sat0["checks"]
     sat_fallbacks = engine.SATURATION["fallbacks"] - sat0["fallbacks"]
@@ -388,11 +416,17 @@ def main():
 
     def latency(per_step):
         v = np.sort(np.asarray(per_step)) * 1e3
+        slow = [int(i) for i in np.argsort(per_step)[::-1][:3]]
         return {"ms_per_step_p50": float(np.percentile(v, 50)), "ms_per_step_p99": float(np.percentile(v, 99)),
-                "ms_per_step_min": float(v[0]), "ms_per_step_max": float(v[-1]), "steps": int(v.size)}
+                "ms_per_step_min": float(v[0]), "ms_per_step_max": float(v[-1]), "steps": int(v.size),
+                "p99_over_p50": float(np.percentile(v, 99) / np.percentile(v, 50)),
+                "slowest_steps": {str(i): round(1e3 * per_step[i], 2) for i in slow}}
 
     value = world * B * args.steps / elapsed
-    head_roof = roofline(args.gemm_mode, prof, t_ref, args.steps, value / world)
+    head_roof = roofline(args.gemm_mode, prof, t_ref, prof_steps, value / world)
+    head_roof["timed_in"] = ("the timed region itself (eager launches)" if not engine.GRAPHS else
+                             f"a second pass of {prof_steps} eager forwards of the same batch right after the timed region, which replays a "
+                             "captured HIP graph (no place for events inside a graph)")
     n_groups = head_roof["concurrent_streams"]
 
     # The reference's own precision, first class: the same batch, the same number of steps and warm-ups under
@@ -400,12 +434,16 @@ def main():
     exact = None
     ref_out = out.double()
     if args.gemm_mode != 0 and world == 1 and not args.no_optional_modes:
-        o0, dt0, ps0, prof0, tref0 = timed_region(0, args.steps, args.warmup)
+        o0, dt0, ps0, prof0, tref0 = timed_region(0, args.steps, args.warmup, profile=not engine.GRAPHS)
         v0 = B * args.steps / dt0
+        ex_steps = args.steps
+        if engine.GRAPHS:
+            _, _, _, prof0, tref0 = timed_region(0, PROF_STEPS, 1, profile=True)
+            ex_steps = PROF_STEPS
         exact = dict({"metric": "utterances/sec (3 s @ 8 kHz) DPRNN-TasNet fwd, exact fp32 MFMA arithmetic (DPRNN_GEMM_MODE=0)",
                       "value": v0, "unit": "utt/s", "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt0 / args.steps,
                       "dtype": "f32", "rel_l2_vs_headline_output": float((o0.double() - ref_out).norm() / ref_out.norm()),
-                      "roofline": roofline(0, prof0, tref0, args.steps, v0)}, **latency(ps0))
+                      "roofline": roofline(0, prof0, tref0, ex_steps, v0)}, **latency(ps0))
         del o0
     # mode 1 (three bf16 pieces, six products: the fall-back arithmetic of a saturated forward), 3 steps after the timed regions
     mode_names = {0: "exact_fp32_mfma", 1: "bf16_split_6_products", 3: "f16_pieces_3_products"}
@@ -441,10 +479,14 @@ def main():
                        "per_gpu_batch": B, "samples": SAMPLES, "parallelism": f"utterance-sharded x{world}",
                        "fast_activations": bool(args.fast_act), "stream_groups": engine.STREAM_GROUPS,
                        "stream_groups_used": n_groups, "rowgemm_grid": lib.dprnn_get_rowgemm_grid(),
+                       "hip_graphs": bool(engine.GRAPHS), "graph_replays_in_timed_region": graph_replays,
                        "gemm_mode": {0: "exact fp32 MFMA (DPRNN_GEMM_MODE=0)", 1: "fp32-equivalent bf16 split, 6 products (DPRNN_GEMM_MODE=1)",
                                      3: "fp32-equivalent f16 pieces, 3 products (DPRNN_GEMM_MODE=3)"}[args.gemm_mode]
                        + (" (default)" if args.gemm_mode == engine.DEFAULT_GEMM_MODE else "")},
             "latency": latency(per_step),
+            "host": dict(host_delta.get(args.gemm_mode, {}), gc="disabled in the timed region",
+                         note="deltas over the timed region: driver-level allocations / frees of the caching allocator, allocation "
+                              "retries, cgroup CPU-throttling periods of this process; reserved_GiB at its end"),
             "saturation": {"checks": sat_checks, "fallbacks": sat_fallbacks,
                            "note": "every forward in the f16-pieces arithmetic reads its saturation flags before it returns (inside the "
                                    "timed region); a fall-back re-runs the forward in mode 1"},

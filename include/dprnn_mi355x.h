@@ -43,6 +43,8 @@ int dprnn_num_cus(void);
  * 2e-7 rel-L2 against the reference output end to end, tests/test_gpu_parity.py), 0 = libm expf/tanhf */
 void dprnn_set_fast_activations(int on);        /* LSTM gates (dprnn_bilstm_fwd) */
 void dprnn_set_fast_head_activations(int on);   /* mask head tanh/sigmoid */
+int dprnn_get_fast_activations(void);
+int dprnn_get_fast_head_activations(void);
 /* Arithmetic mode of the contractions (gate GEMM of the LSTM recurrence; in mode 3 also the Linear after it, the bottleneck and
  * the mask head):
  *   0 = exact fp32 operands on the fp32 MFMA: bit-for-bit an fma chain (the library's own default; what GRU / Elman cells

@@ -452,3 +452,80 @@ def test_trained_like_weights_in_every_fp32_class_mode(name, mode):
           f"max |residual stream| {max(m['residual_stream_absmax_after_block']):.0f}")
     assert r32 <= max(REL_TOL, 3 * gap), (r32, gap)
     assert r64 <= max(3e-6, 2.5 * gap), (r64, gap)
+
+
+# ---- HIP graphs (engine._graphed): the second forward of a (model, shapes, mode, knobs) key is captured, later ones replay
+@pytest.mark.parametrize("kind", ["bss", "spe_bntrain", "ira"])
+def test_graph_replay_equals_eager_forward(kind):
+    """Eager, captured and replayed forwards of the same input agree bit for bit; a replay with NEW input values and with weights
+    changed in place (same parameter storage) equals the eager forward of that input with those weights; a BatchNorm in train mode
+    leaves the same running statistics behind; a NaN sample is still noticed (the graph's own saturation flags) and comes back NaN."""
+    from tss_with_dprnn_amd.synthetic import make_mixture
+    over = dict(chunk_length=50, hop_length=25, n_repeats=2)
+    if kind != "bss":
+        over.update(fusion_type="cat", norm_type="ln")
+    model, sd, cfg = build_model("bss" if kind == "bss" else ("ira" if kind == "ira" else "spe"), over, 91, _dev())
+    if "bntrain" in kind:
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.train()
+    B, T = 3, 3300
+
+    def inputs(seed):
+        a = [torch.from_numpy(make_mixture(B, T, seed=seed)).to(_dev())]
+        if kind != "bss":
+            a += [torch.from_numpy(make_mixture(B, 3000, seed=seed + 50)).to(_dev()), torch.tensor(3000.0)]
+        return a
+
+    def first(o):
+        return (o[0] if isinstance(o, tuple) else o).cpu().numpy()
+
+    def bn_state():
+        return {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    assert engine.GRAPHS
+    engine.drop_graphs()
+    stats0 = dict(engine.GRAPH_STATS)
+    bn0 = bn_state()
+    with torch.no_grad():
+        outs = [first(model(*inputs(1))) for _ in range(4)]                 # eager, capture + replay, replay, replay
+        bn_graph = bn_state()
+        y_new = first(model(*inputs(2)))                                     # replay with other input values
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.01)                                                 # in place: the graph reads the same storage
+        y_w = first(model(*inputs(2)))
+    assert engine.GRAPH_STATS["captures"] == stats0["captures"] + 1 and engine.GRAPH_STATS["replays"] >= stats0["replays"] + 5
+    if "bntrain" not in kind:
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0])
+    old = engine.GRAPHS
+    engine.GRAPHS = False
+    try:
+        with torch.no_grad():
+            want_w = first(model(*inputs(2)))
+            for p in model.parameters():
+                p.div_(1.01)
+            model.load_state_dict({**model.state_dict(), **bn0})
+            eager = [first(model(*inputs(1))) for _ in range(4)]
+            bn_eager = bn_state()
+            want_new = first(model(*inputs(2)))
+    finally:
+        engine.GRAPHS = old
+    for a, b in zip(outs, eager):
+        assert rel_l2(a, b) < 1e-6
+    for k in bn_eager:
+        assert torch.allclose(bn_graph[k].float(), bn_eager[k].float(), rtol=1e-5, atol=1e-7), k
+    assert rel_l2(y_w, want_w) < 1e-6
+    if "bntrain" not in kind:          # (train-mode BatchNorm: y_new saw different running statistics than want_new)
+        assert rel_l2(y_new, want_new) < 1e-6
+    # a NaN sample through the captured graph (bss: the key of inputs(1) is cached again after the eager block above)
+    if kind == "bss":
+        with torch.no_grad():
+            model(*inputs(1)); model(*inputs(1))
+            bad = inputs(3)
+            bad[0][1, 77] = float("nan")
+            before = dict(engine.SATURATION)
+            got = first(model(*bad))
+        assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 1
+        assert np.isnan(got[1]).all() and np.isfinite(got[[0, 2]]).all()
+    engine.drop_graphs()

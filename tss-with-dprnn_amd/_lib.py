@@ -137,6 +137,8 @@ _SPECIAL = {
     "dprnn_num_cus": ([], c_i),
     "dprnn_get_gemm_mode": ([], c_i),
     "dprnn_get_rowgemm_grid": ([], c_i),
+    "dprnn_get_fast_activations": ([], c_i),
+    "dprnn_get_fast_head_activations": ([], c_i),
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),

@@ -554,6 +554,7 @@ extern "C" int dprnn_lstm_pack(const float* w_ih, const float* w_hh, const float
 
 static int g_fast_act = 1;   // v_exp_f32/v_rcp_f32 gate activations: 2e-7 rel-L2 end to end, same as the libm forms
 extern "C" void dprnn_set_fast_activations(int on) { g_fast_act = on; }
+extern "C" int dprnn_get_fast_activations(void) { return g_fast_act; }
 int dprnn_fast_activations_enabled(void) { return g_fast_act; }      // train_recur.hip
 
 static int bilstm_dispatch(RecurArgs a, int mode, int seq_tile, hipStream_t st) {

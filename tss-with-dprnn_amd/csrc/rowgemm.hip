@@ -27,6 +27,7 @@ extern "C" void dprnn_set_rowgemm_grid(int workgroups) { g_rowgemm_grid.store(wo
 extern "C" int dprnn_get_rowgemm_grid(void) { return rg::rowgemm_grid_cap(); }
 static int g_fast_head = 1;
 extern "C" void dprnn_set_fast_head_activations(int on) { g_fast_head = on; }
+extern "C" int dprnn_get_fast_head_activations(void) { return g_fast_head; }
 
 static int bottleneck(const float* wav, const float* enc_w, const float* sc, const float* sh,
                       const float* Wb, int ldw, const float* bb, const float* row_bias, const float* row_scale, float* Y,

@@ -9,6 +9,7 @@ those kernels.  Stage order follows the reference forward:
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import ctypes
 import functools
@@ -100,12 +101,13 @@ def _bn_buffers(module):
             for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
 
 
-def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None):
+def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None):
     """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
     f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
     fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
     flags come back with a 32-byte copy).  Nested calls are covered by the outermost guard.
-    active: whether detection is needed at all (default: the thread's mode is 3)."""
+    active: whether detection is needed at all (default: the thread's mode is 3).  flags: the device buffer to register (a captured
+    HIP graph's kernels carry the address of the buffer that was registered when they were captured)."""
     if active is None:
         active = current_mode() == 3
     if not active or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
@@ -113,7 +115,8 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
     lib = load_library()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
+        if flags is None:
+            flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
         bufs = _bn_buffers(module)
         keep = [b.clone() for b in bufs]
         check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
@@ -311,6 +314,28 @@ def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geome
     """Encoder -> bottleneck norm -> (fusion) -> bottleneck 1x1 conv, output Y [B][L][F]."""
     sc, sh = bottleneck_affine(st, wav, enc_w, bott_norm, geo, stats_slot, mul, add)
     return bottleneck_frames(st, wav, enc_w, sc, sh, bott_conv, geo, row_bias)
+
+
+# Side streams of the utterance groups: the SAME streams for every forward of a (thread, device).  torch.cuda.Stream() hands out
+# the 32 streams of its pool round-robin, and HIP maps streams onto a few hardware queues: taking fresh streams per forward made
+# every 16th forward of the bench (the position of the cycle whose two streams collide on a queue) 5 ms slower -- the stall that
+# round 2 could not place (profiles/r03_host_stall.txt).
+_SIDE_POOL: dict = {}
+
+
+def _side_streams(dev, n: int):
+    key = (threading.get_ident(), str(dev))
+    pool = _SIDE_POOL.get(key)
+    if pool is None:
+        # tools/probes/stream_pair_timing.py: of the 16 pairs of torch's pool exactly one -- the first two streams it hands out in
+        # a process -- makes every forward 5 ms slower (80.3 against 75.2 ms, both times it comes round); when nobody has taken
+        # streams before us those are the ones we would get, so they are taken and left unused
+        if not _SIDE_POOL:
+            _SIDE_POOL["_skipped"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pool = _SIDE_POOL.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 def _rnn_tensors(rnn, dev):
@@ -513,8 +538,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
         fork = torch.cuda.Event()
         fork.record(st.tstream)
         groups = []
-        for b0, b1 in parts:
-            side = torch.cuda.Stream(device=dev)
+        for (b0, b1), side in zip(parts, _side_streams(dev, len(parts))):
             side.wait_event(fork)
             groups.append(_Group(Stage(dev, side), geo, b0, b1, dev))
 
@@ -569,7 +593,8 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             done = torch.cuda.Event()
             done.record(g.st.tstream)
             st.tstream.wait_event(done)
-            g.arena.record_stream(g.st.tstream)
+            if not getattr(_TLS, "capturing", False):       # a captured graph owns its memory pool: nothing to hand over
+                g.arena.record_stream(g.st.tstream)
     return (taps, masked) if want_masked else taps
 
 
@@ -1339,6 +1364,110 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
         return [(est[0, 0, :], logits[0]) for est, logits in r3]
 
 
+# ------------------------------------------------------------------------------------------------ HIP graphs
+# A forward is ~300 kernel launches enqueued from Python (~5 ms of host time at B = 64, 2-3 x the GPU time at B = 1).  Shapes are
+# static and parameters are read through their (stable) device addresses, so the launch sequence of a forward -- every stream of
+# it -- is captured once per (model, input shapes, mode, knobs) into a HIP graph and replayed with ONE launch: inputs are copied
+# into the graph's static buffers, outputs are cloned out of them, the saturation flags are the graph's own buffer (its kernels
+# carry that address) and are read after every replay exactly as after an eager forward.  The first forward of a key runs
+# eagerly (it also performs the one-time hipFuncSetAttribute calls), the second captures, later ones replay; GRAPH_CACHE_MAX
+# graphs are kept (each holds its forward's workspace: 6.4 GB at 64 x 3 s).  DPRNN_GRAPHS=0 turns it off.
+GRAPHS = os.environ.get("DPRNN_GRAPHS", "1") != "0"
+GRAPH_CACHE_MAX = 4
+GRAPH_STATS = {"captures": 0, "replays": 0}
+_GRAPH_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_GRAPH_SEEN: "collections.OrderedDict" = collections.OrderedDict()
+_GRAPH_LOCK = threading.Lock()
+_CAPTURE_LOCK = threading.Lock()         # torch registers generator state per capture, process-wide: one capture at a time
+
+
+def _clone_out(o):
+    if isinstance(o, torch.Tensor):
+        return o.clone()
+    if isinstance(o, (tuple, list)):
+        return type(o)(_clone_out(v) for v in o)
+    return o
+
+
+class _Graphed:
+    def __init__(self, dev, fn, inputs):
+        lib = load_library()
+        self.inputs = [t.clone() for t in inputs]
+        self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
+        prev = getattr(_TLS, "guard", 0)
+        _TLS.guard, _TLS.capturing = 1, True
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.outputs = fn(*self.inputs)
+        finally:
+            _TLS.guard, _TLS.capturing = prev, False
+            lib.dprnn_saturation_begin(0, 0)
+
+    def replay(self, inputs):
+        for s_, t in zip(self.inputs, inputs):
+            s_.copy_(t)
+        self.graph.replay()
+        return _clone_out(self.outputs)
+
+
+def _graph_key(kind: str, model, inputs, extra=()):
+    lib = load_library()
+    params = tuple(p.data_ptr() for p in model.parameters()) + tuple(b.data_ptr() for b in model.buffers())
+    bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
+    knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
+             SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
+             lib.dprnn_get_rowgemm_grid())
+    return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
+
+
+def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
+    """fn(*inputs) -- an inference forward over device tensors -- eagerly, or through its captured HIP graph (see above); either
+    way under the saturation guard, falling back to an eager forward in mode 1."""
+    dev = inputs[0].device
+    eager = lambda: fn(*inputs)
+    usable = (GRAPHS and PROFILE is None and getattr(_TLS, "guard", 0) == 0 and not getattr(_TLS, "capturing", False)
+              and not torch.is_grad_enabled())
+    if not usable:
+        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+    key = _graph_key(kind, model, inputs, extra)
+    with _GRAPH_LOCK:
+        g = _GRAPH_CACHE.get(key)
+        if g is not None:
+            _GRAPH_CACHE.move_to_end(key)
+        else:
+            seen = _GRAPH_SEEN.get(key, 0) + 1
+            _GRAPH_SEEN[key] = seen
+            _GRAPH_SEEN.move_to_end(key)
+            while len(_GRAPH_SEEN) > 64:
+                _GRAPH_SEEN.popitem(last=False)
+    if g is None and seen < 2:
+        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+    with torch.cuda.device(dev):
+        if g is None:
+            with _CAPTURE_LOCK:
+                g = _Graphed(dev, fn, inputs)
+            GRAPH_STATS["captures"] += 1
+            with _GRAPH_LOCK:
+                _GRAPH_CACHE[key] = g
+                while len(_GRAPH_CACHE) > GRAPH_CACHE_MAX:
+                    _GRAPH_CACHE.popitem(last=False)
+
+        def run():
+            GRAPH_STATS["replays"] += 1
+            return g.replay(inputs)
+        return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags)
+
+
+def drop_graphs() -> None:
+    """Forget every captured forward (frees their workspaces)."""
+    with _GRAPH_LOCK:
+        _GRAPH_CACHE.clear()
+        _GRAPH_SEEN.clear()
+
+
 # ------------------------------------------------------------------------------------------------ guarded entry points
 # What the model classes call.  Each runs its forward with saturation detection (see _guarded) and, should the f16-pieces
 # arithmetic have met a value beyond its range, again in mode 1 (three bf16 pieces: no range assumption).
@@ -1351,14 +1480,20 @@ def _in_mode(mode: int, fn):
 
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
     wav = check_input(wav)
-    run = lambda: _tasnet_forward_impl(model, wav, debug)
-    return _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None)
+    if debug is not None:
+        run = lambda: _tasnet_forward_impl(model, wav, debug)
+        return _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None)
+    return _graphed("tasnet", model, (wav,), lambda w: _tasnet_forward_impl(model, w, None), "DPRNNTasNet.forward")
 
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
-    wav = check_input(wav)
-    run = lambda: _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
-    return _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation)
+    wav, aux = check_input(wav), check_input(aux, "aux")
+    if debug is not None:
+        run = lambda: _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
+        return _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation)
+    alen = _aux_len_tensor(aux_len, wav.shape[0], wav.device)          # a device tensor: one of the graph's inputs
+    return _graphed("ira" if ira else "spe", model, (wav, aux, alen), lambda w, a, n: _spe_forward_impl(model, w, a, n, ira, None),
+                    "DPRNNSpeTasNet.forward", model.separation)
 
 
 def separator_masks(sep, frames: torch.Tensor):
