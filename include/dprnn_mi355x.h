@@ -74,8 +74,11 @@ void dprnn_pack_forget(const void* packed);
 /* ---- saturation flags of the f16-pieces arithmetic (mode 3, and the f16 forms of the backward).  A thread registers a
  * device buffer of DPRNN_SAT_SLOTS int32 (zeroed by the call, on `stream`); every f16-pieces kernel launched by that thread
  * afterwards ORs 1 into slot s when a value it converted exceeded the f16 range (Inf / NaN inputs included):
- *   0 recurrence input rows, 1 rows of the Linear after a recurrence, 2 rows of the other row GEMMs (bottleneck, mask head,
- *   data gradients), 3 gate gradients of the BPTT, 4 operands of the weight-gradient GEMM, 5 non-finite input: the statistics
+ *   0 recurrence input rows; 2 rows of the row GEMMs whose operand is not bounded by construction (bottleneck, mask-head conv and
+ *   gate; NOT the Linear after a recurrence, whose rows are h = o tanh(c) in (-1, 1), the mask + decode kernel, whose rows are
+ *   tanh * sigmoid products, or the data gradients, which scale from their own measured maximum: slot 1 stays 0); 4 gate gradients
+ *   of the f16 BPTT (clamped there, seen by dprnn_wgrad_lstm_f16 when it reads them back; slot 3 stays 0) and the f16 weight-gradient
+ *   GEMMs' own operands; 5 non-finite input: the statistics
  *   dprnn_bottleneck_prep reads are NaN / Inf, i.e. the utterance holds such a sample (the conversion sites track maxima, which
  *   see Inf but skip NaN; every forward passes dprnn_bottleneck_prep first).
  * dprnn_saturation_flags copies them to `host_out` (DPRNN_SAT_SLOTS int32 of host memory) after synchronising `stream`, and

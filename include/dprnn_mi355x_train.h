@@ -52,12 +52,6 @@ int64_t dprnn_rnn_pack_bwd_floats(int ndir);
 void dprnn_wgrad_use_f16_pieces(const float* grad_max);
 /* the same for the NEXT dprnn_dgrad call of shape 128 -> 256 (dH = dZ @ W of a bidirectional path's Linear); other shapes ignore it */
 void dprnn_dgrad_use_f16_pieces(const float* grad_max);
-/* Saturation of the f16-pieces BPTT (dprnn_mi355x.h: dprnn_saturation_begin / _flags): the BPTT kernel itself does not follow the
- * largest gate gradient (it sits at the register limit); dG, which it writes, is read back under the SAME scale by the f16-pieces
- * weight-gradient GEMM, which raises flag 4 for it.  A host that runs the fp32 weight-gradient kernel on a mode-3 BPTT's dG calls
- * this instead: one pass over dG (n floats, n % 4 == 0) against the range of the scale taken from *grad_max (packedT +
- * dprnn_rnn_bwd_gradmax_offset(ndir)), raising flag 3.  No-op when the thread has no flag buffer registered. */
-int dprnn_bwd_range_check(const float* dG, int64_t n, const float* grad_max, void* stream);
 /* max |x| over n floats (n % 4 == 0) into *out: the scale source for a P that no BPTT launch has measured (the Linears' dZ) */
 int dprnn_absmax(const float* x, int64_t n, float* out, void* stream);
 int64_t dprnn_rnn_bwd_gradmax_offset(int ndir);
@@ -88,6 +82,22 @@ int dprnn_rnn_pack_bwd(int cell, const float* w_ih, const float* w_hh, const flo
 int dprnn_rnn_bwd(int cell, const float* dH, const float* tape, const float* packedT, float* dX, float* dG,
                   int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                   int64_t inner_stride, int64_t t_stride, int ndir, void* stream);
+/* floats of dG for dprnn_rnn_bwd.  The fp32 kernel (any cell) writes dG [rows][ndir * G * 128] in slab row order.  Mode 3 (LSTM) writes
+ * the QUAD layout  dG4[dir][t][seq / 4][gate * 128 + unit] = 16 bytes {first f16 pieces of S_g da for sequences 4 j .. 4 j + 3 | second
+ * pieces}: the BPTT stores 16 bytes per lane instead of four times 4, and dprnn_wgrad_lstm_f16 -- the only reader, which multiplies in
+ * the same pieces under the same scale S_g -- loads four consecutive rows of its reduction in one load without converting anything
+ * (sequence count rounded up to 4; the bytes of an fp32 dG).  A gate gradient beyond the scale's range is clamped by the BPTT and
+ * seen (|p1 + p2| = 65000) by dprnn_wgrad_lstm_f16, which raises saturation flag 4. */
+int64_t dprnn_rnn_bwd_dg_floats(int cell, int bwd_gemm_mode, int nseq, int T, int ndir);
+/* LSTM weight gradients of ONE direction from the quad-layout dG of a mode-3 BPTT: dWcat [512][256] = [dW_ih | dW_hh] (gate rows
+ * i,f,g,o; pitch 256), db0 / db1 [512] (optional; b_ih and b_hh receive the same values).  dG4: that direction's block of dG
+ * (dG + dir * T * ceil(nseq / 4) * 2048 floats); X: slab rows [.][128]; Hd: the h columns of the direction (H + dir * 128), pitch ldh
+ * = ndir * 128; reverse != 0: the recurrent operand is h_{t+1}.  Sequence addressing as dprnn_rnn_fwd.  grad_max: the device float the
+ * BPTT launch scaled by (packedT + dprnn_rnn_bwd_gradmax_offset(ndir)).  workspace: dprnn_wgrad_workspace_floats(512, 256, T *
+ * roundup(nseq, 32)) floats.  f16 pieces, fixed-order reduction (reproducible), saturation flag 4. */
+int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, const float* X, const float* Hd, int ldh, int reverse,
+                         int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
+                         float* dWcat, float* db0, float* db1, float* workspace, void* stream);
 /* the same with every selector as an argument (no per-thread state involved): gemm modes as in dprnn_mi355x.h / above;
  * dh_absmax = device float holding max|dH| (NULL: dprnn_rnn_bwd measures it with a pass over dH; mode 3 only) */
 int dprnn_rnn_fwd_train_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,

@@ -109,11 +109,11 @@ def test_lstm_backward_matches_autograd(path, B, S, K):
 
 def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
     """The f16-pieces BPTT multiplies da by 2^(6 - e), e = exponent of max|dH| (handed over by dH's producer); a gate gradient more
-    than 2^10 above that does not fit f16 and is clamped.  The gate gradients land in dG, which the f16 weight-gradient GEMM reads
-    back under the same scale and flags (4); dprnn_bwd_range_check is the explicit pass for hosts that run the fp32 weight-gradient
-    kernel (3).  With the true maximum nothing is flagged and dX / dW match autograd; with a maximum 2^13 too small (what an
-    exploding recurrence amounts to) both flags are up -- training.backward then repeats the step in the exact kernels.  Also:
-    the backward pack carries its format like the forward's (DPRNN_EFORMAT on a mismatch)."""
+    than 2^10 above that does not fit f16 and is clamped.  The gate gradients go to dG as the very pieces the BPTT multiplied with
+    (quad layout), and the weight-gradient GEMM that reads them back sees a clamped pair and raises flag 4.  With the true maximum
+    nothing is flagged and dX / dW / db match autograd; with a maximum 2^13 too small (what an exploding recurrence amounts to) the
+    flag is up -- training.backward then repeats the step in the exact kernels.  Also: the backward pack carries its format like
+    the forward's (DPRNN_EFORMAT on a mismatch)."""
     import ctypes
     B, S, K = 2, 9, 23
     rng = np.random.default_rng(11)
@@ -135,11 +135,14 @@ def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
     Xd, dHd = _t(X), _t(dH)
     H = torch.empty(rows, 256, device=DEV)
     dXd = torch.empty(2, rows, 128, device=DEV)
-    dG = torch.empty(rows, 1024, device=DEV)
+    dG = torch.empty(lib.dprnn_rnn_bwd_dg_floats(0, 3, addr[0], addr[1], 2), device=DEV)       # quad layout (27 sequences -> 7 quads)
     st.call("dprnn_rnn_pack_ex", 0, 0, *[_p(t) for t in w], _p(packed), _p(bsum))
     st.call("dprnn_rnn_fwd_train_ex", 0, 0, _p(Xd), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), _p(tape), *addr, 2)
-    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(512, 256, rows), device=DEV)
+    ws = torch.empty(lib.dprnn_wgrad_workspace_floats(512, 256, K * 32 * (-(-addr[0] // 32))), device=DEV)
     dW = torch.empty(512, 256, device=DEV)
+    dWr = torch.empty(512, 256, device=DEV)
+    db = torch.empty(512, device=DEV)
+    nsq = -(-addr[0] // 4)
 
     def run(hmax_value):
         hmax = torch.full((1,), hmax_value, device=DEV)
@@ -149,9 +152,10 @@ def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
         try:
             st.call("dprnn_rnn_pack_bwd_ex", 3, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
             st.call("dprnn_rnn_bwd_ex", 3, _p(hmax), 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2)
-            st.call("dprnn_wgrad_ex", packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2), dG.data_ptr(), 1024, 512,
-                    _p(Xd), 128, 128, 0, H.data_ptr(), 256, 128, 1, rows, 1, K, _p(dW), 256, 1, 0, 0, 0, _p(ws))
-            st.call("dprnn_bwd_range_check", _p(dG), dG.numel(), packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2))
+            gm = packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(2)
+            st.call("dprnn_wgrad_lstm_f16", gm, dG.data_ptr(), _p(Xd), H.data_ptr(), 256, 0, *addr, _p(dW), _p(db), 0, _p(ws))
+            st.call("dprnn_wgrad_lstm_f16", gm, dG.data_ptr() + 4 * K * nsq * 2048, _p(Xd), H.data_ptr() + 4 * 128, 256, 1, *addr,
+                    _p(dWr), 0, 0, _p(ws))
             rc = lib.dprnn_saturation_flags(ctypes.addressof(host), st.stream)
         finally:
             lib.dprnn_saturation_begin(0, 0)
@@ -162,9 +166,11 @@ def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
     dX = (dXd[0] + dXd[1]).cpu().numpy().reshape(B, S, K, 128)
     assert rel_l2(dX, Xr.grad.numpy()) < 5e-6
     g = np.concatenate([lstm.weight_ih_l0.grad.numpy(), lstm.weight_hh_l0.grad.numpy()], axis=1)
-    assert rel_l2(dW.cpu().numpy(), g) < 1e-5
+    gr = np.concatenate([lstm.weight_ih_l0_reverse.grad.numpy(), lstm.weight_hh_l0_reverse.grad.numpy()], axis=1)
+    assert rel_l2(dW.cpu().numpy(), g) < 1e-5 and rel_l2(dWr.cpu().numpy(), gr) < 1e-5
+    assert rel_l2(db.cpu().numpy(), lstm.bias_ih_l0.grad.numpy()) < 1e-5
     rc, flags = run(true_max / 8192.0)
-    assert rc == 1 and flags[3] == 1 and flags[4] == 1 and not any(flags[:3]), flags
+    assert rc == 1 and flags[4] == 1 and not any(flags[:4]), flags
     # pack / launch mismatch in either direction, and a forward pack handed to the backward
     st.call("dprnn_rnn_pack_bwd_ex", 0, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
     assert lib.dprnn_rnn_bwd_ex(3, 0, 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2, st.stream) == -3

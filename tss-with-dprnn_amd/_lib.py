@@ -79,7 +79,7 @@ SIGNATURES = {
     "dprnn_dgrad_ex": [c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp, c_i, c_fp, c_i, c_i, c_i64, c_fp],
     "dprnn_gn_bwd_dz_ex": [c_fp] * 6 + [c_f, c_i, c_i64, c_fp, c_fp],
     "dprnn_absmax": [c_fp, c_i64, c_fp, c_fp],
-    "dprnn_bwd_range_check": [c_fp, c_i64, c_fp, c_fp],
+    "dprnn_wgrad_lstm_f16": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dprnn_rnn_bwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_lstm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_wgrad": [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i, c_fp, c_i64, c_i64,
@@ -143,6 +143,7 @@ _SPECIAL = {
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
     "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),
+    "dprnn_rnn_bwd_dg_floats": ([c_i, c_i, c_i, c_i, c_i], c_i64),
     "dprnn_get_bwd_gemm_mode": ([], c_i),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),

@@ -108,7 +108,7 @@ int dprnn_check_launch(const char* what);
 // largest |scaled value| it converts (as float bits: Inf and NaN patterns order above every finite value) and, at kernel end,
 // raises flag `slot` of the calling thread's registered device buffer when the limit was crossed -- one ballot per wave, one
 // atomic per wave that saw it.  The host checks the flags once per forward / backward and re-runs in a range-free arithmetic.
-enum { DPRNN_SAT_RECUR_X = 0, DPRNN_SAT_PROJ_ROWS = 1, DPRNN_SAT_GEMM_ROWS = 2, DPRNN_SAT_BPTT_DA = 3, DPRNN_SAT_WGRAD = 4,
+enum { DPRNN_SAT_RECUR_X = 0, DPRNN_SAT_PROJ_ROWS = 1 /* unused: |h| < 1 */, DPRNN_SAT_GEMM_ROWS = 2, DPRNN_SAT_BPTT_DA = 3 /* reported through 4 */, DPRNN_SAT_WGRAD = 4,
        DPRNN_SAT_NONFINITE = 5, DPRNN_SAT_SLOTS = 8 };
 int* dprnn_sat_ptr();        // device int32[DPRNN_SAT_SLOTS] registered by the calling thread, or nullptr (detection off)
 // Tracking costs one v_max3_f32 per two converted values (|.| is an operand modifier).  A float maximum skips NaN operands, so a NaN

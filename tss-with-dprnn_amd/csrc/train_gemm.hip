@@ -382,6 +382,221 @@ void wgrad_f16_kernel(WgradArgs a, const float* __restrict__ pmax, int* sat) {
     }
 }
 
+// ---- LSTM weight gradients from the QUAD layout of dG (train_recur_f16.hip: dG4[t][seq / 4][512 columns] = 16 bytes {first f16 pieces
+// of S_g da for sequences 4 j .. 4 j + 3 | second pieces}, one direction):
+//     dWcat[m][n] = sum over (t, seq) of dG(t, seq, m) * [x(t, seq) | h(t -+ 1, seq)][n]        m < 512 gate rows, n < 256
+// The rows of this GEMM are the MFMA k dimension.  In the quad layout four consecutive k of one column m sit in one 16-byte load,
+// already as the pieces the BPTT multiplied with: a thread loads two quads (8 rows of one column) and writes ONE 16-byte A fragment
+// per piece ([piece][8-row group][column][16 B]) -- no conversion, no transposition; a wave's fragment read is a plain,
+// conflict-free ds_read_b128.  The bias gradient (column sums of dG) is rebuilt as p1 + p2 by the x blocks, which also see a
+// clamped pair there (|p1 + p2| = 65000: saturation flag).  Q (x and
+// h rows, row-major in the slab) keeps the swizzled row-major image + ds_read_b64_tr_b16 of wgrad_f16_kernel, but its rows are now
+// addressed as the recurrence addresses them -- row(t, seq) = (seq / inner_n) outer + (seq % inner_n) inner + t t_stride -- because the
+// k order is (t, seq), not slab order.  k runs over t * nseq32 + seq with the sequence count rounded up to 32 (a chunk never
+// straddles two time steps); sequences beyond nseq read as zero on both sides.  Same 256 x 128 blocks, row-range splits, workspace
+// and reduce kernel as dprnn_wgrad.
+struct WgLstmArgs {
+    const float* P4; const float* X; const float* Hd;      // dG4 of this direction; x rows [.][128]; h columns of this direction, pitch ldh
+    int ldh, dt;                                           // dt: +1 forward direction (h_{t-1}), -1 reverse (h_{t+1})
+    int nseq, nseq32, nsq, T, inner_n;
+    long long outer_stride, inner_stride, t_stride;
+    long long rows_per_split;                              // in k = t * nseq32 + seq, a multiple of 32
+    float* part; float* part_b;
+    int splits;
+};
+
+__global__ __launch_bounds__(WG_THREADS, 2)
+void wgrad_lstm_f16_kernel(WgLstmArgs a, const float* __restrict__ pmax, int* sat) {
+    extern __shared__ __attribute__((aligned(16))) char wimg[];           // [buf 2][P piece 0 | P piece 1 | Q piece 0 | Q piece 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int Mpad = 512, Npad = 256;
+    // blocks: mb in {0, 1} (256 gate rows each), nb in {0: x, 1: h}; the four siblings of a row range share an XCD (wgrad_block)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int sib = jj & 3, ks = (jj >> 2) * 8 + xcd;
+    if (ks >= a.splits) return;
+    const int mb = sib & 1, nb = sib >> 1;
+    const long long total = (long long)a.T * a.nseq32;
+    const long long r0 = (long long)ks * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > total) r1 = total;
+
+    float sg;
+    {
+        const float m = *pmax;
+        int ex = 0;
+        if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+        ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+        sg = ldexpf(1.f, 6 - ex);
+    }
+    const float inv = 1.f / (sg * F16P_XS);
+
+    // P staging: thread = (column pcol of the block, half kgh); 8-row groups kg = kgh + 2 j, j < 2; quads 2 kg, 2 kg + 1
+    const int pcol = tid & 255, kgh = tid >> 8;
+    // Q staging (as wgrad_f16_kernel): rows qrow + 16 j (j < 2), float4 chunk qc4
+    const int qc4 = tid & 31, qrow = tid >> 5;
+    const float* const qbase = nb == 0 ? a.X : a.Hd;
+    const int qld = nb == 0 ? 128 : a.ldh;
+    const int qdt = nb == 0 ? 0 : a.dt;
+    // (t, first sequence) of the current chunk and, per Q row of this thread, the sequence's (quotient, remainder) by inner_n
+    int t = (int)(r0 / a.nseq32), s0 = (int)(r0 % a.nseq32);
+    int qq[2], qr[2];
+    auto seq_split = [&](int seq, int& quo, int& rem) { quo = seq / a.inner_n; rem = seq - quo * a.inner_n; };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) seq_split(s0 + qrow + 16 * j, qq[j], qr[j]);
+
+    rg_u32x4 pv[2][2];
+    f32x4 qv[2];
+    float psum = 0.f;
+    unsigned satm = 0u;
+    const bool bias_block = a.part_b && nb == 0;
+    auto load = [&]() __attribute__((always_inline)) {      // the chunk at (t, s0)
+        const float* pt = a.P4 + ((size_t)t * a.nsq + (size_t)(s0 >> 2)) * (Mpad * 4) + (size_t)(mb * WG_MB + pcol) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qd = 2 * (kgh + 2 * j) + h;            // quad of the chunk: sequences s0 + 4 qd ..
+                pv[j][h] = (s0 + 4 * qd < a.nseq) ? *reinterpret_cast<const rg_u32x4*>(pt + (size_t)qd * (Mpad * 4)) : rg_u32x4{0u, 0u, 0u, 0u};
+            }
+        const int tq = t - qdt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int seq = s0 + qrow + 16 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (seq < a.nseq && tq >= 0 && tq < a.T) {
+                const long long row = (long long)qq[j] * a.outer_stride + (long long)qr[j] * a.inner_stride + (long long)tq * a.t_stride;
+                v = *reinterpret_cast<const f32x4*>(qbase + row * qld + 4 * qc4);
+            }
+            qv[j] = v;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {   // to the next chunk of 32 rows
+        s0 += WF_R;
+        if (s0 >= a.nseq32) {
+            s0 = 0; ++t;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) seq_split(qrow + 16 * j, qq[j], qr[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { qr[j] += WF_R; while (qr[j] >= a.inner_n) { qr[j] -= a.inner_n; ++qq[j]; } }
+        }
+    };
+    auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
+        unsigned a1, a2, b1, b2;
+        f16_pieces2(c[0], c[1], a1, a2);
+        f16_pieces2(c[2], c[3], b1, b2);
+        lo = (unsigned long long)a1 | ((unsigned long long)b1 << 32);
+        hi = (unsigned long long)a2 | ((unsigned long long)b2 << 32);
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+        char* const pb = wimg + buf * WF_BUF;
+        char* const qb = pb + 2 * WF_PPL;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* d = pb + (((kgh + 2 * j) * WG_MB + pcol) << 4);       // A fragment of (8-row group, column): rows 8 kg .. 8 kg + 7
+            *reinterpret_cast<rg_u32x4*>(d) = rg_u32x4{pv[j][0][0], pv[j][0][1], pv[j][1][0], pv[j][1][1]};                // first pieces
+            *reinterpret_cast<rg_u32x4*>(d + WF_PPL) = rg_u32x4{pv[j][0][2], pv[j][0][3], pv[j][1][2], pv[j][1][3]};      // second pieces
+            if (bias_block) {                                           // S_g da = p1 + p2 (22+ bits): column sum and range
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const unsigned u1 = pv[j][h][w], u2 = pv[j][h][2 + w];
+                        const float v0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u1 & 0xffffu)) +
+                                         (float)__builtin_bit_cast(_Float16, (unsigned short)(u2 & 0xffffu));
+                        const float v1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u1 >> 16)) +
+                                         (float)__builtin_bit_cast(_Float16, (unsigned short)(u2 >> 16));
+                        sat_track(satm, v0, v1);
+                        psum += v0 + v1;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = qrow + 16 * j;
+            unsigned long long lo, hi;
+            pieces4(qv[j], F16P_XS, lo, hi);
+            char* d = qb + row * (WG_NB * 2) + (((unsigned)qc4 ^ wf_swz(row)) << 3);
+            *reinterpret_cast<unsigned long long*>(d) = lo;
+            *reinterpret_cast<unsigned long long*>(d + WF_QPL) = hi;
+        }
+    };
+
+    const int g = lane >> 4, l = lane & 15, qqq = l >> 2, pp = l & 3;
+    const unsigned ub = (unsigned)(pp | (qqq << 2) | ((g & 1) << 4));
+    unsigned pa[4], qa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pa[j] = (unsigned)((g * WG_MB + 64 * wm + 16 * j + l) << 4);                    // lane (l, g): column 64 wm + 16 j + l, rows 8 g .. 8 g + 7
+        qa[j] = (unsigned)((8 * g + qqq) * (WG_NB * 2)) + ((((unsigned)(16 * wn + 4 * j)) ^ ub) << 3);
+    }
+    auto tr8 = [&](const char* plane, unsigned off, int pitch) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) wf_s4* lptr;
+        const wf_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off));
+        const wf_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off + 4 * pitch));
+        rg_u32x4 out;
+        const unsigned long long a0 = __builtin_bit_cast(unsigned long long, lo), a1 = __builtin_bit_cast(unsigned long long, hi);
+        out[0] = (unsigned)a0; out[1] = (unsigned)(a0 >> 32); out[2] = (unsigned)a1; out[3] = (unsigned)(a1 >> 32);
+        return out;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (r0 < r1) {
+        load();
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long k0 = r0; k0 < r1; k0 += WF_R, buf ^= 1) {
+            const bool more = k0 + WF_R < r1;
+            if (more) { advance(); load(); }
+            const char* const pb = wimg + buf * WF_BUF;
+            const char* const qb = pb + 2 * WF_PPL;
+            rg_u32x4 q1[4], q2[4];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) { q1[jn] = tr8(qb, qa[jn], WG_NB * 2); q2[jn] = tr8(qb + WF_QPL, qa[jn], WG_NB * 2); }
+#pragma unroll
+            for (int jm = 0; jm < 4; ++jm) {
+                const rg_u32x4 p1 = *reinterpret_cast<const rg_u32x4*>(pb + pa[jm]), p2 = *reinterpret_cast<const rg_u32x4*>(pb + WF_PPL + pa[jm]);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) {
+                    acc[jm][jn] = mfma_f16p(p1, q2[jn], acc[jm][jn]);
+                    acc[jm][jn] = mfma_f16p(p2, q1[jn], acc[jm][jn]);
+                    acc[jm][jn] = mfma_f16p(p1, q1[jn], acc[jm][jn]);
+                }
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX * 0.99999f);          // a clamped pair is exactly +-65000
+    // acc[jm][jn][e] = dW[m][n], m = 256 mb + 64 wm + 16 jm + 4 g + e, n = 128 nb + 64 wn + 16 jn + l
+    float* const out = a.part + (long long)ks * Mpad * Npad;
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = WG_MB * mb + 64 * wm + 16 * jm + 4 * g + e;
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) out[(long long)m * Npad + WG_NB * nb + 64 * wn + 16 * jn + l] = acc[jm][jn][e] * inv;
+        }
+    if (a.part_b && nb == 0) {                              // bias gradient: column sums of dG (threads tid and tid + 256 hold the same column)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(wimg);
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 256) a.part_b[(long long)ks * Mpad + WG_MB * mb + tid] = (red[tid] + red[tid + 256]) * (1.f / sg);
+    }
+}
+
 // dW[m*ldm + n*ldn] = (accumulate ? dW : 0) + sum_s part[s][m][n];  db likewise (two optional destinations: the
 // LSTM's b_ih and b_hh receive the same gradient).  A workgroup of 4 waves sums 64 float4 column groups: wave w adds the
 // partials s = w, w+4, ... (eight independent loads in flight), the four wave sums are added in wave order -- a fixed
@@ -520,6 +735,47 @@ extern "C" int dprnn_wgrad_ex(const float* f16_grad_max, const float* P, int ldp
                               float* dW, int64_t ldm, int64_t ldn, float* db0, float* db1, int accumulate,
                               float* workspace, void* stream) {
     return wgrad_impl(f16_grad_max, P, ldp, M, Q0, ldq0, n0, dt0, Q1, ldq1, n1, dt1, rows, t_stride, T, dW, ldm, ldn, db0, db1, accumulate, workspace, stream);
+}
+
+// LSTM weight gradients of one direction from the quad-layout dG of a mode-3 BPTT (wgrad_lstm_f16_kernel): dWcat [512][256] =
+// [dW_ih | dW_hh] (row-major, pitch 256), db0 / db1 [512] (optional, the same values: b_ih and b_hh).  dG4: this direction's block of
+// dprnn_rnn_bwd's dG (dir * T * ceil(nseq / 4) * 2048 floats in); X: slab rows [.][128]; Hd: the h columns of this direction
+// (H + dir * 128, pitch ldh = ndir * 128); reverse != 0: h_prev is h_{t+1}.  Sequence addressing as dprnn_rnn_fwd.  grad_max: the
+// device float the BPTT launch scaled by (packedT + dprnn_rnn_bwd_gradmax_offset).  workspace: dprnn_wgrad_workspace_floats(512, 256,
+// T * roundup(nseq, 32)) floats.
+extern "C" int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, const float* X, const float* Hd, int ldh, int reverse,
+                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
+                                    float* dWcat, float* db0, float* db1, float* workspace, void* stream) {
+    if (!grad_max || !dG4 || !X || !Hd || !dWcat || !workspace) { dprnn_set_error("dprnn_wgrad_lstm_f16: null pointer"); return -1; }
+    if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ldh != 128 && ldh != 256) || outer_stride < 0 || inner_stride < 0 || t_stride < 0) {
+        dprnn_set_error("dprnn_wgrad_lstm_f16: bad sizes nseq=%d T=%d inner_n=%d ldh=%d", nseq, T, inner_n, ldh);
+        return -1;
+    }
+    WgLstmArgs a{};
+    a.P4 = dG4; a.X = X; a.Hd = Hd; a.ldh = ldh; a.dt = reverse ? -1 : 1;
+    a.nseq = nseq; a.nseq32 = (nseq + 31) / 32 * 32; a.nsq = (nseq + 3) / 4; a.T = T; a.inner_n = inner_n;
+    a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
+    const long long rows = (long long)T * a.nseq32;
+    int mblocks, nblocks; long long splits, per;
+    wgrad_plan(512, 256, rows, mblocks, nblocks, splits, per);
+    a.rows_per_split = per; a.splits = (int)splits;
+    a.part = workspace;
+    a.part_b = (db0 || db1) ? workspace + splits * 512LL * 256 : nullptr;
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lstm_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WF_BUF);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(wgrad_lstm_f16): %s", hipGetErrorString(e)); return -2; }
+        dprnn_attr_done(attr_mask, attr_dev);
+    }
+    const unsigned grid = (unsigned)(4 * ((splits + 7) / 8 * 8));
+    hipLaunchKernelGGL(wgrad_lstm_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, grad_max, dprnn_sat_ptr());
+    int rc = dprnn_check_launch("wgrad_lstm_f16_kernel");
+    if (rc) return rc;
+    const int items = 512 * (256 / 4) + (a.part_b ? 512 / 4 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       a.part, a.part_b, (int)splits, 512, 256, 512, 256, dWcat, 256LL, 1LL, db0, db1, 0);
+    return dprnn_check_launch("wgrad_reduce_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------ data gradients

@@ -10,12 +10,17 @@
 // j of both halves of the GEMM (dx column j, dh column j), so dh_rec and dc_rec never leave registers; that unit mapping is
 // the fp32 training kernel's, so the tape ([dir][32-sequence workgroup][step][wave][nt][u][slot][lane] float4) is read with
 // 16-byte coalesced loads: a 64-sequence tile is two of those workgroups.  da_t goes to LDS as two piece planes
-// [piece][seq][512] (1 KB rows, 16-byte chunks XOR-ed with seq & 15) and, unscaled, to HBM for the weight-gradient GEMM.
+// [piece][seq][512] (1 KB rows, 16-byte chunks XOR-ed with seq & 15) and to HBM for the weight-gradient GEMM -- as the SAME two
+// f16 pieces of S_g da, in the QUAD layout  dG4[dir][t][seq / 4][gate * 128 + unit] = 16 bytes {first pieces of sequences 4 j .. 4 j + 3
+// | second pieces}  (dprnn_rnn_bwd_dg_floats: the bytes of an fp32 dG): a lane holds one unit of FOUR sequences (the MFMA's
+// accumulator rows 4 q + e), so a quad is one 16-byte store (16 per lane and step instead of 64 four-byte ones on the in-order
+// vector-memory queue), and dprnn_wgrad_lstm_f16 -- whose MFMA k dimension is the row and which multiplies in the same pieces under
+// the same scale -- loads its A fragments without converting anything.
 //
 // Saturation: da S_g beyond the f16 range is clamped in the piece conversion.  The kernel itself does not track it (it sits at the
 // register limit: following the maximum cost 84 bytes of scratch per lane and 14 % of its time); the gate gradients it writes to dG
-// are read back under the SAME scale by the weight-gradient GEMM (wgrad_f16_kernel tracks its P operand: flag DPRNN_SAT_WGRAD), and a
-// host that runs the fp32 weight-gradient kernel instead calls dprnn_bwd_range_check(dG, ...) after the launch (flag DPRNN_SAT_BPTT_DA).
+// are read back, as the very pieces of S_g da, by the weight-gradient GEMM (wgrad_lstm_f16_kernel: flag DPRNN_SAT_WGRAD);
+// the weight-gradient GEMM is the only reader of this dG (dprnn_wgrad_lstm_f16 sees a clamped piece pair as |p1 + p2| = 65000).
 // Range: gradients have no natural scale, so da is multiplied by S_g = 2^(6 - e), e = exponent of max|dH| over the launch
 // (dh_absmax_kernel, one pass over dH before the launch): the largest incoming gradient sits at 2^6, a factor 2^10 below the
 // f16 limit for what the recurrence adds (beyond that the piece conversion clamps), and everything above 2^-20 of it keeps a
@@ -134,19 +139,20 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
     const int seq0 = blockIdx.x * NSR;
     const int T = a.T;
     const int unit = 32 * w4 + 16 * wu + r;              // this lane's hidden unit = its dx / dh output column
-    unsigned gcol = (unsigned)(dir * 512 + unit) * 4u;   // column offsets in a dG (+ gate * 512 bytes) / dH / dX row
+    unsigned gcol = (unsigned)unit * 16u;                // this lane's unit inside a quad row of dG4 (+ gate * 2048 bytes; 16 bytes = 4 sequences)
     unsigned hcol = (unsigned)(dir * HD + unit) * 4u, xcol = (unsigned)unit * 4u;
 
     auto rowbase = [&](int seq) {
         return (long long)(seq / a.inner_n) * a.outer_stride + (long long)(seq % a.inner_n) * a.inner_stride;
     };
     const long long row0 = rowbase(seq0);
-    const int hpitch = a.ndir * HD, gpitch = a.ndir * KG;
+    const int hpitch = a.ndir * HD;
+    const int nsq = (a.nseq + 3) >> 2;                   // quads of sequences per time step in dG4
     for (int j = tid; j < NSR; j += 512) {
         const bool valid = seq0 + j < a.nseq;
         const unsigned ro = (unsigned)(rowbase(valid ? seq0 + j : seq0) - row0);
         off_h[j] = valid ? ro * (unsigned)hpitch * 4u : OOB;
-        off_g[j] = valid ? ro * (unsigned)gpitch * 4u : OOB;
+        off_g[j] = valid ? (unsigned)(((seq0 + j) >> 2) * KG) * 16u : OOB;        // quad (seq / 4) of this time step: [quad][512 columns][4]
         off_x[j] = valid ? ro * (unsigned)F * 4u : OOB;
     }
     auto rsrc_at = [&](const void* p) __attribute__((always_inline)) {
@@ -242,7 +248,7 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ab[0][j]), "+v"(ab[1][j]), "+v"(wb[0][j]), "+v"(wb[1][j]));
         asm volatile("" : "+v"(gcol), "+v"(hcol), "+v"(xcol));
         // ---- gate derivatives (torch.nn.LSTM backward), lane-local; da -> LDS pieces (scaled) and HBM (unscaled)
-        const __amdgpu_buffer_rsrc_t dgs = rsrc_at(a.dG + trow * gpitch);
+        const __amdgpu_buffer_rsrc_t dgs = rsrc_at(a.dG + ((size_t)dir * T + (size_t)t_of(fs)) * nsq * (KG * 4));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             fence();
@@ -261,21 +267,23 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             cc[nt] = cp[nt];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                unsigned qw[4];                          // the quad's pieces as they go to HBM: {p1(e0,e1), p1(e2,e3), p2(e0,e1), p2(e2,e3)}
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
                     const float s0 = __builtin_amdgcn_fmed3f(da[g][2 * p2] * sg, -F16_XMAX, F16_XMAX);
                     const float s1 = __builtin_amdgcn_fmed3f(da[g][2 * p2 + 1] * sg, -F16_XMAX, F16_XMAX);
                     unsigned w1, w2;
                     split2_pair_f16(s0, s1, w1, w2);
+                    qw[p2] = w1; qw[2 + p2] = w2;
                     char* const d0 = img + nt * 16384 + g * 256, *const d1 = d0;
                     *reinterpret_cast<unsigned short*>(d0 + wb[0][2 * p2]) = (unsigned short)w1;
                     *reinterpret_cast<unsigned short*>(d1 + wb[0][2 * p2 + 1]) = (unsigned short)(w1 >> 16);
                     *reinterpret_cast<unsigned short*>(d0 + wb[1][2 * p2]) = (unsigned short)w2;
                     *reinterpret_cast<unsigned short*>(d1 + wb[1][2 * p2 + 1]) = (unsigned short)(w2 >> 16);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(da[g][e]), dgs, off_g[16 * nt + 4 * q + e] + gcol + (unsigned)(g * 512), 0, SAUX);
+                // rows 4 q .. 4 q + 3 of the tile are one quad of sequences (a quad whose first sequence exists is stored whole: the
+                // gate gradients of sequences beyond nseq are zero, their tape and dH lanes read as zero)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, dgs, off_g[16 * nt + 4 * q] + gcol + (unsigned)(g * 2048), 0, SAUX);
             }
         }
         fence();
@@ -380,22 +388,11 @@ extern "C" int dprnn_absmax(const float* x, int64_t n, float* out, void* stream)
     return dprnn_check_launch("dh_absmax_kernel");
 }
 
-// max|x| * S_g against the f16 range, S_g from *grad_max as the BPTT launch derived it: raises DPRNN_SAT_BPTT_DA (see the header comment)
-namespace {
-__global__ __launch_bounds__(256)
-void grad_range_check_kernel(const float* __restrict__ x, long long n4, const float* __restrict__ grad_max, int* __restrict__ sat) {
-    unsigned m = 0u;
-    const f32x4* p = reinterpret_cast<const f32x4*>(x);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) sat_track(m, p[i]);
-    sat_commit(sat, DPRNN_SAT_BPTT_DA, m, F16_XMAX / pow2_scale_to(*grad_max, 6));
-}
-}  // namespace
-extern "C" int dprnn_bwd_range_check(const float* dG, int64_t n, const float* grad_max, void* stream) {
-    if (!dG || !grad_max || n <= 0 || (n % 4)) { dprnn_set_error("dprnn_bwd_range_check: null pointer or n not a multiple of 4"); return -1; }
-    int* sat = dprnn_sat_ptr();
-    if (!sat) return 0;                                  // no flag buffer registered on this thread: nothing to report to
-    hipLaunchKernelGGL(grad_range_check_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, dG, (long long)(n / 4), grad_max, sat);
-    return dprnn_check_launch("grad_range_check_kernel");
+// floats of dG for dprnn_rnn_bwd: mode 3 with the LSTM cell writes the quad layout (sequence count rounded up to 4)
+extern "C" int64_t dprnn_rnn_bwd_dg_floats(int cell, int bwd_gemm_mode, int nseq, int T, int ndir) {
+    const int64_t kg = cell == 2 ? 128 : 512;
+    if (cell == 0 && bwd_gemm_mode == 3) return (int64_t)ndir * T * ((nseq + 3) / 4) * 4 * kg;
+    return (int64_t)ndir * kg * nseq * T;
 }
 
 extern "C" int64_t dprnn_rnn_pack_bwd_floats(int ndir) { return (int64_t)ndir * BWD_PACK_WORDS_PER_DIR + BWD_EXTRA; }

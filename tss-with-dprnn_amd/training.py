@@ -38,23 +38,22 @@ PACKT_PER_DIR = 512 * 256
 # passes fill the CUs another group's serial recurrence launches leave idle.
 TRAIN_STREAM_GROUPS = 0              # 0 = choose from the launch geometry (_auto_groups); n > 0 = up to n groups
 MIN_TRAIN_GROUP = 8                  # utterances per group at least (explicit group counts only)
-# Gate-GEMM arithmetic of the training FORWARD (recurrence with tape + the Linear after it): 3 = two f16 pieces / three products
-# as in inference (engine.GEMM_MODE 3; LSTM cells only, others fall back), 0 = exact fp32 MFMA.  The backward kernels (BPTT,
-# data and weight gradients) always run on the exact fp32 MFMA: gradients span too many orders of magnitude for f16 pieces
-# without per-tensor exponents.  DPRNN_TRAIN_GEMM_MODE overrides.
+# Gate-GEMM arithmetic of the training FORWARD (recurrence with tape + the Linear after it + mask head): 3 = two f16 pieces / three
+# products as in inference (LSTM cells only, others fall back), 0 = exact fp32 MFMA.  DPRNN_TRAIN_GEMM_MODE overrides.
 TRAIN_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_GEMM_MODE", "3"))
-# Step GEMM of the LSTM backward (BPTT): 3 = two f16 pieces / three products with a per-launch power-of-two gradient scale
-# (train_recur_f16.hip), 0 = exact fp32 MFMA.  DPRNN_TRAIN_BWD_GEMM_MODE overrides.  Weight and data gradients of the Linears
-# stay on the fp32 MFMA.
+# Step GEMM of the LSTM backward (BPTT) AND the LSTM weight gradients dG^T [x | h_prev]: 3 = two f16 pieces / three products with a
+# per-launch power-of-two gradient scale (train_recur_f16.hip; the BPTT then writes dG in the quad layout that only
+# dprnn_wgrad_lstm_f16 reads), 0 = exact fp32 MFMA for both.  DPRNN_TRAIN_BWD_GEMM_MODE overrides.
 TRAIN_BWD_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_BWD_GEMM_MODE", "3"))
-# ... and, with it, the LSTM weight-gradient GEMMs dG^T [x | h_prev] in f16 pieces with the same gradient scale (wgrad_f16_kernel)
+# ... and, with mode 3, the gradient GEMMs of the Linear after each recurrence (dZ @ W, dZ^T H) in f16 pieces, dZ scaled from its own
+# maximum (DPRNN_TRAIN_WGRAD_F16=0: fp32 MFMA for those).  Mask-head and bottleneck gradients are always fp32 MFMA.
 TRAIN_WGRAD_F16 = os.environ.get("DPRNN_TRAIN_WGRAD_F16", "1") != "0"
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 _TLS = threading.local()
 
 
 def train_modes():
-    """(forward gate-GEMM mode, BPTT mode, f16 weight gradients) of this thread's training calls: the module settings unless a
+    """(forward gate-GEMM mode, BPTT + LSTM weight-gradient mode, f16 gradient GEMMs of the Linears) of this thread's training calls: the module settings unless a
     `use_train_modes` block is active on the thread (the saturation fall-back runs one)."""
     o = getattr(_TLS, "modes", None)
     fwd = TRAIN_GEMM_MODE if o is None or o[0] is None else o[0]
@@ -280,7 +279,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
 
     # one workspace for every weight-gradient GEMM of this pass: (M, N, rows) of all dprnn_wgrad calls below
     shapes = [(N, F_BUILT, R), (2 * F_BUILT, F_BUILT, R), (2 * F_BUILT, F_BUILT, B * L), (F_BUILT, 2 * F_BUILT, rows),
-              (4 * F_BUILT, 2 * F_BUILT, rows), (F_BUILT, N, B * L)]
+              (4 * F_BUILT, 2 * F_BUILT, rows), (F_BUILT, N, B * L),
+              (4 * F_BUILT, 2 * F_BUILT, K * (-(-(B * S) // 32) * 32)), (4 * F_BUILT, 2 * F_BUILT, S * (-(-(B * K) // 32) * 32))]
     ws = torch.empty(max(lib.dprnn_wgrad_workspace_floats(m_, n_, r_) for m_, n_, r_ in shapes), **f32)
 
     _, bwd_mode, wgrad_f16 = train_modes()
@@ -374,14 +374,13 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         # recurrence (dprnn.py:86,95)
         addr = _addr(geo, intra)
         kg = F_BUILT if cell == 2 else 4 * F_BUILT          # gate-gradient columns per direction: LSTM i,f,g,o; GRU r,z,n_x,n_h; RNN a
-        dG = torch.empty(rows, ndir * kg, **f32)
         bm = 3 if bptt_f16 else 0                               # layout of the pack = kernel of the launch (checked by the library)
+        # fp32 kernel: dG [rows][ndir * kg]; f16 BPTT: the quad layout [dir][t][seq / 4][512][4] that dprnn_wgrad_lstm_f16 reads
+        dG = torch.empty(lib.dprnn_rnn_bwd_dg_floats(cell, bm, addr[0], addr[1], ndir), **f32)
         st.call("dprnn_rnn_pack_bwd_ex", bm, cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
         st.call("dprnn_rnn_bwd_ex", bm, hmax.data_ptr() if bptt_f16 else 0, cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG),
                 rows, *addr, ndir)
         del dH
-        if bptt_f16 and not wgrad_f16:      # nobody will read dG under the BPTT's scale: check its range here (flag 3)
-            st.call("dprnn_bwd_range_check", _p(dG), dG.numel(), packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir))
         pre = f"{blk}_rnn.rnn."
         for d in range(ndir):
             suf = "_reverse" if d == 1 else ""
@@ -390,10 +389,14 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
             if cell == 0:         # one GEMM: dG^T [x | h_prev] -> [W_ih | W_hh] (torch rows i,f,g,o)
                 gcat = torch.empty(4 * F_BUILT, 2 * F_BUILT, **f32)
                 gbias = torch.empty(4 * F_BUILT, **f32)
-                # with the f16 BPTT: dG^T [x | h_prev] in f16 pieces, dG scaled like the BPTT's da
-                wgrad(gbase, ndir * kg, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, *hprev, rows, addr[5], addr[1],
-                      gcat, 2 * F_BUILT, 1, gbias, None,
-                      f16_max=(packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir)) if (bptt_f16 and wgrad_f16) else 0)
+                if bptt_f16:      # quad-layout dG of the f16 BPTT, f16 pieces under the BPTT's gradient scale (and its saturation check)
+                    nsq = -(-addr[0] // 4)
+                    st.call("dprnn_wgrad_lstm_f16", packedT.data_ptr() + 4 * lib.dprnn_rnn_bwd_gradmax_offset(ndir),
+                            dG.data_ptr() + 4 * d * addr[1] * nsq * 4 * kg, _p(X[p]), hprev[0], hp, d, addr[0], addr[1], addr[2],
+                            addr[3], addr[4], addr[5], _p(gcat), _p(gbias), 0, _p(ws))
+                else:
+                    wgrad(gbase, ndir * kg, 4 * F_BUILT, _p(X[p]), F_BUILT, F_BUILT, 0, *hprev, rows, addr[5], addr[1],
+                          gcat, 2 * F_BUILT, 1, gbias, None)
                 g_ih, g_hh = gcat[:, :F_BUILT].contiguous(), gcat[:, F_BUILT:].contiguous()
                 b_ih, b_hh = gbias, gbias.clone()
             elif cell == 1:       # torch rows r,z,n: W_ih pairs with (r, z, n_x), W_hh with (r, z, n_h)
