@@ -378,13 +378,14 @@ def main():
         piece = "f16" if mode == 3 else "bf16"
         traffic, traffic_src = None, None
         try:
-            name, key = {0: ("r01_pmc_traffic.json", "bilstm_kernel"), 1: ("r02_pmc_traffic.json", "bilstm_split8_kernel"),
-                         3: ("r02_pmc_traffic_f16.json", "bilstm_split8_kernel_f16")}[mode]
+            names, key = {0: (["r01_pmc_traffic.json"], "bilstm_kernel"), 1: (["r02_pmc_traffic.json"], "bilstm_split8_kernel"),
+                          3: (["r03_pmc_traffic_f16.json", "r02_pmc_traffic_f16.json"], "bilstm_split8_kernel_f16")}[mode]
+            name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)[key]
             if pm["group_batch"] * n_groups == B:
                 traffic, traffic_src = pm["traffic_GB_per_launch"], name
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         return {"bound": "mfma",
                 "kernel": "bilstm_kernel (dprnn_rnn_fwd_ex, LSTM cell, exact fp32 MFMA)" if mode == 0 else

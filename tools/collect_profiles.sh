@@ -4,6 +4,7 @@
 tag=${1:-r02}
 export TMPDIR=/tmp
 set -o pipefail
+export DPRNN_GRAPHS=0        # eager launches: one trace record per kernel of every forward (a replayed graph is one launch)
 B="--steps 3 --warmup 1 --no-cpu-baseline --no-optional-modes"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace_mode3 -o t -- python3 bench.py $B > gpurun_out/${tag}_trace_mode3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace_mode1 -o t -- python3 bench.py $B --gemm-mode 1 > gpurun_out/${tag}_trace_mode1.log 2>&1 || exit 1
