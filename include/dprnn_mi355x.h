@@ -220,7 +220,9 @@ int dprnn_rnn_fwd_ex(int gemm_mode, int cell, const float* X, const float* Z, co
                      int64_t t_stride, int ndir, int seq_tile, void* stream);
 
 /* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
- * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; used by tools/bench_recur.py only. */
+ * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; in the split modes (seq_tile 2064)
+ * stamps[workgroup][2][8] for waves 0 and 4 = {shader cycles, ticks, h half (or whole MFMA phase), cell update, own x half, wait + x staging,
+ * barrier wait, 0}; used by tools/bench_recur.py only. */
 int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
                              int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                              int64_t t_stride, int ndir, int seq_tile, unsigned long long* stamps, void* stream);

@@ -215,7 +215,7 @@ def stamps_split(st, seq_tile, T, ndir=2):
     w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
          torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
     st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
-    buf = torch.zeros(nwg, 8, device="cuda", dtype=torch.int64)
+    buf = torch.zeros(nwg, 16, device="cuda", dtype=torch.int64)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for it in range(12):
         if it == 4:
@@ -227,6 +227,10 @@ def stamps_split(st, seq_tile, T, ndir=2):
     ms = e0.elapsed_time(e1) / 8
     tf = nseq * T * ndir * 2 * 256 * 512 / ms / 1e9
     b = buf.cpu().double()
+    for wv, name in ((0, "wave 0"), (8, "wave 4 (its SIMD partner)")):
+        m = [b[:, wv + i].median().item() / T for i in range(7)]
+        print(f"   {name}: per step total {m[0]:.0f} cyc: h half (or whole MFMA phase) {m[2]:.0f}, cell update {m[3]:.0f}, own x half {m[4]:.0f}, "
+              f"wait + x staging {m[5]:.0f}, barrier wait {m[6]:.0f}")
     cyc, ticks, mf, cell = b[:, 0].median(), b[:, 1].median(), b[:, 2].median(), b[:, 3].median()
     tiles = (seq_tile % 1000 + 15) // 16
     products = 3 if st.lib.dprnn_get_gemm_mode() == 3 else 6

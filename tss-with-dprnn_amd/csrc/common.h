@@ -88,6 +88,27 @@ template <bool FAST> __device__ __forceinline__ f32x2 tanh_k2(f32x2 x, float k, 
     }
 }
 
+// ... and with a bias per element
+template <bool FAST> __device__ __forceinline__ f32x2 sigmoid_k2v(f32x2 x, float k, f32x2 bk) {
+    const f32x2 a = x * f32x2{k, k} + bk;
+    if constexpr (FAST) {
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    } else {
+        return f32x2{sigmoid_acc(a[0]), sigmoid_acc(a[1])};
+    }
+}
+template <bool FAST> __device__ __forceinline__ f32x2 tanh_k2v(f32x2 x, float k, f32x2 bk) {
+    const f32x2 a = x * f32x2{k, k} + bk;
+    if constexpr (FAST) {
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.f, 1.f};
+        const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return f32x2{1.f, 1.f} - f32x2{2.f, 2.f} * r;
+    } else {
+        return f32x2{tanh_acc(a[0]), tanh_acc(a[1])};
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

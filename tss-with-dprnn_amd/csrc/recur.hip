@@ -771,7 +771,7 @@ extern "C" int dprnn_lstm_fwd_train(const float* X, const float* Z, const double
                                nseq, T, inner_n, outer_stride, inner_stride, t_stride, ndir, stream);
 }
 
-// Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][8] u64
+// Diagnostic (tools/bench_recur.py --stamps): same kernel with s_memtime stamps; stamps = [workgroups][8] u64 (exact kernel), [workgroups][2][8] (split kernels: waves 0 and 4)
 // {cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles}.  Not part of the product path.
 extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, const float* bsum, float* H,
                                         int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,

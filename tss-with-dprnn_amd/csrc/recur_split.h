@@ -27,6 +27,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef const u32x4 __attribute__((address_space(1)))* gfrag_ptr;
 
+// f16 pieces: column j of weight tile (wave, u) is hidden unit 32 wave + 16 u + j (CONTIGUOUS units), so that with the weight
+// fragment as the MFMA's row operand a lane's four accumulator elements are four adjacent units of one sequence: 8-byte LDS and
+// 16-byte global stores of h (recur_split8.h, TRANS).  bf16 pieces (mode 1) keep the interleaved order 32 wave + 2 j + u.
+#ifndef DPRNN_SPLIT8_TRANS
+#define DPRNN_SPLIT8_TRANS 1
+#endif
+constexpr bool F16_UNITS_CONTIGUOUS = DPRNN_SPLIT8_TRANS;
 constexpr int NSLAB = 8;                       // k-slabs of 32 over [x | h]
 constexpr int PITCH = 528;                     // bytes per LDS row (256 bf16 + 16 B pad)
 

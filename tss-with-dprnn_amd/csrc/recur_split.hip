@@ -92,7 +92,7 @@ __global__ void lstm_pack_f16_kernel(const float* __restrict__ w_ih, const float
     const int dw = idx & 3, lane = (idx >> 2) & 63, gu = (idx >> 8) & 7, slab = (idx >> 11) & 7;
     const int wave = (idx >> 14) & 3, dir = idx >> 16;
     const int gate = gu >> 1, u = gu & 1, r = lane & 15, q = lane >> 4;
-    const int row = gate * HD + 32 * wave + 2 * r + u;
+    const int row = gate * HD + 32 * wave + (F16_UNITS_CONTIGUOUS ? 16 * u + r : 2 * r + u);
     const float* wi = dir ? w_ih_r : w_ih;
     const float* wh = dir ? w_hh_r : w_hh;
     float v[2];

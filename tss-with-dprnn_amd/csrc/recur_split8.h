@@ -13,6 +13,10 @@ namespace rsplit {
 //   per step: [gate GEMM (8 k-slabs: x half, then h half)] [cell update + staging of x_{t+1}] barrier
 // (Round 3 also measured a skewed loop -- the x half of step t+1 before the barrier, so that one wave's cell update runs under its
 // SIMD partner's MFMAs: correct, 2 % slower; the per-phase stamps and the reasons are in profiles/r03_recur_skew.txt.)
+// (Round 3 also measured an ASYMMETRIC order -- waves 0-3 [h half][cell][x half of t+1], waves 4-7 [x half][h half][cell], x staged two
+// steps ahead behind an LDS counter, so that one wave of every SIMD multiplies while the other does vector work: correct, 2 % slower;
+// a wave alone on the matrix pipe needs 25 cycles per MFMA, not 16, its weight requests stall its own in-order stream:
+// profiles/r03_recur_asym.txt.)
 // (A staggered form -- cell update of one wave group beside the x half of the other's next step -- was measured in round 2
 // and removed in round 3: two accumulator sets spill at 64 sequences, 15.1 against 11.6 us per step; profiles/r02_split_wide.txt.)
 // Image: regions h (x 2) | x (x 2) when double-buffered, each [piece][NSR][256 B], 16-byte chunks XOR-swizzled by (row & 15).
@@ -43,6 +47,13 @@ void bilstm_split8_kernel(RecurArgs a) {
     static_assert(NP == 6 || (F16 && NP == 3), "three bf16 pieces / six products, or two f16 pieces / three products");
     constexpr int NT = NSR / 16;
     constexpr int NPC = NP == 6 ? 3 : 2;
+    // UC: the f16 pack's unit order (recur_split.h).  TRANS: weights as the MFMA's ROW operand, so the accumulator quad of lane
+    // (r, q) is units 4q .. 4q + 3 of sequence 16 nt + r instead of sequences 4q .. 4q + 3 of unit r: per tile the h pieces are two
+    // 8-byte LDS stores (were eight 2-byte ones) and h one 16-byte global store (were four 4-byte ones, in the vmcnt queue in front
+    // of the next step's weight loads).  The tape of the training forward is laid out over sequence quads, so SAVE keeps the
+    // sequence-major accumulators.
+    constexpr bool UC = F16 && F16_UNITS_CONTIGUOUS;
+    constexpr bool TRANS = UC && !SAVE;
     constexpr int PL = NSR * 256;                      // bytes of one piece plane of one region
     constexpr int REG = NPC * PL;                      // bytes of one region
     // DB (f16 pieces, up to 64 sequences: 128 KB): h and x images double-buffered by step parity, which removes the barrier
@@ -102,14 +113,16 @@ void bilstm_split8_kernel(RecurArgs a) {
     const int c4 = tid & 31, xrow0 = tid >> 5;         // x quad: row xrow0 + 16 m, floats 4 c4 .. 4 c4 + 3
     const int xl = xrow0 * 256 + (((c4 >> 1) ^ xrow0) << 4) + ((c4 & 1) << 3);
     auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
-    const int unit0 = 32 * w4 + 2 * r + wu;             // this lane's hidden unit
+    const int unit0 = TRANS ? 32 * w4 + 16 * wu + 4 * q : UC ? 32 * w4 + 16 * wu + r : 32 * w4 + 2 * r + wu;   // this lane's (first) hidden unit
 
-    float bias[4];
+    float bias[4][TRANS ? 4 : 1];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float b = a.bsum[dir * 4 * HD + g * HD + unit0];
-        bias[g] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
-    }
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < (TRANS ? 4 : 1); ++e) {
+            const float b = a.bsum[dir * 4 * HD + g * HD + unit0 + e];
+            bias[g][e] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+        }
     // f16 form: the accumulators are S_x S_w times the gate pre-activations; inv = 1 / (S_x S_w) rides on the multiply the
     // nonlinearity starts with anyway
     const float inv = F16 ? a.Wp[F16_SCALE_WORD + 1] : 1.f;
@@ -258,7 +271,11 @@ void bilstm_split8_kernel(RecurArgs a) {
     // h element (row 16 nt + 4q + e, this lane's unit): + nt * 4096 + piece * PL
     int hb[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hb[e] = (4 * q + e) * 256 + ((((w4 ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3) + 2 * wu;
+    for (int e = 0; e < 4; ++e)
+        hb[e] = UC ? (4 * q + e) * 256 + ((((w4 ^ q) << 2) | ((2 * wu + (r >> 3)) ^ e)) << 4) + 2 * (r & 7)      // unit 32 w4 + 16 wu + r
+                   : (4 * q + e) * 256 + ((((w4 ^ q) << 2) | ((r >> 2) ^ e)) << 4) + 4 * (r & 3) + 2 * wu;       // unit 32 w4 + 2 r + wu
+    // TRANS: units 4q .. 4q + 3 of the wave's 16 (chunk 4 w4 + 2 wu + (q >> 1), its half q & 1) in row 16 nt + r: 8 bytes per piece
+    const int hbt = r * 256 + (((4 * w4 + 2 * wu + (q >> 1)) ^ r) << 4) + 8 * (q & 1);
     const unsigned hcol = (unsigned)(dir * HD + unit0) * 4u;
 
     // WRES (f16 pieces, 16-sequence tile: the low-latency form for a few utterances): a step of a small tile is bound by the
@@ -287,8 +304,9 @@ void bilstm_split8_kernel(RecurArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                ac[nt][g] = F16 ? mfma_f16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g])
-                                : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
+                ac[nt][g] = TRANS ? mfma_f16(bw[g][wpc], af[nt], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g])
+                            : F16 ? mfma_f16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g])
+                                  : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
         if (WRES && wpc == 0 && sn < RES) return;      // resident
@@ -304,7 +322,9 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ac[nt][g] = mfma_f16(af[nt], wres[WRES && sc < RES ? sc : 0][g], ac[nt][g]);
+            for (int nt = 0; nt < NT; ++nt)
+                ac[nt][g] = TRANS ? mfma_f16(wres[WRES && sc < RES ? sc : 0][g], af[nt], ac[nt][g])
+                                  : mfma_f16(af[nt], wres[WRES && sc < RES ? sc : 0][g], ac[nt][g]);
     };
     // k-slab s4 of region reg (weights of global slab `s` are in bw; those of slab `sn` are requested as pieces die)
     auto slab = [&](f32x4 (&ac)[NT][4], const char* reg, u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int sn, bool have_p, bool prefetch,
@@ -351,7 +371,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     // LSTM cell of this wave's 16 units for every row, h -> image (3 pieces) and HBM
     // tape (SAVE): float index inside a 32-sequence workgroup's step = ((nt_b*2 + u)*5 + slot)*256 + wave_b*5120 + lane_b*4 + e with
     // wave_b = unit / 32, u = (unit % 32) / 16, lane_b = 16 q + unit % 16 -- per lane a constant plus (nt_b*10 + slot) KiB
-    const int tv = 2 * r + wu;                          // unit index inside its 32-unit group
+    const int tv = UC ? 16 * wu + r : 2 * r + wu;       // unit index inside its 32-unit group
     const unsigned toff = (unsigned)(w4 * 5120 + (tv >> 4) * 5 * 256 + (q * 16 + (tv & 15)) * 4) * 4u;
     const int nwg_b = (a.nseq + 31) / 32;
     auto cell = [&](f32x4 (&ac)[NT][4], long long t, int step = 0, char* hw = nullptr) __attribute__((always_inline)) {
@@ -362,19 +382,40 @@ void bilstm_split8_kernel(RecurArgs a) {
             fence();
             float hv[4];
             f32x4 sv[SAVE ? 5 : 1];
+            if constexpr (TRANS) {
+                unsigned w1[2], w2[2];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const f32x2 ig = sigmoid_k2v<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]});
+                    const f32x2 fg = sigmoid_k2v<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]});
+                    const f32x2 gg = tanh_k2v<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]});
+                    const f32x2 og = sigmoid_k2v<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]});
+                    const f32x2 cn = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
+                    const f32x2 h2 = og * tanh_f2<FAST>(cn);
+                    c[nt][2 * p2] = cn[0]; c[nt][2 * p2 + 1] = cn[1];
+                    hv[2 * p2] = h2[0]; hv[2 * p2 + 1] = h2[1];
+                    split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1[p2], w2[p2]);      // pieces of units 4q + 2 p2, + 1
+                }
+                char* d = hw + hbt + nt * 4096;
+                *reinterpret_cast<u32x2*>(d) = u32x2{w1[0], w1[1]};
+                *reinterpret_cast<u32x2*>(d + PL) = u32x2{w2[0], w2[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(hv[0]), __float_as_uint(hv[1]), __float_as_uint(hv[2]), __float_as_uint(hv[3])},
+                                                       hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 f32x2 ig, fg, gg, og;
                 if constexpr (F16) {
-                    ig = sigmoid_k2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, bias[0]);
-                    fg = sigmoid_k2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, bias[1]);
-                    gg = tanh_k2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, bias[2]);
-                    og = sigmoid_k2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, bias[3]);
+                    ig = sigmoid_k2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, bias[0][0]);
+                    fg = sigmoid_k2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, bias[1][0]);
+                    gg = tanh_k2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, bias[2][0]);
+                    og = sigmoid_k2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, bias[3][0]);
                 } else {
-                    ig = sigmoid_b2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, bias[0]);
-                    fg = sigmoid_b2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, bias[1]);
-                    gg = tanh_b2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, bias[2]);
-                    og = sigmoid_b2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, bias[3]);
+                    ig = sigmoid_b2<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, bias[0][0]);
+                    fg = sigmoid_b2<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, bias[1][0]);
+                    gg = tanh_b2<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, bias[2][0]);
+                    og = sigmoid_b2<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, bias[3][0]);
                 }
                 const f32x2 cn = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
                 const f32x2 h2 = og * tanh_f2<FAST>(cn);
@@ -440,13 +481,13 @@ void bilstm_split8_kernel(RecurArgs a) {
     }
     if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX / F16_XS);
     if constexpr (STAMP) {
-        if (tid == 0 && a.stamps) {
-            unsigned long long* o = a.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        if ((tid == 0 || tid == 256) && a.stamps) {               // waves 0 and 4: a SIMD's pair; [workgroup][2][8] words
+            unsigned long long* o = a.stamps + 16 * (blockIdx.y * gridDim.x + blockIdx.x) + (tid ? 8 : 0);
             o[0] = __builtin_amdgcn_s_memtime() - st_t0;
             o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
             o[2] = st_p1;                                         // MFMA phase
             o[3] = st_p2;                                         // cell + staging
-            o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = 0; o[7] = 0;
+            o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0;
         }
     }
 }
