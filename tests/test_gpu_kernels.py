@@ -208,7 +208,7 @@ def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
         assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
 
 
-@pytest.mark.parametrize("seq_tile", [2016, 2032, 2048, 2064, 2080, 2096])
+@pytest.mark.parametrize("seq_tile", [2016, 2032, 2048, 2064, 2080, 2096, 3064])
 @pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
 @pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (37.0, 0.02), (1e-3, 40.0)])
 def test_bilstm_f16_pieces(seq_tile, path, fused, wscale, xscale):
@@ -277,7 +277,7 @@ def _sat_flags(st, fn):
     return rc, list(host)
 
 
-@pytest.mark.parametrize("seq_tile", [2016, 2064, 2080])
+@pytest.mark.parametrize("seq_tile", [2016, 2064, 2080, 3064])
 @pytest.mark.parametrize("huge", [5000.0, 1e6, float("inf")])
 def test_bilstm_f16_pieces_flag_values_beyond_the_f16_range(seq_tile, huge):
     """|x| > 4062 does not fit 2^4 x in f16: the piece conversion clamps AND raises saturation flag 0 (Inf likewise; a NaN sample is

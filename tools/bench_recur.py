@@ -36,7 +36,7 @@ def run(st, seq_tile, nwg, T, ndir=2, iters=3):
     return ms, flops / ms / 1e9
 
 
-def run_forward_shapes(st, B=32, S=194, K=250, iters=5):
+def run_forward_shapes(st, B=32, S=194, K=250, iters=5, tile=2064):
     """The forward's own launches alone on the chip: one 32-utterance group's intra-chunk (B S sequences of K steps) and inter-chunk
     (B K sequences of S steps) recurrences, 64-sequence tiles, without and with the pending norm + residual folded into the x loads."""
     rows = B * S * K
@@ -56,9 +56,9 @@ def run_forward_shapes(st, B=32, S=194, K=250, iters=5):
         for fuse in (0, 1):
             if fuse:
                 args = (0, X.data_ptr(), Z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-8, per, S * K, X2.data_ptr(),
-                        packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, 2064)
+                        packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, tile)
             else:
-                args = (0, X.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, 2064)
+                args = (0, X.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, tile)
             st.call("dprnn_rnn_fwd", *args)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,6 +71,42 @@ def run_forward_shapes(st, B=32, S=194, K=250, iters=5):
             wgs = 2 * -(-addr[0] // 64)
             print(f"{name} of {B} utterances ({addr[0]} sequences x {T} steps, {wgs} workgroups), pending norm {'folded in' if fuse else 'none'}: "
                   f"{ms:.3f} ms = {ms / T * 1e3:.2f} us per step, {addr[0] * T * 2 * 2 * 256 * 512 / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+
+def power_probe(st, tile, B=32, S=194, K=250, launches=1500):
+    """One launch shape (intra-chunk of 32 utterances) queued `launches` times; rocm-smi is read while the queue drains: time per
+    launch, socket power, shader clock.  For the energy probes (DPRNN_LIB = a -DDPRNN_SPLIT8_DIAG build): the chip runs this kernel
+    at its power cap, so time follows energy per step, not cycles per step (profiles/r03_power_bound.txt)."""
+    import re
+    import subprocess
+    rows = B * S * K
+    X = torch.randn(rows, 128, device="cuda") * 0.5
+    H = torch.empty(rows, 256, device="cuda")
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device="cuda")
+    bsum = torch.empty(2 * 512, device="cuda")
+    w = [torch.randn(512, 128, device="cuda") * 0.08, torch.randn(512, 128, device="cuda") * 0.08,
+         torch.randn(512, device="cuda") * 0.05, torch.randn(512, device="cuda") * 0.05]
+    st.call("dprnn_rnn_pack", 0, *[t.data_ptr() for t in w], *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    args = (0, X.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), B * S, K, B * S, 0, K, 1, 2, tile)
+    for _ in range(20):
+        st.call("dprnn_rnn_fwd", *args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        st.call("dprnn_rnn_fwd", *args)
+    e1.record()
+    samples = []
+    for _ in range(4):
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True).stdout
+        pw = re.search(r"Power \(W\): ([0-9.]+)", out)
+        ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        if pw and ck and not e1.query():
+            samples.append((float(pw.group(1)), int(ck.group(1))))
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    print(f"power probe tile {tile} lib {os.environ.get('DPRNN_LIB', 'default')}: {ms:.3f} ms per launch = {ms / K * 1e3:.2f} us per step; "
+          f"(socket W, sclk MHz) while the queue drained: {samples}", flush=True)
 
 
 def run_train(st, nwg, T, ndir=2, iters=3):
@@ -249,6 +285,8 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3, 3 f16 pieces x3")
     ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
     ap.add_argument("--forward-shapes", type=int, default=0, help="1: the forward's own launches of one 32-utterance group, alone on the chip")
+    ap.add_argument("--power", type=int, default=0, help="1: queue one launch shape 1500 times and read rocm-smi meanwhile (time, W, sclk)")
+    ap.add_argument("--tile", type=int, default=2064, help="seq_tile code of --forward-shapes (3064: the sixteen-wave kernel, mode 3)")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()
@@ -257,11 +295,14 @@ def main():
     st = engine.Stage(torch.device("cuda:0"))
     ncu = lib.dprnn_num_cus()
     print(f"CUs {ncu} fast={a.fast} T={a.T}")
+    if a.power:
+        power_probe(st, a.tile)
+        return
     if a.forward_shapes:
-        run_forward_shapes(st)
+        run_forward_shapes(st, tile=a.tile)
         return
     if a.stamps and a.gemm_mode in (1, 3):
-        for seq_tile in (2064,):
+        for seq_tile in (a.tile,):
             stamps_split(st, seq_tile, a.T)
         return
     if a.stamps:

@@ -54,4 +54,6 @@ int launch_bilstm_split(const RecurArgs& a, int gemm_mode, int seq_tile, bool fa
 int launch_split8_bf16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                            // recur_split8_bf16.hip
 int launch_split8_f16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                             // recur_split8_f16.hip
 int launch_split8_f16_train(const RecurArgs& a, bool fast, hipStream_t st);                                // ... with the gate tape (a.tape)
+int launch_wide16_f16(const RecurArgs& a, bool fast, hipStream_t st);                                      // recur_wide16.hip: sixteen waves, 64 sequences
+int pack_wide16_f16(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, void* packed, int ndir, hipStream_t st);
 }  // namespace recur

@@ -783,7 +783,7 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     hipStream_t st = (hipStream_t)stream;
     if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, g_gemm_mode, ndir, "dprnn_bilstm_fwd_stamped")) return rc;
     if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // eight-wave split kernel with stamps (packed by dprnn_rnn_pack in the same mode)
-        if (seq_tile != 2064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064"); return -1; }
+        if (seq_tile != 2064 && !(seq_tile == 3064 && g_gemm_mode == 3)) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064 (and 3064 in mode 3)"); return -1; }
         return launch_bilstm_split(a, g_gemm_mode, seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {

@@ -26,6 +26,9 @@ namespace rsplit {
 #ifndef DPRNN_SPLIT8_PRIO
 #define DPRNN_SPLIT8_PRIO 1
 #endif
+#ifndef DPRNN_SPLIT8_DIAG
+#define DPRNN_SPLIT8_DIAG 0                            // 1 / 2 / 3: energy probes of tools (wrong results): no weight stream / fewer LDS reads / fewer MFMAs
+#endif
 #ifndef DPRNN_SPLIT8_RES32
 #define DPRNN_SPLIT8_RES32 1
 #endif
@@ -265,6 +268,9 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sl[j] = (j ^ ((r >> 2) & 3)) << 6;
     auto aload = [&](u32x4 (&af)[NT], const char* reg, int pc, int s4) __attribute__((always_inline)) {
+#if DPRNN_SPLIT8_DIAG == 2
+        if (s4 != 0) return;                           // energy probe: a quarter of the fragment reads (results are wrong)
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) af[nt] = *reinterpret_cast<const u32x4*>(reg + pc * PL + nt * 4096 + abase + sl[s4]);
     };
@@ -300,6 +306,9 @@ void bilstm_split8_kernel(RecurArgs a) {
     f32x4 acc[NT][4];
     u32x4 fa[NT], fb[NT];
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
+#if DPRNN_SPLIT8_DIAG == 3
+        if (wpc != 1 || !first) return;                // energy probe: one product of the first k-slab only (results are wrong)
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -309,6 +318,9 @@ void bilstm_split8_kernel(RecurArgs a) {
                                   : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
+#if DPRNN_SPLIT8_DIAG == 1
+        return;                                        // energy probe: no weight stream (results are wrong)
+#endif
         if (WRES && wpc == 0 && sn < RES) return;      // resident
         if (LRES > 0 && wpc == 1 && sn >= NSLAB - LRES) {      // from LDS
 #pragma unroll

@@ -27,7 +27,7 @@ F_BUILT = 128      # feature_size / hidden_size the kernels are built for (confi
 N_BUILT = 64       # input_size (config_bss.yaml:18)
 KS_MAX = 8
 PACK_PER_DIR = 4 * 16 * 8 * 256            # fp32 fragments of one direction (floats)
-PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4   # the split modes' piece planes (u32 words; three planes of bf16 pieces, two of f16)
+PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4 + 16 * 16 * 2 * 64 * 4   # the split modes' piece planes (u32 words; three planes of bf16 pieces, two of f16) + the f16 form's sixteen-wave fragments
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
