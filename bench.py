@@ -20,17 +20,23 @@ no data-path collective (weak scaling: 64 utterances per GPU).  Rank 0 prints ON
                  peak = the ceiling of the arithmetic that runs (2500 / 3 = 833 algorithmic TFLOP/s for three f16
                  products per product; 157.3 for the fp32 MFMA).  chip_level_tflops = the same FLOPs / the union of
                  the (overlapping) launch intervals;
+  power        : socket power and shader clock (rocm-smi) during the timed region: the forward runs at the board's power limit
+                 (~1380 W), which holds the clock near 1.73 of 2.4 GHz (profiles/r03_power_bound.txt);
   cpu_baseline : the reference's CPU path (oracle/dprnn_torch_cpu.py: the same ATen CPU ops the
                  reference dispatches to) timed on this host's cores per BASELINE.md section 3 (N=1 only).
   distributed  : what torch.distributed actually saw (world size, backend, one device name per rank).
 """
 import argparse
+import contextlib
 import gc
 import json
 import os
+import re
+import shutil
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +63,7 @@ def parse_args(argv=None):
                          "+ clip + Adam (configs[3], 64 utterances per GPU)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, shader clock) during the timed region")
     ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
@@ -290,7 +297,8 @@ def main():
         return
 
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
-    REC = "dprnn_rnn_fwd_ex"            # the recurrence launches (the dominant kernel)
+    REC = "dprnn_rnn_fwd_ex"            # the recurrence launches (the dominant kernel) ...
+    REC_NAMES = {REC, "dprnn_rnn_fwd_hp_ex"}     # ... under either entry point (mode 3 hands h to the projection as f16 piece quads)
 
     def host_state():
         """What can stall the enqueueing host: the caching allocator going back to the driver (segments allocated / freed, retries) and
@@ -305,7 +313,47 @@ def main():
                 break
         return out
 
-    def timed_region(mode, steps, warmup, profile=False):
+    class PowerSampler:
+        """Socket power and shader clock (rocm-smi, a child process every 0.4 s) while a timed region runs: the forward runs at
+        the board's power limit, and the clock the power management leaves it is what the kernel cycle counts have to be read
+        against (profiles/r03_power_bound.txt).  Rank 0 only; absent or unreadable rocm-smi -> no samples, nothing else changes."""
+
+        def __init__(self, on):
+            self.samples, self._stop, self._thread = [], threading.Event(), None
+            self.on = on and shutil.which("rocm-smi") is not None
+
+        def _run(self):
+            while not self._stop.is_set():
+                try:
+                    txt = subprocess.run(["rocm-smi", "-d", str(local_rank), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                    pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+                    ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                    if pw and ck:
+                        self.samples.append((float(pw.group(1)), int(ck.group(1))))
+                except Exception:
+                    return
+                self._stop.wait(0.4)
+
+        def __enter__(self):
+            if self.on:
+                self._thread = threading.Thread(target=self._run, daemon=True)
+                self._thread.start()
+            return self
+
+        def __exit__(self, *exc):
+            self._stop.set()
+            if self._thread is not None:
+                self._thread.join(timeout=15)
+
+        def summary(self):
+            if not self.samples:
+                return None
+            tail = self.samples[len(self.samples) // 2:]            # rocm-smi's power is a running average: the later half has settled
+            return {"socket_W": round(sum(p for p, _ in tail) / len(tail), 1), "sclk_MHz": round(sum(c for _, c in tail) / len(tail)),
+                    "samples": len(self.samples), "sclk_MHz_max_of_part": 2400,
+                    "note": "rocm-smi --showpower --showclocks every 0.4 s during the timed region, mean of the later half of the samples"}
+
+    def timed_region(mode, steps, warmup, profile=False, power=None):
         """`warmup` untimed forwards, then exactly `steps` timed ones between barriers, under gate-GEMM mode `mode`.  Every
         forward ends with the saturation check of the f16-pieces arithmetic (one stream synchronisation), so the host clock
         around each call is that step's latency.  profile: HIP events around every recurrence launch (engine.PROFILE) -- this
@@ -315,7 +363,7 @@ def main():
             for _ in range(warmup):
                 o = model(x)
             sync()
-            engine.PROFILE = {"names": {REC}, "events": {}} if profile else None
+            engine.PROFILE = {"names": set(REC_NAMES), "events": {}} if profile else None
             gc.collect()
             gc.disable()                # the host enqueues ~300 launches per step: no collector pauses inside the timed region
             t_ref = torch.cuda.Event(enable_timing=True)
@@ -324,15 +372,16 @@ def main():
             h0 = host_state()
             t0 = time.perf_counter()
             tp = t0
-            for _ in range(steps):
-                o = model(x)
-                if mode != 3:           # modes without the check return before the GPU is done: make the step boundary explicit
-                    torch.cuda.current_stream(dev).synchronize()
-                tn = time.perf_counter()
-                per_step.append(tn - tp)
-                tp = tn
-            sync()
-            dt = time.perf_counter() - t0
+            with (power if power is not None else contextlib.nullcontext()):
+                for _ in range(steps):
+                    o = model(x)
+                    if mode != 3:           # modes without the check return before the GPU is done: make the step boundary explicit
+                        torch.cuda.current_stream(dev).synchronize()
+                    tn = time.perf_counter()
+                    per_step.append(tn - tp)
+                    tp = tn
+                sync()
+                dt = time.perf_counter() - t0
             h1 = host_state()
             gc.enable()
             prof, engine.PROFILE = engine.PROFILE, None
@@ -346,7 +395,8 @@ def main():
     # With HIP graphs on (the engine's default) the timed region replays the captured forward; the per-launch kernel timing of the
     # roofline then comes from a second, eager pass of the same batch (PROF_STEPS steps).  DPRNN_GRAPHS=0: one region serves both.
     PROF_STEPS = min(args.steps, 10)
-    out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup, profile=not engine.GRAPHS)
+    power = PowerSampler(rank == 0 and not args.no_power)
+    out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup, profile=not engine.GRAPHS, power=power)
     graph_replays = engine.GRAPH_STATS["replays"] - graphs0["replays"]
     prof_steps = args.steps
     if engine.GRAPHS:
@@ -367,7 +417,7 @@ def main():
 
     def roofline(mode, prof, t_ref, steps, utt_per_s):
         """Roofline object of the recurrence kernel for a timed region run under `mode`."""
-        kern_ms, union_ms, conc, n_ev = _launch_stats(prof["events"].get(REC, []), t_ref)
+        kern_ms, union_ms, conc, n_ev = _launch_stats([ev for nm in sorted(REC_NAMES) for ev in prof["events"].get(nm, [])], t_ref)
         engine.GEMM_MODE = mode
         n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
         flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
@@ -399,6 +449,11 @@ def main():
                 f"{BF16_PEAK:.0f} TFLOP/s dense {piece} MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
                 f"{PEAK_F32_MFMA_TFLOPS} (achieved / that = {per_launch / PEAK_F32_MFMA_TFLOPS:.2f})",
                 "executed_mfma_tflops": None if mode == 0 else per_launch * products,
+                # the data-sheet peak assumes 2.4 GHz; this forward runs at the board's power limit, which holds the shader clock
+                # lower (the line's `power` object), and a register-only f16 MFMA loop reaches 2024 TFLOP/s on this chip for the
+                # same reason (profiles/r03_power_bound.txt): frac against `peak` cannot exceed ~0.8
+                "peak_at_power_limit_note": None if mode == 0 else "2024 TFLOP/s dense f16 MFMA measured with operands in registers "
+                "(tools/probes/mfma_f16_coexec.hip) = 675 algorithmic; the forward holds the socket at ~1380 W (see `power`)",
                 "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                 # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
                 # the previous norm is folded in: all launches of a forward but the first]
@@ -485,6 +540,7 @@ def main():
                                      3: "fp32-equivalent f16 pieces, 3 products (DPRNN_GEMM_MODE=3)"}[args.gemm_mode]
                        + (" (default)" if args.gemm_mode == engine.DEFAULT_GEMM_MODE else "")},
             "latency": latency(per_step),
+            "power": power.summary(),
             "host": dict(host_delta.get(args.gemm_mode, {}), gc="disabled in the timed region",
                          note="deltas over the timed region: driver-level allocations / frees of the caching allocator, allocation "
                               "retries, cgroup CPU-throttling periods of this process; reserved_GiB at its end"),

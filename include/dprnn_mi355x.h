@@ -219,6 +219,21 @@ int dprnn_rnn_fwd_ex(int gemm_mode, int cell, const float* X, const float* Z, co
                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                      int64_t t_stride, int ndir, int seq_tile, void* stream);
 
+/* The same recurrence with H written as the NEXT kernel's operand (gate-GEMM mode 3, LSTM, inference): per row and four adjacent units
+ * H holds the 16 bytes {first f16 pieces of 2^4 h x 4 | second pieces x 4} instead of four floats (same addresses, same bytes) -- exactly
+ * the words the f16-pieces projection would form from fp32 h, so dprnn_proj_stats_hp_fwd multiplies with them as loaded and its result
+ * is bit-identical to dprnn_rnn_fwd_ex + dprnn_proj_stats_fwd.  Replaces SingleRNN's output tensor between dprnn.py:86 and :88 (95 / 96),
+ * which no one else reads. */
+int dprnn_rnn_fwd_hp_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                        const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                        const float* packed, const float* bsum, float* H,
+                        int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                        int64_t t_stride, int ndir, int seq_tile, void* stream);
+/* intra_linear / inter_linear + GroupNorm sums on such an H (utt_starts == NULL: rows_per_utt rows per utterance; otherwise the ragged
+ * form with utterance u owning rows [utt_starts[u], utt_starts[u+1])) */
+int dprnn_proj_stats_hp_fwd(const float* Hp, const float* W, const float* bias, float* Z, double* stats,
+                            int64_t M, int64_t rows_per_utt, const int64_t* utt_starts, int n_utt, int kdim, void* stream);
+
 /* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
  * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; in the split modes (seq_tile 2064)
  * stamps[workgroup][2][8] for waves 0 and 4 = {shader cycles, ticks, h half (or whole MFMA phase), cell update, own x half, wait + x staging,
@@ -270,6 +285,10 @@ int dprnn_rnn_fwd_ragged_ex(int gemm_mode, const float* X, const float* Z, const
                             const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
                             int n_items, float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
                             void* stream);
+int dprnn_rnn_fwd_ragged_hp_ex(int gemm_mode, const float* X, const float* Z, const double* stats, const float* gamma,
+                               const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                               int n_items, float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
+                               void* stream);      /* H as f16 piece quads, for dprnn_proj_stats_hp_fwd (above) */
 int dprnn_proj_stats_ragged_fwd(const float* H, const float* W, const float* bias, float* Z, double* stats,
                                 int64_t M, const int64_t* utt_starts, int n_utt, int kdim, void* stream);
 

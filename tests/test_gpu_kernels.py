@@ -208,7 +208,7 @@ def test_bilstm_split_wide_tiles(seq_tile, mode, tol, path, fused):
         assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
 
 
-@pytest.mark.parametrize("seq_tile", [2016, 2032, 2048, 2064, 2080, 2096, 3064])
+@pytest.mark.parametrize("seq_tile", [2016, 2032, 2048, 2064, 2080, 2096])
 @pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
 @pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (37.0, 0.02), (1e-3, 40.0)])
 def test_bilstm_f16_pieces(seq_tile, path, fused, wscale, xscale):
@@ -277,7 +277,7 @@ def _sat_flags(st, fn):
     return rc, list(host)
 
 
-@pytest.mark.parametrize("seq_tile", [2016, 2064, 2080, 3064])
+@pytest.mark.parametrize("seq_tile", [2016, 2064, 2080])
 @pytest.mark.parametrize("huge", [5000.0, 1e6, float("inf")])
 def test_bilstm_f16_pieces_flag_values_beyond_the_f16_range(seq_tile, huge):
     """|x| > 4062 does not fit 2^4 x in f16: the piece conversion clamps AND raises saturation flag 0 (Inf likewise; a NaN sample is
@@ -436,6 +436,59 @@ def test_proj_stats_and_norm_residual(kdim, mode, rows_per):
                 _t(beta).data_ptr(), eps, Xd.data_ptr(), B, rows_per)
         torch.cuda.synchronize()
         assert rel_l2(Xd.cpu().numpy().reshape(B, rows_per, 128), want) < 1e-6
+
+
+@pytest.mark.parametrize("seq_tile", [2016, 2032, 2064, 2096])
+@pytest.mark.parametrize("ndir,ragged", [(2, False), (1, False), (2, True)])
+def test_h_as_piece_quads_feeds_the_projection_bit_for_bit(seq_tile, ndir, ragged):
+    """dprnn_rnn_fwd_hp_ex writes H as the f16 piece quads the mode-3 projection forms itself (recur_split8.h TRANS, rowgemm.hip PIECES):
+    dprnn_proj_stats_hp_fwd on it returns EXACTLY the Z and the GroupNorm sums of dprnn_rnn_fwd_ex + dprnn_proj_stats_fwd, on both
+    addressing forms, uni- and bidirectional, with a partial last tile; the piece quads decode to the fp32 h of the plain launch."""
+    B, S, K = 3, 9, 21
+    rng = np.random.default_rng(seq_tile + ndir)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(46)
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + ([_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names] if ndir == 2 else [None] * 4)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    st.call("dprnn_rnn_pack_ex", 3, 0, *[ptr(t) for t in w], packed.data_ptr(), bsum.data_ptr())
+    Xd = _t(X)
+    kd = ndir * 128
+    M = B * S * K
+    W = _t((rng.standard_normal((128, kd)) / np.sqrt(kd)).astype(np.float32))
+    b = _t(rng.standard_normal(128).astype(np.float32))
+    addr = (B * K, S, K, S * K, 1, K)                      # inter-chunk addressing: sequences (b, k) walk s
+    starts = _t(np.arange(B + 1, dtype=np.int64) * S * K)
+    out = {}
+    for hp in (False, True):
+        H = torch.full((M, kd), float("nan"), device=DEV)
+        Z = torch.full((M, 128), float("nan"), device=DEV)
+        stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+        st.call("dprnn_rnn_fwd_hp_ex" if hp else "dprnn_rnn_fwd_ex", 3, 0, Xd.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(),
+                bsum.data_ptr(), H.data_ptr(), *addr, ndir, seq_tile)
+        st.lib.dprnn_set_gemm_mode(3)
+        try:
+            if hp:
+                st.call("dprnn_proj_stats_hp_fwd", H.data_ptr(), W.data_ptr(), b.data_ptr(), Z.data_ptr(), stats.data_ptr(), M, S * K,
+                        starts.data_ptr() if ragged else 0, B if ragged else 0, kd)
+            elif ragged:
+                st.call("dprnn_proj_stats_ragged_fwd", H.data_ptr(), W.data_ptr(), b.data_ptr(), Z.data_ptr(), stats.data_ptr(), M,
+                        starts.data_ptr(), B, kd)
+            else:
+                st.call("dprnn_proj_stats_fwd", H.data_ptr(), W.data_ptr(), b.data_ptr(), Z.data_ptr(), stats.data_ptr(), M, S * K, kd)
+        finally:
+            st.lib.dprnn_set_gemm_mode(0)
+        torch.cuda.synchronize()
+        out[hp] = (H.cpu().numpy(), Z.cpu().numpy(), stats.cpu().numpy())
+    assert np.isfinite(out[False][1]).all()
+    assert np.array_equal(out[True][1], out[False][1]), "Z differs"
+    assert np.array_equal(out[True][2], out[False][2]), "GroupNorm sums differ"
+    q = out[True][0].view(np.float16).reshape(M, kd // 4, 2, 4).astype(np.float64)      # [row][unit quad][piece][unit]
+    h = ((q[:, :, 0] + q[:, :, 1]) / 16.0).reshape(M, kd)
+    assert np.abs(h - out[False][0].astype(np.float64)).max() < 2.0 ** -22
 
 
 @pytest.mark.parametrize("mode", [0, 3])

@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
     ap.add_argument("--forward-shapes", type=int, default=0, help="1: the forward's own launches of one 32-utterance group, alone on the chip")
     ap.add_argument("--power", type=int, default=0, help="1: queue one launch shape 1500 times and read rocm-smi meanwhile (time, W, sclk)")
-    ap.add_argument("--tile", type=int, default=2064, help="seq_tile code of --forward-shapes (3064: the sixteen-wave kernel, mode 3)")
+    ap.add_argument("--tile", type=int, default=2064, help="seq_tile code of --forward-shapes / --stamps / --power")
     ap.add_argument("--only", type=str, default="", help="seq_tile,wgs_per_cu: run just this configuration (for rocprofv3 --pmc)")
     a = ap.parse_args()
     lib = pkg.load_library()

@@ -40,6 +40,10 @@ SIGNATURES = {
     "dprnn_rnn_pack_ex": [c_i, c_i] + [c_fp] * 10 + [c_fp],
     "dprnn_rnn_fwd_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
                          c_i64, c_i, c_i, c_fp],
+    "dprnn_rnn_fwd_hp_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
+                            c_i64, c_i, c_i, c_fp],
+    "dprnn_proj_stats_hp_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_fp, c_i, c_i, c_fp],
+    "dprnn_rnn_fwd_ragged_hp_ex": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
     "dprnn_lstm_pack_f16": [c_fp] * 10 + [c_fp],
     "dprnn_bilstm_fwd_stamped": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_i, c_fp, c_fp],

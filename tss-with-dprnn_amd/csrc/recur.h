@@ -34,6 +34,8 @@ struct RecurArgs {
                                                       // its sequences are rows row0 + j * inner_stride, it runs T steps (inter-chunk path)
     const int* seq_utt;                               // utterance of every sequence (intra-chunk path; wg_desc == nullptr)
     const long long* utt_rows;                        // rows of every utterance (count of its pending norm); nullptr: rows_per_utt
+    int h_pieces;                                     // f16-pieces kernels, inference: H receives, per four adjacent units, the 16 bytes {first f16 pieces x 4 | second
+                                                      // pieces x 4} of 2^4 h instead of four floats -- the operand dprnn_proj_stats_hp_fwd multiplies with
     int* sat;                                         // f16-pieces kernels: saturation flags of the calling thread (common.h), may be null
 };
 
@@ -54,6 +56,4 @@ int launch_bilstm_split(const RecurArgs& a, int gemm_mode, int seq_tile, bool fa
 int launch_split8_bf16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                            // recur_split8_bf16.hip
 int launch_split8_f16(const RecurArgs& a, int nsr, bool fast, hipStream_t st);                             // recur_split8_f16.hip
 int launch_split8_f16_train(const RecurArgs& a, bool fast, hipStream_t st);                                // ... with the gate tape (a.tape)
-int launch_wide16_f16(const RecurArgs& a, bool fast, hipStream_t st);                                      // recur_wide16.hip: sixteen waves, 64 sequences
-int pack_wide16_f16(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, void* packed, int ndir, hipStream_t st);
 }  // namespace recur

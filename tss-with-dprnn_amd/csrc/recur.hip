@@ -640,6 +640,22 @@ extern "C" int dprnn_rnn_fwd_ex(int gemm_mode, int cell, const float* X, const f
                                     inner_n, outer_stride, inner_stride, t_stride, ndir), gemm_mode, seq_tile, (hipStream_t)stream);
 }
 
+// H as f16 piece quads (RecurArgs::h_pieces) for dprnn_proj_stats_hp_fwd: mode 3, LSTM, the eight-wave f16 tiles
+extern "C" int dprnn_rnn_fwd_hp_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
+                                   const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                                   const float* packed, const float* bsum, float* H,
+                                   int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
+                                   int64_t t_stride, int ndir, int seq_tile, void* stream) {
+    if (gemm_mode != 3 || cell != 0) {
+        dprnn_set_error("dprnn_rnn_fwd_hp_ex: piece output exists for the LSTM in gate-GEMM mode 3 (got mode %d, cell %d)", gemm_mode, cell);
+        return -1;
+    }
+    RecurArgs a = rnn_args(cell, X, Z, stats, gamma, beta, eps, seqs_per_utt, rows_per_utt, Xout, packed, bsum, H, nseq, T,
+                           inner_n, outer_stride, inner_stride, t_stride, ndir);
+    a.h_pieces = 1;
+    return bilstm_dispatch(a, gemm_mode, seq_tile, (hipStream_t)stream);
+}
+
 extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
                                      const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
                                      const float* packed, const float* bsum, float* H,
@@ -661,7 +677,7 @@ extern "C" int dprnn_bilstm_norm_fwd(const float* X, const float* Z, const doubl
 static int rnn_fwd_ragged(int mode, const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
                           float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
                           float* Xout, const float* packed, const float* bsum, float* H, int T, int K, int ndir,
-                          void* stream) {
+                          void* stream, int h_pieces = 0) {
     if (!X || !packed || !bsum || !H) { dprnn_set_error("dprnn_rnn_fwd_ragged: null pointer"); return -1; }
     if (mode != 1 && mode != 3) {
         dprnn_set_error("dprnn_rnn_fwd_ragged: needs a split gate-GEMM mode, 1 (bf16 pieces) or 3 (f16 pieces); got %d", mode);
@@ -679,13 +695,20 @@ static int rnn_fwd_ragged(int mode, const float* X, const float* Z, const double
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = n_items; a.T = T; a.ndir = ndir; a.cell = 0;
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Xout = Xout;
     a.seqs_per_utt = 1; a.rows_per_utt = 1; a.utt_rows = reinterpret_cast<const long long*>(utt_rows);
-    a.seq_utt = seq_utt; a.wg_desc = wg_desc;
+    a.seq_utt = seq_utt; a.wg_desc = wg_desc; a.h_pieces = h_pieces;
     if (wg_desc) { a.inner_n = 1 << 30; a.outer_stride = 0; a.inner_stride = 1; a.t_stride = K; }
     else { a.inner_n = n_items; a.outer_stride = 0; a.inner_stride = K; a.t_stride = 1; }
     if ((long long)64 * K * ndir * HD * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_fwd_ragged: chunk_length too large"); return -1; }
     if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, mode, ndir, "dprnn_rnn_fwd_ragged")) return rc;
     a.sat = dprnn_sat_ptr();
     return launch_bilstm_split(a, mode, 2064, g_fast_act != 0, (hipStream_t)stream);
+}
+extern "C" int dprnn_rnn_fwd_ragged_hp_ex(int gemm_mode, const float* X, const float* Z, const double* stats, const float* gamma,
+                                          const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                                          int n_items, float* Xout, const float* packed, const float* bsum, float* H, int T, int K,
+                                          int ndir, void* stream) {
+    if (gemm_mode != 3) { dprnn_set_error("dprnn_rnn_fwd_ragged_hp_ex: piece output exists in gate-GEMM mode 3 (got %d)", gemm_mode); return -1; }
+    return rnn_fwd_ragged(gemm_mode, X, Z, stats, gamma, beta, eps, utt_rows, seq_utt, wg_desc, n_items, Xout, packed, bsum, H, T, K, ndir, stream, 1);
 }
 extern "C" int dprnn_rnn_fwd_ragged(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
                                     float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc, int n_items,
@@ -783,7 +806,7 @@ extern "C" int dprnn_bilstm_fwd_stamped(const float* X, const float* packed, con
     hipStream_t st = (hipStream_t)stream;
     if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, g_gemm_mode, ndir, "dprnn_bilstm_fwd_stamped")) return rc;
     if (g_gemm_mode == 1 || g_gemm_mode == 3) {   // eight-wave split kernel with stamps (packed by dprnn_rnn_pack in the same mode)
-        if (seq_tile != 2064 && !(seq_tile == 3064 && g_gemm_mode == 3)) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064 (and 3064 in mode 3)"); return -1; }
+        if (seq_tile != 2064) { dprnn_set_error("dprnn_bilstm_fwd_stamped: split mode stamps exist for seq_tile 2064"); return -1; }
         return launch_bilstm_split(a, g_gemm_mode, seq_tile, true, st);
     }
     auto go = [&](auto kern, int NS) {

@@ -323,13 +323,13 @@ int launch_split(const RecurArgs& a, hipStream_t st) {
 // 2000 + n = the eight-wave kernel with n sequences per workgroup, one workgroup per CU (bf16: 64 / 80 / 96; f16: 16 .. 96).
 int recur::launch_bilstm_split(const RecurArgs& a, int gemm_mode, int seq_tile, bool fast, hipStream_t st) {
     const int nsr = seq_tile % 1000;
+    if (a.h_pieces && (gemm_mode != 3 || !F16_UNITS_CONTIGUOUS || a.tape)) {
+        dprnn_set_error("dprnn_rnn_fwd: H as f16 pieces exists in the inference kernels of gate-GEMM mode 3 only");
+        return -1;
+    }
     if (gemm_mode == 3) {                                  // f16 pieces: the eight-wave kernels only
-        if (seq_tile == 3064) {
-            if (a.tape) { dprnn_set_error("dprnn_rnn_fwd: the sixteen-wave tile (3064) has no training form"); return -1; }
-            return launch_wide16_f16(a, fast, st);
-        }
         if (seq_tile < 2000 || seq_tile >= 3000 || (nsr != 16 && nsr != 32 && nsr != 48 && nsr != 64 && nsr != 80 && nsr != 96)) {
-            dprnn_set_error("dprnn_rnn_fwd: gemm mode 3 has seq_tile 2016, 2032, 2048, 2064, 2080, 2096, 3064 (got %d)", seq_tile);
+            dprnn_set_error("dprnn_rnn_fwd: gemm mode 3 has seq_tile 2016, 2032, 2048, 2064, 2080, 2096 (got %d)", seq_tile);
             return -1;
         }
         return launch_split8_f16(a, nsr, fast, st);
@@ -354,10 +354,8 @@ extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const f
     const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
     hipLaunchKernelGGL(lstm_pack_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
-    if (int rc = dprnn_check_launch("lstm_pack_f16_kernel")) return rc;
-    if (int rc = pack_wide16_f16(w_ih, w_hh, w_ih_r, w_hh_r, packed, ndir, (hipStream_t)stream)) return rc;     // the sixteen-wave fragments, appended
     dprnn_pack_note(packed, DPRNN_PACK_FWD, 0, 3, ndir);
-    return 0;
+    return dprnn_check_launch("lstm_pack_f16_kernel");
 }
 
 extern "C" int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,

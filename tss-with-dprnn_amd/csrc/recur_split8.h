@@ -411,8 +411,10 @@ void bilstm_split8_kernel(RecurArgs a) {
                 char* d = hw + hbt + nt * 4096;
                 *reinterpret_cast<u32x2*>(d) = u32x2{w1[0], w1[1]};
                 *reinterpret_cast<u32x2*>(d + PL) = u32x2{w2[0], w2[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(hv[0]), __float_as_uint(hv[1]), __float_as_uint(hv[2]), __float_as_uint(hv[3])},
-                                                       hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
+                // h_pieces: the next kernel is the f16-pieces projection, which would split 2^4 h into exactly these words again
+                const u32x4 hout = a.h_pieces ? u32x4{w1[0], w1[1], w2[0], w2[1]}
+                                              : u32x4{__float_as_uint(hv[0]), __float_as_uint(hv[1]), __float_as_uint(hv[2]), __float_as_uint(hv[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(hout, hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
                 continue;
             }
 #pragma unroll

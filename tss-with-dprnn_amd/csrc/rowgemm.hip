@@ -77,7 +77,10 @@ extern "C" int dprnn_bottleneck_att_fwd(const float* wav, const float* enc_w, co
 namespace {
 typedef rg_u32x4 u32x4_t;
 
-template <int KD>
+// PIECES: H holds, per four adjacent units, {first f16 pieces x 4 | second pieces x 4} of 2^4 h as written by the recurrence
+// (dprnn_rnn_fwd_hp_ex) -- the same 16 bytes per quad and the very words this kernel would form, so the loads ARE the operands:
+// no conversion (40 vector instructions per 24 MFMAs otherwise), bit-identical results.
+template <int KD, bool PIECES>
 __global__ __launch_bounds__(512, 1)
 void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ H,
                      float* __restrict__ Z, double* __restrict__ stats, long long M, long long rows_per_b,
@@ -186,6 +189,12 @@ void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias
             u32x4_t h1[RT], h2[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (PIECES) {
+                    const u32x4_t ql = __builtin_bit_cast(u32x4_t, a[cb][rt][0]), qh = __builtin_bit_cast(u32x4_t, a[cb][rt][1]);
+                    h1[rt] = u32x4_t{ql[0], ql[1], qh[0], qh[1]};
+                    h2[rt] = u32x4_t{ql[2], ql[3], qh[2], qh[3]};
+                    continue;
+                }
                 f32x4 lo = a[cb][rt][0], hi = a[cb][rt][1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {                               // rows are RNN outputs, |h| < 1 by construction (o * tanh(c)):
@@ -260,11 +269,11 @@ void proj_f16_kernel(const float* __restrict__ W, const float* __restrict__ bias
     flush();
 }
 
-template <int KD>
+template <int KD, bool PIECES = false>
 int launch_proj_f16(const char* what, const float* W, const float* bias, const float* H, float* Z, double* stats, long long M,
                     long long rows_per_b, const long long* starts, int n_utt, hipStream_t st) {
     const size_t lds = (size_t)KD * 128 * 4 + 128 * 4;
-    auto kern = &proj_f16_kernel<KD>;
+    auto kern = &proj_f16_kernel<KD, PIECES>;
     static std::atomic<unsigned long long> attr_mask{0};
     int attr_dev;
     if (dprnn_attr_needed(attr_mask, &attr_dev)) {
@@ -305,6 +314,20 @@ extern "C" int dprnn_proj_stats_fwd(const float* H, const float* W, const float*
     EpProjStats<RT, 8> ep{Z, bias, stats, (long long)rows_per_utt, nullptr, 0};
     if (kdim == 256) return launch_rowgemm<256, 128, RT, false, PROJ_NW>("proj_stats256", W, 256, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
     return launch_rowgemm<128, 128, RT, false, PROJ_NW>("proj_stats128", W, 128, 128, nullptr, 0, M, al, ep, (hipStream_t)stream);
+}
+
+// H as f16 piece quads (written by dprnn_rnn_fwd_hp_ex / dprnn_rnn_fwd_ragged_hp_ex): gate-GEMM mode 3 only; utt_starts != NULL: ragged
+extern "C" int dprnn_proj_stats_hp_fwd(const float* Hp, const float* W, const float* bias, float* Z, double* stats,
+                                       int64_t M, int64_t rows_per_utt, const int64_t* utt_starts, int n_utt, int kdim, void* stream) {
+    if (!Hp || !W || !bias || !Z || !stats) { dprnn_set_error("dprnn_proj_stats_hp_fwd: null pointer"); return -1; }
+    if (M <= 0 || (!utt_starts && rows_per_utt <= 0) || (utt_starts && n_utt < 1) || (kdim != 256 && kdim != 128)) {
+        dprnn_set_error("dprnn_proj_stats_hp_fwd: bad sizes M=%lld rows_per_utt=%lld n_utt=%d kdim=%d", (long long)M, (long long)rows_per_utt, n_utt, kdim);
+        return -1;
+    }
+    const long long* st_ = reinterpret_cast<const long long*>(utt_starts);
+    const long long rpu = utt_starts ? 1 : rows_per_utt;
+    if (kdim == 256) return launch_proj_f16<256, true>("proj_f16_256p", W, bias, Hp, Z, stats, M, rpu, st_, utt_starts ? n_utt : 0, (hipStream_t)stream);
+    return launch_proj_f16<128, true>("proj_f16_128p", W, bias, Hp, Z, stats, M, rpu, st_, utt_starts ? n_utt : 0, (hipStream_t)stream);
 }
 
 // ragged batch: utterance u owns rows [utt_starts[u], utt_starts[u + 1]) of the concatenated slab

@@ -27,7 +27,8 @@ F_BUILT = 128      # feature_size / hidden_size the kernels are built for (confi
 N_BUILT = 64       # input_size (config_bss.yaml:18)
 KS_MAX = 8
 PACK_PER_DIR = 4 * 16 * 8 * 256            # fp32 fragments of one direction (floats)
-PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4 + 16 * 16 * 2 * 64 * 4   # the split modes' piece planes (u32 words; three planes of bf16 pieces, two of f16) + the f16 form's sixteen-wave fragments
+PACK_PER_DIR_MAX = 4 * 8 * 8 * 3 * 64 * 4   # the split modes' piece planes (u32 words; three planes of bf16 pieces, two of f16)
+H_PIECES = os.environ.get("DPRNN_H_PIECES", "1") != "0"     # mode 3: the recurrence writes h as the projection's f16 piece operand
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
@@ -393,11 +394,14 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         tile = 32
     if cell == 0 and g.mode != 0:
         tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
+    # f16 pieces: the recurrence hands the projection its operand (H as piece quads, dprnn_rnn_fwd_hp_ex) -- unless someone wants to see h
+    hp = H_PIECES and g.mode == 3 and cell == 0 and dbg is None and tile >= 2000
+    rnn_fwd = "dprnn_rnn_fwd_hp_ex" if hp else "dprnn_rnn_fwd_ex"
     if g.pending is None:
-        st.call("dprnn_rnn_fwd_ex", g.mode, cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
+        st.call(rnn_fwd, g.mode, cell, _p(g.X), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
     else:       # previous path's norm + residual applied on the fly; x' lands in the other slab
         pstats, pg, pb, peps = g.pending
-        st.call("dprnn_rnn_fwd_ex", g.mode, cell, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
+        st.call(rnn_fwd, g.mode, cell, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, S if intra else K, S * K,
                 _p(g.X2), _p(packed), _p(bsum), _p(Hbuf), *addr, ndir, tile)
         g.X, g.X2 = g.X2, g.X
         g.pending = None
@@ -406,8 +410,12 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     w = _param(lin.weight, "linear.weight", dev)
     if w.shape != (F_BUILT, ndir * F_BUILT):
         raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
-    st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
-            geo.rows, S * K, ndir * F_BUILT)
+    if hp:
+        st.call("dprnn_proj_stats_hp_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
+                geo.rows, S * K, 0, 0, ndir * F_BUILT)
+    else:
+        st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
+                geo.rows, S * K, ndir * F_BUILT)
     gamma, beta, eps = _norm_params(norm)
     gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
     if fuse:
@@ -1212,7 +1220,8 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             slot = 2 * i + (0 if intra else 1)
             ndir = 2 if rnn.rnn.bidirectional else 1
             pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
-            st.call("dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
+            hp = H_PIECES and mode == 3
+            st.call("dprnn_rnn_fwd_ragged_hp_ex" if hp else "dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
                     int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
                     K if intra else 0, K, ndir)
             if pending is not None:
@@ -1220,8 +1229,12 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             w = _param(lin.weight, "linear.weight", dev)
             if w.shape != (F_BUILT, ndir * F_BUILT):
                 raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
-            st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
-                    total, _p(utt_starts), n, ndir * F_BUILT)
+            if hp:
+                st.call("dprnn_proj_stats_hp_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
+                        total, 1, _p(utt_starts), n, ndir * F_BUILT)
+            else:
+                st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
+                        total, _p(utt_starts), n, ndir * F_BUILT)
             gamma, beta, eps = _norm_params(norm)
             pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
 
@@ -1419,7 +1432,7 @@ def _graph_key(kind: str, model, inputs, extra=()):
     bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
     knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
              SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
-             lib.dprnn_get_rowgemm_grid())
+             lib.dprnn_get_rowgemm_grid(), H_PIECES)
     return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
 
 
