@@ -181,6 +181,48 @@ def cpu_baseline(sd, cfg, model, dev):
     return base, parity
 
 
+class PowerSampler:
+    """Socket power and shader clock (rocm-smi, a child process every 0.4 s) while a timed region runs: the forward runs at
+    the board's power limit, and the clock the power management leaves it is what the kernel cycle counts have to be read
+    against (profiles/r03_power_bound.txt).  Rank 0 only; absent or unreadable rocm-smi -> no samples, nothing else changes."""
+
+    def __init__(self, on, device_index=0):
+        self.device_index = device_index
+        self.samples, self._stop, self._thread = [], threading.Event(), None
+        self.on = on and shutil.which("rocm-smi") is not None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+                ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                if pw and ck:
+                    self.samples.append((float(pw.group(1)), int(ck.group(1))))
+            except Exception:
+                return
+            self._stop.wait(0.4)
+
+    def __enter__(self):
+        if self.on:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=15)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        tail = self.samples[len(self.samples) // 2:]            # rocm-smi's power is a running average: the later half has settled
+        return {"socket_W": round(sum(p for p, _ in tail) / len(tail), 1), "sclk_MHz": round(sum(c for _, c in tail) / len(tail)),
+                "samples": len(self.samples), "sclk_MHz_max_of_part": 2400,
+                "note": "rocm-smi --showpower --showclocks every 0.4 s during the timed region, mean of the later half of the samples"}
+
+
 def _launch_stats(events, t_ref):
     """Per-launch HIP-event durations on the launch streams.  With utterance groups on several streams the launches
     overlap, so the chip-level rate is (sum of algorithmic FLOPs) / (union of the launch intervals); kernel_ms is the
@@ -313,46 +355,6 @@ def main():
                 break
         return out
 
-    class PowerSampler:
-        """Socket power and shader clock (rocm-smi, a child process every 0.4 s) while a timed region runs: the forward runs at
-        the board's power limit, and the clock the power management leaves it is what the kernel cycle counts have to be read
-        against (profiles/r03_power_bound.txt).  Rank 0 only; absent or unreadable rocm-smi -> no samples, nothing else changes."""
-
-        def __init__(self, on):
-            self.samples, self._stop, self._thread = [], threading.Event(), None
-            self.on = on and shutil.which("rocm-smi") is not None
-
-        def _run(self):
-            while not self._stop.is_set():
-                try:
-                    txt = subprocess.run(["rocm-smi", "-d", str(local_rank), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
-                    pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
-                    ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
-                    if pw and ck:
-                        self.samples.append((float(pw.group(1)), int(ck.group(1))))
-                except Exception:
-                    return
-                self._stop.wait(0.4)
-
-        def __enter__(self):
-            if self.on:
-                self._thread = threading.Thread(target=self._run, daemon=True)
-                self._thread.start()
-            return self
-
-        def __exit__(self, *exc):
-            self._stop.set()
-            if self._thread is not None:
-                self._thread.join(timeout=15)
-
-        def summary(self):
-            if not self.samples:
-                return None
-            tail = self.samples[len(self.samples) // 2:]            # rocm-smi's power is a running average: the later half has settled
-            return {"socket_W": round(sum(p for p, _ in tail) / len(tail), 1), "sclk_MHz": round(sum(c for _, c in tail) / len(tail)),
-                    "samples": len(self.samples), "sclk_MHz_max_of_part": 2400,
-                    "note": "rocm-smi --showpower --showclocks every 0.4 s during the timed region, mean of the later half of the samples"}
-
     def timed_region(mode, steps, warmup, profile=False, power=None):
         """`warmup` untimed forwards, then exactly `steps` timed ones between barriers, under gate-GEMM mode `mode`.  Every
         forward ends with the saturation check of the f16-pieces arithmetic (one stream synchronisation), so the host clock
@@ -395,7 +397,7 @@ def main():
     # With HIP graphs on (the engine's default) the timed region replays the captured forward; the per-launch kernel timing of the
     # roofline then comes from a second, eager pass of the same batch (PROF_STEPS steps).  DPRNN_GRAPHS=0: one region serves both.
     PROF_STEPS = min(args.steps, 10)
-    power = PowerSampler(rank == 0 and not args.no_power)
+    power = PowerSampler(rank == 0 and not args.no_power, local_rank)
     out, elapsed, per_step, prof, t_ref = timed_region(args.gemm_mode, args.steps, args.warmup, profile=not engine.GRAPHS, power=power)
     graph_replays = engine.GRAPH_STATS["replays"] - graphs0["replays"]
     prof_steps = args.steps
@@ -586,11 +588,13 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
     engine.PROFILE = {"names": names, "events": {}}
     t_ref = torch.cuda.Event(enable_timing=True)
     t_ref.record()
+    power = PowerSampler(rank == 0 and not args.no_power, dev.index or 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.train_step(model, lossm, opt, mix_d, tgt_d, clip_norm=5, reducer=reducer)
-    sync()
-    elapsed = time.perf_counter() - t0
+    with power:
+        for _ in range(args.steps):
+            loss, _ = trainer.train_step(model, lossm, opt, mix_d, tgt_d, clip_norm=5, reducer=reducer)
+        sync()
+        elapsed = time.perf_counter() - t0
     prof, engine.PROFILE = engine.PROFILE, None
     on_device = dist is None or dist.get_backend() == "nccl"
     elapsed = sharding.max_over_ranks(elapsed, device=dev if on_device else None)
@@ -638,6 +642,7 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
         "roofline": dict(roof, kernel_ms=kern_ms, launches_timed=n_ev, busy_ms_per_step=union_ms / args.steps, mean_concurrency=conc,
                          whole_step_tflops=value / world * 3 * FLOP_PER_UTT / 1e12,
                          whole_step_frac_of_fp32_mfma_peak=value / world * 3 * FLOP_PER_UTT / 1e12 / PEAK_F32_MFMA_TFLOPS),
+        "power": power.summary(),
         "loss": float(loss.item()), "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2**30,
     }
 
