@@ -98,3 +98,29 @@ def test_package_import_sets_dmabuf_ipc_before_torch(tmp_path):
     r = _spy(tmp_path, "import tss_with_dprnn_amd")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "AT_TORCH_IMPORT 0" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_power_sampler_reads_rocm_smi_and_survives_without_it(tmp_path, monkeypatch):
+    """bench.PowerSampler: parses rocm-smi's "Power (W)" / "sclk clock level" lines from a child process while a region runs; no
+    rocm-smi on PATH (or unparsable output) means no samples and a null `power` object, never an error."""
+    import importlib
+    import time
+    bench = importlib.import_module("bench")
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\ncat <<EOT\n"
+                    "GPU[0]\t\t: mclk clock level: 3: (2000Mhz)\n"
+                    "GPU[0]\t\t: sclk clock level: 1: (1731Mhz)\n"
+                    "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1386.0\nEOT\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    ps = bench.PowerSampler(True, 0)
+    with ps:
+        time.sleep(1.0)
+    out = ps.summary()
+    assert out is not None and out["socket_W"] == 1386.0 and out["sclk_MHz"] == 1731 and out["samples"] >= 1
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    ps = bench.PowerSampler(True, 0)
+    with ps:
+        pass
+    assert ps.summary() is None
+    assert bench.PowerSampler(False, 0).summary() is None

@@ -282,7 +282,7 @@ def main():
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--stamps", type=int, default=0)
-    ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 2 bf16 split x3, 3 f16 pieces x3")
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 exact fp32, 1 bf16 split x6, 3 f16 pieces x3")
     ap.add_argument("--train", type=int, default=0, help="1: time the training recurrences (fwd with tape, BPTT) on a full grid")
     ap.add_argument("--forward-shapes", type=int, default=0, help="1: the forward's own launches of one 32-utterance group, alone on the chip")
     ap.add_argument("--power", type=int, default=0, help="1: queue one launch shape 1500 times and read rocm-smi meanwhile (time, W, sclk)")
