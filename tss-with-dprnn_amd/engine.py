@@ -1461,12 +1461,23 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
     with torch.cuda.device(dev):
         if g is None:
             with _CAPTURE_LOCK:
+                # Make room BEFORE capturing, and hand the evicted graphs' workspaces (their private pools, GBs each) back to the driver
+                # here, outside any capture.  With the eviction after the capture those pools stayed with the caching allocator until
+                # it next needed memory, and the sixteenth capture of a long-running process (cache of 4, batch sizes 16 .. 96 at full
+                # length) segfaulted inside hipGraphLaunch on its first replay; tools/probes/graph_churn.py reproduces it and passes
+                # 21 captures up to B = 128 with this order (gpurun_out/r09f, r09g).
+                evicted = []
+                with _GRAPH_LOCK:
+                    while len(_GRAPH_CACHE) >= max(1, GRAPH_CACHE_MAX):
+                        evicted.append(_GRAPH_CACHE.popitem(last=False)[1])
+                if evicted:
+                    torch.cuda.synchronize(dev)
+                    del evicted
+                    torch.cuda.empty_cache()
                 g = _Graphed(dev, fn, inputs)
             GRAPH_STATS["captures"] += 1
             with _GRAPH_LOCK:
                 _GRAPH_CACHE[key] = g
-                while len(_GRAPH_CACHE) > GRAPH_CACHE_MAX:
-                    _GRAPH_CACHE.popitem(last=False)
 
         def run():
             GRAPH_STATS["replays"] += 1
@@ -1479,6 +1490,9 @@ def drop_graphs() -> None:
     with _GRAPH_LOCK:
         _GRAPH_CACHE.clear()
         _GRAPH_SEEN.clear()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------ guarded entry points
