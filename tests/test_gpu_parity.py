@@ -529,3 +529,34 @@ def test_graph_replay_equals_eager_forward(kind):
         assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 1
         assert np.isnan(got[1]).all() and np.isfinite(got[[0, 2]]).all()
     engine.drop_graphs()
+
+
+def test_graph_cache_evicts_before_it_captures(monkeypatch):
+    """More keys than GRAPH_CACHE_MAX in one process: the engine evicts the oldest graph BEFORE capturing the next (and returns its pool
+    to the driver outside the capture), the cache never exceeds its bound, a key that comes back is captured again, and every replay
+    equals the eager forward of the same input.  (The full-size walk that used to segfault in hipGraphLaunch: tools/probes/graph_churn.py.)"""
+    from tss_with_dprnn_amd import engine
+    model, _, _ = build_model("bss", dict(n_repeats=2, chunk_length=50, hop_length=25), 91, _dev())
+    monkeypatch.setattr(engine, "GRAPH_CACHE_MAX", 2)
+    assert engine.GRAPHS
+    engine.drop_graphs()
+    c0 = engine.GRAPH_STATS["captures"]
+    xs = {B: torch.from_numpy(make_mixture(B, 2400, seed=B)).to(_dev()) for B in (1, 2, 3, 4)}
+    want = {}
+    old = engine.GRAPHS
+    engine.GRAPHS = False
+    try:
+        with torch.no_grad():
+            for B, x in xs.items():
+                want[B] = model(x).cpu().numpy()
+    finally:
+        engine.GRAPHS = old
+    with torch.no_grad():
+        for B in (1, 2, 3, 4, 1, 3):                       # 1 and 3 come back after their graphs were evicted
+            outs = [model(xs[B]).cpu().numpy() for _ in range(3)]            # eager or capture, then replays
+            assert len(engine._GRAPH_CACHE) <= 2
+            for o in outs:
+                assert rel_l2(o, want[B]) < 1e-6
+    assert engine.GRAPH_STATS["captures"] == c0 + 6
+    engine.drop_graphs()
+    assert len(engine._GRAPH_CACHE) == 0

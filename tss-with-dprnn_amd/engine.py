@@ -1487,12 +1487,15 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
 
 def drop_graphs() -> None:
     """Forget every captured forward (frees their workspaces)."""
-    with _GRAPH_LOCK:
-        _GRAPH_CACHE.clear()
-        _GRAPH_SEEN.clear()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+    with _CAPTURE_LOCK:                  # never while another thread captures: the pools go back to the driver here
+        with _GRAPH_LOCK:
+            dropped = list(_GRAPH_CACHE.values())
+            _GRAPH_CACHE.clear()
+            _GRAPH_SEEN.clear()
+        if dropped and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            del dropped
+            torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------ guarded entry points
