@@ -99,6 +99,9 @@ TRAINED_CASES = [
     ("bss_full_trained_rms1", "bss", dict(), 2, 24000, 90, 1.0, FULL_RMS1),
     ("bss_full_trained_rms1e-3", "bss", dict(), 2, 24000, 90, 1e-3, FULL_RMS1EM3),
     ("bss_wide_trained_small", "bss", dict(WIDE), 3, 300, 92, 1.0, LITERAL),
+    # the speaker-conditioned family under the same weight statistics (shipped config, cat fusion, BatchNorm in eval mode)
+    ("spe_full_trained_rms1", "spe", dict(fusion_type="cat", norm_type="ln"), 1, 24000, 94, 1.0, FULL_RMS1),
+    ("ira_wide_trained_small", "ira", dict(WIDE, fusion_type="film", norm_type="ln"), 2, 300, 95, 1.0, FULL_RMS1),
 ]
 # gradients are less forgiving than outputs: the reference's own fp32-vs-float64 gradient distance at the shipped size is
 # 4.8e-5 with default-init weights, 5.5e-5 with gains / forget offsets alone (this recipe), 1.3e-4 .. 3.6e-4 with rows
@@ -328,17 +331,26 @@ def make_trained_cases(only):
         hooks = [blk.register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, float(out.detach().abs().max())))
                  for i, blk in enumerate(model.separation.dprnn_blocks)]
         mix = make_mixture(B, T, seed=1000 + seed, scale=scale)
+        extra = {}
         with torch.no_grad():
-            out = model(torch.from_numpy(mix))
-            for h in hooks:
-                h.remove()
-            out64 = model.double()(torch.from_numpy(mix).double())
+            if kind == "bss":
+                out = model(torch.from_numpy(mix))
+                for h in hooks:
+                    h.remove()
+                out64 = model.double()(torch.from_numpy(mix).double())
+            else:
+                aux = make_mixture(B, T, seed=2000 + seed, scale=scale)
+                out, logits = model(torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(float(T)))
+                for h in hooks:
+                    h.remove()
+                out64, logits64 = model.double()(torch.from_numpy(mix).double(), torch.from_numpy(aux).double(), torch.tensor(float(T)).double())
+                extra = dict(aux=aux, aux_len=np.float32(T), logits=logits.numpy(), logits64=logits64.numpy())
         model.float()
         gap = float((out.double() - out64).norm() / out64.norm())
         meta = dict(name=name, kind=kind, cfg={k: cfg[k] for k in SPE_KEYS}, batch=B, samples=T, seed=seed, style="trained",
                     recipe=recipe, input_scale=scale, bn_training=False, torch=torch.__version__, ref_fp32_vs_fp64_rel_l2=gap,
                     residual_stream_absmax_after_block=[taps[i] for i in sorted(taps)])
-        save = dict(mix=mix, out=out.numpy(), out64=out64.numpy(), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+        save = dict(mix=mix, out=out.numpy(), out64=out64.numpy(), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **extra)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
         print(f"{name:32s} out {tuple(out.shape)} |out| {float(out.abs().max()):.4f}  reference fp32 vs float64 {gap:.2e}  "
               f"max |residual stream| per block {[round(taps[i], 1) for i in sorted(taps)]}")

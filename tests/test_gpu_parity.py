@@ -430,7 +430,7 @@ def test_two_threads_two_modes():
 #   * against the reference's float64 output: no further than 2.5 x the reference's own fp32 distance from it.
 # And none of them may have needed the saturation fall-back: these magnitudes are inside the f16-pieces range.
 @pytest.mark.parametrize("mode", [0, 1, 3])
-@pytest.mark.parametrize("name", golden_names("bss", trained=True))
+@pytest.mark.parametrize("name", golden_names("bss", trained=True) + golden_names("spe", trained=True) + golden_names("ira", trained=True))
 def test_trained_like_weights_in_every_fp32_class_mode(name, mode):
     g = load_golden(name)
     m = g["meta"]
@@ -442,7 +442,12 @@ def test_trained_like_weights_in_every_fp32_class_mode(name, mode):
     try:
         assert engine.effective_gemm_mode(1) == mode
         with torch.no_grad():
-            out = model(torch.from_numpy(g["mix"]).to(_dev())).cpu().numpy()
+            if m["kind"] == "bss":
+                out = model(torch.from_numpy(g["mix"]).to(_dev())).cpu().numpy()
+            else:           # the speaker-conditioned families: estimate and speaker logits (dprnn_spe.py:314-327, dprnn_spe_ira.py:179-190)
+                est, logits = model(torch.from_numpy(g["mix"]).to(_dev()), torch.from_numpy(g["aux"]).to(_dev()), torch.tensor(float(g["aux_len"])))
+                out = est.cpu().numpy()
+                assert rel_l2(logits.cpu().numpy(), g["logits"]) <= max(REL_TOL, 3 * gap)
     finally:
         engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = old
     assert engine.SATURATION["fallbacks"] == before["fallbacks"], engine.SATURATION

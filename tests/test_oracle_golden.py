@@ -204,3 +204,26 @@ def test_torch_cpu_oracle_matches_reference_on_trained_like_weights_full_size():
     out_t = otc.tasnet_forward(otc.to_torch_state(state_from_meta(m)), m["cfg"], torch.from_numpy(g["mix"])).numpy()
     assert rel_l2(out_t, g["out"]) < max(TOL, 3 * m["ref_fp32_vs_fp64_rel_l2"])
     assert rel_l2(out_t, g["out64"]) < 3 * m["ref_fp32_vs_fp64_rel_l2"]
+
+
+@pytest.mark.parametrize("name", golden_names("spe", trained=True) + golden_names("ira", trained=True))
+def test_oracles_match_reference_on_trained_like_weights_speaker_conditioned(name):
+    """The Spe / IRA families under the same weight statistics (make_golden.TRAINED_CASES): both restatements against the reference's
+    fp32 output and logits, the numpy one in float64 against the reference's float64 run (small case only: the shipped size takes the
+    numpy oracle minutes)."""
+    g = load_golden(name)
+    m = g["meta"]
+    gap = m["ref_fp32_vs_fp64_rel_l2"]
+    sd = state_from_meta(m)
+    if m["cfg"]["fusion_type"] == "cat":                 # the torch-CPU restatement covers the cat fusion (the others: numpy)
+        fwd_t = otc.spe_forward if m["kind"] == "spe" else otc.ira_forward
+        out_t, logits_t = fwd_t(otc.to_torch_state(sd), m["cfg"], torch.from_numpy(g["mix"]), torch.from_numpy(g["aux"]),
+                                torch.tensor(float(g["aux_len"])))
+        assert rel_l2(out_t.numpy(), g["out"]) < max(TOL, 3 * gap), (rel_l2(out_t.numpy(), g["out"]), gap)
+        assert rel_l2(logits_t.numpy(), g["logits"]) < max(TOL, 3 * gap)
+    if "full" not in name:
+        fwd_n = onp.spe_forward if m["kind"] == "spe" else onp.ira_forward
+        out64, logits64 = fwd_n(sd, m["cfg"], g["mix"], g["aux"], float(g["aux_len"]), dtype=np.float64)
+        assert rel_l2(out64, g["out64"]) < 1e-9 and rel_l2(logits64, g["logits64"]) < 1e-9
+        out32, _ = fwd_n(sd, m["cfg"], g["mix"], g["aux"], float(g["aux_len"]), dtype=np.float32)
+        assert rel_l2(out32, g["out"]) < max(TOL, 3 * gap)
