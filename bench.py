@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, shader clock) during the timed region")
     ap.add_argument("--no-optional-modes", action="store_true", help="skip the extra timing of the opt-in gate-GEMM modes")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the lines of BASELINE.json configs[2] (DPRNN-Spe cat, B=64) and configs[4] (DPRNN-Spe-IRA, full-length "
+                         "utterances) that follow the headline region")
     ap.add_argument("--fast-act", type=int, default=1)
     ap.add_argument("--groups", type=int, default=None, help="utterance groups on separate HIP streams")
     ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
@@ -522,6 +525,13 @@ def main():
                 dt = (time.perf_counter() - t1) / 3
                 optional[mode_names[mode]] = {"value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt,
                                               "rel_l2_vs_headline_mode": float((o.double() - ref_out).norm() / ref_out.norm())}
+    others = None
+    if world == 1 and not args.no_other_configs and not args.no_optional_modes:
+        t_oc = time.perf_counter()
+        others = bench_other_configs(args, dev, args.gemm_mode)
+        others["seconds_spent"] = time.perf_counter() - t_oc
+        others["note"] = ("timed after the headline region on the same GPU, same arithmetic as `value` (dtype), inputs resident in HBM; "
+                          "NOT part of `value`")
     engine.GEMM_MODE = args.gemm_mode
     dtype = {0: "f32", 1: "f32 via 3 x bf16 split, 6 products, f32 accumulate",
              3: "f32 via 2 x f16 pieces of 2^e-scaled operands (22+ bits), 3 products, f32 accumulate; saturation-checked per forward"}[args.gemm_mode]
@@ -557,12 +567,123 @@ def main():
         if optional:
             line["other_gemm_modes"] = dict(optional, note="the same batch under the other split setting of engine.GEMM_MODE / "
                                             "DPRNN_GEMM_MODE, 3 steps after the timed regions; NOT part of `value`")
+        if others:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(sd, cfg, model, dev)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+SPE_CTOR = CTOR + ["O", "P", "embeddings_size", "num_spks", "fusion_type"]
+FLOP_PER_UTT_SPE = 356.4e9       # DPRNN-Spe (cat), 3-s mixture + 3-s reference
+FLOP_PER_UTT_IRA = 712.8e9       # two speaker-encoder + two DPRNN passes, per 3 s of mixture
+
+
+def bench_other_configs(args, dev, mode):
+    """BASELINE.json configs[2] and configs[4] on this GPU, after the headline region, under the same discipline (untimed
+    warm-ups, then timed steps between synchronisations, inputs resident in HBM), in the headline's arithmetic:
+      spe_cat_b64      DPRNN-Spe (cat fusion), 64 x (3-s mixture + 3-s reference)            dprnn_spe.py:314-327
+      ira_full_length  DPRNN-Spe-IRA over full-length utterances (Libri2Mix-test length distribution, one rank's
+                       length-balanced eighth of the 3000), batch-of-one semantics per utterance through
+                       inference.separate_many's ragged batches                              dprnn_spe_ira.py:179-190, inferencer_spe.py:20-54
+    Each carries value (utt/s), ms_per_step, its algorithmic GFLOP and a roofline object: the recurrence launches timed with HIP
+    events (one eager pass), algorithmic FLOPs per launch / mean launch duration against the arithmetic's ceiling."""
+    import numpy as np
+    import torch
+    import tss_with_dprnn_amd as pkg
+    from tss_with_dprnn_amd import engine, inference, sharding
+    from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_state
+    products = {0: 1, 1: 6, 3: 3}[mode]
+    peak = PEAK_F32_MFMA_TFLOPS if mode == 0 else 2500.0 / products
+    engine.GEMM_MODE = mode
+    rec_names = {"dprnn_rnn_fwd_ex", "dprnn_rnn_fwd_hp_ex", "dprnn_rnn_fwd_ragged_ex", "dprnn_rnn_fwd_ragged_hp_ex"}
+
+    def build(kind, cls):
+        cfg = full_cfg(norm_type="ln", fusion_type="cat")
+        m = cls(**{k: cfg[k] for k in SPE_CTOR}).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state(kind, cfg, 0).items()}, strict=True)
+        return m.to(dev)
+
+    def timed(fn, warmup, steps):
+        with torch.no_grad():
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / steps
+
+    def rec_roofline(fn, flop_per_launch_of, whole_tflops):
+        """One eager pass with HIP events around every recurrence launch."""
+        engine.PROFILE = {"names": set(rec_names), "events": {}}
+        t_ref = torch.cuda.Event(enable_timing=True)
+        t_ref.record()
+        try:
+            with torch.no_grad():
+                fn()
+            torch.cuda.synchronize(dev)
+        finally:
+            prof, engine.PROFILE = engine.PROFILE, None
+        ev = [e for n in sorted(rec_names) for e in prof["events"].get(n, [])]
+        kern_ms, union_ms, conc, n_ev = _launch_stats(ev, t_ref)
+        per_launch = flop_per_launch_of(n_ev) / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "the fused BiLSTM recurrence (bilstm_split8_kernel / bilstm_kernel), as in the headline's roofline",
+                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)", "frac": per_launch / peak,
+                "traffic": None, "kernel_ms": kern_ms, "launches_timed": n_ev, "mean_concurrency": conc,
+                "whole_forward_tflops": whole_tflops, "whole_forward_frac": whole_tflops / peak,
+                "timed_in": "one eager pass after the timed steps (HIP events on the launch streams)"}
+
+    out = {}
+    # ---- configs[2]: DPRNN-Spe (cat), B = 64
+    B = PER_GPU_BATCH
+    m = build("spe", pkg.DPRNNSpeTasNet)
+    x = torch.from_numpy(make_mixture(B, SAMPLES, seed=2)).to(dev)
+    a = torch.from_numpy(make_mixture(B, SAMPLES, seed=3)).to(dev)
+    ln = torch.tensor(float(SAMPLES))
+    steps, warm = min(args.steps, 20), max(3, min(args.warmup, 5))         # eager, capture, replay: three forwards before the clock
+    dt = timed(lambda: m(x, a, ln), warm, steps)
+    geo = engine.make_geometry(B, SAMPLES, 64, 250, 125, 2, 1)
+    n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
+    out["spe_cat_b64"] = {
+        "workload": "DPRNN-Spe (cat fusion) TSS inference with the speaker-embedding branch, synthetic 3-s mixture + 3-s reference, "
+                    "batch=64 (BASELINE.json configs[2])",
+        "value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warm,
+        "algorithmic_gflop_per_utterance": FLOP_PER_UTT_SPE / 1e9,
+        "roofline": rec_roofline(lambda: m(x, a, ln), lambda n_ev: geo.rows / n_groups * 2 * (2 * 256 * 512), B / dt * FLOP_PER_UTT_SPE / 1e12)}
+    del m, x, a
+    engine.drop_graphs()
+    # ---- configs[4]: DPRNN-Spe-IRA, full-length utterances (this rank's eighth of the 3000-utterance test-set length distribution)
+    m = build("ira", pkg.DPRNNSpeIRATasNet)
+    rng = np.random.default_rng(0)
+    lens = np.clip(np.exp(rng.normal(np.log(36720), 0.38, 3000)), 24000, 111920).astype(int)
+    share = sharding.shard_by_length(lens.tolist(), 8)[0]
+    order = sorted(share, key=lambda i: -lens[i])            # length-sorted: a ragged batch holds utterances of similar length
+    wavs = [torch.from_numpy(make_mixture(1, int(lens[i]), seed=100 + i)[0]).to(dev) for i in order]
+    aux = [(torch.from_numpy(make_mixture(1, SAMPLES, seed=900 + i)[0]).to(dev), float(SAMPLES)) for i in order]
+    secs = float(sum(lens[i] for i in order)) / 8000.0
+    gflop = float(sum(FLOP_PER_UTT_IRA * lens[i] / SAMPLES for i in order)) / 1e9
+    run = lambda: inference.separate_many(m, wavs, extra_inputs=aux, ragged=True)
+    dt = timed(run, 1, 1)
+    rows_total = float(sum(engine.make_geometry(1, int(lens[i]), 64, 250, 125, 2, 1).rows for i in order))
+    n_batches = -(-len(order) // inference.RAGGED_MAX_UTTS)
+    out["ira_full_length"] = {
+        "workload": f"DPRNN-Spe-IRA 2-iteration refined inference, {len(order)} full-length utterances (one rank's length-balanced "
+                    "eighth of 3000 drawn from the Libri2Mix-test length distribution, 3 .. 14 s), batch-of-one semantics per utterance, "
+                    f"ragged batches of <= {inference.RAGGED_MAX_UTTS} (BASELINE.json configs[4], one GPU's share)",
+        "value": len(order) / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": 1, "warmup": 1,
+        "step": "one pass over the rank's whole share", "audio_seconds": secs, "times_real_time": secs / dt,
+        "algorithmic_gflop_per_step": gflop, "algorithmic_gflop_per_utterance_of_3s": FLOP_PER_UTT_IRA / 1e9,
+        # launches of a pass: 2 DPRNN passes x 12 paths per ragged batch; mean FLOPs per launch = all slab rows x 2 dirs x 2*256*512 x 24 / launches
+        "roofline": rec_roofline(run, lambda n_ev: rows_total * 2 * (2 * 256 * 512) * 24 / max(n_ev, 1), gflop / dt / 1e3),
+        "ragged_batches_per_step": n_batches}
+    del m, wavs, aux
+    engine.drop_graphs()
+    return out
 
 
 def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, make_sources):

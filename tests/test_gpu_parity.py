@@ -565,3 +565,111 @@ def test_graph_cache_evicts_before_it_captures(monkeypatch):
     assert engine.GRAPH_STATS["captures"] == c0 + 6
     engine.drop_graphs()
     assert len(engine._GRAPH_CACHE) == 0
+
+
+
+def test_captured_forwards_share_one_pool_and_replay_in_any_order():
+    """Round 4: every capture allocates from the engine's one memory pool, so four cached graphs hold the workspace of the LARGEST
+    forward, not the sum; graphs that share addresses are serialised on the pool, so replays interleaved over two streams still equal
+    the eager forwards."""
+    from tss_with_dprnn_amd import engine
+    model, _, _ = build_model("bss", dict(n_repeats=2), 91, _dev())
+    assert engine.GRAPHS
+    engine.drop_graphs()
+    sizes = (4, 3, 2, 1)                                   # largest first: later captures fit into what the first one reserved
+    xs = {B: torch.from_numpy(make_mixture(B, 8000, seed=B)).to(_dev()) for B in sizes}
+    old = engine.GRAPHS
+    engine.GRAPHS = False
+    try:
+        with torch.no_grad():
+            want = {B: model(xs[B]).cpu().numpy() for B in sizes}
+    finally:
+        engine.GRAPHS = old
+    torch.cuda.synchronize()
+    engine.empty_cache()
+    with torch.no_grad():
+        model(xs[4]); model(xs[4])                         # eager, capture
+        torch.cuda.synchronize()
+        pool_after_first = engine._pool_reserved_bytes(engine._engine_pool(_dev()))
+        for B in sizes[1:]:
+            model(xs[B]); model(xs[B])
+        torch.cuda.synchronize()
+        pool_after_all = engine._pool_reserved_bytes(engine._engine_pool(_dev()))
+        assert len(engine._GRAPH_CACHE) == 4
+        assert pool_after_first > 0 and pool_after_all <= 1.15 * pool_after_first, (pool_after_first, pool_after_all)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        got = []
+        for i, B in enumerate((1, 4, 2, 4, 3, 1, 4)):
+            with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+                got.append((B, model(xs[B])))
+        torch.cuda.synchronize()
+    for B, o in got:
+        assert rel_l2(o.cpu().numpy(), want[B]) < 1e-6, B
+    engine.drop_graphs()
+    assert not engine._POOLS
+
+
+def test_failed_capture_and_short_memory_leave_the_forward_eager(monkeypatch):
+    """A capture that raises (or that the device has no room for) must not reach the caller, and must not be attempted again on every
+    call of that key: the forward stays on eager launches, with one warning."""
+    import warnings
+    from tss_with_dprnn_amd import engine
+    model, _, _ = build_model("bss", dict(n_repeats=2, chunk_length=50, hop_length=25), 91, _dev())
+    x = torch.from_numpy(make_mixture(2, 2400, seed=4)).to(_dev())
+    engine.drop_graphs()
+    old = engine.GRAPHS
+    engine.GRAPHS = False
+    try:
+        with torch.no_grad():
+            want = model(x).cpu().numpy()
+    finally:
+        engine.GRAPHS = old
+    calls = {"n": 0}
+    real = engine._Graphed
+
+    class Boom(real):
+        def __init__(self, *a, **k):
+            calls["n"] += 1
+            raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(engine, "_Graphed", Boom)
+    f0 = engine.GRAPH_STATS["capture_failures"]
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        outs = [model(x).cpu().numpy() for _ in range(5)]
+    assert calls["n"] == 1 and engine.GRAPH_STATS["capture_failures"] == f0 + 1
+    assert sum("stays on eager launches" in str(m.message) for m in w) == 1
+    for o in outs:
+        assert rel_l2(o, want) < 1e-6
+    monkeypatch.setattr(engine, "_Graphed", real)
+    engine.drop_graphs()
+    # not enough free memory for the forward's workspace: no capture either
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (1 << 20, 1 << 40))
+    k0, c0 = engine.GRAPH_STATS["kept_eager_for_memory"], engine.GRAPH_STATS["captures"]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        outs = [model(x).cpu().numpy() for _ in range(4)]
+    assert engine.GRAPH_STATS["kept_eager_for_memory"] == k0 + 1 and engine.GRAPH_STATS["captures"] == c0
+    for o in outs:
+        assert rel_l2(o, want) < 1e-6
+    engine.drop_graphs()
+
+
+def test_graph_key_separates_inference_mode():
+    """Static inputs cloned under torch.inference_mode() are inference tensors; a replay under plain no_grad could not copy into
+    them.  The key carries the state: each gets its own graph, both replay."""
+    from tss_with_dprnn_amd import engine
+    model, _, _ = build_model("bss", dict(n_repeats=2, chunk_length=50, hop_length=25), 91, _dev())
+    x = torch.from_numpy(make_mixture(2, 2400, seed=4)).to(_dev())
+    engine.drop_graphs()
+    c0 = engine.GRAPH_STATS["captures"]
+    with torch.inference_mode():
+        a = [model(x).cpu().numpy() for _ in range(3)]
+    with torch.no_grad():
+        b = [model(x).cpu().numpy() for _ in range(3)]
+    with torch.inference_mode():
+        a.append(model(x).cpu().numpy())
+    assert engine.GRAPH_STATS["captures"] == c0 + 2
+    for o in a + b:
+        assert rel_l2(o, a[0]) < 1e-6
+    engine.drop_graphs()

@@ -109,6 +109,33 @@ template <bool FAST> __device__ __forceinline__ f32x2 tanh_k2v(f32x2 x, float k,
     }
 }
 
+// LSTM cell with SHARED reciprocals (hardware-activation builds).  Arguments are the pre-scaled exponents the separate forms use
+// (ai = -log2e (i + b_i), af, ao likewise; ag = 2 log2e (g + b_g)); with Ei = 2^ai = e^-i, Ef = e^-f, G = 2^ag = e^2g:
+//     c' = sigmoid(f) c + sigmoid(i) tanh(g) = [c (1 + Ei)(G + 1) + (G - 1)(1 + Ef)] / [(1 + Ef)(1 + Ei)(G + 1)]      ONE v_rcp_f32
+//     h  = sigmoid(o) tanh(c')               = (Gc - 1) / [(1 + Eo)(Gc + 1)],   Gc = e^2c'                           ONE v_rcp_f32
+// 5 v_exp_f32 + 2 v_rcp_f32 per unit-step where the separate forms (dprnn.py:23-28 = torch's LSTM cell, one reciprocal per
+// sigmoid / tanh) take 5 + 5; every factor is >= 1, so nothing cancels that the separate forms do not cancel too (G - 1 is
+// tanh's own numerator).  Range: an exponential near 2^127 would overflow a denominator (Inf -> quotient NaN) or push its
+// reciprocal into the flushed denormals (quotient 0): `dmax` follows the largest denominator and the caller recomputes a tile
+// whose dmax is not below 2^100 with the separate forms -- pre-activations beyond about -60, never seen on the goldens.
+__device__ __forceinline__ void lstm_cell_shared2(f32x2 ai, f32x2 af, f32x2 ag, f32x2 ao, f32x2 c, f32x2& cn, f32x2& h, float& dmax) {
+    const f32x2 one = f32x2{1.f, 1.f};
+    const f32x2 Ei = f32x2{__builtin_amdgcn_exp2f(ai[0]), __builtin_amdgcn_exp2f(ai[1])};
+    const f32x2 Ef = f32x2{__builtin_amdgcn_exp2f(af[0]), __builtin_amdgcn_exp2f(af[1])};
+    const f32x2 G = f32x2{__builtin_amdgcn_exp2f(ag[0]), __builtin_amdgcn_exp2f(ag[1])};
+    const f32x2 Eo = f32x2{__builtin_amdgcn_exp2f(ao[0]), __builtin_amdgcn_exp2f(ao[1])};
+    const f32x2 C = Ef + one;
+    const f32x2 P = (Ei + one) * (G + one);
+    const f32x2 den = P * C;
+    const f32x2 num = c * P + (G - one) * C;
+    cn = num * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 acn = cn * f32x2{2.8853900817779268f, 2.8853900817779268f};
+    const f32x2 Gc = f32x2{__builtin_amdgcn_exp2f(acn[0]), __builtin_amdgcn_exp2f(acn[1])};
+    const f32x2 D = (Eo + one) * (Gc + one);
+    h = (Gc - one) * f32x2{__builtin_amdgcn_rcpf(D[0]), __builtin_amdgcn_rcpf(D[1])};
+    dmax = __builtin_fmaxf(dmax, __builtin_fmaxf(__builtin_fmaxf(den[0], den[1]), __builtin_fmaxf(D[0], D[1])));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

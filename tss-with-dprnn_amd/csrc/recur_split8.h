@@ -27,7 +27,13 @@ namespace rsplit {
 #define DPRNN_SPLIT8_PRIO 1
 #endif
 #ifndef DPRNN_SPLIT8_DIAG
-#define DPRNN_SPLIT8_DIAG 0                            // 1 / 2 / 3: energy probes of tools (wrong results): no weight stream / fewer LDS reads / fewer MFMAs
+#define DPRNN_SPLIT8_DIAG 0                            // energy probes of tools/energy_budget.py (results are WRONG, timing and energy valid); a bit mask:
+#endif                                                 //   1 no weight stream from L2 | 2 a quarter of the LDS fragment reads | 4 one MFMA product of the first k-slab only (1 / 24)
+                                                       //   8 no cell arithmetic (h = clamp(scaled sum of the four gate accumulators)) | 16 no x staging at all (HBM loads, norm, split, LDS writes, x' store)
+                                                       //   32 no h store to HBM | 64 no x' store | 128 the x / z loads of every step read step 0's rows: L2 hits instead of HBM reads
+constexpr bool diag(int bit) { return (DPRNN_SPLIT8_DIAG & bit) != 0; }
+#ifndef DPRNN_CELL_SHARED_RCP
+#define DPRNN_CELL_SHARED_RCP 1                        // hardware-activation builds of the TRANS forms: two reciprocals per unit-step instead of five
 #endif
 #ifndef DPRNN_SPLIT8_RES32
 #define DPRNN_SPLIT8_RES32 1
@@ -210,6 +216,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     constexpr bool XPF = NT <= 4;
     f32x4 xq[XPF ? NT : 1], zq[XPF ? NT : 1];
     auto x_issue = [&](long long t) __attribute__((always_inline)) {
+        if (diag(128)) t = 0;                          // energy probe: every step loads the rows of step 0 -- L2 hits instead of HBM reads (results are wrong)
         const __amdgpu_buffer_rsrc_t xrs = rsrc_at(a.X + tbase(t) * F);
         const __amdgpu_buffer_rsrc_t zrs = rsrc_at(a.Z + tbase(t) * F);
         fence();
@@ -233,7 +240,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
                 const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo : OOB, 0, 0);
+                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo : OOB, 0, 0);
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
@@ -268,9 +275,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sl[j] = (j ^ ((r >> 2) & 3)) << 6;
     auto aload = [&](u32x4 (&af)[NT], const char* reg, int pc, int s4) __attribute__((always_inline)) {
-#if DPRNN_SPLIT8_DIAG == 2
-        if (s4 != 0) return;                           // energy probe: a quarter of the fragment reads (results are wrong)
-#endif
+        if (diag(2) && s4 != 0) return;                // energy probe: a quarter of the fragment reads (results are wrong)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) af[nt] = *reinterpret_cast<const u32x4*>(reg + pc * PL + nt * 4096 + abase + sl[s4]);
     };
@@ -306,9 +311,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     f32x4 acc[NT][4];
     u32x4 fa[NT], fb[NT];
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
-#if DPRNN_SPLIT8_DIAG == 3
-        if (wpc != 1 || !first) return;                // energy probe: one product of the first k-slab only (results are wrong)
-#endif
+        if (diag(4) && (wpc != 1 || !first)) return;   // energy probe: one product of the first k-slab only (results are wrong)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -318,9 +321,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                                   : mfma_bf16(af[nt], bw[g][wpc], first ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[nt][g]);
     };
     auto wreload = [&](int sn, int wpc) __attribute__((always_inline)) {
-#if DPRNN_SPLIT8_DIAG == 1
-        return;                                        // energy probe: no weight stream (results are wrong)
-#endif
+        if (diag(1)) return;                           // energy probe: no weight stream (results are wrong)
         if (WRES && wpc == 0 && sn < RES) return;      // resident
         if (LRES > 0 && wpc == 1 && sn >= NSLAB - LRES) {      // from LDS
 #pragma unroll
@@ -396,17 +397,49 @@ void bilstm_split8_kernel(RecurArgs a) {
             f32x4 sv[SAVE ? 5 : 1];
             if constexpr (TRANS) {
                 unsigned w1[2], w2[2];
+                f32x2 cn2[2], hh[2];
+                bool separate = true;                                  // the five-reciprocal forms (libm build, or the guard below)
+                if constexpr (diag(8)) {                               // energy probe: no cell arithmetic (results are wrong)
+                    separate = false;
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        cn2[p2] = f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]};
+                        const f32x2 sg = (f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]} + f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}) +
+                                         (f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]} + f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]});      // every gate's MFMAs stay live
+                        hh[p2] = f32x2{__builtin_amdgcn_fmed3f(sg[0] * ksig, -1.f, 1.f), __builtin_amdgcn_fmed3f(sg[1] * ksig, -1.f, 1.f)};
+                    }
+                } else if constexpr (FAST && DPRNN_CELL_SHARED_RCP) {
+                    // shared reciprocals (common.h: lstm_cell_shared2): 5 v_exp_f32 + 2 v_rcp_f32 per unit-step instead of 5 + 5
+                    float dmax = 0.f;
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const f32x2 kk = f32x2{ksig, ksig};
+                        const f32x2 ai = f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]} * kk + f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]};
+                        const f32x2 af = f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]} * kk + f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]};
+                        const f32x2 ag = f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]} * f32x2{ktanh, ktanh} + f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]};
+                        const f32x2 ao = f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]} * kk + f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]};
+                        lstm_cell_shared2(ai, af, ag, ao, f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]}, cn2[p2], hh[p2], dmax);
+                    }
+                    // a denominator beyond 2^100 (a pre-activation below -60 or so; Inf included: the comparison fails) leaves the range in
+                    // which the shared quotient is exact to fp32: that tile is recomputed with the separate forms (wave-uniform branch)
+                    separate = __builtin_amdgcn_ballot_w64(!(dmax < 0x1p100f)) != 0ull;
+                }
+                if (separate) {
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const f32x2 ig = sigmoid_k2v<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]});
+                        const f32x2 fg = sigmoid_k2v<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]});
+                        const f32x2 gg = tanh_k2v<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]});
+                        const f32x2 og = sigmoid_k2v<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]});
+                        cn2[p2] = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
+                        hh[p2] = og * tanh_f2<FAST>(cn2[p2]);
+                    }
+                }
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
-                    const f32x2 ig = sigmoid_k2v<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]});
-                    const f32x2 fg = sigmoid_k2v<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]});
-                    const f32x2 gg = tanh_k2v<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]});
-                    const f32x2 og = sigmoid_k2v<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]});
-                    const f32x2 cn = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
-                    const f32x2 h2 = og * tanh_f2<FAST>(cn);
-                    c[nt][2 * p2] = cn[0]; c[nt][2 * p2 + 1] = cn[1];
-                    hv[2 * p2] = h2[0]; hv[2 * p2 + 1] = h2[1];
-                    split2_pair_f16(h2[0] * F16_XS, h2[1] * F16_XS, w1[p2], w2[p2]);      // pieces of units 4q + 2 p2, + 1
+                    c[nt][2 * p2] = cn2[p2][0]; c[nt][2 * p2 + 1] = cn2[p2][1];
+                    hv[2 * p2] = hh[p2][0]; hv[2 * p2 + 1] = hh[p2][1];
+                    split2_pair_f16(hh[p2][0] * F16_XS, hh[p2][1] * F16_XS, w1[p2], w2[p2]);      // pieces of units 4q + 2 p2, + 1
                 }
                 char* d = hw + hbt + nt * 4096;
                 *reinterpret_cast<u32x2*>(d) = u32x2{w1[0], w1[1]};
@@ -414,7 +447,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                 // h_pieces: the next kernel is the f16-pieces projection, which would split 2^4 h into exactly these words again
                 const u32x4 hout = a.h_pieces ? u32x4{w1[0], w1[1], w2[0], w2[1]}
                                               : u32x4{__float_as_uint(hv[0]), __float_as_uint(hv[1]), __float_as_uint(hv[2]), __float_as_uint(hv[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(hout, hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
+                if (!diag(32)) __builtin_amdgcn_raw_buffer_store_b128(hout, hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
                 continue;
             }
 #pragma unroll
@@ -483,11 +516,12 @@ void bilstm_split8_kernel(RecurArgs a) {
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
             half(acc, xreg + rb * REG, 0, true);
-            half(acc, hreg + rb * REG, 4, false, XPF, tn);
+            half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             if constexpr (!DB) __syncthreads();        // single-buffered: every wave is done reading the image of this step
             cell(acc, t, step, hreg + wb * REG);
-            if constexpr (XPF) x_finish(tn, wb, more);
+            if constexpr (diag(16)) { }                // energy probe: the image keeps the first step's x (results are wrong)
+            else if constexpr (XPF) x_finish(tn, wb, more);
             else x_stage(tn, wb, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
             __syncthreads();

@@ -72,7 +72,14 @@ ON_SATURATION = os.environ.get("DPRNN_ON_SATURATION", "fallback")
 # would then be clamped silently, so no product path sets it.
 SATURATION_CHECK = os.environ.get("DPRNN_SATURATION_CHECK", "1") != "0"
 SATURATION = {"checks": 0, "fallbacks": 0, "last_flags": None, "last_what": None}
+_STATS_LOCK = threading.Lock()       # SATURATION / GRAPH_STATS are process-wide counters updated from any thread
 _TLS = threading.local()
+
+
+def _count(stats: dict, key: str, n: int = 1) -> int:
+    with _STATS_LOCK:
+        stats[key] = stats[key] + n
+        return stats[key]
 
 
 def current_mode() -> int:
@@ -131,17 +138,18 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
             lib.dprnn_saturation_begin(0, 0)
         if rc < 0:
             check(lib, rc, "dprnn_saturation_flags")
-        SATURATION["checks"] += 1
+        _count(SATURATION, "checks")
         if rc == 0:
             return out
         hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
-        SATURATION["fallbacks"] += 1
-        SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
+        n_fallbacks = _count(SATURATION, "fallbacks")
+        with _STATS_LOCK:
+            SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
         msg = (f"{what}: the f16-pieces arithmetic met values beyond its range ({', '.join(hit)}: |x| > 4062 after scaling, or "
                "Inf / NaN)")
         if ON_SATURATION == "raise":
             raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
-        if SATURATION["fallbacks"] == 1:
+        if n_fallbacks == 1:
             warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
                           "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=3)
         del out
@@ -318,25 +326,41 @@ def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geome
 
 
 # Side streams of the utterance groups: the SAME streams for every forward of a (thread, device).  torch.cuda.Stream() hands out
-# the 32 streams of its pool round-robin, and HIP maps streams onto a few hardware queues: taking fresh streams per forward made
+# the 32 streams of its per-device pool round-robin, and HIP maps streams onto a few hardware queues: taking fresh streams per forward made
 # every 16th forward of the bench (the position of the cycle whose two streams collide on a queue) 5 ms slower -- the stall that
-# round 2 could not place (profiles/r03_host_stall.txt).
+# round 2 could not place (profiles/r03_host_stall.txt).  Pools are created under a lock (forwards may come from several threads).
 _SIDE_POOL: dict = {}
+_STREAM_LOCK = threading.Lock()
+# tools/probes/stream_pair_timing.py (round 3, one box): of the 16 pairs of torch's pool exactly one -- the first two streams it hands
+# out in a process -- made every EAGER forward 5 ms slower.  DPRNN_SKIP_FIRST_STREAM_PAIR=1 takes those two and leaves them unused
+# (only meaningful when nobody took streams before the engine; box- and torch-version-specific, hence opt-in).  The default path
+# replays a captured graph, whose launch topology does not depend on the stream pool.
+SKIP_FIRST_STREAM_PAIR = os.environ.get("DPRNN_SKIP_FIRST_STREAM_PAIR", "0") == "1"
+
+
+def _persistent_streams(pools: dict, key, dev, n: int):
+    with _STREAM_LOCK:
+        pool = pools.get(key)
+        if pool is None:
+            if SKIP_FIRST_STREAM_PAIR and not _SIDE_POOL and "_skipped" not in _SIDE_POOL:
+                _SIDE_POOL["_skipped"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            pool = pools.setdefault(key, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[:n]
 
 
 def _side_streams(dev, n: int):
-    key = (threading.get_ident(), str(dev))
-    pool = _SIDE_POOL.get(key)
-    if pool is None:
-        # tools/probes/stream_pair_timing.py: of the 16 pairs of torch's pool exactly one -- the first two streams it hands out in
-        # a process -- makes every forward 5 ms slower (80.3 against 75.2 ms, both times it comes round); when nobody has taken
-        # streams before us those are the ones we would get, so they are taken and left unused
-        if not _SIDE_POOL:
-            _SIDE_POOL["_skipped"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        pool = _SIDE_POOL.setdefault(key, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
+    return _persistent_streams(_SIDE_POOL, (threading.get_ident(), str(dev)), dev, n)
+
+
+_BUCKET_POOL: dict = {}
+
+
+def bucket_streams(dev, n: int):
+    """Persistent streams for the per-bucket pipelines of inference.separate_many (fresh streams per call walk torch's pool and
+    change the queue mapping from call to call)."""
+    return _persistent_streams(_BUCKET_POOL, (threading.get_ident(), str(dev)), dev, n)
 
 
 def _rnn_tensors(rnn, dev):
@@ -1112,12 +1136,10 @@ class _Fan:
         self.main = st
         n = min(RAGGED_STREAMS, n_items) if enable else 0
         if n > 1:
-            pool = _FAN_POOL.setdefault(st.device, [])
-            while len(pool) < n:
-                pool.append(torch.cuda.Stream(device=st.device))
+            pool = _persistent_streams(_FAN_POOL, (threading.get_ident(), str(st.device)), st.device, n)
             fork = torch.cuda.Event()
             fork.record(st.tstream)
-            self.stages = [Stage(st.device, s) for s in pool[:n]]
+            self.stages = [Stage(st.device, s) for s in pool]
             for sg in self.stages:
                 sg.tstream.wait_event(fork)
         else:
@@ -1383,15 +1405,57 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
 # it -- is captured once per (model, input shapes, mode, knobs) into a HIP graph and replayed with ONE launch: inputs are copied
 # into the graph's static buffers, outputs are cloned out of them, the saturation flags are the graph's own buffer (its kernels
 # carry that address) and are read after every replay exactly as after an eager forward.  The first forward of a key runs
-# eagerly (it also performs the one-time hipFuncSetAttribute calls), the second captures, later ones replay; GRAPH_CACHE_MAX
-# graphs are kept (each holds its forward's workspace: 6.4 GB at 64 x 3 s).  DPRNN_GRAPHS=0 turns it off.
+# eagerly (it also performs the one-time hipFuncSetAttribute calls), the second captures, later ones replay.
+#
+# Memory (round 4): every capture of a device allocates from ONE engine-owned pool (torch.cuda.MemPool, held for the life of
+# the process or until release_graph_pool()).  A forward's workspace dies inside its own capture, so the next capture reuses the
+# same addresses: the pool is as large as the largest forward that was captured (6.4 GB at 64 x 3 s), not the sum over cached
+# graphs (round 3: a private pool per capture, 25 GB for four graphs), and evicting a graph frees no device memory -- the event
+# round 3's crash was traced to (segments of evicted graphs' private pools going back to the driver while a later capture was in
+# progress: DESIGN.md 6b).  Graphs that share memory must not run concurrently: replays are serialised on the pool (a lock around
+# the enqueue, an event between consecutive replays), whatever thread or stream they come from.  Before a capture the engine
+# synchronises and returns the caching allocator's unused segments to the driver (empty_cache() below, under the capture lock), and
+# it does not capture at all when the device has less free memory than the forward needs (the caching allocator's out-of-memory
+# retry frees cached segments, and would do so inside the capture): such a key stays eager, with one warning.  A capture that
+# raises leaves its key eager for good as well.  DPRNN_GRAPHS=0 turns graphs off.
 GRAPHS = os.environ.get("DPRNN_GRAPHS", "1") != "0"
-GRAPH_CACHE_MAX = 4
-GRAPH_STATS = {"captures": 0, "replays": 0}
+GRAPH_CACHE_MAX = 16
+GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_for_memory": 0}
 _GRAPH_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _GRAPH_SEEN: "collections.OrderedDict" = collections.OrderedDict()
+_GRAPH_EAGER_KEYS: set = set()            # keys whose capture failed or did not fit: eager from then on
 _GRAPH_LOCK = threading.Lock()
-_CAPTURE_LOCK = threading.Lock()         # torch registers generator state per capture, process-wide: one capture at a time
+_CAPTURE_LOCK = threading.RLock()        # torch registers generator state per capture, process-wide: one capture at a time; also
+                                         # held by empty_cache() / drop_graphs(): no segment goes back to the driver during a capture
+
+
+class _EnginePool:
+    """The memory pool every captured forward of one device allocates from, and the order of their replays."""
+
+    def __init__(self):
+        self.pool = torch.cuda.MemPool()
+        self.lock = threading.RLock()
+        self.last = None                 # event recorded behind the latest replay
+
+
+_POOLS: dict = {}
+
+
+def _engine_pool(dev) -> _EnginePool:
+    key = str(dev)
+    with _GRAPH_LOCK:
+        ep = _POOLS.get(key)
+        if ep is None:
+            ep = _POOLS[key] = _EnginePool()
+        return ep
+
+
+def empty_cache() -> None:
+    """torch.cuda.empty_cache() that waits for a capture in progress (use this one beside a serving engine: segments must not go
+    back to the driver while another thread captures a forward)."""
+    with _CAPTURE_LOCK:
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
 
 
 def _clone_out(o):
@@ -1403,27 +1467,38 @@ def _clone_out(o):
 
 
 class _Graphed:
-    def __init__(self, dev, fn, inputs):
+    def __init__(self, dev, fn, inputs, ep: _EnginePool):
         lib = load_library()
-        self.inputs = [t.clone() for t in inputs]
-        self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
+        self.ep, self.dev = ep, dev
         self.graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
-        check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
         prev = getattr(_TLS, "guard", 0)
         _TLS.guard, _TLS.capturing = 1, True
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.inputs = [t.clone() for t in inputs]           # static inputs and flags: ordinary allocations (a few MB)
+            self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
+            with torch.cuda.graph(self.graph, pool=ep.pool.id, capture_error_mode="thread_local"):
                 self.outputs = fn(*self.inputs)
         finally:
             _TLS.guard, _TLS.capturing = prev, False
             lib.dprnn_saturation_begin(0, 0)
 
     def replay(self, inputs):
-        for s_, t in zip(self.inputs, inputs):
-            s_.copy_(t)
-        self.graph.replay()
-        return _clone_out(self.outputs)
+        ep = self.ep
+        with ep.lock:                    # graphs of one pool share their workspace addresses: one at a time, in enqueue order
+            cur = torch.cuda.current_stream(self.dev)
+            if ep.last is not None:
+                cur.wait_event(ep.last)
+            for s_, t in zip(self.inputs, inputs):
+                s_.copy_(t)
+            self.graph.replay()
+            out = _clone_out(self.outputs)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            ep.last = ev
+        return out
 
 
 def _graph_key(kind: str, model, inputs, extra=()):
@@ -1432,13 +1507,34 @@ def _graph_key(kind: str, model, inputs, extra=()):
     bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
     knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
              SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
-             lib.dprnn_get_rowgemm_grid(), H_PIECES)
+             lib.dprnn_get_rowgemm_grid(), H_PIECES,
+             # static inputs cloned under inference_mode are inference tensors: a replay outside it could not copy into them
+             torch.is_inference_mode_enabled())
     return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
 
 
-def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
+def _pool_reserved_bytes(ep: _EnginePool) -> int:
+    try:
+        return sum(int(seg.get("total_size", 0)) for seg in torch.cuda.memory_snapshot(ep.pool.id))
+    except Exception:
+        return 0
+
+
+def _keep_eager(key, why: str) -> None:
+    with _GRAPH_LOCK:
+        first = not _GRAPH_EAGER_KEYS
+        _GRAPH_EAGER_KEYS.add(key)
+        while len(_GRAPH_EAGER_KEYS) > 256:
+            _GRAPH_EAGER_KEYS.pop()
+    if first:
+        warnings.warn(f"HIP-graph capture skipped, this forward stays on eager launches: {why} (further ones are counted in "
+                      "engine.GRAPH_STATS without a warning)", RuntimeWarning, stacklevel=4)
+
+
+def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), need_bytes=None):
     """fn(*inputs) -- an inference forward over device tensors -- eagerly, or through its captured HIP graph (see above); either
-    way under the saturation guard, falling back to an eager forward in mode 1."""
+    way under the saturation guard, falling back to an eager forward in mode 1.  need_bytes: device memory the forward allocates
+    (a number or a callable), checked against what is free before capturing."""
     dev = inputs[0].device
     eager = lambda: fn(*inputs)
     usable = (GRAPHS and PROFILE is None and getattr(_TLS, "guard", 0) == 0 and not getattr(_TLS, "capturing", False)
@@ -1448,9 +1544,10 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
     key = _graph_key(kind, model, inputs, extra)
     with _GRAPH_LOCK:
         g = _GRAPH_CACHE.get(key)
+        seen = 0
         if g is not None:
             _GRAPH_CACHE.move_to_end(key)
-        else:
+        elif key not in _GRAPH_EAGER_KEYS:
             seen = _GRAPH_SEEN.get(key, 0) + 1
             _GRAPH_SEEN[key] = seen
             _GRAPH_SEEN.move_to_end(key)
@@ -1460,41 +1557,60 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=()):
         return _guarded(dev, eager, _in_mode(1, eager), what, module)
     with torch.cuda.device(dev):
         if g is None:
+            ep = _engine_pool(dev)
             with _CAPTURE_LOCK:
-                # Make room BEFORE capturing, and hand the evicted graphs' workspaces (their private pools, GBs each) back to the driver
-                # here, outside any capture.  With the eviction after the capture those pools stayed with the caching allocator until
-                # it next needed memory, and the sixteenth capture of a long-running process (cache of 4, batch sizes 16 .. 96 at full
-                # length) segfaulted inside hipGraphLaunch on its first replay; tools/probes/graph_churn.py reproduces it and passes
-                # 21 captures up to B = 128 with this order (gpurun_out/r09f, r09g).
-                evicted = []
                 with _GRAPH_LOCK:
+                    evicted = []
                     while len(_GRAPH_CACHE) >= max(1, GRAPH_CACHE_MAX):
                         evicted.append(_GRAPH_CACHE.popitem(last=False)[1])
-                if evicted:
-                    torch.cuda.synchronize(dev)
-                    del evicted
-                    torch.cuda.empty_cache()
-                g = _Graphed(dev, fn, inputs)
-            GRAPH_STATS["captures"] += 1
+                # nothing of the eager forwards' cached segments is left for the allocator to release while the capture runs
+                torch.cuda.synchronize(dev)
+                del evicted
+                torch.cuda.empty_cache()
+                need = need_bytes() if callable(need_bytes) else need_bytes
+                if need is not None:
+                    free, _ = torch.cuda.mem_get_info(dev)
+                    have = free + _pool_reserved_bytes(ep)
+                    if 1.1 * need > have:
+                        _count(GRAPH_STATS, "kept_eager_for_memory")
+                        _keep_eager(key, f"{what} needs about {need / 2**30:.1f} GiB, {have / 2**30:.1f} GiB are free on {dev}")
+                        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+                try:
+                    g = _Graphed(dev, fn, inputs, ep)
+                except Exception as exc:          # out of memory in the pool, a synchronising call inside the forward, ...
+                    _count(GRAPH_STATS, "capture_failures")
+                    try:
+                        torch.cuda.synchronize(dev)
+                    except Exception:
+                        pass
+                    _keep_eager(key, f"capture of {what} raised {type(exc).__name__}: {exc}")
+                    g = None
+            if g is None:
+                return _guarded(dev, eager, _in_mode(1, eager), what, module)
+            _count(GRAPH_STATS, "captures")
             with _GRAPH_LOCK:
                 _GRAPH_CACHE[key] = g
 
         def run():
-            GRAPH_STATS["replays"] += 1
+            _count(GRAPH_STATS, "replays")
             return g.replay(inputs)
         return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags)
 
 
-def drop_graphs() -> None:
-    """Forget every captured forward (frees their workspaces)."""
-    with _CAPTURE_LOCK:                  # never while another thread captures: the pools go back to the driver here
+def drop_graphs(release_pool: bool = True) -> None:
+    """Forget every captured forward; release_pool also hands the engine's graph memory pool back to the driver."""
+    with _CAPTURE_LOCK:                  # never while another thread captures: segments go back to the driver here
         with _GRAPH_LOCK:
             dropped = list(_GRAPH_CACHE.values())
             _GRAPH_CACHE.clear()
             _GRAPH_SEEN.clear()
-        if dropped and torch.cuda.is_available():
+            _GRAPH_EAGER_KEYS.clear()
+            pools = list(_POOLS.values()) if release_pool else []
+            if release_pool:
+                _POOLS.clear()
+        if torch.cuda.is_available() and (dropped or pools):
             torch.cuda.synchronize()
-            del dropped
+            del dropped, pools
             torch.cuda.empty_cache()
 
 
@@ -1508,12 +1624,24 @@ def _in_mode(mode: int, fn):
     return run
 
 
+def _forward_bytes(model, wav, factor: float, aux=None) -> int:
+    """Device memory one forward allocates, about: the library's own workspace figure for the geometry (dprnn_workspace_bytes) times
+    a margin for what surrounds the slab (outputs, the speaker branch's activations over the reference utterance)."""
+    cfg = model.cfg
+    geo = make_geometry(wav.shape[0], wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
+    need = factor * workspace_parts(geo, len(model.separation.dprnn_blocks), True)["total"]
+    if aux is not None:
+        need += 8 * aux.numel() * F_BUILT * 4          # frames x 128 channels x a handful of ResBlock intermediates
+    return int(need)
+
+
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
     wav = check_input(wav)
     if debug is not None:
         run = lambda: _tasnet_forward_impl(model, wav, debug)
         return _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None)
-    return _graphed("tasnet", model, (wav,), lambda w: _tasnet_forward_impl(model, w, None), "DPRNNTasNet.forward")
+    return _graphed("tasnet", model, (wav,), lambda w: _tasnet_forward_impl(model, w, None), "DPRNNTasNet.forward",
+                    need_bytes=lambda: _forward_bytes(model, wav, 1.25))
 
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
@@ -1523,7 +1651,7 @@ def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dic
         return _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation)
     alen = _aux_len_tensor(aux_len, wav.shape[0], wav.device)          # a device tensor: one of the graph's inputs
     return _graphed("ira" if ira else "spe", model, (wav, aux, alen), lambda w, a, n: _spe_forward_impl(model, w, a, n, ira, None),
-                    "DPRNNSpeTasNet.forward", model.separation)
+                    "DPRNNSpeTasNet.forward", model.separation, need_bytes=lambda: _forward_bytes(model, wav, 2.0, aux))
 
 
 def separator_masks(sep, frames: torch.Tensor):

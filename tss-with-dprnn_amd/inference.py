@@ -88,7 +88,7 @@ def _separate_many(model, wavs, max_streams, extra_inputs, ragged) -> List:
         buckets[key].append(i)
     order = sorted(buckets.items(), key=lambda kv: -kv[0][0] * len(kv[1]))     # most work first
     main = torch.cuda.current_stream(dev)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(max_streams, len(order))))]
+    pool = engine.bucket_streams(dev, max(1, min(max_streams, len(order))))       # the same streams on every call
     fork = torch.cuda.Event()
     fork.record(main)
     outs: List = [None] * len(wavs)
