@@ -390,7 +390,8 @@ def main():
             h1 = host_state()
             gc.enable()
             prof, engine.PROFILE = engine.PROFILE, None
-        host_delta[mode] = {k: (h1[k] - h0[k] if k != "reserved_GiB" else h1[k]) for k in h1}
+        if not profile or not engine.GRAPHS:      # (the eager profiling pass after a graph-replay region is not the region the line reports)
+            host_delta[mode] = {k: (h1[k] - h0[k] if k != "reserved_GiB" else h1[k]) for k in h1}
         return o, dt, per_step, prof, t_ref
 
     host_delta = {}

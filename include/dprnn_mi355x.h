@@ -89,6 +89,22 @@ void dprnn_pack_forget(const void* packed);
 int dprnn_saturation_begin(void* flags, void* stream);
 int dprnn_saturation_flags(void* host_out, void* stream);
 
+/* Adaptive activation scale of the f16-pieces arithmetic (mode 3).  Activations are multiplied by 2^s before they are split into
+ * f16 pieces; without a record s = 4 (|x| <= 4062, beyond that the saturation flags above).  A host that wants s to follow the
+ * model -- unbounded norm gains (reference: dprnn.py:76-77) can put the residual stream anywhere -- keeps one device record per
+ * model, float32[2 * DPRNN_SCALE_SLOTS]: word [slot] is the largest |x| conversion site `slot` has met so far (dprnn_scale_init
+ * sets 256: s = 4), word [DPRNN_SCALE_SLOTS + slot] the largest of the forward in progress.  Per forward, on the calling thread:
+ * dprnn_scale_begin(record); before every dprnn_rnn_pack_ex / recurrence launch / bottleneck / mask-head launch
+ * dprnn_scale_slot(k) with the k of that site (a pack call and the launches that read the pack share a slot: the pack folds
+ * 2^(4 - s) into W_ih, h keeps 2^4); dprnn_scale_update(record, stream) once at the end (sticky maximum); dprnn_scale_begin(NULL).
+ * s = clamp(13 - exponent(max), -8, 4): 8 x headroom, and never above 4, so a model that stays below 512 computes what it
+ * computed without a record.  The forward that first meets large values still raises the saturation flags. */
+#define DPRNN_SCALE_SLOTS 32
+int dprnn_scale_init(void* record, void* stream);
+int dprnn_scale_begin(void* record);
+int dprnn_scale_slot(int slot);
+int dprnn_scale_update(void* record, void* stream);
+
 /* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order; the f16 form uses
  * two planes and keeps its scale 2^e, and 1 / (2^4 2^e), in words 512 and 513 of the third) */
 int dprnn_lstm_pack_split(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
@@ -363,6 +379,18 @@ int dprnn_linear_small_fwd(const float* in, int in_pitch, const float* W, int ld
 /* ---- per-utterance (sum, sumsq) of a materialised [B][rows_per_utt][C] tensor: GroupNorm(1,N) of d0 in the
  * second IRA pass (dprnn_spe_ira.py:84 -> dprnn_spe.py:116).  stats zeroed by the caller. */
 int dprnn_rows_stats(const float* A, double* stats, int B, int64_t rows_per_utt, int C, void* stream);
+
+/* Per-frame glue of the separator-level surfaces (callers that hold encoder outputs [B, N, L] and drive the separator's pieces
+ * themselves: reference src/models/dprnn_rawnet.py:79-105), on channels-last rows [M][C]:
+ * dprnn_rows_affine_fwd: out[row][c] = (A[row][c] * sc[u][c] + sh[u][c]) * row_scale[row], u = row / rows_per_utt (sc, sh [U][C],
+ *   row_scale [M]; each optional) -- nn.GroupNorm(1, C) / norms.GlobLN apply with (sc, sh) from dprnn_bottleneck_prep
+ *   (dprnn.py:131-136, norms.py:27-31), the add / mul / film fusions (dprnn_spe.py:194-229), the 'att' frame scale (:214-222);
+ * dprnn_att_row_scale_rows: dprnn_att_row_scale on materialised (optionally still un-normalised: sc0 / sh0) rows instead of the
+ *   waveform (dprnn_spe.py:98-105,178-183). */
+int dprnn_rows_affine_fwd(const float* A, const float* sc, const float* sh, const float* row_scale, float* out, int64_t M, int C,
+                          int64_t rows_per_utt, void* stream);
+int dprnn_att_row_scale_rows(const float* rows, int pitch, const float* sc0, const float* sh0, const float* avg_w, const float* avg_b,
+                             const float* a, float* scores, float* row_scale, int B, int L, int N, int ks_a, void* stream);
 
 #ifdef __cplusplus
 }

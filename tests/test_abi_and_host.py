@@ -249,6 +249,9 @@ def test_bottleneck_selects_its_arithmetic_and_puts_the_library_mode_back():
             self.mode = m
         def dprnn_get_gemm_mode(self):
             return self.mode
+        def dprnn_scale_slot(self, slot):            # the bottleneck names its activation-scale slot before it launches
+            seen.append(("slot", slot))
+            return 0
 
     class FakeStage:
         lib = FakeLib()

@@ -319,6 +319,60 @@ def test_bilstm_f16_pieces_flag_values_beyond_the_f16_range(seq_tile, huge):
         assert rel_l2(H.cpu().numpy(), want) < 2e-6
 
 
+@pytest.mark.parametrize("seq_tile", [2016, 2064])
+@pytest.mark.parametrize("amp,want_s", [(3000.0, 1), (3.0e5, -6), (3.0, 4)])
+def test_bilstm_f16_pieces_follow_the_activation_scale_record(seq_tile, amp, want_s):
+    """Round 4: the x scale 2^s of the f16-pieces recurrence comes from a device record (dprnn_scale_begin / _slot / _update).  First
+    launch under a fresh record: s = 4, an input of amplitude `amp` saturates (beyond 4062) and leaves its maximum in the record;
+    after dprnn_scale_update the same launch (and the pack, which folds 2^(4 - s) into W_ih) runs at s = clamp(13 - exponent, -8, 4):
+    no flag, fp32-class accuracy against the numpy oracle -- h keeps its 2^4 scale whatever x does."""
+    B, S, K = 2, 5, 33
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    X *= np.float32(amp / np.abs(X).max())
+    sd, p = _lstm_sd(46)
+    sd = {k: (v * np.float32(1.0 / amp) if ".rnn.weight_ih" in k else v) for k, v in sd.items()}      # gates stay in their active range
+    want = onp.single_rnn(sd, p, X.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    st = _st()
+    lib = st.lib
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    H = torch.full((B, S, K, 256), float("nan"), device=DEV)
+    Xd = _t(X)
+    rec = torch.empty(64, device=DEV)
+    st.call("dprnn_scale_init", rec.data_ptr())
+    slot = 7
+
+    def run():
+        assert lib.dprnn_scale_begin(rec.data_ptr()) == 0 and lib.dprnn_scale_slot(slot) == 0
+        try:
+            st.call("dprnn_rnn_pack_ex", 3, 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+            st.call("dprnn_rnn_fwd_ex", 3, 0, Xd.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(),
+                    B * S, K, B * S, 0, K, 1, 2, seq_tile)
+            st.call("dprnn_scale_update", rec.data_ptr())
+        finally:
+            lib.dprnn_scale_begin(0)
+        torch.cuda.synchronize()
+    rc, flags = _sat_flags(st, run)
+    assert (rc == 1 and flags[0] == 1) == (amp > 4062.0 / 1.0001), (amp, flags)
+    state = rec.cpu().numpy()
+    assert abs(state[slot] - max(256.0, amp)) <= 1e-3 * amp and state[32 + slot] == 0.0          # sticky maximum, tracker reset
+    assert all(state[i] == 256.0 for i in range(32) if i != slot)
+    rc, flags = _sat_flags(st, run)
+    assert rc == 0 and not any(flags), flags
+    got = H.cpu().numpy()
+    assert rel_l2(got, want) < 1e-6, (amp, rel_l2(got, want))
+    import math
+    assert max(-8, min(4, 13 - math.frexp(float(state[slot]))[1])) == want_s
+    # without a record the library behaves as before: s = 4
+    rc, flags = _sat_flags(st, lambda: (st.call("dprnn_rnn_pack_ex", 3, 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr()),
+                                         st.call("dprnn_rnn_fwd_ex", 3, 0, Xd.data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(),
+                                                 H.data_ptr(), B * S, K, B * S, 0, K, 1, 2, seq_tile), torch.cuda.synchronize()))
+    assert (rc == 1) == (amp > 4062.0)
+
+
 def test_packed_weights_carry_their_format():
     """The layout dprnn_rnn_pack writes depends on the cell and on the gate-GEMM mode; the library records it with the buffer and
     every launch checks it: a launch under another mode, on a buffer nobody packed, or on the backward's pack is an error

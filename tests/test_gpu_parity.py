@@ -351,14 +351,15 @@ def test_values_beyond_the_f16_range_fall_back_to_bf16_pieces(kind, where):
         assert np.isnan(got[1]).all() and np.isnan(want[1]).all()
         got, want = got[[0, 2]], want[[0, 2]]
     r = _close(got, want, f"{kind} / {where} after the fall-back")
-    # the clamped arithmetic alone would have been wrong: that is what the flag is for
-    old = engine.ON_SATURATION
-    engine.ON_SATURATION = "raise"
+    # the clamped arithmetic alone would have been wrong: that is what the flag is for (with the constant 2^4 scale of rounds 2 / 3:
+    # the model's activation-scale record has adapted by now, the same input would fit)
+    old, old_ad = engine.ON_SATURATION, engine.ADAPTIVE_SCALE
+    engine.ON_SATURATION, engine.ADAPTIVE_SCALE = "raise", False
     try:
         with torch.no_grad(), pytest.raises(DprnnError, match="beyond its range"):
             model(*args)
     finally:
-        engine.ON_SATURATION = old
+        engine.ON_SATURATION, engine.ADAPTIVE_SCALE = old, old_ad
     # the same model in mode 1 from the start: no detection needed, same answer
     with torch.no_grad(), engine.use_gemm_mode(1):
         again = model(*args)
@@ -367,6 +368,80 @@ def test_values_beyond_the_f16_range_fall_back_to_bf16_pieces(kind, where):
         again = again[[0, 2]]
     assert rel_l2(again, got) < 1e-6
     print(f"{kind} / {where}: flags {flags}, rel-L2 vs CPU oracle after the fall-back {r:.2e}")
+
+
+@pytest.mark.parametrize("where", ["residual_stream", "bottleneck"])
+def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
+    """Round 4 (unbounded affine gains, dprnn.py:76-77): a norm gain of 3000 puts the residual stream / the bottleneck rows beyond
+    |x| = 4062.  The FIRST forward saturates and is repeated in mode 1; it leaves its maxima in the model's activation-scale
+    record, so forwards 2 .. 10 run in mode 3 under a scale that fits: exactly one fall-back over ten forwards, every one of the
+    ten within 1e-5 of the CPU oracle, and forwards 3 .. 10 (graph replays) within 1.1 x of the same model's time with ordinary
+    gains."""
+    import time
+    import warnings
+    from tss_with_dprnn_amd.synthetic import make_mixture
+    over = dict(chunk_length=50, hop_length=25, n_repeats=2)
+    key = "separation.dprnn_blocks.0.intra_norm.weight" if where == "residual_stream" else "separation.bottleneck.0.weight"
+    xs = [make_mixture(6, 6000, seed=40 + i) for i in range(10)]
+
+    def timed_forwards(model):
+        outs, ts = [], []
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for x in xs:
+                xd = torch.from_numpy(x).to(_dev())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o = model(xd)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                outs.append(o.cpu().numpy())
+        return outs, ts
+    engine.drop_graphs()
+    plain, _, _ = build_model("bss", over, 21, _dev())
+    _, t_plain = timed_forwards(plain)
+    model, sd, cfg = build_model("bss", over, 21, _dev())
+    sd = dict(sd)
+    sd[key] = (np.asarray(sd[key]) * 3000.0).astype(np.float32)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    before = dict(engine.SATURATION)
+    outs, t_big = timed_forwards(model)
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 1, "exactly one fall-back over ten forwards"
+    assert engine.SATURATION["checks"] == before["checks"] + 10
+    tsd = otc.to_torch_state(sd)
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(x)).numpy()
+        _close(o, want, f"forward {i + 1} of 10 ({where})")
+    s = engine.scale_exponents(model)
+    assert min(s.values()) < 4 and not model.__dict__.get("_dprnn_pin_mode1", False), s
+    ratio = float(np.median(t_big[2:]) / np.median(t_plain[2:]))
+    assert ratio < 1.1, (ratio, t_big, t_plain)
+    print(f"{where}: scale exponents {sorted(set(s.values()))}, forwards 3..10 at {ratio:.3f} x the unsaturated time")
+    engine.drop_graphs()
+
+
+def test_repeated_saturation_pins_the_model_to_mode_1():
+    """Values no scale can hold (here a NaN sample: flagged where every forward begins, the record ignores it) saturate every
+    forward: after two in a row the model runs in mode 1 directly -- one warning, no further repeats -- until engine.unpin."""
+    import warnings
+    from tss_with_dprnn_amd.synthetic import make_mixture
+    model, _, _ = build_model("bss", dict(chunk_length=50, hop_length=25, n_repeats=2), 22, _dev())
+    x = make_mixture(2, 3000, seed=3)
+    x[1, 100] = np.nan
+    xd = torch.from_numpy(x).to(_dev())
+    before = dict(engine.SATURATION)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        outs = [model(xd).cpu().numpy() for _ in range(5)]
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 2 and model.__dict__["_dprnn_pin_mode1"]
+    assert sum("now runs in gate-GEMM mode 1" in str(m.message) for m in w) == 1
+    for o in outs:
+        assert np.isnan(o[1]).all() and np.isfinite(o[0]).all() and rel_l2(o[0], outs[0][0]) < 1e-6
+    engine.unpin(model)
+    good = torch.from_numpy(make_mixture(2, 3000, seed=3)).to(_dev())
+    with torch.no_grad():
+        model(good)
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 2 and not model.__dict__["_dprnn_pin_mode1"]
 
 
 def test_in_range_forwards_do_not_fall_back():
@@ -655,21 +730,22 @@ def test_failed_capture_and_short_memory_leave_the_forward_eager(monkeypatch):
     engine.drop_graphs()
 
 
-def test_graph_key_separates_inference_mode():
-    """Static inputs cloned under torch.inference_mode() are inference tensors; a replay under plain no_grad could not copy into
-    them.  The key carries the state: each gets its own graph, both replay."""
+def test_one_graph_serves_inference_mode_and_no_grad():
+    """Static inputs cloned under torch.inference_mode() would be inference tensors (a replay under plain no_grad could not copy into
+    them) and torch's generator state created at a first capture under inference mode breaks later captures outside it: the engine
+    always captures outside inference mode, and the one graph replays under both."""
     from tss_with_dprnn_amd import engine
     model, _, _ = build_model("bss", dict(n_repeats=2, chunk_length=50, hop_length=25), 91, _dev())
     x = torch.from_numpy(make_mixture(2, 2400, seed=4)).to(_dev())
     engine.drop_graphs()
-    c0 = engine.GRAPH_STATS["captures"]
+    c0, f0 = engine.GRAPH_STATS["captures"], engine.GRAPH_STATS["capture_failures"]
     with torch.inference_mode():
         a = [model(x).cpu().numpy() for _ in range(3)]
     with torch.no_grad():
         b = [model(x).cpu().numpy() for _ in range(3)]
     with torch.inference_mode():
         a.append(model(x).cpu().numpy())
-    assert engine.GRAPH_STATS["captures"] == c0 + 2
+    assert engine.GRAPH_STATS["captures"] == c0 + 1 and engine.GRAPH_STATS["capture_failures"] == f0
     for o in a + b:
         assert rel_l2(o, a[0]) < 1e-6
     engine.drop_graphs()

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import build_model, load_golden, rel_l2
+from tss_with_dprnn_amd._lib import DprnnError
 from oracle import dprnn_numpy as onp
 from oracle.weights import make_mixture
 
@@ -181,6 +182,60 @@ def test_rawnet_style_subclass_uses_the_device_pieces():
         masks, logits = sub(torch.from_numpy(enc).to(DEV), torch.from_numpy(aenc).to(DEV))
     assert rel_l2(masks.cpu().numpy(), want) <= REL_TOL
     assert rel_l2(logits.cpu().numpy(), emb @ sd["separation.pred_linear.weight"].T + sd["separation.pred_linear.bias"]) <= REL_TOL
+
+
+@pytest.mark.parametrize("fusion", ["cat", "add", "mul", "film", "att"])
+@pytest.mark.parametrize("norm_type", ["ln", "gLN"])
+def test_separator_glue_modules_run_on_the_hip_kernels(fusion, norm_type):
+    """Round 4: bottleneck[0] (GroupNorm / gLN), _fusion (all five), bottleneck[1] (1x1 conv, 192 input channels for 'cat'),
+    pred_linear / fusion_linear* (per-utterance Linears) -- the pieces a DPRNNRawNet-style subclass calls one by one
+    (dprnn_rawnet.py:79-105) -- against the stock torch CPU operators the reference's modules are (float64), on odd frame counts."""
+    from conftest import build_model, rel_l2
+    import torch.nn.functional as F
+    model, _, cfg = build_model("spe", dict(chunk_length=16, hop_length=8, n_repeats=1, fusion_type=fusion, norm_type=norm_type), 78, DEV)
+    sep = model.separation
+    rng = np.random.default_rng(5)
+    B, N, L = 3, 64, 301
+    x = torch.from_numpy((rng.standard_normal((B, N, L)) * 2.0 + 0.3).astype(np.float32))
+    emb = torch.from_numpy(rng.standard_normal((B, 128)).astype(np.float32))
+    cpu = {k: v.detach().cpu().double() for k, v in sep.state_dict().items()}
+    with torch.no_grad():
+        got_n = sep.bottleneck[0](x.to(DEV))
+        got_f = sep._fusion(emb.to(DEV), got_n, L)
+        got_c = sep.bottleneck[1](got_f)
+        got_p = sep.pred_linear(emb.to(DEV))
+    xd = x.double()
+    if norm_type == "ln":
+        want_n = F.group_norm(xd, 1, cpu["bottleneck.0.weight"], cpu["bottleneck.0.bias"], 1e-5)
+    else:
+        mean = xd.mean(dim=(1, 2), keepdim=True)
+        var = (xd - mean).pow(2).mean(dim=(1, 2), keepdim=True)
+        want_n = (xd - mean) / (var + 1e-8).sqrt() * cpu["bottleneck.0.gamma"].view(1, -1, 1) + cpu["bottleneck.0.beta"].view(1, -1, 1)
+    assert rel_l2(got_n.cpu().numpy(), want_n.numpy()) < 2e-6
+    e = emb.double()
+    lin = lambda n: F.linear(e, cpu[n + ".weight"], cpu[n + ".bias"]).unsqueeze(-1)
+    if fusion == "cat":
+        want_f = torch.cat((want_n, e.unsqueeze(-1).expand(-1, -1, L)), dim=1)
+    elif fusion == "add":
+        want_f = want_n + lin("fusion_linear")
+    elif fusion == "mul":
+        want_f = want_n * lin("fusion_linear")
+    elif fusion == "film":
+        want_f = want_n * lin("fusion_linear_1") + lin("fusion_linear_2")
+    else:
+        a = lin("fusion_linear")
+        avg = F.conv1d(want_n, cpu["average.weight"], cpu["average.bias"], stride=2, groups=N)
+        att = torch.softmax((avg * a).sum(dim=1, keepdim=True), dim=-1)
+        want_f = want_n * F.interpolate(att * a + a, size=L, mode="nearest")
+    assert got_f.shape == want_f.shape and rel_l2(got_f.cpu().numpy(), want_f.numpy()) < 3e-6
+    want_c = F.conv1d(want_f, cpu["bottleneck.1.weight"], cpu["bottleneck.1.bias"])
+    assert rel_l2(got_c.cpu().numpy(), want_c.numpy()) < 3e-6
+    assert rel_l2(got_p.cpu().numpy(), F.linear(e, cpu["pred_linear.weight"], cpu["pred_linear.bias"]).numpy()) < 2e-6
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        sep.pred_linear(emb.to(DEV))                       # gradients enabled: no silent torch fallback
+    with pytest.raises(DprnnError, match="HIP device"):
+        with torch.no_grad():
+            sep.bottleneck[0](x)                           # CPU tensor: no CPU fallback
 
 
 # ---- sub-module forwards (inference): the reference's classes have them (dprnn.py:33-37,79-99, encoder_decoder.py:25-33,40-49,

@@ -159,6 +159,32 @@ def summarise(paths):
               f"time {comp_t:.2f} + {rest['us_per_step']:.2f} = {tot_t:.2f} us against {full['us_per_step']:.2f} ({100 * tot_t / full['us_per_step']:.1f} %)")
 
 
+def cumulative(paths):
+    """Telescoping budget: the builds remove one more component each, in file order, so consecutive differences are the
+    components and they add up to the full kernel by construction; the marginal view (each component removed alone from the full
+    kernel: summarise) does not, because a shorter step runs at a higher clock and a different power."""
+    rs = []
+    for pth in paths:
+        for line in open(pth):
+            if line.strip().startswith("{"):
+                rs.append(json.loads(line))
+    full = rs[0]
+    print(f"# energy source: {full['energy_source']}; shape {full['shape']}; idle {full['idle_watts']:.0f} W; full kernel "
+          f"{full['millijoules_per_step']:.3f} mJ and {full['us_per_step']:.2f} us per step at {full['mean_watts']:.0f} W")
+    print(f"{'build (cumulative removal)':32s} {'us/step':>8s} {'mean W':>7s} {'mJ/step':>8s}   component removed at this stage: mJ/step (share of full), us/step (share)")
+    prev = None
+    for r in rs:
+        extra = ""
+        if prev is not None:
+            de, dt = prev["millijoules_per_step"] - r["millijoules_per_step"], prev["us_per_step"] - r["us_per_step"]
+            extra = f"   {de:7.3f} ({100 * de / full['millijoules_per_step']:5.1f} %)  {dt:6.2f} ({100 * dt / full['us_per_step']:5.1f} %)"
+        print(f"{r['label']:32s} {r['us_per_step']:8.2f} {r['mean_watts']:7.0f} {r['millijoules_per_step']:8.3f}{extra}")
+        prev = r
+    last = rs[-1]
+    print(f"{'what is left (loop, barriers)':32s} {'':8s} {'':7s} {'':8s}   {last['millijoules_per_step']:7.3f} ({100 * last['millijoules_per_step'] / full['millijoules_per_step']:5.1f} %)  "
+          f"{last['us_per_step']:6.2f} ({100 * last['us_per_step'] / full['us_per_step']:5.1f} %)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--label", default="full")
@@ -168,8 +194,11 @@ if __name__ == "__main__":
     ap.add_argument("--tile", type=int, default=2064)
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--summarise", nargs="*")
+    ap.add_argument("--cumulative", nargs="*")
     a = ap.parse_args()
-    if a.summarise is not None:
+    if a.cumulative is not None:
+        cumulative(a.cumulative)
+    elif a.summarise is not None:
         summarise(a.summarise)
     else:
         measure(a.label, a.seconds, a.workgroups, a.steps, a.tile, a.fuse)

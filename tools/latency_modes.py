@@ -15,7 +15,43 @@ cfg = full_cfg()
 model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state("bss", cfg, 0).items()})
 model = model.to("cuda:0")
-sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128]
+def _sizes(spec):
+    out = []
+    for part in spec.split(","):
+        if ":" in part:                      # a:b:step, b inclusive
+            a, b, st = (int(v) for v in part.split(":"))
+            out += list(range(a, b + 1, st))
+        else:
+            out.append(int(part))
+    return out
+
+
+sizes = _sizes(sys.argv[1]) if len(sys.argv) > 1 else [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128]
+modes = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (0, 1, 3)
+if modes != (0, 1, 3):
+    names = {0: "exact fp32", 1: "bf16 split x6", 3: "f16 pieces x3"}
+    prev = {m: 0.0 for m in modes}
+    for B in sizes:
+        x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
+        cells = []
+        for mode in modes:
+            engine.GEMM_MODE, engine.SPLIT_MIN_BATCH = mode, 0
+            with torch.no_grad():
+                for _ in range(3):
+                    model(x)
+                torch.cuda.synchronize()
+                n = 4 if B >= 32 else 8
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    model(x)
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            ups = B / ms * 1e3
+            cells.append(f"{names[mode]} {ms:8.2f} ms {ups:7.1f} utt/s {'  <-- below B-1 by %.1f %%' % (100 * (1 - ups / prev[mode])) if ups < 0.98 * prev[mode] else ''}")
+            prev[mode] = max(prev[mode], ups) if False else ups
+        print(f"B={B:3d}: " + "   ".join(cells), flush=True)
+        engine.drop_graphs(release_pool=False)
+    sys.exit(0)
 for B in sizes:
     x = torch.from_numpy(make_mixture(B, 24000, seed=1)).to("cuda:0")
     row = []

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """Captures and replays forwards of many (batch size, mode) keys in one process: does graph eviction / re-capture hold up?
     python tools/probes/graph_churn.py CACHE_MAX SIZES [ROUNDS]      e.g.  4 16,24,32,48,64,96,128
-    CHURN_LEGACY=1 ...   round 3's FIRST scheme, rebuilt here for the record: a private pool per capture, eviction AFTER the capture,
-                         nothing returned to the driver by hand -- the arm that segfaulted inside hipGraphLaunch at the sixteenth capture.
-Around every capture the caching allocator's driver-level counters are printed (segments allocated / freed, retries): a free between
-"before" and "after" of one capture is a hipFree issued while that capture was in progress."""
+    CHURN_LEGACY=1 ...   round 3's FIRST scheme, rebuilt here for the record: a private pool per capture, the oldest graph destroyed
+                         AFTER the new one is captured (between its instantiation and its first launch), nothing returned to the driver
+                         by hand -- the arm that segfaulted inside hipGraphLaunch at the sixteenth capture.
+    CHURN_LEGACY=2 ...   the same private pools and the same absence of empty_cache() calls, but the oldest graph is destroyed BEFORE
+                         the new capture begins.  (torch.cuda.graph.__enter__ calls empty_cache() itself right before capture_begin in
+                         BOTH arms, so in both the destroyed graphs' segments go back to the driver outside any capture.)
+The caching allocator's driver-level counters (segments allocated / freed, retries) are printed around every capture and -- "inside" --
+between the first and the last launch of the captured forward: a free counted "inside" is a hipFree issued while the capture was in
+progress."""
 import collections, faulthandler, os, sys
 faulthandler.enable()
 import numpy as np, torch
@@ -20,7 +25,8 @@ engine.GRAPH_CACHE_MAX = int(sys.argv[1])
 sizes = [int(v) for v in sys.argv[2].split(",")]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 samples = int(os.environ.get("SAMPLES", "24000"))
-legacy = os.environ.get("CHURN_LEGACY") == "1"
+legacy = os.environ.get("CHURN_LEGACY") in ("1", "2")
+evict_first = os.environ.get("CHURN_LEGACY") == "2"
 cfg = full_cfg()
 model = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state("bss", cfg, 0).items()})
@@ -45,7 +51,9 @@ class LegacyGraphed:                       # engine._Graphed as it was before th
         engine._TLS.guard, engine._TLS.capturing = 1, True
         try:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.inside0 = counters()
                 self.outputs = fn(*self.inputs)
+                self.inside1 = counters()
         finally:
             engine._TLS.guard, engine._TLS.capturing = 0, False
             lib.dprnn_saturation_begin(0, 0)
@@ -68,14 +76,16 @@ for rd in range(rounds):
                 if legacy:
                     fn = lambda w: engine._tasnet_forward_impl(model, w, None)
                     outs = [fn(x)]
+                    while evict_first and len(cache) >= engine.GRAPH_CACHE_MAX:     # arm 2: the oldest graph dies BEFORE the capture
+                        cache.popitem(last=False)
                     c0 = counters()
                     g = LegacyGraphed(fn, (x,))
                     c1 = counters()
                     ncap += 1
                     cache[(B, mode)] = g
-                    while len(cache) > engine.GRAPH_CACHE_MAX:          # AFTER the capture, nothing handed back by hand
+                    while len(cache) > engine.GRAPH_CACHE_MAX:          # arm 1: AFTER the capture, before the new graph's first launch
                         cache.popitem(last=False)
-                    print(f"  capture {ncap}: before {c0} after {c1}; first replay ...", flush=True)
+                    print(f"  capture {ncap}: before {c0} inside {g.inside0} .. {g.inside1} after {c1}; first replay ...", flush=True)
                     outs += [g.replay((x,)) for _ in range(3)]
                 else:
                     c0 = counters()

@@ -53,6 +53,10 @@ SIGNATURES = {
     "dprnn_rnn_fwd_ragged_ex": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_saturation_begin": [c_fp, c_fp],
     "dprnn_saturation_flags": [c_fp, c_fp],
+    "dprnn_rows_affine_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp],
+    "dprnn_att_row_scale_rows": [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_scale_init": [c_fp, c_fp],
+    "dprnn_scale_update": [c_fp, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_head_conv_ola_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -149,12 +153,15 @@ _SPECIAL = {
     "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),
     "dprnn_rnn_bwd_dg_floats": ([c_i, c_i, c_i, c_i, c_i], c_i64),
     "dprnn_get_bwd_gemm_mode": ([], c_i),
+    "dprnn_scale_begin": ([c_fp], c_i),
+    "dprnn_scale_slot": ([c_i], c_i),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
 ABI_VERSION = 2             # DPRNN_ABI_VERSION of include/dprnn_mi355x.h this binding is written against
 SAT_SLOTS = 8               # DPRNN_SAT_SLOTS
+SCALE_SLOTS = 32            # DPRNN_SCALE_SLOTS
 SAT_NAMES = ("recurrence input rows", "rows of the Linear after a recurrence", "rows of a row GEMM (bottleneck / mask head / data gradient)",
              "BPTT gate gradients", "weight-gradient operands", "non-finite input (NaN / Inf samples)", "", "")
 

@@ -52,6 +52,41 @@ extern "C" int dprnn_saturation_flags(void* host_out, void* stream) {
     return any;
 }
 
+// ---- adaptive activation scale (common.h): the calling thread's record and the slot of the next tracked launch
+static thread_local float* g_scale_state = nullptr;
+static thread_local int g_scale_slot = 0;
+ScaleRef dprnn_scale_ref() {
+    if (!g_scale_state) return ScaleRef{nullptr, nullptr};
+    return ScaleRef{g_scale_state + g_scale_slot, reinterpret_cast<unsigned*>(g_scale_state) + DPRNN_SCALE_SLOTS + g_scale_slot};
+}
+extern "C" int dprnn_scale_begin(void* state) { g_scale_state = static_cast<float*>(state); g_scale_slot = 0; return 0; }
+extern "C" int dprnn_scale_slot(int slot) {
+    if (slot < 0 || slot >= DPRNN_SCALE_SLOTS) { dprnn_set_error("dprnn_scale_slot: slot %d of %d", slot, DPRNN_SCALE_SLOTS); return -1; }
+    g_scale_slot = slot;
+    return 0;
+}
+__global__ void scale_update_kernel(float* state, int init) {
+    const int i = threadIdx.x;
+    if (i >= DPRNN_SCALE_SLOTS) return;
+    unsigned* track = reinterpret_cast<unsigned*>(state) + DPRNN_SCALE_SLOTS;
+    if (init) state[i] = 256.f;
+    else {
+        const float seen = __uint_as_float(track[i]);                  // NaN / Inf patterns (a non-finite input) leave the record alone
+        if (seen < 3.0e38f && seen > state[i]) state[i] = seen;
+    }
+    track[i] = 0u;
+}
+extern "C" int dprnn_scale_init(void* state, void* stream) {
+    if (!state) { dprnn_set_error("dprnn_scale_init: null pointer"); return -1; }
+    hipLaunchKernelGGL(scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<float*>(state), 1);
+    return dprnn_check_launch("scale_update_kernel");
+}
+extern "C" int dprnn_scale_update(void* state, void* stream) {
+    if (!state) { dprnn_set_error("dprnn_scale_update: null pointer"); return -1; }
+    hipLaunchKernelGGL(scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<float*>(state), 0);
+    return dprnn_check_launch("scale_update_kernel");
+}
+
 // ---- packed-weight formats, keyed by device address (common.h)
 static std::mutex g_pack_mu;
 static std::unordered_map<const void*, unsigned> g_pack_fmt;

@@ -176,11 +176,40 @@ __device__ __forceinline__ void sat_track(unsigned& m, float a, float b) {
 #endif
 }
 __device__ __forceinline__ void sat_track(unsigned& m, const f32x4& v) { sat_track(m, v[0], v[1]); sat_track(m, v[2], v[3]); }
-__device__ __forceinline__ void sat_commit(int* flags, int slot, unsigned m, float limit) {
-    if (!flags) return;
-    const bool over = m > __float_as_uint(limit);        // non-negative floats order like their bit patterns
-    if (__builtin_amdgcn_ballot_w64(over) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + slot, 1);
+// amax_dst (optional): the launch's largest tracked magnitude, as float bits, folded into a device word with one atomic per
+// wave (adaptive activation scale below).
+__device__ __forceinline__ void sat_commit(int* flags, int slot, unsigned m, float limit, unsigned* amax_dst = nullptr) {
+    if (flags) {
+        const bool over = m > __float_as_uint(limit);    // non-negative floats order like their bit patterns
+        if (__builtin_amdgcn_ballot_w64(over) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + slot, 1);
+    }
+    if (amax_dst) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+        if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(amax_dst, m);
+    }
 }
+
+// ---- adaptive activation scale of the f16-pieces arithmetic (round 4; api.hip: dprnn_scale_begin / _slot / _update).
+// Activations are multiplied by 2^s before they are split into f16 pieces; s was the constant 4 (|x| <= 4062).  A model whose
+// residual stream runs higher (norm gains are unbounded, dprnn.py:76-77) would saturate on EVERY forward and pay the range-free
+// repeat each time.  Now s follows the data: the calling thread registers a device record `state` of 2 x DPRNN_SCALE_SLOTS words
+// -- [slot] = the largest |x| the conversion site `slot` has ever met (sticky, float; 256 at first: s = 4), [SLOTS + slot] = the
+// largest it met in the forward in progress (float bits, atomicMax) -- and every tracked launch reads its scale from the first
+// and leaves its maximum in the second; dprnn_scale_update folds the second into the first at the end of the forward.  So the
+// forward that first meets large values still saturates and is repeated (engine._guarded), the next ones run under a scale that
+// fits, with 8 x headroom: s = clamp(13 - exponent(amax), -8, 4), 2^s amax in [2^12, 2^13).  s never exceeds 4: models that stay
+// below 512 compute exactly what they computed with the constant, run to run.  No record registered: s = 4, nothing tracked.
+constexpr int DPRNN_SCALE_SLOTS = 32;
+struct ScaleRef { const float* src; unsigned* dst; };
+ScaleRef dprnn_scale_ref();                              // the calling thread's (record, current slot), or {nullptr, nullptr}
+__host__ __device__ __forceinline__ int act_scale_exp(float amax) {
+    int ex = 9;
+    if (amax > 0.f && amax < 3.0e38f) frexpf(amax, &ex);               // amax = f 2^ex, f in [0.5, 1)
+    const int s = 13 - ex;
+    return s < -8 ? -8 : s > 4 ? 4 : s;
+}
+__device__ __forceinline__ float act_scale(const float* src) { return src ? ldexpf(1.f, act_scale_exp(*src)) : 16.f; }
 
 // ---- packed-weight formats (api.hip).  The recurrence kernels read weights in a layout that depends on the cell and on the
 // arithmetic mode the pack call ran under; every pack entry point records the format of the buffer it filled (keyed by the

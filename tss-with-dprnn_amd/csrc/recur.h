@@ -37,6 +37,8 @@ struct RecurArgs {
     int h_pieces;                                     // f16-pieces kernels, inference: H receives, per four adjacent units, the 16 bytes {first f16 pieces x 4 | second
                                                       // pieces x 4} of 2^4 h instead of four floats -- the operand dprnn_proj_stats_hp_fwd multiplies with
     int* sat;                                         // f16-pieces kernels: saturation flags of the calling thread (common.h), may be null
+    const float* xs_src;                              // f16-pieces kernels: the record word the x scale 2^s is chosen from (common.h: act_scale), null: 2^4
+    unsigned* xmax_dst;                               // ... and where the launch leaves the largest |x| it converted, null: nowhere
 };
 
 // The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's

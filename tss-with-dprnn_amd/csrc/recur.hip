@@ -577,6 +577,7 @@ static int bilstm_dispatch(RecurArgs a, int mode, int seq_tile, hipStream_t st) 
     }
     if (int rc = dprnn_pack_expect(a.Wp, DPRNN_PACK_FWD, a.cell, mode, a.ndir, "dprnn_rnn_fwd")) return rc;
     a.sat = dprnn_sat_ptr();
+    { const ScaleRef sr = dprnn_scale_ref(); a.xs_src = sr.src; a.xmax_dst = sr.dst; }
     if (seq_tile == 0) seq_tile = mode != 0 ? 2064 : (a.nseq <= 16 ? 16 : 32);
     const bool fast = g_fast_act != 0;
     // 16-sequence tiles run on eight waves (half the MFMA chain per wave and step: the small-batch latency form);
@@ -701,6 +702,7 @@ static int rnn_fwd_ragged(int mode, const float* X, const float* Z, const double
     if ((long long)64 * K * ndir * HD * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_fwd_ragged: chunk_length too large"); return -1; }
     if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, mode, ndir, "dprnn_rnn_fwd_ragged")) return rc;
     a.sat = dprnn_sat_ptr();
+    { const ScaleRef sr = dprnn_scale_ref(); a.xs_src = sr.src; a.xmax_dst = sr.dst; }
     return launch_bilstm_split(a, mode, 2064, g_fast_act != 0, (hipStream_t)stream);
 }
 extern "C" int dprnn_rnn_fwd_ragged_hp_ex(int gemm_mode, const float* X, const float* Z, const double* stats, const float* gamma,
@@ -761,6 +763,7 @@ static int rnn_fwd_train(int mode, int cell, const float* X, const float* Z, con
     }
     if (int rc = dprnn_pack_expect(a.Wp, DPRNN_PACK_FWD, cell, mode, ndir, "dprnn_rnn_fwd_train")) return rc;
     a.sat = dprnn_sat_ptr();
+    { const ScaleRef sr = dprnn_scale_ref(); a.xs_src = sr.src; a.xmax_dst = sr.dst; }
     hipStream_t st = (hipStream_t)stream;
     if (mode == 3) return launch_split8_f16_train(a, g_fast_act != 0, st);      // f16 pieces, same tape
     if (cell == 1) return g_fast_act ? launch_bilstm<2, true, 1, true>(a, st) : launch_bilstm<2, false, 1, true>(a, st);

@@ -47,16 +47,20 @@ __global__ void lstm_pack_split_kernel(const float* __restrict__ w_ih, const flo
 constexpr int ABSMAX_BLOCKS = 32;
 __global__ __launch_bounds__(256)
 void lstm_absmax_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ w_ih_r,
-                        const float* __restrict__ w_hh_r, float* __restrict__ packed_f) {
+                        const float* __restrict__ w_hh_r, float* __restrict__ packed_f, const float* __restrict__ xs_src) {
     __shared__ float part[4];
     const float* src[4] = {w_ih, w_hh, w_ih_r, w_hh_r};
+    // W_ih is packed as 2^(4 - s) W_ih (s = the x scale exponent of the launches that will read this pack, 4 without a record):
+    // the common weight scale is found over what is actually packed
+    const float fih = ldexpf(1.f, 4 - (xs_src ? act_scale_exp(*xs_src) : 4));
     float m = 0.f;
     for (int k = 0; k < 4; ++k) {
         if (!src[k]) continue;
         const f32x4* p = reinterpret_cast<const f32x4*>(src[k]);
+        const float f = (k & 1) ? 1.f : fih;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < 4 * HD * F / 4; i += ABSMAX_BLOCKS * 256) {   // W_ih [4H][F], W_hh [4H][H]: same size (F == H)
             const f32x4 v = p[i];
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            m = fmaxf(m, f * fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
     }
 #pragma unroll
@@ -80,11 +84,12 @@ __global__ void lstm_pack_f16_kernel(const float* __restrict__ w_ih, const float
                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                      const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
                                      const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
-                                     unsigned* __restrict__ packed, float* __restrict__ bsum, int ndir) {
+                                     unsigned* __restrict__ packed, float* __restrict__ bsum, int ndir, const float* __restrict__ xs_src) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_dir = 4 * NSLAB * 8 * 64 * 4;
     if (idx >= ndir * per_dir) return;
     const float sw = f16_weight_scale(reinterpret_cast<const float*>(packed));
+    const float swih = sw * ldexpf(1.f, 4 - (xs_src ? act_scale_exp(*xs_src) : 4));      // x arrives as 2^s x, h as 2^4 h
     if (idx == 0) {                                     // what the recurrence reads: S_w and 1 / (S_x S_w)
         reinterpret_cast<float*>(packed)[F16_SCALE_WORD] = sw;
         reinterpret_cast<float*>(packed)[F16_SCALE_WORD + 1] = 1.f / (F16_XS * sw);
@@ -99,7 +104,7 @@ __global__ void lstm_pack_f16_kernel(const float* __restrict__ w_ih, const float
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int k = 32 * slab + 8 * q + 2 * dw + half;
-        v[half] = sw * (k < F ? wi[row * F + k] : wh[row * HD + (k - F)]);
+        v[half] = k < F ? swih * wi[row * F + k] : sw * wh[row * HD + (k - F)];
     }
     unsigned w1, w2;
     split2_pair_f16(v[0], v[1], w1, w2);
@@ -350,10 +355,11 @@ extern "C" int dprnn_lstm_pack_f16(const float* w_ih, const float* w_hh, const f
     if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !bsum) { dprnn_set_error("dprnn_lstm_pack_f16: null pointer"); return -1; }
     const int ndir = w_ih_r ? 2 : 1;
     if (ndir == 2 && (!w_hh_r || !b_ih_r || !b_hh_r)) { dprnn_set_error("dprnn_lstm_pack_f16: incomplete reverse direction"); return -1; }
-    hipLaunchKernelGGL(lstm_absmax_kernel, dim3(ABSMAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh, w_ih_r, w_hh_r, (float*)packed);
+    const float* xs_src = dprnn_scale_ref().src;           // the record word of the launches that will read this pack (dprnn_scale_slot)
+    hipLaunchKernelGGL(lstm_absmax_kernel, dim3(ABSMAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh, w_ih_r, w_hh_r, (float*)packed, xs_src);
     const int n = ndir * 4 * NSLAB * 8 * 64 * 4;
     hipLaunchKernelGGL(lstm_pack_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir);
+                       w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, (unsigned*)packed, bsum, ndir, xs_src);
     dprnn_pack_note(packed, DPRNN_PACK_FWD, 0, 3, ndir);
     return dprnn_check_launch("lstm_pack_f16_kernel");
 }

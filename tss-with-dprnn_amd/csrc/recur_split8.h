@@ -159,6 +159,10 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
     auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     unsigned satm = 0u;                                    // f16 pieces: bits of the largest |x| this lane converted (common.h: sat_track)
+    // x is split as 2^s x with s from the launch's record word (common.h: adaptive activation scale; 2^4 without one).  h keeps
+    // 2^4 -- |h| < 1, and its pieces are also the projection's operand -- so the pack kernel has multiplied W_ih by 2^(4 - s):
+    // the accumulators come out scaled by 2^4 S_w whatever s is.
+    const float xs = F16 ? act_scale(a.xs_src) : 1.f;
     // x of one time step -> bf16 pieces in x buffer xb, one quad (4 floats of one row) per thread and m; XG quads are in
     // flight together (registers: the partner wave on the SIMD covers the rest of the latency)
     auto x_stage = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
@@ -194,7 +198,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                 if constexpr (F16) {
                     sat_track(satm, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * xs, -F16_XMAX, F16_XMAX);
                     split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                     split2_pair_f16(v[2], v[3], pb[0], pb[1]);
                 } else {
@@ -246,7 +250,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             if constexpr (F16) {
                 sat_track(satm, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * F16_XS, -F16_XMAX, F16_XMAX);
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * xs, -F16_XMAX, F16_XMAX);
                 split2_pair_f16(v[0], v[1], pa[0], pa[1]);
                 split2_pair_f16(v[2], v[3], pb[0], pb[1]);
             } else {
@@ -527,7 +531,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             __syncthreads();
         }
     }
-    if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX / F16_XS);
+    if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX / xs, a.xmax_dst);
     if constexpr (STAMP) {
         if ((tid == 0 || tid == 256) && a.stamps) {               // waves 0 and 4: a SIMD's pair; [workgroup][2][8] words
             unsigned long long* o = a.stamps + 16 * (blockIdx.y * gridDim.x + blockIdx.x) + (tid ? 8 : 0);

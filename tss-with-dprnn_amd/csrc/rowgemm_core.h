@@ -710,7 +710,8 @@ struct EpTMaskDecode {
 template <int KD, int ND, int RT, bool XC, class AL, class EPT, bool WT = false, bool TRACK = true>
 __global__ __launch_bounds__(512, 1)
 void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const float* __restrict__ W1, int ldw1,
-                         long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr, int* sat = nullptr) {
+                         long long M, AL al, EPT ep, const float* __restrict__ amax = nullptr, int* sat = nullptr,
+                         unsigned* __restrict__ amax_dst = nullptr) {
     constexpr int NCT = ND / 16, NS = KD / 32, K8 = KD / 8, NW = 8;
     unsigned satm = 0u;                                                // bits of the largest |row element| converted to f16 pieces
     constexpr int PF = XC ? (NS >= 4 ? 3 : NS - 1) : (NS >= 4 ? 2 : 1);
@@ -764,7 +765,8 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
     ep.begin(tid);
     __syncthreads();
     float xs = F16P_XS;
-    if (amax) {
+    if (amax && amax_dst) xs = act_scale(amax);        // forward rows: the adaptive activation scale of the launch's record word (common.h)
+    else if (amax) {                                   // gradients: scaled from their own measured maximum
         const float am = *amax;
         int ea = 0;
         if (am > 0.f && am < 3.0e38f) frexpf(am, &ea);
@@ -850,7 +852,7 @@ void rowgemm_f16t_kernel(const float* __restrict__ W0, int ldw0, int nd0, const 
                 for (int rt = 0; rt < RT; ++rt) { a[s][rt][0] = al.load(rt, 2 * s); a[s][rt][1] = al.load(rt, 2 * s + 1); }
         }
     }
-    if constexpr (TRACK) sat_commit(sat, DPRNN_SAT_GEMM_ROWS, satm, F16P_XMAX / xs);
+    if constexpr (TRACK) sat_commit(sat, DPRNN_SAT_GEMM_ROWS, satm, F16P_XMAX / xs, amax_dst);
     ep.end(lane);
 }
 
@@ -868,7 +870,13 @@ int launch_rowgemm_f16t(const char* what, const float* W0, int ldw0, int nd0, co
     }
     constexpr int ROWS_IT = 8 * RT * 16;
     const long long grid = rowgemm_f16_grid((M + ROWS_IT - 1) / ROWS_IT);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax, dprnn_sat_ptr());
+    unsigned* amax_dst = nullptr;
+    if (TRACK && !amax) {                              // forward rows: scale from / report to the calling thread's record word (common.h)
+        const ScaleRef sr = dprnn_scale_ref();
+        amax = sr.src;
+        amax_dst = sr.dst;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W0, ldw0, nd0, W1, ldw1, M, al, ep, amax, dprnn_sat_ptr(), amax_dst);
     return dprnn_check_launch(what);
 }
 

@@ -271,6 +271,57 @@ __global__ __launch_bounds__(256) void att_softmax_upsample_kernel(const float* 
     }
 }
 
+// 'att' scores from MATERIALISED rows xn[b][l][c] (separator-level callers hold encoder outputs, not the waveform): the same
+// sums as att_scores_kernel with the rows in place of the recomputed encoder output.
+__global__ __launch_bounds__(256) void att_scores_rows_kernel(const float* __restrict__ rows, int pitch, const float* __restrict__ sc0,
+                                                              const float* __restrict__ sh0, const float* __restrict__ avg_w,
+                                                              const float* __restrict__ avg_b, const float* __restrict__ a,
+                                                              float* __restrict__ scores, int L, int La, int N, int ks_a) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= La) return;
+    float s = 0.f;
+    for (int c = 0; c < N; ++c) {
+        float av = avg_b[c];
+        for (int j = 0; j < ks_a; ++j) {
+            const float e = rows[((long long)b * L + (long long)t * ks_a + j) * pitch + c];
+            av = fmaf(avg_w[c * ks_a + j], sc0 ? fmaf(e, sc0[b * N + c], sh0[b * N + c]) : e, av);
+        }
+        s = fmaf(av, a[b * N + c], s);
+    }
+    scores[(long long)b * La + t] = s;
+}
+
+// out[row][c] = (A[row][c] * sc[u][c] + sh[u][c]) * row_scale[row], u = row / rows_per_utt; sc / sh / row_scale optional (1, 0, 1).
+// The per-frame glue of the separator-level surfaces: GroupNorm / gLN apply, add / mul / film fusion, the 'att' frame scale.
+__global__ __launch_bounds__(256) void rows_affine_kernel(const f32x4* __restrict__ A, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                          const float* __restrict__ row_scale, f32x4* __restrict__ out,
+                                                          long long M, int C4, long long rows_per_utt) {
+    const long long n = M * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long row = i / C4;
+        const int c4 = (int)(i - row * C4);
+        const long long u = row / rows_per_utt;
+        f32x4 v = A[i];
+        if (sc) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(sc + (u * C4 + c4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= s[e];
+        }
+        if (sh) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(sh + (u * C4 + c4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
+        if (row_scale) {
+            const float r = row_scale[row];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= r;
+        }
+        out[i] = v;
+    }
+}
+
 template <int KD>
 int launch_pointwise(const AffineRows<4>& al, const EpStoreColStats<4>& ep, const float* W, int ldw, long long M, hipStream_t st) {
     return launch_rowgemm<KD, 128, 4>("pointwise", W, ldw, 128, nullptr, 0, M, al, ep, st);
@@ -348,6 +399,29 @@ extern "C" int dprnn_rows_stats(const float* A, double* stats, int B, int64_t ro
     hipLaunchKernelGGL(rows_stats_kernel, dim3((unsigned)g, B), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(A), stats, per4);
     return dprnn_check_launch("rows_stats_kernel");
+}
+
+extern "C" int dprnn_att_row_scale_rows(const float* rows, int pitch, const float* sc0, const float* sh0, const float* avg_w, const float* avg_b,
+                                        const float* a, float* scores, float* row_scale, int B, int L, int N, int ks_a, void* stream) {
+    if (!rows || !avg_w || !avg_b || !a || !scores || !row_scale || ((sc0 == nullptr) != (sh0 == nullptr))) { dprnn_set_error("dprnn_att_row_scale_rows: null pointer"); return -1; }
+    if (ks_a < 1 || L < ks_a || pitch < N || B < 1) { dprnn_set_error("dprnn_att_row_scale_rows: bad sizes L=%d ks_a=%d pitch=%d N=%d", L, ks_a, pitch, N); return -1; }
+    const int La = (L - ks_a) / ks_a + 1;
+    hipLaunchKernelGGL(att_scores_rows_kernel, dim3((La + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, rows, pitch, sc0, sh0, avg_w, avg_b, a,
+                       scores, L, La, N, ks_a);
+    int rc = dprnn_check_launch("att_scores_rows_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(att_softmax_upsample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, row_scale, La, L);
+    return dprnn_check_launch("att_softmax_upsample_kernel");
+}
+
+extern "C" int dprnn_rows_affine_fwd(const float* A, const float* sc, const float* sh, const float* row_scale, float* out, int64_t M, int C,
+                                     int64_t rows_per_utt, void* stream) {
+    if (!A || !out || M < 1) { dprnn_set_error("dprnn_rows_affine_fwd: null pointer / M"); return -1; }
+    if (C < 4 || (C % 4) || rows_per_utt < 1) { dprnn_set_error("dprnn_rows_affine_fwd: C=%d must be a multiple of 4, rows_per_utt >= 1", C); return -1; }
+    long long g = (M * (C / 4) + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rows_affine_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(A), sc, sh, row_scale,
+                       reinterpret_cast<f32x4*>(out), (long long)M, C / 4, (long long)rows_per_utt);
+    return dprnn_check_launch("rows_affine_kernel");
 }
 
 extern "C" int dprnn_att_row_scale(const float* wav, const float* enc_w, const float* sc0, const float* sh0,

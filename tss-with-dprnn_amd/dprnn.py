@@ -14,6 +14,7 @@ import warnings
 import torch
 from torch import nn
 
+from . import device_modules as dm
 from . import engine, norms
 from ._lib import DprnnError
 from .encoder_decoder import Decoder, Encoder
@@ -82,7 +83,7 @@ def _make_norm(norm_type, channels):
     if norm_type == "gLN":
         return norms.GlobLN(channels)
     if norm_type == "ln":
-        return nn.GroupNorm(1, channels)
+        return dm.GroupNorm(1, channels)     # nn.GroupNorm whose forward runs on the HIP kernels (device_modules.py)
     return None           # the reference silently leaves the attribute undefined (dprnn.py:72-77)
 
 
@@ -119,7 +120,7 @@ class DPRNN(nn.Module):
         self.activation_type = activation_type
 
         linear_norm = _make_norm(norm_type, input_size)
-        start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+        start_conv1d = dm.Conv1d(input_size, feature_size, 1)
         self.bottleneck = nn.Sequential(*([linear_norm] if linear_norm is not None else []), start_conv1d)
         self.dprnn_blocks = nn.Sequential(*[
             DPRNNBlock(rnn_type=rnn_type, feature_size=feature_size, hidden_size=hidden_size, norm_type=norm_type,

@@ -10,6 +10,7 @@ scripts/test/config_bss.yaml:12 targets ``src.models.dprnn_spe.DPRNNTasNet``.
 import torch
 from torch import nn
 
+from . import device_modules as dm
 from . import engine, norms
 from ._lib import DprnnError
 from .dprnn import DPRNN, DPRNNTasNet  # noqa: F401  (DPRNNTasNet: see module docstring)
@@ -50,25 +51,25 @@ class DPRNNSpe(DPRNN):
         self.fusion_type = fusion_type
         start_conv1d = None
         if fusion_type == 'cat':
-            start_conv1d = nn.Conv1d(input_size + embeddings_size, feature_size, 1)
+            start_conv1d = dm.Conv1d(input_size + embeddings_size, feature_size, 1)
         if fusion_type in ('add', 'mul'):
-            self.fusion_linear = nn.Linear(embeddings_size, input_size)
-            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+            self.fusion_linear = dm.Linear(embeddings_size, input_size)
+            start_conv1d = dm.Conv1d(input_size, feature_size, 1)
         if fusion_type == 'film':
-            self.fusion_linear_1 = nn.Linear(embeddings_size, input_size)
-            self.fusion_linear_2 = nn.Linear(embeddings_size, input_size)
-            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+            self.fusion_linear_1 = dm.Linear(embeddings_size, input_size)
+            self.fusion_linear_2 = dm.Linear(embeddings_size, input_size)
+            start_conv1d = dm.Conv1d(input_size, feature_size, 1)
         if fusion_type == 'att':
-            self.fusion_linear = nn.Linear(embeddings_size, input_size)
+            self.fusion_linear = dm.Linear(embeddings_size, input_size)
             self.average = nn.Conv1d(input_size, input_size, kernel_size, kernel_size, groups=input_size)
             self.average.weight = nn.Parameter(torch.ones(input_size, 1, kernel_size) / kernel_size)
             self.average.bias = nn.Parameter(torch.zeros(input_size))
             for p in self.average.parameters():
                 p.requires_grad = False
-            start_conv1d = nn.Conv1d(input_size, feature_size, 1)
+            start_conv1d = dm.Conv1d(input_size, feature_size, 1)
         if start_conv1d is None:
             raise UnboundLocalError("local variable 'start_conv1d' referenced before assignment")   # as the reference does
-        linear_norm = norms.GlobLN(input_size) if norm_type == 'gLN' else nn.GroupNorm(1, input_size)   # dprnn_spe.py:108-111
+        linear_norm = norms.GlobLN(input_size) if norm_type == 'gLN' else dm.GroupNorm(1, input_size)   # dprnn_spe.py:108-111
         self.bottleneck = nn.Sequential(linear_norm, start_conv1d)
         self.spk_encoder = nn.Sequential(
             nn.GroupNorm(1, input_size),
@@ -78,14 +79,15 @@ class DPRNNSpe(DPRNN):
             ResBlock(P, P),
             nn.Conv1d(P, embeddings_size, 1),
         )
-        self.pred_linear = nn.Linear(embeddings_size, num_spks)
+        self.pred_linear = dm.Linear(embeddings_size, num_spks)
 
     # Separation-level entry points for code that holds encoder outputs [B, N, L] and drives the pieces itself -- the
-    # reference's DPRNNRawNet subclass overrides _auxiliary and calls bottleneck[i], _fusion, _dprnn_process and pred_linear
-    # (src/models/dprnn_rawnet.py:79-105).  The speaker encoder and the DPRNN stack (99 % of the FLOPs) run in the HIP
-    # kernels; the per-frame glue in between (norm module, fusion broadcast, 1x1 conv, pred_linear) is a handful of torch
-    # device ops here, because its inputs and outputs are torch tensors in the reference's [B, C, L] layout by contract.
-    # DPRNNSpeTasNet / DPRNNSpeIRATasNet do NOT use these: their forward is fused from the waveform (engine.spe_forward).
+    # reference's DPRNNRawNet subclass overrides _auxiliary and calls bottleneck[0], _fusion, bottleneck[1], _dprnn_process and
+    # pred_linear (src/models/dprnn_rawnet.py:79-105).  Every piece runs on the library's HIP kernels: the speaker encoder and the
+    # DPRNN stack (99 % of the FLOPs) as in the fused path, the per-frame glue through device_modules (norm: dprnn_rows_stats +
+    # dprnn_bottleneck_prep + dprnn_rows_affine_fwd; 1x1 conv: dprnn_pointwise_fwd; Linears: dprnn_linear_small_fwd) and
+    # engine.fusion_forward (dprnn_rows_affine_fwd, dprnn_att_row_scale_rows); what torch does here is layout (transposes, the
+    # 'cat' copy).  Inference only.  DPRNNSpeTasNet / DPRNNSpeIRATasNet do NOT use these: their forward is fused from the waveform.
     def forward(self, input, aux, aux_len):
         """dprnn_spe.py:125-154: (mixture encoding [B,N,L], reference encoding [B,N,La], aux_len) -> (masks [B,2,N,L],
         speaker logits [B,num_spks])."""
@@ -102,24 +104,7 @@ class DPRNNSpe(DPRNN):
 
     def _fusion(self, aux, output, L):
         """dprnn_spe.py:165-229 on device tensors: aux [B,E], output [B,N,L] (already normalised) -> fused [B,C,L]."""
-        if not output.is_cuda:
-            raise DprnnError(f"_fusion input is on {output.device}: the DPRNN MI355X path runs only on a HIP device")
-        ft = self.fusion_type
-        if ft == 'cat':
-            return torch.cat((output, aux.unsqueeze(-1).expand(-1, -1, L)), dim=1)
-        if ft == 'film':
-            return output * self.fusion_linear_1(aux).unsqueeze(-1) + self.fusion_linear_2(aux).unsqueeze(-1)
-        a = self.fusion_linear(aux).unsqueeze(-1)                        # [B, N, 1]
-        if ft == 'add':
-            return output + a
-        if ft == 'mul':
-            return output * a
-        if ft == 'att':
-            avg = self.average(output)                                    # depth-wise mean over kernel_size frames
-            att = torch.softmax((avg * a).sum(dim=1, keepdim=True), dim=-1)
-            att = att * a + a
-            return output * nn.functional.interpolate(att, size=L, mode='nearest')
-        raise DprnnError(f"unknown fusion_type {ft!r}")
+        return engine.fusion_forward(self, aux, output, L)
 
 
 def _wants_grad(module):

@@ -5,6 +5,7 @@ import torch
 from torch import nn
 
 from ._lib import DprnnError
+from . import device_modules as dm
 from .dprnn_spe import DPRNNSpe, DPRNNSpeTasNet
 
 
@@ -17,13 +18,13 @@ class DPRNNSpeIRA(DPRNNSpe):
         super().__init__(input_size, feature_size, hidden_size, chunk_length, hop_length, n_repeats, bidirectional,
                          rnn_type, norm_type, activation_type, dropout, O, P, embeddings_size, num_spks, kernel_size,
                          fusion_type)
-        self.aux_linear = nn.Linear(2 * embeddings_size, embeddings_size)
+        self.aux_linear = dm.Linear(2 * embeddings_size, embeddings_size)
 
     def forward(self, input, aux, aux_len):
         """dprnn_spe_ira.py:53-115 on encoder outputs: (mixture encoding [B,N,L], reference encoding [B,N,La], aux_len) ->
         (d1 = mask_0 * input of the second pass [B,N,L], speaker logits [B,num_spks]).  Built from the same device pieces as
-        DPRNNSpe.forward (speaker encoder and DPRNN stack in HIP kernels, the per-frame glue as torch device ops); inference
-        only.  Note the reference normalises the embedding of d0 with the REFERENCE utterance's aux_len (:84): kept."""
+        DPRNNSpe.forward (all of them HIP kernels; mask * encoding and the embedding concatenation are torch element-wise /
+        copy ops); inference only.  Note the reference normalises the embedding of d0 with the REFERENCE utterance's aux_len (:84): kept."""
         B, _, L = input.size()
         v0 = self._auxiliary(aux, aux_len)
         output_norm = self.bottleneck[0](input)                              # cached for the second pass (:62,:96)

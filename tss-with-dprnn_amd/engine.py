@@ -21,7 +21,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import SAT_NAMES, SAT_SLOTS, DprnnError, check, load_library
+from ._lib import SAT_NAMES, SAT_SLOTS, SCALE_SLOTS, DprnnError, check, load_library
 
 F_BUILT = 128      # feature_size / hidden_size the kernels are built for (config_bss.yaml:19-20)
 N_BUILT = 64       # input_size (config_bss.yaml:18)
@@ -102,6 +102,83 @@ def use_gemm_mode(mode: int):
         _TLS.mode = prev
 
 
+# ---- adaptive activation scale of the f16-pieces arithmetic (include/dprnn_mi355x.h: dprnn_scale_*; csrc/common.h).  One device
+# record per (model, device): the largest |x| every conversion site has met; the kernels of a forward read their scale 2^s from it
+# and leave their maxima in it, all on the device (no host round trip, and the same addresses on every replay of a captured
+# forward).  A model whose residual stream leaves the default range (|x| > 4062) is therefore repeated in mode 1 ONCE; its next
+# forwards run in mode 3 under a scale that fits.  DPRNN_ADAPTIVE_SCALE=0: the constant 2^4 of rounds 2 and 3.
+ADAPTIVE_SCALE = os.environ.get("DPRNN_ADAPTIVE_SCALE", "1") != "0"
+SLOT_BOTTLENECK, SLOT_AUX_BOTTLENECK, SLOT_HEAD_CONV, SLOT_HEAD_GATE, SLOT_PATH0 = 0, 1, 2, 3, 4
+PIN_AFTER_FALLBACKS = 2          # consecutive saturated forwards after which a model stays in mode 1
+
+
+def path_slot(i_block: int, inter: bool) -> int:
+    """Record slot of DPRNN path (block, intra / inter): its pack call, its recurrence launch."""
+    return SLOT_PATH0 + (2 * i_block + int(inter)) % (SCALE_SLOTS - SLOT_PATH0)
+
+
+def _set_slot(lib, slot: int) -> None:
+    lib.dprnn_scale_slot(slot)
+
+
+def _scale_tensor(owner, dev):
+    recs = owner.__dict__.setdefault("_dprnn_scale_records", {})
+    rec = recs.get(str(dev))
+    if rec is None:
+        if getattr(_TLS, "capturing", False):
+            raise DprnnError("activation-scale record created inside a graph capture (the first forward of a key runs eagerly)")
+        lib = load_library()
+        rec = torch.empty(2 * SCALE_SLOTS, device=dev, dtype=torch.float32)
+        check(lib, lib.dprnn_scale_init(rec.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_scale_init")
+        recs[str(dev)] = rec
+    return rec
+
+
+@contextlib.contextmanager
+def _scale_record(owner, dev):
+    """Registers `owner`'s record with the library for the launches of this block (this thread, mode 3 only); yields the record
+    or None.  The caller ends its forward with dprnn_scale_update on the record."""
+    if owner is None or not ADAPTIVE_SCALE or current_mode() != 3 or getattr(_TLS, "scale_depth", 0) > 0:
+        yield None
+        return
+    lib = load_library()
+    rec = _scale_tensor(owner, dev)
+    lib.dprnn_scale_begin(rec.data_ptr())
+    _TLS.scale_depth = 1
+    try:
+        yield rec
+    finally:
+        _TLS.scale_depth = 0
+        lib.dprnn_scale_begin(0)
+
+
+def scale_exponents(owner, dev=None):
+    """{slot: s} of a model's record (2^s multiplies the activations of that site before the f16 split; 4 = the default): a
+    synchronising read, for tests and diagnostics."""
+    import math
+    recs = getattr(owner, "_dprnn_scale_records", {})
+    if not recs:
+        return {}
+    rec = recs[str(dev)] if dev is not None else next(iter(recs.values()))
+    out = {}
+    for i, v in enumerate(rec[:SCALE_SLOTS].cpu().tolist()):
+        ex = math.frexp(v)[1] if 0.0 < v < 3.0e38 else 9
+        out[i] = max(-8, min(4, 13 - ex))
+    return out
+
+
+def _scale_end(st, rec) -> None:
+    """Last launch of a forward that ran under a record: the forward's maxima become part of the sticky ones."""
+    if rec is not None:
+        st.call("dprnn_scale_update", rec.data_ptr())
+
+
+def unpin(owner) -> None:
+    """Let a model that was pinned to mode 1 after repeated saturation try the default arithmetic again."""
+    owner.__dict__["_dprnn_pin_mode1"] = False
+    owner.__dict__["_dprnn_sat_streak"] = 0
+
+
 def _bn_buffers(module):
     if module is None:
         return []
@@ -109,7 +186,8 @@ def _bn_buffers(module):
             for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
 
 
-def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None):
+def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None,
+             owner=None):
     """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
     f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
     fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
@@ -140,6 +218,8 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
             check(lib, rc, "dprnn_saturation_flags")
         _count(SATURATION, "checks")
         if rc == 0:
+            if owner is not None:
+                owner.__dict__["_dprnn_sat_streak"] = 0
             return out
         hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
         n_fallbacks = _count(SATURATION, "fallbacks")
@@ -149,6 +229,16 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
                "Inf / NaN)")
         if ON_SATURATION == "raise":
             raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
+        if owner is not None:
+            # The activation-scale record has adapted by now (the saturated forward left its maxima): the next forward normally fits.
+            # A model that saturates again and again (values that grow from call to call, Inf / NaN inputs) stops paying twice.
+            streak = owner.__dict__.get("_dprnn_sat_streak", 0) + 1
+            owner.__dict__["_dprnn_sat_streak"] = streak
+            if streak >= PIN_AFTER_FALLBACKS and not owner.__dict__.get("_dprnn_pin_mode1", False):
+                owner.__dict__["_dprnn_pin_mode1"] = True
+                warnings.warn(f"{what}: {streak} consecutive forwards left the range of the f16-pieces arithmetic; this model now runs in "
+                              "gate-GEMM mode 1 (three bf16 pieces, no range assumption) -- engine.unpin(model) returns it to the default",
+                              RuntimeWarning, stacklevel=3)
         if n_fallbacks == 1:
             warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
                           "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=3)
@@ -291,7 +381,8 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
     return sc, sh
 
 
-def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None, gemm_mode=None):
+def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None, gemm_mode=None,
+                      scale_slot: int = SLOT_BOTTLENECK):
     """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias,
     'att' fusion as row_scale).  gemm_mode: arithmetic of the product (3: f16 pieces like the Linears and the mask head, else the
     fp32 MFMA); default GEMM_MODE's.  This call comes before dprnn_process selects the forward's mode, so it selects its own and
@@ -304,6 +395,7 @@ def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bi
     mode = current_mode() if gemm_mode is None else gemm_mode
     prev = st.lib.dprnn_get_gemm_mode()
     st.lib.dprnn_set_gemm_mode(3 if mode == 3 else 0)
+    _set_slot(st.lib, scale_slot)
     try:
         if row_scale is not None:
             st.call("dprnn_bottleneck_att_fwd", _p(wav), _p(enc_w), _p(sc), _p(sh), _p(w), w.shape[1],
@@ -393,8 +485,9 @@ class _Group:
         self.mode = 0                 # gate-GEMM mode of this forward (set by dprnn_process; the packed weights are in it)
 
 
-def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool):
+def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool, scale_slot: int = SLOT_PATH0):
     st, geo, Z, Hbuf = g.st, g.geo, g.Z, g.H
+    _set_slot(st.lib, scale_slot)            # the record word this path's pack call ran under
     dev = Z.device
     ndir = 2 if rnn.rnn.bidirectional else 1
     B, S, K = geo.B, geo.S, geo.K
@@ -542,6 +635,11 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     reference: dprnn.py:171-186 (== dprnn_spe.py:231-248), dprnn.py:277, encoder_decoder.py:40-42.
     Returns taps [B][2][L][ks] (and mask*enc of speaker 0 as [B][L][N] if want_masked).
     stats: [1 + 2*n_blocks][B][2] float64, zeroed; slot 0 belongs to the bottleneck."""
+    # Y in a one-element list: the caller hands the frames over -- they are dead once segmented (0.8 GB at 64 x 3 s), and with no
+    # reference left their block serves the forward's later allocations (a captured forward's pool is that much smaller)
+    owned = isinstance(Y, list)
+    if owned:
+        Y = Y.pop()
     dev = Y.device
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
     blocks = list(sep.dprnn_blocks)
@@ -554,6 +652,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
             _, fw, bw = _rnn_tensors(rnn, dev)
+            _set_slot(st.lib, path_slot(i, j == 1))     # the pack folds the path's x scale into W_ih
             st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
                     _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
@@ -580,6 +679,11 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
         g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
         debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()
+    if owned:
+        if len(groups) > 1 and not getattr(_TLS, "capturing", False):
+            for g in groups:
+                Y.record_stream(g.st.tstream)       # read by the groups' streams: the allocator waits for them before it reuses the block
+        del Y
     for i, blk in enumerate(blocks):
         for intra in (True, False):
             rnn, lin, norm = (blk.intra_rnn, blk.intra_linear, blk.intra_norm) if intra else \
@@ -588,7 +692,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             dbg = [] if debug is not None else None
             for g in groups:            # interleaved submission: every group advances one path at a time
                 _run_path(g, rnn, lin, norm, stats[slot][g.b0:], packed[2 * i + (0 if intra else 1)],
-                          bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse)
+                          bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse, path_slot(i, not intra))
             if debug is not None:
                 debug[f"block{i}." + ("intra_rnn" if intra else "inter_rnn")] = dbg[0]
                 debug[f"block{i}" + (".mid" if intra else "")] = groups[0].X.view(B, S, K, F_BUILT).clone()
@@ -599,6 +703,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
         V = g.H[gB * L * 2 * F_BUILT: 2 * gB * L * 2 * F_BUILT]
         head_w = (_p(_param(sep.prelu.weight, "prelu.weight", dev)), _p(_param(sep.conv2d.weight, "conv2d.weight", dev)),
                   _p(_param(sep.conv2d.bias, "conv2d.bias", dev)))
+        _set_slot(st.lib, SLOT_HEAD_CONV)
         if g.pending is None:
             g.st.call("dprnn_head_conv_ola_fwd", _p(g.X), *head_w, _p(U), gB, L, K, P, S)
         else:
@@ -606,6 +711,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             g.st.call("dprnn_head_conv_ola_norm_fwd", _p(g.X), _p(g.Z), _p(pstats), _p(pg), _p(pb), peps, *head_w,
                       _p(U), gB, L, K, P, S)
             g.pending = None
+        _set_slot(st.lib, SLOT_HEAD_GATE)
         g.st.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
                   _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
                   _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), gB * L * 2)
@@ -655,7 +761,7 @@ def _tasnet_forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None)
     check_supported(cfg)
     wav = check_input(wav)
     dev = wav.device
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
         st = Stage(dev)
         geo = make_geometry(wav.shape[0], wav.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"],
                             cfg["kernel_size"], cfg["stride"])
@@ -665,11 +771,13 @@ def _tasnet_forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None)
         enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
         dec_w = _param(model.decoder.weight, "decoder.weight", dev)
         stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), geo.B, 2, device=dev, dtype=torch.float64)
-        Y = frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0])
+        frames = [frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0])]
         if debug is not None:
-            debug["bottleneck"] = Y.clone()
-        taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
-        return decode(st, taps, geo, 2)
+            debug["bottleneck"] = frames[0].clone()
+        taps = dprnn_process(st, sep, frames, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
+        out = decode(st, taps, geo, 2)
+        _scale_end(st, rec)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ DPRNN-Spe / IRA
@@ -809,7 +917,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
     if aux.shape[0] != wav.shape[0]:
         raise DprnnError("mixture and reference batch sizes differ")
     dev = wav.device
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
         st = Stage(dev)
         N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
         geo = make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
@@ -826,7 +934,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
 
         # speaker embedding of the reference utterance (dprnn_spe.py:156-163)
         sc_a, sh_a = bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats[-1])
-        A0 = bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a).view(B * geo_a.L, F_BUILT)
+        A0 = bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=SLOT_AUX_BOTTLENECK).view(B * geo_a.L, F_BUILT)
         v0 = speaker_embedding(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
         if debug is not None:
             debug["emb"] = v0.clone()
@@ -869,6 +977,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
             v_last = v1
         logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last)
         est = decode(st, taps, geo, 1)                    # speaker 0 only (dprnn_spe.py:325)
+        _scale_end(st, rec)
         return est[:, 0, :], logits
 
 
@@ -906,7 +1015,7 @@ def _separator_masks_impl(sep, frames: torch.Tensor) -> torch.Tensor:
     dev = frames.device
     B, _, L = frames.shape
     N = sep.input_size
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _scale_record(sep, dev) as rec:
         st = Stage(dev)
         Y = frames.transpose(1, 2).contiguous()                       # channels-last frames [B][L][F] (layout plumbing)
         # the mask kernel also forms decoder taps of mask * encoder(wav); here there is no waveform: a 1-tap all-zero
@@ -917,6 +1026,7 @@ def _separator_masks_impl(sep, frames: torch.Tensor) -> torch.Tensor:
         stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
         masks = torch.empty(B, L, 2, N, device=dev, dtype=torch.float32)         # rows (b, l, speaker)
         dprnn_process(st, sep, Y, zero_x, zero_w, zero_w, geo, stats, sep.activation_type == "relu", masks_out=masks)
+        _scale_end(st, rec)
         return masks.permute(0, 2, 3, 1).contiguous()                 # [B, 2, N, L] as dprnn.py:185
 
 
@@ -986,8 +1096,9 @@ def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError(f"rnn_type {rnn.rnn.mode!r}")
 
     def run():
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _scale_record(rnn, dev) as rec:
             st = Stage(dev)
+            _set_slot(st.lib, SLOT_PATH0)
             xc = x.contiguous()
             ndir, fw, bw = _rnn_tensors(rnn, dev)
             cell = CELL_ID[rnn.rnn.mode]
@@ -1002,6 +1113,7 @@ def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
             if cell != 0 and tile > 32:
                 tile = 32
             st.call("dprnn_rnn_fwd_ex", mode, cell, _p(xc), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), n, T, n, 0, T, 1, ndir, tile)
+            _scale_end(st, rec)
             return H
     return _guarded(dev, run, _in_mode(1, run), "SingleRNN.forward")
 
@@ -1019,7 +1131,7 @@ def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
     B, _, K, S = x.shape
 
     def run():
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _scale_record(blk, dev) as rec:
             st = Stage(dev)
             import types
             geo = Geometry(B, 0, 0, K, 1, S, 1, 1, N_BUILT)
@@ -1040,11 +1152,13 @@ def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
                 for j, (rnn, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
                                                              (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
                     _, fw, bw = _rnn_tensors(rnn, dev)
+                    _set_slot(st.lib, path_slot(0, j == 1))
                     st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
                             _p(packed[j]), _p(bsum[j]))
-                    _run_path(g, rnn, lin, norm, stats[j], packed[j], bsum[j], intra, None, False)
+                    _run_path(g, rnn, lin, norm, stats[j], packed[j], bsum[j], intra, None, False, path_slot(0, j == 1))
             finally:
                 st.lib.dprnn_set_gemm_mode(prev)
+            _scale_end(st, rec)
             return g.X.view(B, S, K, F_BUILT).permute(0, 3, 2, 1).contiguous()
     return _guarded(dev, run, _in_mode(1, run), "DPRNNBlock.forward")
 
@@ -1111,6 +1225,123 @@ def resblock_forward(blk, x: torch.Tensor) -> torch.Tensor:
         st = Stage(dev)
         rows = x.transpose(1, 2).contiguous().view(B * T, cin)
         out, _ = _resblock(st, blk, rows, B, T, cin, cout)
+        return out.transpose(1, 2).contiguous()
+
+
+# ---- the per-frame glue of the separator-level surfaces as HIP kernels (round 4): a subclass of the reference's DPRNNSpe that
+# calls bottleneck[0], _fusion, bottleneck[1], pred_linear itself (src/models/dprnn_rawnet.py:79-105) gets these through the
+# modules of device_modules.py -- no MIOpen / rocBLAS kernel behind a surface INTEGRATION.md calls "on the HIP kernels".
+def _device_f32(x, what: str):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise DprnnError(f"{what}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise DprnnError(f"{what} must be float32 (got {x.dtype})")
+    return x
+
+
+def norm_forward(norm, x: torch.Tensor) -> torch.Tensor:
+    """nn.GroupNorm(1, C) / norms.GlobLN on [B, C, ...] (dprnn.py:131-136, norms.py:27-31): per-utterance statistics in fp64
+    (dprnn_rows_stats), affine from dprnn_bottleneck_prep, applied by dprnn_rows_affine_fwd."""
+    x = _device_f32(x, "norm input")
+    _no_grad_only(type(norm).__name__ + ".forward", x, module=norm)
+    if x.dim() < 3:
+        raise DprnnError("norm input must be [batch, channels, ...]")
+    B, C = x.shape[:2]
+    if C % 4:
+        raise NotImplementedError("norm over a channel count that is not a multiple of 4")
+    dev = x.device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        rows = x.reshape(B, C, -1).transpose(1, 2).contiguous()                # channels-last rows [B][R][C] (layout plumbing)
+        R = rows.shape[1]
+        sc, sh = _rows_affine(st, rows, norm, B, R, C)
+        out = torch.empty_like(rows)
+        st.call("dprnn_rows_affine_fwd", _p(rows), _p(sc), _p(sh), 0, _p(out), B * R, C, R)
+        return out.transpose(1, 2).reshape(x.shape).contiguous()
+
+
+def conv1x1_forward(conv, x: torch.Tensor) -> torch.Tensor:
+    """nn.Conv1d(C_in, C_out, 1) on [B, C_in, L] as a row GEMM (dprnn_pointwise_fwd).  C_in up to 256 (zero-padded to 64 / 128 /
+    256: the 'cat' fusion's 192 channels), C_out a multiple of 128."""
+    x = _device_f32(x, "conv input")
+    _no_grad_only("Conv1d.forward", x, module=conv)
+    if x.dim() != 3 or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1 or conv.padding != (0,):
+        raise NotImplementedError("Conv1d MI355X path: 1x1 convolutions over [batch, channels, frames]")
+    B, cin, L = x.shape
+    cout = conv.out_channels
+    if cin != conv.in_channels or cin > 256 or cout % 128:
+        raise NotImplementedError(f"Conv1d MI355X path: in_channels <= 256 and out_channels a multiple of 128 (got {cin} -> {cout})")
+    dev = x.device
+    kdim = 64 if cin <= 64 else 128 if cin <= 128 else 256
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        w = _param(conv.weight, "conv.weight", dev).reshape(cout, cin)
+        if kdim == cin:
+            rows = x.transpose(1, 2).contiguous().view(B * L, cin)
+        else:                                                                # zero columns: plumbing, no arithmetic
+            rows = torch.zeros(B * L, kdim, device=dev, dtype=torch.float32)
+            rows.view(B, L, kdim)[:, :, :cin] = x.transpose(1, 2)
+            wp = torch.zeros(cout, kdim, device=dev, dtype=torch.float32)
+            wp[:, :cin] = w
+            w = wp
+        out = torch.empty(B * L, cout, device=dev, dtype=torch.float32)
+        bias = _param(conv.bias, "conv.bias", dev) if conv.bias is not None else None
+        for col0 in range(0, cout, 128):
+            st.call("dprnn_pointwise_fwd", _p(rows), kdim, kdim, 0, 0, 0, 0, 0, 0, _p(w), kdim, _p(bias), _p(out), cout, col0, 0, B * L)
+        return out.view(B, L, cout).transpose(1, 2).contiguous()
+
+
+def linear_forward(lin, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear on [..., in_features] through dprnn_linear_small_fwd (the per-utterance Linears: fusion_linear*, aux_linear,
+    pred_linear; dprnn_spe.py:88-105,123, dprnn_spe_ira.py:51)."""
+    x = _device_f32(x, "linear input")
+    _no_grad_only("Linear.forward", x, module=lin)
+    if x.shape[-1] != lin.in_features:
+        raise DprnnError(f"Linear expects {lin.in_features} input features, got {x.shape[-1]}")
+    dev = x.device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        flat = x.reshape(-1, lin.in_features).contiguous()
+        out = _linear_small(st, lin.weight, lin.bias, flat)
+        return out.view(*x.shape[:-1], lin.out_features)
+
+
+def fusion_forward(sep, emb: torch.Tensor, output: torch.Tensor, L: int) -> torch.Tensor:
+    """DPRNNSpe._fusion (dprnn_spe.py:165-229) on device tensors: emb [B, E], output [B, N, L] (already normalised) -> the fused
+    [B, C, L].  The per-utterance vectors come from dprnn_linear_small_fwd, the broadcast arithmetic runs in dprnn_rows_affine_fwd,
+    the 'att' scores / softmax / nearest upsampling in dprnn_att_row_scale_rows; 'cat' is a copy."""
+    output = _device_f32(output, "_fusion input")
+    emb = _device_f32(emb, "speaker embedding")
+    _no_grad_only("_fusion", output, emb, module=sep)
+    ft = sep.fusion_type
+    if ft == "cat":
+        return torch.cat((output, emb.unsqueeze(-1).expand(-1, -1, L)), dim=1)
+    B, N, _ = output.shape
+    dev = output.device
+    with torch.cuda.device(dev):
+        st = Stage(dev)
+        rows = output.transpose(1, 2).contiguous()                            # [B][L][N]
+        out = torch.empty_like(rows)
+        lin = lambda m: _linear_small(st, m.weight, m.bias, emb.contiguous())
+        if ft == "film":
+            st.call("dprnn_rows_affine_fwd", _p(rows), _p(lin(sep.fusion_linear_1)), _p(lin(sep.fusion_linear_2)), 0, _p(out), B * L, N, L)
+        elif ft == "add":
+            st.call("dprnn_rows_affine_fwd", _p(rows), 0, _p(lin(sep.fusion_linear)), 0, _p(out), B * L, N, L)
+        elif ft == "mul":
+            st.call("dprnn_rows_affine_fwd", _p(rows), _p(lin(sep.fusion_linear)), 0, 0, _p(out), B * L, N, L)
+        elif ft == "att":
+            a = lin(sep.fusion_linear)
+            ks_a = sep.average.kernel_size[0]
+            if sep.average.stride[0] != ks_a or sep.average.groups != N:
+                raise DprnnError("unexpected averaging conv geometry in the 'att' fusion")
+            La = (L - ks_a) // ks_a + 1
+            scores = torch.empty(B, La, device=dev, dtype=torch.float32)
+            row_scale = torch.empty(B, L, device=dev, dtype=torch.float32)
+            st.call("dprnn_att_row_scale_rows", _p(rows), N, 0, 0, _p(_param(sep.average.weight, "average.weight", dev)),
+                    _p(_param(sep.average.bias, "average.bias", dev)), _p(a), _p(scores), _p(row_scale), B, L, N, ks_a)
+            st.call("dprnn_rows_affine_fwd", _p(rows), _p(a), 0, _p(row_scale), _p(out), B * L, N, L)      # output * a * (att + 1)
+        else:
+            raise DprnnError(f"unknown fusion_type {ft!r}")
         return out.transpose(1, 2).contiguous()
 
 
@@ -1217,6 +1448,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     for i, blk in enumerate(blocks):
         for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
             _, fw, bw = _rnn_tensors(rnn, dev)
+            _set_slot(st.lib, path_slot(i, j == 1))
             st.call("dprnn_rnn_pack_ex", mode, 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
 
     m = total * F_BUILT
@@ -1243,6 +1475,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             ndir = 2 if rnn.rnn.bidirectional else 1
             pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
             hp = H_PIECES and mode == 3
+            _set_slot(st.lib, path_slot(i, not intra))
             st.call("dprnn_rnn_fwd_ragged_hp_ex" if hp else "dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
                     int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
                     K if intra else 0, K, ndir)
@@ -1269,11 +1502,13 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
         Hu = H[int(head_off[u]): int(head_off[u + 1])]                        # this utterance's U | V scratch
         U, V = Hu[: g.L * 2 * F_BUILT], Hu[g.L * 2 * F_BUILT: 2 * g.L * 2 * F_BUILT]
         assert V.numel() == g.L * 2 * F_BUILT
+        _set_slot(sg.lib, SLOT_HEAD_CONV)
         if pending is None:
             sg.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
         else:
             sg.call("dprnn_head_conv_ola_norm_fwd", _p(X[r0 * F_BUILT:]), _p(Z[r0 * F_BUILT:]), _p(pending[0][u]), _p(pending[1]),
                     _p(pending[2]), pending[3], *head_w, _p(U), 1, g.L, K, P, g.S)
+        _set_slot(sg.lib, SLOT_HEAD_GATE)
         sg.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
                 _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
                 _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), g.L * 2)
@@ -1297,7 +1532,7 @@ def _tasnet_forward_ragged_impl(model, wavs):
     cfg = model.cfg
     check_supported(cfg)
     dev = wavs[0].device
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
         st = Stage(dev)
         sep = model.separation
         enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
@@ -1314,6 +1549,7 @@ def _tasnet_forward_ragged_impl(model, wavs):
         fan = _Fan(st, len(ws))
         outs = [fan.run(u, lambda sg, u=u: decode(sg, taps[u], geos[u], 2)) for u in range(len(ws))]
         fan.join()
+        _scale_end(st, rec)
         return [o[0] for o in outs]
 
 
@@ -1324,7 +1560,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
     cfg = model.cfg
     check_supported_spe(cfg)
     dev = wavs[0].device
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
         st = Stage(dev)
         N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
         sep = model.separation
@@ -1343,7 +1579,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             geo_a = make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
             alen = _aux_len_tensor(aux_lens[u], 1, dev)
             sc_a, sh_a = bottleneck_affine(sg, axs[u], enc_w, se[0], geo_a, stats[u, 1])
-            A0 = bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a).view(geo_a.L, F_BUILT)
+            A0 = bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=SLOT_AUX_BOTTLENECK).view(geo_a.L, F_BUILT)
             v0 = speaker_embedding(sg, sep, A0, 1, geo_a.L, alen, ks)
             mul, add, row_bias = _fusion_operands(sg, sep, cfg, v0)
             sc, sh = bottleneck_affine(sg, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
@@ -1396,6 +1632,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
         fan = _Fan(st, n)
         r3 = [fan.run(u, lambda sg, u=u: last(sg, u)) for u in range(n)]
         fan.join()
+        _scale_end(st, rec)
         return [(est[0, 0, :], logits[0]) for est, logits in r3]
 
 
@@ -1470,17 +1707,21 @@ class _Graphed:
     def __init__(self, dev, fn, inputs, ep: _EnginePool):
         lib = load_library()
         self.ep, self.dev = ep, dev
-        self.graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize(dev)
         prev = getattr(_TLS, "guard", 0)
         _TLS.guard, _TLS.capturing = 1, True
+        # Captured OUTSIDE inference mode whatever the caller's state: tensors created under torch.inference_mode() are inference
+        # tensors -- the static inputs could then not be copied into from a plain no_grad caller, and torch's CUDA generator creates
+        # its graph-safe state tensors at the first capture of a process: made under inference mode they break every later capture
+        # outside it ("Inplace update to inference tensor outside InferenceMode", seen on the MI355X).  One graph serves both states.
         try:
-            self.inputs = [t.clone() for t in inputs]           # static inputs and flags: ordinary allocations (a few MB)
-            self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize(dev)
-            check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
-            with torch.cuda.graph(self.graph, pool=ep.pool.id, capture_error_mode="thread_local"):
-                self.outputs = fn(*self.inputs)
+            with torch.inference_mode(False), torch.no_grad():
+                self.graph = torch.cuda.CUDAGraph()
+                self.inputs = [t.clone() for t in inputs]           # static inputs and flags: ordinary allocations (a few MB)
+                self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize(dev)
+                check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
+                with torch.cuda.graph(self.graph, pool=ep.pool.id, capture_error_mode="thread_local"):
+                    self.outputs = fn(*self.inputs)
         finally:
             _TLS.guard, _TLS.capturing = prev, False
             lib.dprnn_saturation_begin(0, 0)
@@ -1507,9 +1748,7 @@ def _graph_key(kind: str, model, inputs, extra=()):
     bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
     knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
              SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
-             lib.dprnn_get_rowgemm_grid(), H_PIECES,
-             # static inputs cloned under inference_mode are inference tensors: a replay outside it could not copy into them
-             torch.is_inference_mode_enabled())
+             lib.dprnn_get_rowgemm_grid(), H_PIECES)
     return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
 
 
@@ -1531,7 +1770,7 @@ def _keep_eager(key, why: str) -> None:
                       "engine.GRAPH_STATS without a warning)", RuntimeWarning, stacklevel=4)
 
 
-def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), need_bytes=None):
+def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), need_bytes=None, owner=None):
     """fn(*inputs) -- an inference forward over device tensors -- eagerly, or through its captured HIP graph (see above); either
     way under the saturation guard, falling back to an eager forward in mode 1.  need_bytes: device memory the forward allocates
     (a number or a callable), checked against what is free before capturing."""
@@ -1540,7 +1779,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
     usable = (GRAPHS and PROFILE is None and getattr(_TLS, "guard", 0) == 0 and not getattr(_TLS, "capturing", False)
               and not torch.is_grad_enabled())
     if not usable:
-        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
     key = _graph_key(kind, model, inputs, extra)
     with _GRAPH_LOCK:
         g = _GRAPH_CACHE.get(key)
@@ -1554,7 +1793,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
             while len(_GRAPH_SEEN) > 64:
                 _GRAPH_SEEN.popitem(last=False)
     if g is None and seen < 2:
-        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
     with torch.cuda.device(dev):
         if g is None:
             ep = _engine_pool(dev)
@@ -1574,7 +1813,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                     if 1.1 * need > have:
                         _count(GRAPH_STATS, "kept_eager_for_memory")
                         _keep_eager(key, f"{what} needs about {need / 2**30:.1f} GiB, {have / 2**30:.1f} GiB are free on {dev}")
-                        return _guarded(dev, eager, _in_mode(1, eager), what, module)
+                        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
                 try:
                     g = _Graphed(dev, fn, inputs, ep)
                 except Exception as exc:          # out of memory in the pool, a synchronising call inside the forward, ...
@@ -1585,16 +1824,23 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                         pass
                     _keep_eager(key, f"capture of {what} raised {type(exc).__name__}: {exc}")
                     g = None
-            if g is None:
-                return _guarded(dev, eager, _in_mode(1, eager), what, module)
-            _count(GRAPH_STATS, "captures")
-            with _GRAPH_LOCK:
-                _GRAPH_CACHE[key] = g
+                if g is not None:
+                    _count(GRAPH_STATS, "captures")
+                    with _GRAPH_LOCK:
+                        _GRAPH_CACHE[key] = g
+                    # The new graph's FIRST launch happens here, still under the capture lock: graphs are destroyed only under this
+                    # lock (eviction above, drop_graphs), and a graph destroyed between another graph's instantiation and its first
+                    # launch is what crashed hipGraphLaunch in round 3 (profiles/r04_graph_churn.txt).
+                    return _replay_guarded(g, dev, inputs, eager, what, module, owner)
+            return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
+        return _replay_guarded(g, dev, inputs, eager, what, module, owner)
 
-        def run():
-            _count(GRAPH_STATS, "replays")
-            return g.replay(inputs)
-        return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags)
+
+def _replay_guarded(g, dev, inputs, eager, what, module, owner):
+    def run():
+        _count(GRAPH_STATS, "replays")
+        return g.replay(inputs)
+    return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner)
 
 
 def drop_graphs(release_pool: bool = True) -> None:
@@ -1635,23 +1881,31 @@ def _forward_bytes(model, wav, factor: float, aux=None) -> int:
     return int(need)
 
 
+def _pinned(model, fn):
+    """fn() under mode 1 when repeated saturation has pinned `model` there (see _guarded), else as is."""
+    if model.__dict__.get("_dprnn_pin_mode1", False) and current_mode() == 3:
+        with use_gemm_mode(1):
+            return fn()
+    return fn()
+
+
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
     wav = check_input(wav)
     if debug is not None:
         run = lambda: _tasnet_forward_impl(model, wav, debug)
-        return _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None)
-    return _graphed("tasnet", model, (wav,), lambda w: _tasnet_forward_impl(model, w, None), "DPRNNTasNet.forward",
-                    need_bytes=lambda: _forward_bytes(model, wav, 1.25))
+        return _pinned(model, lambda: _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None, owner=model))
+    return _pinned(model, lambda: _graphed("tasnet", model, (wav,), lambda w: _tasnet_forward_impl(model, w, None), "DPRNNTasNet.forward",
+                                           need_bytes=lambda: _forward_bytes(model, wav, 1.25), owner=model))
 
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
     wav, aux = check_input(wav), check_input(aux, "aux")
     if debug is not None:
         run = lambda: _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
-        return _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation)
+        return _pinned(model, lambda: _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation, owner=model))
     alen = _aux_len_tensor(aux_len, wav.shape[0], wav.device)          # a device tensor: one of the graph's inputs
-    return _graphed("ira" if ira else "spe", model, (wav, aux, alen), lambda w, a, n: _spe_forward_impl(model, w, a, n, ira, None),
-                    "DPRNNSpeTasNet.forward", model.separation, need_bytes=lambda: _forward_bytes(model, wav, 2.0, aux))
+    return _pinned(model, lambda: _graphed("ira" if ira else "spe", model, (wav, aux, alen), lambda w, a, n: _spe_forward_impl(model, w, a, n, ira, None),
+                                           "DPRNNSpeTasNet.forward", model.separation, need_bytes=lambda: _forward_bytes(model, wav, 2.0, aux), owner=model))
 
 
 def separator_masks(sep, frames: torch.Tensor):

@@ -27,11 +27,9 @@ class GlobLN(nn.Module):
     def forward(self, x, EPS: float = GLN_EPS):
         """norms.py:6-31 on a device tensor [B, C, ...]: glue for code that calls ``bottleneck[0](x)`` itself
         (src/models/dprnn_rawnet.py:85); the TasNet wrappers never call it -- their norms are folded into the HIP kernels
-        (dprnn_bottleneck_prep, dprnn_proj_stats_fwd + the consumers' loaders)."""
-        if not x.is_cuda:
-            raise DprnnError(f"GlobLN input is on {x.device}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
-        dims = tuple(range(1, x.dim()))
-        mean = x.mean(dim=dims, keepdim=True)
-        var = (x - mean).pow(2).mean(dim=dims, keepdim=True)               # biased, as torch.var(unbiased=False)
-        shape = (1, -1) + (1,) * (x.dim() - 2)
-        return (x - mean) / (var + EPS).sqrt() * self.gamma.view(shape) + self.beta.view(shape)
+        (dprnn_bottleneck_prep, dprnn_proj_stats_fwd + the consumers' loaders).  Here: dprnn_rows_stats +
+        dprnn_bottleneck_prep + dprnn_rows_affine_fwd."""
+        if EPS != GLN_EPS:
+            raise NotImplementedError("GlobLN MI355X path: the reference's eps (1e-8)")
+        from . import engine
+        return engine.norm_forward(self, x)
