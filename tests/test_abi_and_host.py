@@ -283,3 +283,26 @@ def test_bottleneck_selects_its_arithmetic_and_puts_the_library_mode_back():
     with pytest.raises(engine.DprnnError):
         engine.bottleneck_frames(*args, gemm_mode=3)
     assert st.lib.mode == 1
+
+
+def test_utterance_groups_partition_the_batch_and_leave_one_pipeline_only_while_it_fits_one_round():
+    """engine.group_parts / plan_groups (round 4): the groups are a balanced partition of the batch; a single pipeline is chosen only
+    while every recurrence launch of the batch fits ONE round of workgroups on the chip (16-sequence tiles, 3-s utterances: 194 chunks of
+    250 positions) -- beyond that a lone pipeline pays for a partly filled second round of every launch and throughput per utterance
+    drops when a caller adds utterances (profiles/r04_batch_sweep_before.txt: B = 9 was 11 % below B = 8)."""
+    from tss_with_dprnn_amd import engine
+    S, K, ncu = 194, 250, 256
+    for mode in (0, 3):
+        prev_n = 1
+        for B in range(1, 129):
+            parts = engine.group_parts(B, mode)
+            assert parts[0][0] == 0 and parts[-1][1] == B and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+            n = len(parts)
+            assert n == min(B, engine.plan_groups(B, mode)) and n >= prev_n          # never fewer pipelines for a larger batch
+            prev_n = n
+            if n == 1 and mode == 3:
+                for nseq in (B * S, B * K):                                        # intra- and inter-chunk launches, both directions
+                    assert 2 * -(-nseq // 16) <= ncu, (B, nseq)
+    assert engine.plan_groups(9, 3) == 2 and engine.plan_groups(64, 3) == 2 and engine.plan_groups(64, 0) == 4

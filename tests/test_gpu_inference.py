@@ -189,3 +189,92 @@ def test_ragged_full_config_against_cpu_oracle(split_gate_gemm):
     for i, x in enumerate(xs):
         want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(x)).numpy()[0]
         assert rel_l2(got[i].cpu().numpy(), want) <= 1e-5, (i, rel_l2(got[i].cpu().numpy(), want))
+
+
+@pytest.mark.parametrize("kind", ["bss", "spe"])
+def test_forward_async_keeps_forwards_in_flight_and_checks_them_at_the_ticket(kind):
+    """Round 4: engine.forward_async enqueues a forward WITHOUT the stream synchronisation of the saturation check and returns
+    (output, ticket); ticket.result() performs the 32-byte read.  Three forwards in flight (eager, capture + first replay, replay),
+    collected afterwards: each equals the synchronous forward of the same input, and every one was checked exactly once."""
+    from tss_with_dprnn_amd import engine
+    over = dict(chunk_length=50, hop_length=25, n_repeats=2)
+    if kind == "spe":
+        over.update(fusion_type="cat", norm_type="ln")
+    model, _, _ = build_model(kind, over, 31, DEV)
+    engine.drop_graphs()
+
+    def inputs(seed):
+        a = [torch.from_numpy(make_mixture(3, 3300, seed=seed)).to(DEV)]
+        if kind == "spe":
+            a += [torch.from_numpy(make_mixture(3, 3000, seed=seed + 50)).to(DEV), torch.tensor(3000.0)]
+        return a
+    first = lambda o: (o[0] if isinstance(o, tuple) else o)
+    before = dict(engine.SATURATION)
+    with torch.no_grad():
+        pending = [engine.forward_async(model, *inputs(s)) for s in (1, 2, 3, 1)]
+        assert engine.SATURATION["checks"] == before["checks"], "nothing is checked before a ticket is asked"
+        got = [first(t.result()).cpu().numpy() for _, t in pending]
+        assert engine.SATURATION["checks"] == before["checks"] + 4 and engine.SATURATION["fallbacks"] == before["fallbacks"]
+        for (out, t), g in zip(pending, got):
+            assert t.ready() and first(t.result()) is first(out)              # no fall-back: the ticket hands back the enqueued output
+        want = [first(model(*inputs(s))).cpu().numpy() for s in (1, 2, 3, 1)]
+    for g, w in zip(got, want):
+        assert rel_l2(g, w) < 1e-6
+    assert np.array_equal(got[0], got[3]) or rel_l2(got[0], got[3]) < 1e-6
+    with pytest.raises(NotImplementedError):
+        engine.forward_async(model, *inputs(1))                                # gradients enabled: not an inference call
+    engine.drop_graphs()
+
+
+def test_a_flagged_async_forward_still_returns_the_range_free_result():
+    """The asynchronous path keeps the safety of the synchronous one: a forward whose values leave the f16 range (norm gain x 3000,
+    adaptive scale off so that it saturates every time) comes back from ticket.result() as the mode-1 result, eager and replayed."""
+    import warnings
+    from tss_with_dprnn_amd import engine
+    model, sd, cfg = build_model("bss", dict(chunk_length=50, hop_length=25, n_repeats=2), 21, DEV)
+    sd = dict(sd)
+    key = "separation.dprnn_blocks.0.intra_norm.weight"
+    sd[key] = (np.asarray(sd[key]) * 3000.0).astype(np.float32)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    x = torch.from_numpy(make_mixture(3, 3100, seed=8)).to(DEV)
+    engine.drop_graphs()
+    old = engine.ADAPTIVE_SCALE
+    engine.ADAPTIVE_SCALE = False
+    try:
+        with torch.no_grad(), engine.use_gemm_mode(1):
+            want = model(x).cpu().numpy()
+        before = dict(engine.SATURATION)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            tickets = []
+            for _ in range(2):                                              # (a third would pin the model to mode 1)
+                out, t = engine.forward_async(model, x)
+                tickets.append((out, t))
+                engine.unpin(model)
+            got = [t.result().cpu().numpy() for _, t in tickets]
+            engine.unpin(model)
+        assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 2
+        for g in got:
+            assert rel_l2(g, want) < 1e-6
+    finally:
+        engine.ADAPTIVE_SCALE = old
+        engine.unpin(model)
+        engine.drop_graphs()
+
+
+def test_separate_many_async_equals_separate_many():
+    from tss_with_dprnn_amd import engine
+    from tss_with_dprnn_amd.inference import separate_many, separate_many_async
+    model, _, _ = build_model("bss", dict(chunk_length=50, hop_length=25, n_repeats=2), 21, DEV)
+    lengths = [3000, 4100, 3000, 2500, 4100, 3000, 3333, 2800, 3900, 2500]
+    wavs = [torch.from_numpy(make_mixture(1, n, seed=i)[0]).to(DEV) for i, n in enumerate(lengths)]
+    with torch.no_grad():
+        t1 = separate_many_async(model, wavs[:8])                              # ragged (>= 8 utterances)
+        t2 = separate_many_async(model, wavs[3:], max_streams=3, ragged=False)  # per-length pipelines
+        a, b = t1.result(), t2.result()
+        want = separate_many(model, wavs)
+    torch.cuda.synchronize()
+    for o, w in zip(a, want[:8]):
+        assert rel_l2(o.cpu().numpy(), w.cpu().numpy()) < 1e-6
+    for o, w in zip(b, want[3:]):
+        assert rel_l2(o.cpu().numpy(), w.cpu().numpy()) < 1e-6

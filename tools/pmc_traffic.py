@@ -63,6 +63,17 @@ def main():
                     "note": f"mean over the {n} recurrence launches of the profiled forwards ({fused} with the pending norm folded in: 7 slab "
                             f"units of {unit:.3f} GB, the others 4); the packed weight pieces come from L2.  traffic / algorithmic = "
                             f"{traffic / algo:.3f}"}
+    bw = {k: v for k, v in out["per_launch"].items() if k.startswith("lstm_bwd8_f16_kernel")}
+    if bw:
+        # training step: the BPTT launch of one 32-utterance micro-batch (bench.py --mode train: 64 utterances as 2 x 32), for
+        # bench.py's training roofline.traffic.  Algorithmic bytes per slab row and both directions: tape 2 x 128 units x 5 floats,
+        # dH 256 floats in; dG 1024 four-byte elements (f16 piece pairs in the quad layout) and dX 2 x 128 floats out = 11 264 B
+        n = sum(v["launches"] for v in bw.values())
+        traffic = sum(v["launches"] * (v["hbm_read_GB"] + v["hbm_write_GB"]) for v in bw.values()) / n
+        algo = 32 * 48500 * 11264 / 1e9
+        out["lstm_bwd8_f16_kernel"] = {"group_batch": 32, "traffic_GB_per_launch": round(traffic, 4), "algorithmic_GB_per_launch": round(algo, 4),
+                                       "note": f"mean over {n} BPTT launches; per slab row and both directions: tape 5120 B + dH 1024 B in, dG 4096 B + "
+                                               f"dX 1024 B out; traffic / algorithmic = {traffic / algo:.3f}"}
     json.dump(out, sys.stdout, indent=1)
 
 

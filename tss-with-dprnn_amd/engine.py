@@ -187,13 +187,14 @@ def _bn_buffers(module):
 
 
 def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None,
-             owner=None):
+             owner=None, begin: bool = True):
     """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
     f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
     fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
     flags come back with a 32-byte copy).  Nested calls are covered by the outermost guard.
     active: whether detection is needed at all (default: the thread's mode is 3).  flags: the device buffer to register (a captured
-    HIP graph's kernels carry the address of the buffer that was registered when they were captured)."""
+    HIP graph's kernels carry the address of the buffer that was registered when they were captured).  begin=False: primary()
+    clears and registers the flags itself (a graph replay does it inside its serialised section)."""
     if active is None:
         active = current_mode() == 3
     if not active or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
@@ -205,7 +206,8 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
             flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
         bufs = _bn_buffers(module)
         keep = [b.clone() for b in bufs]
-        check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
+        if begin:
+            check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
         _TLS.guard = 1
         host = (ctypes.c_int32 * SAT_SLOTS)()
         try:
@@ -221,35 +223,102 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
             if owner is not None:
                 owner.__dict__["_dprnn_sat_streak"] = 0
             return out
-        hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
-        n_fallbacks = _count(SATURATION, "fallbacks")
-        with _STATS_LOCK:
-            SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
-        msg = (f"{what}: the f16-pieces arithmetic met values beyond its range ({', '.join(hit)}: |x| > 4062 after scaling, or "
-               "Inf / NaN)")
-        if ON_SATURATION == "raise":
-            raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
-        if owner is not None:
-            # The activation-scale record has adapted by now (the saturated forward left its maxima): the next forward normally fits.
-            # A model that saturates again and again (values that grow from call to call, Inf / NaN inputs) stops paying twice.
-            streak = owner.__dict__.get("_dprnn_sat_streak", 0) + 1
-            owner.__dict__["_dprnn_sat_streak"] = streak
-            if streak >= PIN_AFTER_FALLBACKS and not owner.__dict__.get("_dprnn_pin_mode1", False):
-                owner.__dict__["_dprnn_pin_mode1"] = True
-                warnings.warn(f"{what}: {streak} consecutive forwards left the range of the f16-pieces arithmetic; this model now runs in "
-                              "gate-GEMM mode 1 (three bf16 pieces, no range assumption) -- engine.unpin(model) returns it to the default",
-                              RuntimeWarning, stacklevel=3)
-        if n_fallbacks == 1:
-            warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
-                          "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=3)
         del out
+        return _saturated(dev, list(host), what, bufs, keep, fallback, owner)
+
+
+class ForwardTicket:
+    """What forward_async / separate_many_async hand back beside the (enqueued, not yet checked) output: result() waits for the
+    forward's saturation flags -- 32 bytes copied to pinned host memory behind the forward's last kernel -- and returns the output, or,
+    when the f16-pieces arithmetic met a value beyond its range, the result of the same call repeated in a range-free arithmetic
+    (exactly what the synchronous call does; a caller that never asks keeps a possibly clamped output: always ask)."""
+
+    def __init__(self, dev, out, host, event, fallback, what, bufs, keep, owner):
+        self.dev, self._out, self._host, self._event = dev, out, host, event
+        self._fallback, self._what, self._bufs, self._keep, self._owner = fallback, what, bufs, keep, owner
+        self._done = host is None
+
+    def ready(self) -> bool:
+        """True once the forward and its flag copy have finished on the device (never blocks)."""
+        return self._done or self._event.query()
+
+    def result(self):
+        if self._done:
+            return self._out
+        self._event.synchronize()
+        self._done = True
+        host = [int(v) for v in self._host.tolist()]
+        _count(SATURATION, "checks")
+        if not any(host):
+            if self._owner is not None:
+                self._owner.__dict__["_dprnn_sat_streak"] = 0
+            return self._out
+        self._out = _saturated(self.dev, host, self._what, self._bufs, self._keep, self._fallback, self._owner)
+        return self._out
+
+
+def _saturated(dev, host, what, bufs, keep, fallback, owner):
+    """A forward's flags came back set: count it, say so (once), restore what the discarded forward changed, run the fall-back."""
+    hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
+    n_fallbacks = _count(SATURATION, "fallbacks")
+    with _STATS_LOCK:
+        SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
+    msg = (f"{what}: the f16-pieces arithmetic met values beyond its range ({', '.join(hit)}: |x| > 4062 after scaling, or "
+           "Inf / NaN)")
+    if ON_SATURATION == "raise":
+        raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
+    if owner is not None:
+        # The activation-scale record has adapted by now (the saturated forward left its maxima): the next forward normally fits.
+        # A model that saturates again and again (values that grow from call to call, Inf / NaN inputs) stops paying twice.
+        streak = owner.__dict__.get("_dprnn_sat_streak", 0) + 1
+        owner.__dict__["_dprnn_sat_streak"] = streak
+        if streak >= PIN_AFTER_FALLBACKS and not owner.__dict__.get("_dprnn_pin_mode1", False):
+            owner.__dict__["_dprnn_pin_mode1"] = True
+            warnings.warn(f"{what}: {streak} consecutive forwards left the range of the f16-pieces arithmetic; this model now runs in "
+                          "gate-GEMM mode 1 (three bf16 pieces, no range assumption) -- engine.unpin(model) returns it to the default",
+                          RuntimeWarning, stacklevel=4)
+    if n_fallbacks == 1:
+        warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
+                      "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=4)
+    with torch.cuda.device(dev):
         for b, k in zip(bufs, keep):
             b.copy_(k)
+        prev = getattr(_TLS, "guard", 0)
         _TLS.guard = 1                 # the fall-back arithmetic has no range assumption: nothing to detect
         try:
             return fallback()
         finally:
+            _TLS.guard = prev
+
+
+def _guarded_async(dev, primary, fallback, what: str, module=None, flags: Optional[torch.Tensor] = None, owner=None,
+                   begin: bool = True):
+    """_guarded without its stream synchronisation: primary() is enqueued, the flags travel to pinned host memory behind it, and
+    the check (with the repeat, if needed) happens in ForwardTicket.result().  Returns (output, ticket)."""
+    if current_mode() != 3 or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
+        out = primary()
+        return out, ForwardTicket(dev, out, None, None, None, what, [], [], owner)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        if flags is None:
+            flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
+        bufs = _bn_buffers(module)
+        keep = [b.clone() for b in bufs]
+        host = torch.empty(SAT_SLOTS, dtype=torch.int32).pin_memory()
+        if begin:
+            check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
+        _TLS.guard = 1
+        try:
+            out = primary(host) if not begin else primary()      # a graph replay copies its flags out inside its serialised section
+        finally:
             _TLS.guard = 0
+            lib.dprnn_saturation_begin(0, 0)
+        if begin:
+            host.copy_(flags, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(stream)
+        return out, ForwardTicket(dev, out, host, event, fallback, what, bufs, keep, owner)
 
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
@@ -600,11 +669,26 @@ def _leaves_exact_mode(fn):
     return run
 
 
-def _split_mode_parts(B: int):
-    """Utterance groups of the bf16-split modes: the wide kernels take one workgroup per CU, so few, large pipelines."""
-    n = max(1, min(SPLIT_GROUPS, B // 16))
+def _even_parts(B: int, n: int):
     cuts = [round(i * B / n) for i in range(n + 1)]
-    return [(cuts[i], cuts[i + 1]) for i in range(n)]
+    return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
+
+
+# Utterance groups by batch size (round 4; profiles/r04_batch_sweep.txt, r04_group_sweep.txt).  One group is best while its launches
+# fit one round of workgroups (16-sequence tiles: up to 8 utterances); beyond that a single pipeline pays for every partly filled
+# round of every launch (B = 9: the inter-chunk launch needs 282 workgroups on 256 CUs, a second round for 26 of them), and throughput
+# DROPPED when a caller added utterances: B = 9 was 11 % below B = 8, B = 11 / 17 / 22 likewise.  Two independent pipelines on two
+# streams fill each other's idle CUs -- measured +12 .. +25 % at B = 9 .. 24 in mode 3, +10 .. +13 % at B = 11 .. 44 in mode 0 -- so the
+# split modes run two groups from 9 utterances up (was: from 32), the exact mode two from 11 (was: from 24), three from 40, four from 56.
+def plan_groups(B: int, gemm_mode: int) -> int:
+    if gemm_mode != 0:
+        return 1 if B <= 8 else SPLIT_GROUPS
+    return 1 if B <= 10 else 2 if B < 40 else 3 if B < 56 else min(4, STREAM_GROUPS)
+
+
+def _split_mode_parts(B: int):
+    """Utterance groups of the split modes: the wide kernels take one workgroup per CU, so few, large pipelines."""
+    return _even_parts(B, max(1, min(plan_groups(B, 3), B)))
 
 
 def group_parts(B: int, gemm_mode: int):
@@ -620,11 +704,11 @@ def _split(B: int):
         for n_ in GROUP_SIZES:
             cuts.append(cuts[-1] + n_)
         return [(cuts[i], cuts[i + 1]) for i in range(len(GROUP_SIZES))]
-    # about MIN_GROUP_BATCH utterances per group, rounded to the nearest count (measured: B = 24 as 2 x 12 runs 11 %
-    # faster than as one group, B = 40 is better as 2 x 20 than as 3; tools/sweep_batch_groups.sh)
-    n = max(1, min(STREAM_GROUPS, round(B / MIN_GROUP_BATCH)))
-    cuts = [round(i * B / n) for i in range(n + 1)]
-    return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
+    if MIN_GROUP_BATCH != 16 or STREAM_GROUPS != 4:          # explicit knobs (bench.py --groups / --min-group, sweeps): the old rule
+        n = max(1, min(STREAM_GROUPS, round(B / MIN_GROUP_BATCH)))
+    else:
+        n = plan_groups(B, 0)
+    return _even_parts(B, n)
 
 
 @_leaves_exact_mode
@@ -863,8 +947,21 @@ def speaker_embedding(st: Stage, sep, A0, B: int, T: int, aux_len_dev, ks: int):
     return emb
 
 
+def _upload(host_tensor: torch.Tensor, dev) -> torch.Tensor:
+    """Host -> device without stalling the host: a copy from pageable memory is staged by the driver in stream order, so the host
+    waits for everything queued on that stream before it; pinned memory + non_blocking does not."""
+    if getattr(_TLS, "capturing", False):
+        raise DprnnError("host-to-device upload inside a graph capture")
+    return host_tensor.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
 def _aux_len_tensor(aux_len, B: int, dev):
-    t = torch.as_tensor(aux_len, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    if isinstance(aux_len, torch.Tensor) and aux_len.device == dev:
+        t = aux_len.to(torch.float32).reshape(-1).contiguous()
+    elif isinstance(aux_len, (int, float)) or (isinstance(aux_len, torch.Tensor) and aux_len.numel() == 1):
+        t = torch.full((1,), float(aux_len), dtype=torch.float32, device=dev)          # a fill kernel: no host-to-device copy at all
+    else:
+        t = _upload(torch.as_tensor(aux_len, dtype=torch.float32).reshape(-1), dev)
     if t.numel() not in (1, B):
         raise DprnnError(f"aux_len must be a scalar or hold one value per utterance (got {t.numel()} for batch {B})")
     return t
@@ -1324,11 +1421,14 @@ def fusion_forward(sep, emb: torch.Tensor, output: torch.Tensor, L: int) -> torc
         out = torch.empty_like(rows)
         lin = lambda m: _linear_small(st, m.weight, m.bias, emb.contiguous())
         if ft == "film":
-            st.call("dprnn_rows_affine_fwd", _p(rows), _p(lin(sep.fusion_linear_1)), _p(lin(sep.fusion_linear_2)), 0, _p(out), B * L, N, L)
+            mul, add = lin(sep.fusion_linear_1), lin(sep.fusion_linear_2)      # (both alive until the launch that reads them is enqueued)
+            st.call("dprnn_rows_affine_fwd", _p(rows), _p(mul), _p(add), 0, _p(out), B * L, N, L)
         elif ft == "add":
-            st.call("dprnn_rows_affine_fwd", _p(rows), 0, _p(lin(sep.fusion_linear)), 0, _p(out), B * L, N, L)
+            add = lin(sep.fusion_linear)
+            st.call("dprnn_rows_affine_fwd", _p(rows), 0, _p(add), 0, _p(out), B * L, N, L)
         elif ft == "mul":
-            st.call("dprnn_rows_affine_fwd", _p(rows), _p(lin(sep.fusion_linear)), 0, 0, _p(out), B * L, N, L)
+            mul = lin(sep.fusion_linear)
+            st.call("dprnn_rows_affine_fwd", _p(rows), _p(mul), 0, 0, _p(out), B * L, N, L)
         elif ft == "att":
             a = lin(sep.fusion_linear)
             ks_a = sep.average.kernel_size[0]
@@ -1435,7 +1535,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             r0 = int(starts[u]) + k0
             desc.append((r0 & 0xFFFFFFFF, r0 >> 32, int(chunks[u]), min(64, K - k0), int(u), 0, 0, 0))
     desc = np.array(desc, dtype=np.int64).astype(np.uint32).view(np.int32)
-    tables = torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), seq_utt, desc.reshape(-1)])).to(dev)
+    tables = _upload(torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), seq_utt, desc.reshape(-1)])), dev)
     o = 0
     utt_rows = tables[o: o + 2 * n]; o += 2 * n
     utt_starts = tables[o: o + 2 * (n + 1)]; o += 2 * (n + 1)
@@ -1726,16 +1826,21 @@ class _Graphed:
             _TLS.guard, _TLS.capturing = prev, False
             lib.dprnn_saturation_begin(0, 0)
 
-    def replay(self, inputs):
+    def replay(self, inputs, host_flags=None):
         ep = self.ep
+        lib = load_library()
         with ep.lock:                    # graphs of one pool share their workspace addresses: one at a time, in enqueue order
             cur = torch.cuda.current_stream(self.dev)
             if ep.last is not None:
                 cur.wait_event(ep.last)
+            # the graph's own flag buffer is cleared (and registered for the read that follows) behind the previous replay
+            check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), cur.cuda_stream), "dprnn_saturation_begin")
             for s_, t in zip(self.inputs, inputs):
                 s_.copy_(t)
             self.graph.replay()
             out = _clone_out(self.outputs)
+            if host_flags is not None:
+                host_flags.copy_(self.flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cur)
             ep.last = ev
@@ -1748,7 +1853,7 @@ def _graph_key(kind: str, model, inputs, extra=()):
     bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
     knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
              SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
-             lib.dprnn_get_rowgemm_grid(), H_PIECES)
+             lib.dprnn_get_rowgemm_grid(), H_PIECES, ADAPTIVE_SCALE, bool(model.__dict__.get("_dprnn_pin_mode1", False)))
     return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
 
 
@@ -1770,6 +1875,13 @@ def _keep_eager(key, why: str) -> None:
                       "engine.GRAPH_STATS without a warning)", RuntimeWarning, stacklevel=4)
 
 
+def _guard_call(dev, primary, fallback, what, module, owner):
+    """_guarded, or -- inside forward_async -- _guarded_async: (output, ticket)."""
+    if getattr(_TLS, "want_ticket", False):
+        return _guarded_async(dev, primary, fallback, what, module, owner=owner)
+    return _guarded(dev, primary, fallback, what, module, owner=owner)
+
+
 def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), need_bytes=None, owner=None):
     """fn(*inputs) -- an inference forward over device tensors -- eagerly, or through its captured HIP graph (see above); either
     way under the saturation guard, falling back to an eager forward in mode 1.  need_bytes: device memory the forward allocates
@@ -1779,7 +1891,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
     usable = (GRAPHS and PROFILE is None and getattr(_TLS, "guard", 0) == 0 and not getattr(_TLS, "capturing", False)
               and not torch.is_grad_enabled())
     if not usable:
-        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
+        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
     key = _graph_key(kind, model, inputs, extra)
     with _GRAPH_LOCK:
         g = _GRAPH_CACHE.get(key)
@@ -1793,7 +1905,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
             while len(_GRAPH_SEEN) > 64:
                 _GRAPH_SEEN.popitem(last=False)
     if g is None and seen < 2:
-        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
+        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
     with torch.cuda.device(dev):
         if g is None:
             ep = _engine_pool(dev)
@@ -1806,6 +1918,8 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                 torch.cuda.synchronize(dev)
                 del evicted
                 torch.cuda.empty_cache()
+                if owner is not None and ADAPTIVE_SCALE and current_mode() == 3:
+                    _scale_tensor(owner, dev)            # the activation-scale record exists before the capture (never allocated inside one)
                 need = need_bytes() if callable(need_bytes) else need_bytes
                 if need is not None:
                     free, _ = torch.cuda.mem_get_info(dev)
@@ -1813,7 +1927,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                     if 1.1 * need > have:
                         _count(GRAPH_STATS, "kept_eager_for_memory")
                         _keep_eager(key, f"{what} needs about {need / 2**30:.1f} GiB, {have / 2**30:.1f} GiB are free on {dev}")
-                        return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
+                        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
                 try:
                     g = _Graphed(dev, fn, inputs, ep)
                 except Exception as exc:          # out of memory in the pool, a synchronising call inside the forward, ...
@@ -1832,15 +1946,17 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                     # lock (eviction above, drop_graphs), and a graph destroyed between another graph's instantiation and its first
                     # launch is what crashed hipGraphLaunch in round 3 (profiles/r04_graph_churn.txt).
                     return _replay_guarded(g, dev, inputs, eager, what, module, owner)
-            return _guarded(dev, eager, _in_mode(1, eager), what, module, owner=owner)
+            return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
         return _replay_guarded(g, dev, inputs, eager, what, module, owner)
 
 
 def _replay_guarded(g, dev, inputs, eager, what, module, owner):
-    def run():
+    def run(host_flags=None):
         _count(GRAPH_STATS, "replays")
-        return g.replay(inputs)
-    return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner)
+        return g.replay(inputs, host_flags)
+    if getattr(_TLS, "want_ticket", False):
+        return _guarded_async(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
+    return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
 
 
 def drop_graphs(release_pool: bool = True) -> None:
@@ -1906,6 +2022,26 @@ def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dic
     alen = _aux_len_tensor(aux_len, wav.shape[0], wav.device)          # a device tensor: one of the graph's inputs
     return _pinned(model, lambda: _graphed("ira" if ira else "spe", model, (wav, aux, alen), lambda w, a, n: _spe_forward_impl(model, w, a, n, ira, None),
                                            "DPRNNSpeTasNet.forward", model.separation, need_bytes=lambda: _forward_bytes(model, wav, 2.0, aux), owner=model))
+
+
+def forward_async(model, *inputs):
+    """model(*inputs) without the host synchronisation that ends every synchronous forward in the default arithmetic (the read of
+    the saturation flags): returns (output, ticket).  The output is enqueued on the current stream like any torch result; it is
+    CHECKED only when ticket.result() is called, which returns it -- or, had a value left the f16 range, the range-free repeat.  A
+    caller can keep several forwards in flight (upload the next batch, compute metrics of the previous one) and collect the tickets
+    in order.  DPRNNTasNet, DPRNNSpeTasNet and DPRNNSpeIRATasNet, inference only."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        raise NotImplementedError("forward_async is an inference entry point (call it under torch.no_grad())")
+    if getattr(_TLS, "want_ticket", False) or getattr(_TLS, "guard", 0) > 0:
+        raise DprnnError("forward_async inside another guarded forward")
+    _TLS.want_ticket = True
+    try:
+        res = model(*inputs)
+    finally:
+        _TLS.want_ticket = False
+    if not (isinstance(res, tuple) and len(res) == 2 and isinstance(res[1], ForwardTicket)):
+        raise DprnnError(f"forward_async: {type(model).__name__}.forward did not go through the guarded inference path")
+    return res
 
 
 def separator_masks(sep, frames: torch.Tensor):

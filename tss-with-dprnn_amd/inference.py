@@ -75,6 +75,27 @@ def separate_many(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, ext
     return engine._guarded(dev, run, engine._in_mode(1, run), "separate_many", getattr(model, "separation", None))
 
 
+def separate_many_async(model, wavs: Sequence[torch.Tensor], max_streams: int = 8, extra_inputs=None, ragged=None):
+    """separate_many without its final host synchronisation: everything is enqueued, and an engine.ForwardTicket comes back whose
+    result() -- after the saturation flags of the whole call have arrived -- returns the list of outputs (or the range-free repeat's).
+    A caller keeps two such calls in flight: enqueue bucket k + 1, then collect bucket k (inferencer.BatchedInferencer)."""
+    from . import engine
+    if len(wavs) == 0:
+        return engine.ForwardTicket(None, [], None, None, None, "separate_many", [], [], None)
+    dev = wavs[0].device
+    if not all(w.is_cuda and w.dim() == 1 and w.dtype == torch.float32 for w in wavs):
+        raise DprnnError("separate_many expects 1-D float32 tensors on a HIP device")
+    run = lambda: _separate_many(model, wavs, max_streams, extra_inputs, ragged)
+    module = getattr(model, "separation", None)
+    if engine._bn_training(module) if module is not None else False:
+        # train-mode BatchNorm updates its running buffers per utterance, in order, and a discarded forward must put them back before
+        # the next one reads them: such models are not pipelined
+        outs = engine._guarded(dev, run, engine._in_mode(1, run), "separate_many", module)
+        return engine.ForwardTicket(dev, outs, None, None, None, "separate_many", [], [], None)
+    _, ticket = engine._guarded_async(dev, run, engine._in_mode(1, run), "separate_many", module)
+    return ticket
+
+
 def _separate_many(model, wavs, max_streams, extra_inputs, ragged) -> List:
     from . import engine
     dev = wavs[0].device

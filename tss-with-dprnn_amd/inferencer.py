@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from . import sharding
 from ._lib import DprnnError, check, load_library
-from .inference import pit_si_sdr, separate_many
+from .inference import RAGGED_MAX_UTTS, pit_si_sdr, separate_many, separate_many_async
 
 
 def si_sdr_metric(est: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
@@ -75,6 +75,26 @@ class BatchedInferencer:
             dist.all_reduce(full)                                 # disjoint supports: the sum is the gather
         return full
 
+    def _pipelined(self, mixes, extra=None):
+        """separate_many over buckets of RAGGED_MAX_UTTS utterances (longest first: a ragged batch then holds utterances of similar
+        length), two buckets in flight: while the device works on bucket k + 1 the host collects bucket k (its saturation check)
+        and the caller's metric kernels queue up behind it -- no host stall between buckets."""
+        order = sorted(range(len(mixes)), key=lambda j: -int(mixes[j].numel()))
+        outs = [None] * len(mixes)
+        pending = None
+        for c0 in range(0, len(order), RAGGED_MAX_UTTS):
+            idx = order[c0: c0 + RAGGED_MAX_UTTS]
+            ticket = separate_many_async(self.model, [mixes[j] for j in idx], self.max_streams,
+                                         extra_inputs=None if extra is None else [extra[j] for j in idx])
+            if pending is not None:
+                for j, o in zip(pending[0], pending[1].result()):
+                    outs[j] = o
+            pending = (idx, ticket)
+        if pending is not None:
+            for j, o in zip(pending[0], pending[1].result()):
+                outs[j] = o
+        return outs
+
     def run(self, test_set) -> Dict[str, float]:
         start = time.time()
         n = len(test_set)
@@ -82,7 +102,7 @@ class BatchedInferencer:
         mine = self._my_items([int(m.shape[-1]) for m, _ in items])
         mixes = [items[i][0].to(self.device).float().reshape(-1) for i in mine]
         with torch.no_grad():
-            outs = separate_many(self.model, mixes, self.max_streams)
+            outs = self._pipelined(mixes)
             rows = []
             for i, mix, out in zip(mine, mixes, outs):
                 src = items[i][1].to(self.device).float()
@@ -103,7 +123,7 @@ class BatchedInferencer:
         mixes = [items[i][0].to(self.device).float().reshape(-1) for i in mine]
         extra = [(items[i][2].to(self.device).float().reshape(-1), float(items[i][2].shape[-1])) for i in mine]
         with torch.no_grad():
-            outs = separate_many(self.model, mixes, self.max_streams, extra_inputs=extra)
+            outs = self._pipelined(mixes, extra)
             rows = []
             for i, mix, (est, _) in zip(mine, mixes, outs):
                 tgt = items[i][1].to(self.device).float().reshape(1, 1, -1)
