@@ -358,3 +358,29 @@ def test_spe_cat_batch_b64_full_size():
     rl = rel_l2(logits.cpu().numpy()[pick], wl.numpy())
     assert r <= 1e-5 and rl <= 1e-5, (r, rl)
     print(f"DPRNN-Spe (cat) B=64 x 24000: rel-L2 vs CPU oracle {r:.2e} (logits {rl:.2e}); worst batched-vs-single {worst:.2e}")
+
+
+def test_a_nan_sample_reaches_the_caller_of_a_sub_module_as_nan():
+    """The f16-pieces conversion clamps and its maximum tracking skips NaN: the sub-module entry points (which do not pass through the
+    bottleneck's statistics, where full forwards are checked) test their input for non-finite values and repeat in the range-free
+    arithmetic, so SingleRNN / DPRNNBlock return NaN where the reference would -- never finite numbers made from a clamped NaN."""
+    import warnings
+    from conftest import build_model
+    from tss_with_dprnn_amd import engine
+    model, _, _ = build_model("bss", dict(chunk_length=16, hop_length=8, n_repeats=1), 77, DEV)
+    blk = model.separation.dprnn_blocks[0]
+    x = torch.randn(3, 20, 128, device=DEV)
+    x[1, 7, 5] = float("nan")
+    before = dict(engine.SATURATION)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        h = blk.intra_rnn(x)
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 1 and engine.SATURATION["last_flags"][5] == 1
+    assert torch.isnan(h[1]).any() and torch.isfinite(h[0]).all() and torch.isfinite(h[2]).all()
+    xb = torch.randn(2, 128, 16, 9, device=DEV)
+    xb[0, 3, 2, 1] = float("inf")
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        y = blk(xb)
+    assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 2
+    assert not torch.isfinite(y[0]).all() and torch.isfinite(y[1]).all()

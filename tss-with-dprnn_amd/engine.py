@@ -109,6 +109,7 @@ def use_gemm_mode(mode: int):
 # forwards run in mode 3 under a scale that fits.  DPRNN_ADAPTIVE_SCALE=0: the constant 2^4 of rounds 2 and 3.
 ADAPTIVE_SCALE = os.environ.get("DPRNN_ADAPTIVE_SCALE", "1") != "0"
 SLOT_BOTTLENECK, SLOT_AUX_BOTTLENECK, SLOT_HEAD_CONV, SLOT_HEAD_GATE, SLOT_PATH0 = 0, 1, 2, 3, 4
+SAT_NONFINITE = 5              # DPRNN_SAT_NONFINITE (csrc/common.h)
 PIN_AFTER_FALLBACKS = 2          # consecutive saturated forwards after which a model stays in mode 1
 
 
@@ -187,14 +188,17 @@ def _bn_buffers(module):
 
 
 def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None,
-             owner=None, begin: bool = True):
+             owner=None, begin: bool = True, finite_inputs=None):
     """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
     f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
     fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
     flags come back with a 32-byte copy).  Nested calls are covered by the outermost guard.
     active: whether detection is needed at all (default: the thread's mode is 3).  flags: the device buffer to register (a captured
     HIP graph's kernels carry the address of the buffer that was registered when they were captured).  begin=False: primary()
-    clears and registers the flags itself (a graph replay does it inside its serialised section)."""
+    clears and registers the flags itself (a graph replay does it inside its serialised section).  finite_inputs: tensors whose
+    NaN / Inf content must raise the non-finite flag here -- the entry points that do not pass through dprnn_bottleneck_prep (where
+    every full forward's input is checked): a float maximum skips NaN and the f16 conversion clamps it, so without this a NaN sample
+    would come back as finite numbers from SingleRNN / DPRNNBlock / _dprnn_process / _auxiliary where the reference returns NaN."""
     if active is None:
         active = current_mode() == 3
     if not active or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
@@ -211,6 +215,8 @@ def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bo
         _TLS.guard = 1
         host = (ctypes.c_int32 * SAT_SLOTS)()
         try:
+            for t in (finite_inputs or ()):              # one reduction per input, OR-ed into the flag record on the device: no extra sync
+                flags[SAT_NONFINITE: SAT_NONFINITE + 1].bitwise_or_(torch.isfinite(t).all().logical_not().to(torch.int32).view(1))
             out = primary()
             rc = lib.dprnn_saturation_flags(ctypes.addressof(host), stream.cuda_stream)
         finally:
@@ -1212,7 +1218,7 @@ def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
             st.call("dprnn_rnn_fwd_ex", mode, cell, _p(xc), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), n, T, n, 0, T, 1, ndir, tile)
             _scale_end(st, rec)
             return H
-    return _guarded(dev, run, _in_mode(1, run), "SingleRNN.forward")
+    return _guarded(dev, run, _in_mode(1, run), "SingleRNN.forward", finite_inputs=[x])
 
 
 def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
@@ -1257,7 +1263,7 @@ def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
                 st.lib.dprnn_set_gemm_mode(prev)
             _scale_end(st, rec)
             return g.X.view(B, S, K, F_BUILT).permute(0, 3, 2, 1).contiguous()
-    return _guarded(dev, run, _in_mode(1, run), "DPRNNBlock.forward")
+    return _guarded(dev, run, _in_mode(1, run), "DPRNNBlock.forward", finite_inputs=[x])
 
 
 def encoder_forward(enc, wav: torch.Tensor) -> torch.Tensor:
@@ -2047,7 +2053,7 @@ def forward_async(model, *inputs):
 def separator_masks(sep, frames: torch.Tensor):
     frames = _check_frames(frames, F_BUILT, "bottleneck output")
     run = lambda: _separator_masks_impl(sep, frames)
-    return _guarded(frames.device, run, _in_mode(1, run), "DPRNN._dprnn_process", None)
+    return _guarded(frames.device, run, _in_mode(1, run), "DPRNN._dprnn_process", None, finite_inputs=[frames])
 
 
 def separator_forward(sep, enc: torch.Tensor):
@@ -2059,7 +2065,7 @@ def separator_forward(sep, enc: torch.Tensor):
 def auxiliary_embedding(sep, aux: torch.Tensor, aux_len):
     aux = _check_frames(aux, sep.input_size, "aux")
     run = lambda: _auxiliary_embedding_impl(sep, aux, aux_len)
-    return _guarded(aux.device, run, _in_mode(1, run), "DPRNNSpe._auxiliary", sep.spk_encoder)
+    return _guarded(aux.device, run, _in_mode(1, run), "DPRNNSpe._auxiliary", sep.spk_encoder, finite_inputs=[aux])
 
 
 def tasnet_forward_ragged(model, wavs):
