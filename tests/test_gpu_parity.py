@@ -266,8 +266,10 @@ def test_headline_batch_b64_full_size():
     print(f"B=64 x 24000: rel-L2 vs CPU oracle {r:.2e}; worst batched-vs-single {worst:.2e}")
 
 
-# every forward golden at the width the HIP path is built for (the "tiny" ones pin the oracle only; grad_* are training steps)
-FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_") and "tiny" not in n]
+# every forward golden (grad_* are training steps).  Since round 4 that includes the widths BELOW the kernels' build -- the 14 "tiny"
+# fixtures (input_size 8, feature / hidden 16, speaker encoder 16 / 24 / 12) and the *_narrow_* ones: they run as zero-padded twins
+# (tss-with-dprnn_amd/padded.py), so they pin the HIP path too, not only the oracle.
+FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_")]
 
 
 @pytest.mark.parametrize("mode", [0, 1, 3])
@@ -442,6 +444,58 @@ def test_repeated_saturation_pins_the_model_to_mode_1():
     with torch.no_grad():
         model(good)
     assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 2 and not model.__dict__["_dprnn_pin_mode1"]
+
+
+def test_narrow_models_run_as_zero_padded_twins_and_follow_their_parameters():
+    """padded.py: a model narrower than the kernels' build is computed on a twin at the built widths whose extra rows / columns are
+    zero.  The twin follows the model (an in-place parameter update shows in the next forward, graph replay included), train-mode
+    BatchNorm statistics land in the NARROW model's buffers as torch's own modules would leave them, widths above the build and
+    training a narrow model raise."""
+    import warnings
+    from tss_with_dprnn_amd import padded
+    over = dict(input_size=48, feature_size=64, hidden_size=64, O=64, P=96, embeddings_size=40, chunk_length=16, hop_length=8, n_repeats=1,
+                fusion_type="cat", norm_type="ln")
+    model, sd, cfg = build_model("spe", over, 64, _dev())
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.train()
+    mix, aux = make_mixture(3, 400, seed=1), make_mixture(3, 350, seed=2)
+    args = (torch.from_numpy(mix).to(_dev()), torch.from_numpy(aux).to(_dev()), torch.tensor(350.0))
+    ref_bufs = {k: v.clone() for k, v in model.named_buffers()}
+    with torch.no_grad():
+        est, logits = model(*args)
+    want, wlog = otc.spe_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(350.0), training_bn=True)
+    _close(est.cpu().numpy(), want.numpy(), "narrow Spe, BatchNorm in train mode")
+    assert rel_l2(logits.cpu().numpy(), wlog.numpy()) <= REL_TOL
+    # the running statistics moved in the caller's model (real channels only), one step of momentum 0.1 from (0, 1)
+    bn = model.separation.spk_encoder[2].batch_norm1
+    assert int(bn.num_batches_tracked) == 1 and bn.running_mean.shape == (64,)
+    assert not torch.equal(bn.running_mean, ref_bufs["separation.spk_encoder.2.batch_norm1.running_mean"])
+    assert float((bn.running_var - 0.9).abs().max()) < 0.2 + 1.0                     # 0.9 * 1 + 0.1 * batch variance, finite
+    tw = model.__dict__["_dprnn_twin"]
+    assert isinstance(tw, padded.Twin) and tw.model.cfg["feature_size"] == 128 and tw.model.cfg["input_size"] == 64
+    # eval mode, replays, and an optimizer-style in-place update of the narrow parameters
+    model.eval()
+    with torch.no_grad():
+        a = [model(*args)[0].cpu().numpy() for _ in range(3)]
+        for prm in model.parameters():
+            prm.mul_(1.01)
+        b = model(*args)[0].cpu().numpy()
+    assert np.array_equal(a[1], a[2]) and rel_l2(a[0], a[1]) < 1e-6
+    sd2 = {k: (np.asarray(v) * np.float32(1.01) if k in dict(model.named_parameters()) else np.asarray(v)) for k, v in sd.items()}
+    sd2.update({k: v.detach().cpu().numpy() for k, v in model.named_buffers()})
+    want2 = otc.spe_forward(otc.to_torch_state(sd2), cfg, torch.from_numpy(mix), torch.from_numpy(aux), torch.tensor(350.0))[0].numpy()
+    _close(b, want2, "narrow Spe after an in-place parameter update")
+    assert rel_l2(b, a[0]) > 1e-4
+    # beyond the build, and training
+    import tss_with_dprnn_amd as pkg
+    big = pkg.DPRNNTasNet(64, 256, 256, 16, 2, 8, 1).to(_dev()).eval()
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="above the kernels' build"):
+        big(torch.from_numpy(make_mixture(1, 300, seed=3)).to(_dev()))
+    model.train()
+    with pytest.raises(NotImplementedError, match="zero-padded twin"):
+        model(*args)
+    engine.drop_graphs()
 
 
 def test_in_range_forwards_do_not_fall_back():

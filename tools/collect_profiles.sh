@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the evidence behind bench.py's numbers.  Outputs under gpurun_out/$1_*; tools/rocpd_kernel_stats.py
 # and tools/pmc_traffic.py turn them into the files committed under profiles/.
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 set -o pipefail
 export DPRNN_GRAPHS=0        # eager launches: one trace record per kernel of every forward (a replayed graph is one launch)

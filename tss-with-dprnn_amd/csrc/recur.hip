@@ -21,6 +21,9 @@
 //   * c stays in registers for the whole sequence; h goes registers -> LDS (next step's operand) and
 //     registers -> HBM (64-byte segments, merged in L2).
 #include "recur.h"
+#ifndef DPRNN_CELL_SHARED_RCP
+#define DPRNN_CELL_SHARED_RCP 1       // inference builds of the LSTM cell: shared reciprocals (common.h: lstm_cell_shared2)
+#endif
 #ifndef DPRNN_CELL_PRIO
 #define DPRNN_CELL_PRIO 1
 #endif
@@ -394,12 +397,29 @@ void bilstm_kernel(RecurArgs a) {
                     // LSTM, gate order i,f,g,o (torch.nn.LSTM), two sequences per instruction where the arithmetic allows
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const f32x2 ig = sigmoid_b2<FAST>(f32x2{acc[nt][0][u][2 * p], acc[nt][0][u][2 * p + 1]}, bias[0][u]);
-                        const f32x2 fg = sigmoid_b2<FAST>(f32x2{acc[nt][1][u][2 * p], acc[nt][1][u][2 * p + 1]}, bias[1][u]);
-                        const f32x2 gg = tanh_b2<FAST>(f32x2{acc[nt][2][u][2 * p], acc[nt][2][u][2 * p + 1]}, bias[2][u]);
-                        const f32x2 og = sigmoid_b2<FAST>(f32x2{acc[nt][3][u][2 * p], acc[nt][3][u][2 * p + 1]}, bias[3][u]);
-                        const f32x2 cn = fg * f32x2{c[nt][u][2 * p], c[nt][u][2 * p + 1]} + ig * gg;
-                        const f32x2 h2 = og * tanh_f2<FAST>(cn);
+                        f32x2 ig, fg, gg, og, cn, h2;
+                        bool separate = true;
+                        if constexpr (FAST && !SAVE && DPRNN_CELL_SHARED_RCP && NT < 4) {      // (the 64-sequence tile has no register left for it: 6 spills)
+                            // inference, hardware activations: two reciprocals per unit-step instead of five (common.h: lstm_cell_shared2).
+                            // On the fp32 MFMA every vector instruction costs matrix time (the shared datapath), transcendentals most:
+                            // 48 fewer v_rcp_f32 per wave and step.  The tape of the training forward wants the gates themselves, so
+                            // SAVE keeps the separate forms.  A pair out of the shared quotient's range is recomputed (wave-uniform).
+                            float dmax = 0.f;
+                            const f32x2 ai = f32x2{acc[nt][0][u][2 * p], acc[nt][0][u][2 * p + 1]} * f32x2{-1.4426950408889634f, -1.4426950408889634f} + f32x2{bias[0][u], bias[0][u]};
+                            const f32x2 af = f32x2{acc[nt][1][u][2 * p], acc[nt][1][u][2 * p + 1]} * f32x2{-1.4426950408889634f, -1.4426950408889634f} + f32x2{bias[1][u], bias[1][u]};
+                            const f32x2 ag = f32x2{acc[nt][2][u][2 * p], acc[nt][2][u][2 * p + 1]} * f32x2{2.8853900817779268f, 2.8853900817779268f} + f32x2{bias[2][u], bias[2][u]};
+                            const f32x2 ao = f32x2{acc[nt][3][u][2 * p], acc[nt][3][u][2 * p + 1]} * f32x2{-1.4426950408889634f, -1.4426950408889634f} + f32x2{bias[3][u], bias[3][u]};
+                            lstm_cell_shared2(ai, af, ag, ao, f32x2{c[nt][u][2 * p], c[nt][u][2 * p + 1]}, cn, h2, dmax);
+                            separate = __builtin_amdgcn_ballot_w64(!(dmax < 0x1p100f)) != 0ull;
+                        }
+                        if (separate) {
+                            ig = sigmoid_b2<FAST>(f32x2{acc[nt][0][u][2 * p], acc[nt][0][u][2 * p + 1]}, bias[0][u]);
+                            fg = sigmoid_b2<FAST>(f32x2{acc[nt][1][u][2 * p], acc[nt][1][u][2 * p + 1]}, bias[1][u]);
+                            gg = tanh_b2<FAST>(f32x2{acc[nt][2][u][2 * p], acc[nt][2][u][2 * p + 1]}, bias[2][u]);
+                            og = sigmoid_b2<FAST>(f32x2{acc[nt][3][u][2 * p], acc[nt][3][u][2 * p + 1]}, bias[3][u]);
+                            cn = fg * f32x2{c[nt][u][2 * p], c[nt][u][2 * p + 1]} + ig * gg;
+                            h2 = og * tanh_f2<FAST>(cn);
+                        }
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             const int e = 2 * p + k;

@@ -396,9 +396,10 @@ def check_supported(cfg: dict) -> None:
     """Fail loudly for constructor settings the HIP kernels are not built for."""
     bad = []
     if cfg["feature_size"] != F_BUILT or cfg["hidden_size"] != F_BUILT:
-        bad.append(f"feature_size/hidden_size must be {F_BUILT} (got {cfg['feature_size']}/{cfg['hidden_size']})")
+        bad.append(f"feature_size/hidden_size must be {F_BUILT} here (got {cfg['feature_size']}/{cfg['hidden_size']}; narrower models run "
+                   "INFERENCE through a zero-padded twin, padded.py -- the backward kernels are built for the shipped widths)")
     if cfg["input_size"] != N_BUILT:
-        bad.append(f"input_size must be {N_BUILT} (got {cfg['input_size']})")
+        bad.append(f"input_size must be {N_BUILT} here (got {cfg['input_size']}; narrower: inference only, padded.py)")
     if cfg["rnn_type"] not in CELL_ID:
         bad.append(f"rnn_type {cfg['rnn_type']!r}: torch.nn has LSTM, GRU and RNN recurrences")
     if cfg["kernel_size"] > KS_MAX:
@@ -413,6 +414,14 @@ def check_supported(cfg: dict) -> None:
         bad.append("hop_length must be in [1, chunk_length]")
     if bad:
         raise NotImplementedError("DPRNN MI355X path: unsupported configuration: " + "; ".join(bad))
+
+
+def _count_scale(stats_slot: torch.Tensor, norm) -> None:
+    """Zero-padded twins of narrow models (padded.py): the kernels divide a global norm's sums by rows x BUILT channels; scaling
+    (sum, sum of squares) by built / real channels makes that rows x REAL channels for the mean and the second moment alike."""
+    f = norm.__dict__.get("_dprnn_count_scale", 1.0)
+    if f != 1.0:
+        stats_slot.mul_(f)
 
 
 def _norm_params(norm: torch.nn.Module):
@@ -449,6 +458,7 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
     dev = wav.device
     gamma, beta, eps = _norm_params(bott_norm)
     st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_slot), geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
+    _count_scale(stats_slot, bott_norm)
     sc = torch.empty(geo.B, geo.N, device=dev, dtype=torch.float32)
     sh = torch.empty_like(sc)
     st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(_param(gamma, "norm.weight", dev)),
@@ -457,7 +467,7 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
 
 
 def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bias=None, row_scale=None, gemm_mode=None,
-                      scale_slot: int = SLOT_BOTTLENECK):
+                      scale_slot: int = SLOT_BOTTLENECK, min_floats: int = 0):
     """1x1 conv of the normalised encoder output -> Y [B][L][F] (dprnn.py:135-136,169; 'cat' fusion as row_bias,
     'att' fusion as row_scale).  gemm_mode: arithmetic of the product (3: f16 pieces like the Linears and the mask head, else the
     fp32 MFMA); default GEMM_MODE's.  This call comes before dprnn_process selects the forward's mode, so it selects its own and
@@ -466,7 +476,9 @@ def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bi
     w = _param(conv.weight, "conv.weight", dev)
     if w.shape[0] != F_BUILT or w.shape[1] < geo.N:
         raise DprnnError(f"1x1 conv weight {tuple(w.shape)} does not fit the {geo.N}->{F_BUILT} kernel")
-    Y = torch.empty(geo.B, geo.L, F_BUILT, device=dev, dtype=torch.float32)
+    # min_floats: the block is sized so that, once the frames are segmented and released, a group's slab fits into it
+    nY = geo.B * geo.L * F_BUILT
+    Y = torch.empty(max(nY, min_floats), device=dev, dtype=torch.float32)[:nY].view(geo.B, geo.L, F_BUILT)
     mode = current_mode() if gemm_mode is None else gemm_mode
     prev = st.lib.dprnn_get_gemm_mode()
     st.lib.dprnn_set_gemm_mode(3 if mode == 3 else 0)
@@ -486,10 +498,10 @@ def bottleneck_frames(st: Stage, wav, enc_w, sc, sh, conv, geo: Geometry, row_bi
 
 
 def frames_from_waveform(st: Stage, wav, enc_w, bott_norm, bott_conv, geo: Geometry, stats_slot,
-                         mul=None, add=None, row_bias=None):
+                         mul=None, add=None, row_bias=None, min_floats: int = 0):
     """Encoder -> bottleneck norm -> (fusion) -> bottleneck 1x1 conv, output Y [B][L][F]."""
     sc, sh = bottleneck_affine(st, wav, enc_w, bott_norm, geo, stats_slot, mul, add)
-    return bottleneck_frames(st, wav, enc_w, sc, sh, bott_conv, geo, row_bias)
+    return bottleneck_frames(st, wav, enc_w, sc, sh, bott_conv, geo, row_bias, min_floats=min_floats)
 
 
 # Side streams of the utterance groups: the SAME streams for every forward of a (thread, device).  torch.cuda.Stream() hands out
@@ -545,19 +557,26 @@ class _Group:
     def __init__(self, st: Stage, geo: Geometry, b0: int, b1: int, dev):
         self.st, self.b0, self.b1 = st, b0, b1
         self.geo = Geometry(b1 - b0, geo.T, geo.L, geo.K, geo.P, geo.S, geo.ks, geo.stride, geo.N)
-        # one arena: X [rows][F] | X2 [rows][F] | Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region.
+        # X [rows][F], X2 [rows][F], Z [rows][F] | H [rows][2F]; U and V (mask head) reuse the H region.
         # X / X2 ping-pong when the norm is folded into the next recurrence (both directions read the old slab).
+        # Allocated in two steps: X before the segmentation (its target), the rest after the bottleneck frames have been released --
+        # the first group's X2 then takes the frames' block (bottleneck_frames sizes it for that), which keeps the peak of a forward,
+        # and with it the pool of a captured one, one slab smaller.
         ws = workspace_parts(self.geo, 0)
-        n, h_floats = ws["X"] // 4, ws["H"] // 4
-        assert n == self.geo.rows * F_BUILT and ws["X2"] == ws["Z"] == ws["X"]
-        self.arena = torch.empty(3 * n + h_floats, device=dev, dtype=torch.float32)
-        self.X = self.arena[:n]
-        self.X2 = self.arena[n: 2 * n]
-        self.Z = self.arena[2 * n: 3 * n]
-        self.H = self.arena[3 * n:]
+        self._n, self._h, self._dev = ws["X"] // 4, ws["H"] // 4, dev
+        assert self._n == self.geo.rows * F_BUILT and ws["X2"] == ws["Z"] == ws["X"]
+        self.X = torch.empty(self._n, device=dev, dtype=torch.float32)
+        self.X2 = self.Z = self.H = None
+        self.buffers = [self.X]
         self.pending = None           # (stats_slot, gamma, beta, eps) of a norm not yet applied to X
         self.n_concurrent = 1         # utterance groups in flight together (set by dprnn_process)
         self.mode = 0                 # gate-GEMM mode of this forward (set by dprnn_process; the packed weights are in it)
+
+    def alloc_rest(self):
+        self.X2 = torch.empty(self._n, device=self._dev, dtype=torch.float32)
+        zh = torch.empty(self._n + self._h, device=self._dev, dtype=torch.float32)
+        self.Z, self.H = zh[: self._n], zh[self._n:]
+        self.buffers += [self.X2, zh]
 
 
 def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool, scale_slot: int = SLOT_PATH0):
@@ -608,6 +627,7 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     else:
         st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
                 geo.rows, S * K, ndir * F_BUILT)
+    _count_scale(stats_slot, norm)
     gamma, beta, eps = _norm_params(norm)
     gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
     if fuse:
@@ -774,6 +794,8 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             for g in groups:
                 Y.record_stream(g.st.tstream)       # read by the groups' streams: the allocator waits for them before it reuses the block
         del Y
+    for g in groups:
+        g.alloc_rest()
     for i, blk in enumerate(blocks):
         for intra in (True, False):
             rnn, lin, norm = (blk.intra_rnn, blk.intra_linear, blk.intra_norm) if intra else \
@@ -822,7 +844,8 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
             done.record(g.st.tstream)
             st.tstream.wait_event(done)
             if not getattr(_TLS, "capturing", False):       # a captured graph owns its memory pool: nothing to hand over
-                g.arena.record_stream(g.st.tstream)
+                for buf in g.buffers:
+                    buf.record_stream(g.st.tstream)
     return (taps, masked) if want_masked else taps
 
 
@@ -861,7 +884,9 @@ def _tasnet_forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None)
         enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
         dec_w = _param(model.decoder.weight, "decoder.weight", dev)
         stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), geo.B, 2, device=dev, dtype=torch.float64)
-        frames = [frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0])]
+        first = group_parts(geo.B, effective_gemm_mode(geo.B, list(sep.dprnn_blocks)))[0] if debug is None else (0, geo.B)
+        frames = [frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0],
+                                       min_floats=(first[1] - first[0]) * geo.S * geo.K * F_BUILT)]
         if debug is not None:
             debug["bottleneck"] = frames[0].clone()
         taps = dprnn_process(st, sep, frames, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
@@ -1056,6 +1081,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
                                      want_masked=True)
             # second embedding from the first estimate d0 = mask0 * enc  (dprnn_spe_ira.py:79-92)
             st.call("dprnn_rows_stats", _p(d0), _p(stats[-2]), B, geo.L, N)
+            _count_scale(stats[-2], se[0])
             g0, b0, _ = _norm_params(se[0])
             sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
             sh_d = torch.empty_like(sc_d)
@@ -1138,6 +1164,7 @@ def _rows_affine(st: Stage, x_cl, norm, B: int, L: int, N: int):
     dev = x_cl.device
     stats = torch.zeros(B, 2, device=dev, dtype=torch.float64)
     st.call("dprnn_rows_stats", _p(x_cl), _p(stats), B, L, N)
+    _count_scale(stats, norm)
     gamma, beta, eps = _norm_params(norm)
     sc = torch.empty(B, N, device=dev, dtype=torch.float32)
     sh = torch.empty_like(sc)
@@ -1596,6 +1623,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             else:
                 st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
                         total, _p(utt_starts), n, ndir * F_BUILT)
+            _count_scale(stats[slot], norm)
             gamma, beta, eps = _norm_params(norm)
             pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
 
@@ -1708,6 +1736,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             def second(sg, u):
                 geo = geos[u]
                 sg.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
+                _count_scale(stats[u, 2], se[0])
                 sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
                 sh_d = torch.empty_like(sc_d)
                 sg.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
@@ -2011,8 +2040,15 @@ def _pinned(model, fn):
     return fn()
 
 
+def _twin(model):
+    """(the model the kernels run, its padded.Twin or None): narrow configurations run as zero-padded twins at the built widths."""
+    from . import padded
+    return padded.twin_of(model)
+
+
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
     wav = check_input(wav)
+    model, _ = _twin(model)
     if debug is not None:
         run = lambda: _tasnet_forward_impl(model, wav, debug)
         return _pinned(model, lambda: _guarded(wav.device, run, _in_mode(1, run), "DPRNNTasNet.forward", None, owner=model))
@@ -2022,6 +2058,21 @@ def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
     wav, aux = check_input(wav), check_input(aux, "aux")
+    narrow = model
+    model, tw = _twin(model)
+    if tw is not None and _bn_training(model.separation):
+        # a train-mode BatchNorm updates its running statistics: they belong to the caller's (narrow) model
+        if getattr(_TLS, "want_ticket", False):
+            raise NotImplementedError("forward_async on a narrow model with BatchNorm in train mode")
+        try:
+            return _spe_forward_twin(model, wav, aux, aux_len, ira, debug)
+        finally:
+            torch.cuda.current_stream(wav.device).synchronize()
+            tw.write_back_buffers(narrow)
+    return _spe_forward_twin(model, wav, aux, aux_len, ira, debug)
+
+
+def _spe_forward_twin(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
     if debug is not None:
         run = lambda: _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
         return _pinned(model, lambda: _guarded(wav.device, run, _in_mode(1, run), "DPRNNSpeTasNet.forward", model.separation, owner=model))
@@ -2071,6 +2122,7 @@ def auxiliary_embedding(sep, aux: torch.Tensor, aux_len):
 def tasnet_forward_ragged(model, wavs):
     for w in wavs:
         check_input(w.reshape(1, -1))
+    model, _ = _twin(model)
     run = lambda: _tasnet_forward_ragged_impl(model, wavs)
     return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNTasNet ragged forward", None)
 
@@ -2078,6 +2130,15 @@ def tasnet_forward_ragged(model, wavs):
 def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
     for w in wavs:
         check_input(w.reshape(1, -1))
+    narrow = model
+    model, tw = _twin(model)
+    if tw is not None and _bn_training(model.separation):
+        try:
+            run = lambda: _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira)
+            return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNSpeTasNet ragged forward", model.separation)
+        finally:
+            torch.cuda.current_stream(wavs[0].device).synchronize()
+            tw.write_back_buffers(narrow)
     run = lambda: _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira)
     return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNSpeTasNet ragged forward", model.separation)
 

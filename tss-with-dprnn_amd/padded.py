@@ -92,9 +92,12 @@ class Twin:
         self.model = type(model)(**{k: wide[k] for k in keys}).to(dev)
         self.model.train(model.training)
         self.model.requires_grad_(False)
-        sep = self.model.separation
-        # (bottleneck / speaker-encoder norms over N channels, DPRNN norms over F channels)
-        sep.__dict__["_dprnn_count_scale"] = (N_BUILT / cfg["input_size"], F_BUILT / cfg["feature_size"])
+        # every global norm of the twin divides by rows x BUILT channels: the engine multiplies its (sum, sum of squares) by this
+        for (_, a), (_, b) in zip(self.model.named_modules(), model.named_modules()):
+            ca = getattr(a, "num_channels", getattr(a, "channel_size", None))
+            cb = getattr(b, "num_channels", getattr(b, "channel_size", None))
+            if ca is not None and cb is not None and not isinstance(a, torch.nn.modules.batchnorm._BatchNorm):
+                a.__dict__["_dprnn_count_scale"] = float(ca) / float(cb)
         self.versions: Tuple = ()
         self.sync(model)
 
