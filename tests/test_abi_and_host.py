@@ -306,3 +306,17 @@ def test_utterance_groups_partition_the_batch_and_leave_one_pipeline_only_while_
                 for nseq in (B * S, B * K):                                        # intra- and inter-chunk launches, both directions
                     assert 2 * -(-nseq // 16) <= ncu, (B, nseq)
     assert engine.plan_groups(9, 3) == 2 and engine.plan_groups(64, 3) == 2 and engine.plan_groups(64, 0) == 4
+
+
+def test_every_engine_setting_is_classified_for_the_graph_key():
+    """engine.LAUNCH_KNOBS (part of every captured graph's key) and engine.OTHER_SETTINGS together name every upper-case module-level
+    setting of engine.py: a knob added later and forgotten fails here instead of replaying a graph captured under another value."""
+    import types
+    from tss_with_dprnn_amd import engine
+    names = {k for k, v in vars(engine).items()
+             if k.isupper() and not k.startswith("_") and not isinstance(v, (types.ModuleType, types.FunctionType, type))
+             and k not in ("SAT_NAMES", "SAT_SLOTS", "SCALE_SLOTS")}                # imported from _lib
+    listed = set(engine.LAUNCH_KNOBS) | set(engine.OTHER_SETTINGS)
+    assert names - listed == set(), f"unclassified settings: {sorted(names - listed)}"
+    assert listed - names == set(), f"listed but gone: {sorted(listed - names)}"
+    assert not set(engine.LAUNCH_KNOBS) & set(engine.OTHER_SETTINGS)

@@ -1882,13 +1882,40 @@ class _Graphed:
         return out
 
 
-def _graph_key(kind: str, model, inputs, extra=()):
+# Every module-level setting of this file is listed in exactly one of these two tuples (tests/test_abi_and_host.py checks that no
+# upper-case name is left out): LAUNCH_KNOBS change the launch sequence of a forward -- which kernels, tiles, streams, arithmetic --
+# and are therefore part of every captured graph's key; the others are constants, bookkeeping, or policy applied outside a capture.
+# A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
+LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE",
+                "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
+                "SATURATION_CHECK")
+OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
+                  "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",
+                  "GRAPHS", "GRAPH_CACHE_MAX", "GRAPH_STATS", "SLOT_BOTTLENECK", "SLOT_AUX_BOTTLENECK", "SLOT_HEAD_CONV", "SLOT_HEAD_GATE",
+                  "SLOT_PATH0", "LAUNCH_KNOBS", "OTHER_SETTINGS")
+
+
+def _freeze(v):
+    if isinstance(v, dict):
+        return tuple(sorted((k, _freeze(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    return v
+
+
+def launch_knobs() -> tuple:
+    """The current value of everything that shapes a forward's launch sequence (this thread's arithmetic mode included)."""
     lib = load_library()
+    g = globals()
+    return tuple((k, _freeze(g[k])) for k in LAUNCH_KNOBS) + (
+        ("mode", current_mode()), ("fast_act", lib.dprnn_get_fast_activations()), ("fast_head_act", lib.dprnn_get_fast_head_activations()),
+        ("rowgemm_grid", lib.dprnn_get_rowgemm_grid()))
+
+
+def _graph_key(kind: str, model, inputs, extra=()):
     params = tuple(p.data_ptr() for p in model.parameters()) + tuple(b.data_ptr() for b in model.buffers())
     bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
-    knobs = (current_mode(), STREAM_GROUPS, MIN_GROUP_BATCH, FUSE_NORM, SPLIT_ONE_GROUP, SPLIT_GROUPS, tuple(GROUP_SIZES or ()),
-             SEQ_TILE["intra"], SEQ_TILE["inter"], SPLIT_MIN_BATCH, lib.dprnn_get_fast_activations(), lib.dprnn_get_fast_head_activations(),
-             lib.dprnn_get_rowgemm_grid(), H_PIECES, ADAPTIVE_SCALE, bool(model.__dict__.get("_dprnn_pin_mode1", False)))
+    knobs = launch_knobs() + (("pinned", bool(model.__dict__.get("_dprnn_pin_mode1", False))),)
     return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
 
 
