@@ -3,6 +3,7 @@
 // fused with the residual add, the time mean and the small per-utterance Linears.
 #include "rowgemm_core.h"
 using namespace rg;
+extern "C" int dprnn_get_gemm_mode(void);
 
 namespace {
 
@@ -322,6 +323,37 @@ __global__ __launch_bounds__(256) void rows_affine_kernel(const f32x4* __restric
     }
 }
 
+// the same store on the transposed f16-pieces tiles (rowgemm_f16t_kernel: a lane owns four adjacent output columns of one row)
+template <int RT, int NCT>
+struct EpTStoreBias {
+    float* out; int pitch; int col0; const float* bias;
+    __device__ void begin(int tid) {}
+    __device__ void end(int lane) {}
+    __device__ void operator()(f32x4 (&acc)[RT][NCT], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x4 v = bias ? *reinterpret_cast<const f32x4*>(bias + col0 + 16 * ct + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[rt][ct][e], inv, v[e]);
+                *reinterpret_cast<f32x4*>(out + row * pitch + col0 + 16 * ct + 4 * q) = v;
+            }
+        }
+    }
+};
+
+// 1x1 convs of the speaker encoder in gate-GEMM mode 3: two f16 pieces per operand, three products (fp32-class, as everywhere in that
+// mode), HBM-bound instead of fp32-MFMA-bound -- 6.3 -> ms of the DPRNN-Spe forward's serial prologue at 64 x 3 s (13 launches).  The rows
+// are BatchNorm / PReLU outputs of no fixed scale: tracked, scaled by the calling thread's activation-scale record.  Batch statistics
+// (train-mode BatchNorm: fp64 column sums in the epilogue) stay on the fp32 kernel.
+template <int KD, int RT>
+int launch_pointwise_f16(const AffineRows<RT>& al, const EpTStoreBias<RT, 8>& ep, const float* W, int ldw, long long M, hipStream_t st) {
+    return launch_rowgemm_f16t<KD, 128, RT, true>("pointwise_f16", W, ldw, 128, nullptr, 0, M, al, ep, st);
+}
+
 template <int KD>
 int launch_pointwise(const AffineRows<4>& al, const EpStoreColStats<4>& ep, const float* W, int ldw, long long M, hipStream_t st) {
     return launch_rowgemm<KD, 128, 4>("pointwise", W, ldw, 128, nullptr, 0, M, al, ep, st);
@@ -340,9 +372,22 @@ extern "C" int dprnn_pointwise_fwd(const float* A, int a_pitch, int kdim, const 
         dprnn_set_error("dprnn_pointwise_fwd: unsupported kdim=%d a_pitch=%d ldw=%d col0=%d out_pitch=%d", kdim, a_pitch, ldw, col0, out_pitch);
         return -1;
     }
+    const float* Wc = W + (long long)col0 * ldw;
+    if (dprnn_get_gemm_mode() == 3 && !col_stats) {
+        const long long rpu = rows_per_utt > 0 ? rows_per_utt : 1;
+        hipStream_t st = (hipStream_t)stream;
+        if (kdim == 256) {                             // two 16-row tiles per wave would spill at K = 256 (73 registers)
+            AffineRows<1> alt{A, a_pitch, in_scale, in_shift, in_mean, aff_stride, rpu, in_prelu};
+            EpTStoreBias<1, 8> ept{out, out_pitch, col0, bias};
+            return launch_pointwise_f16<256, 1>(alt, ept, Wc, ldw, M, st);
+        }
+        AffineRows<2> alt{A, a_pitch, in_scale, in_shift, in_mean, aff_stride, rpu, in_prelu};
+        EpTStoreBias<2, 8> ept{out, out_pitch, col0, bias};
+        if (kdim == 64) return launch_pointwise_f16<64, 2>(alt, ept, Wc, ldw, M, st);
+        return launch_pointwise_f16<128, 2>(alt, ept, Wc, ldw, M, st);
+    }
     AffineRows<4> al{A, a_pitch, in_scale, in_shift, in_mean, aff_stride, (long long)(rows_per_utt > 0 ? rows_per_utt : 1), in_prelu};
     EpStoreColStats<4> ep{out, out_pitch, col0, bias, col_stats};
-    const float* Wc = W + (long long)col0 * ldw;
     // the epilogue indexes bias/out/stats with col0 + col, the weight rows are pre-offset
     ep.col0 = col0;
     hipStream_t st = (hipStream_t)stream;

@@ -108,7 +108,7 @@ def use_gemm_mode(mode: int):
 # forward).  A model whose residual stream leaves the default range (|x| > 4062) is therefore repeated in mode 1 ONCE; its next
 # forwards run in mode 3 under a scale that fits.  DPRNN_ADAPTIVE_SCALE=0: the constant 2^4 of rounds 2 and 3.
 ADAPTIVE_SCALE = os.environ.get("DPRNN_ADAPTIVE_SCALE", "1") != "0"
-SLOT_BOTTLENECK, SLOT_AUX_BOTTLENECK, SLOT_HEAD_CONV, SLOT_HEAD_GATE, SLOT_PATH0 = 0, 1, 2, 3, 4
+SLOT_BOTTLENECK, SLOT_AUX_BOTTLENECK, SLOT_HEAD_CONV, SLOT_HEAD_GATE, SLOT_SPK, SLOT_PATH0 = 0, 1, 2, 3, 4, 5
 SAT_NONFINITE = 5              # DPRNN_SAT_NONFINITE (csrc/common.h)
 PIN_AFTER_FALLBACKS = 2          # consecutive saturated forwards after which a model stays in mode 1
 
@@ -655,7 +655,9 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 
         wgs = ndir * -(-nseq // (tile % 1000))
         two_per_cu = tile % 1000 == 32
         slots = ncu * (2 if two_per_cu else 1)
-        rounds = -(-wgs * concurrent // slots) / concurrent
+        # one pipeline pays for every partly filled round of workgroups; with several pipelines interleaving on the chip the tail of
+        # one launch is filled by the others' kernels, so the cost is the launch's share of the chip's work (at least one workgroup's time)
+        rounds = -(-wgs // slots) if concurrent == 1 else max(1.0, wgs * concurrent / slots) / concurrent
         t = rounds * us
         if two_per_cu and wgs * concurrent <= ncu:     # one 32-sequence workgroup per CU runs at the MFMA's pace, not the L2's
             t *= 0.6
@@ -925,10 +927,18 @@ def _pointwise(st: Stage, A, rows, kdim, conv_w, conv_b, cout, in_scale=None, in
     dev = A.device
     w = _param(conv_w, "conv.weight", dev)
     out = torch.empty(rows, cout, device=dev, dtype=torch.float32)
-    for col0 in range(0, cout, 128):
-        st.call("dprnn_pointwise_fwd", _p(A), kdim, kdim, _p(in_scale), _p(in_shift), _p(in_mean), aff_stride, rows_per_utt,
-                _p(in_prelu), _p(w), kdim, _p(_param(conv_b, "conv.bias", dev)) if conv_b is not None else 0,
-                _p(out), cout, col0, _p(col_stats), rows)
+    # mode 3: the 1x1 convs of the speaker branch run in f16 pieces as well (one activation-scale slot for all of them); a launch that
+    # also has to form BatchNorm batch statistics (col_stats) stays on the fp32 kernel inside the library
+    prev = st.lib.dprnn_get_gemm_mode()
+    st.lib.dprnn_set_gemm_mode(3 if current_mode() == 3 else 0)
+    _set_slot(st.lib, SLOT_SPK)
+    try:
+        for col0 in range(0, cout, 128):
+            st.call("dprnn_pointwise_fwd", _p(A), kdim, kdim, _p(in_scale), _p(in_shift), _p(in_mean), aff_stride, rows_per_utt,
+                    _p(in_prelu), _p(w), kdim, _p(_param(conv_b, "conv.bias", dev)) if conv_b is not None else 0,
+                    _p(out), cout, col0, _p(col_stats), rows)
+    finally:
+        st.lib.dprnn_set_gemm_mode(prev)
     return out
 
 
@@ -1892,7 +1902,7 @@ LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROU
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",
                   "GRAPHS", "GRAPH_CACHE_MAX", "GRAPH_STATS", "SLOT_BOTTLENECK", "SLOT_AUX_BOTTLENECK", "SLOT_HEAD_CONV", "SLOT_HEAD_GATE",
-                  "SLOT_PATH0", "LAUNCH_KNOBS", "OTHER_SETTINGS")
+                  "SLOT_SPK", "SLOT_PATH0", "LAUNCH_KNOBS", "OTHER_SETTINGS")
 
 
 def _freeze(v):
