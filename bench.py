@@ -460,6 +460,9 @@ def main():
                 # same reason (profiles/r03_power_bound.txt): frac against `peak` cannot exceed ~0.8
                 "peak_at_power_limit_note": None if mode == 0 else "2024 TFLOP/s dense f16 MFMA measured with operands in registers "
                 "(tools/probes/mfma_f16_coexec.hip) = 675 algorithmic; the forward holds the socket at ~1380 W (see `power`)",
+                # the kernel runs at the board's power limit, so time = energy: where the joules of a step go (MFMAs 46-56 %, HBM traffic
+                # 19 %, weight stream from L2 8-12 %, cell arithmetic 9-11 %), measured with the socket's energy counter
+                "energy_budget": None if mode == 0 else "profiles/r04_energy_budget.txt",
                 "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                 # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
                 # the previous norm is folded in: all launches of a forward but the first]
