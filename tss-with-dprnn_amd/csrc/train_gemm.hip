@@ -597,6 +597,219 @@ void wgrad_lstm_f16_kernel(WgLstmArgs a, const float* __restrict__ pmax, int* sa
     }
 }
 
+// ---- The same GEMM on 256 x 256 blocks (round 4).  The 256 x 128 form above gives every row range to four sibling workgroups
+// (two gate-row halves x {x, h}), so each dG chunk and each [x | h] chunk is read by TWO workgroups; the XCD's L2 serves only part of
+// the second reads -- PMC: 7.52 GB per launch against 4.77 GB of operands (profiles/r04_pmc_traffic_train_f16.json), in a kernel that
+// runs at the HBM roofline (5.1 TB/s).  Here a workgroup owns 256 gate rows x ALL 256 columns of [x | h]: dG is read once, only the
+// (three times smaller) [x | h] rows by the two siblings.  Waves (wm, wn): 64 gate rows x 128 columns -- wn = 0 multiplies with x,
+// wn = 1 with h_prev -- 128 accumulator registers per lane; the Q image holds both sources side by side (512 B per row and piece),
+// 64 KB per buffer, one workgroup per CU as before.  Staging, fragment formats, split-k plan and the reduce kernel are unchanged.
+constexpr int WFW_QPL = WF_R * 256 * 2;                                       // bytes of one piece plane of a wide Q chunk (16 KB)
+constexpr int WFW_BUF = 2 * WF_PPL + 2 * WFW_QPL;                            // 64 KB
+
+__global__ __launch_bounds__(WG_THREADS, 2)
+void wgrad_lstm_f16_wide_kernel(WgLstmArgs a, const float* __restrict__ pmax, int* sat) {
+    extern __shared__ __attribute__((aligned(16))) char wimg[];           // [buf 2][P piece 0 | P piece 1 | Q piece 0 | Q piece 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int Mpad = 512, Npad = 256, QP = 512;                       // QP: bytes of a Q row of one piece ([x 128 | h 128] f16)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int mb = jj & 1, ks = (jj >> 1) * 8 + xcd;                      // the two siblings of a row range share an XCD
+    if (ks >= a.splits) return;
+    const long long total = (long long)a.T * a.nseq32;
+    const long long r0 = (long long)ks * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > total) r1 = total;
+
+    float sg;
+    {
+        const float m = *pmax;
+        int ex = 0;
+        if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+        ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+        sg = ldexpf(1.f, 6 - ex);
+    }
+    const float inv = 1.f / (sg * F16P_XS);
+
+    const int pcol = tid & 255, kgh = tid >> 8;
+    const int qc4 = tid & 31, qrow = tid >> 5;
+    int t = (int)(r0 / a.nseq32), s0 = (int)(r0 % a.nseq32);
+    int qq[2], qr[2];
+    auto seq_split = [&](int seq, int& quo, int& rem) { quo = seq / a.inner_n; rem = seq - quo * a.inner_n; };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) seq_split(s0 + qrow + 16 * j, qq[j], qr[j]);
+
+    rg_u32x4 pv[2][2];
+    f32x4 qv[2][2];                                                       // [row j][0: x(t), 1: h(t - dt)]
+    float psum = 0.f;
+    unsigned satm = 0u;
+    auto load = [&]() __attribute__((always_inline)) {
+        const float* pt = a.P4 + ((size_t)t * a.nsq + (size_t)(s0 >> 2)) * (Mpad * 4) + (size_t)(mb * WG_MB + pcol) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qd = 2 * (kgh + 2 * j) + h;
+                pv[j][h] = (s0 + 4 * qd < a.nseq) ? *reinterpret_cast<const rg_u32x4*>(pt + (size_t)qd * (Mpad * 4)) : rg_u32x4{0u, 0u, 0u, 0u};
+            }
+        const int th = t - a.dt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int seq = s0 + qrow + 16 * j;
+            f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vh = {0.f, 0.f, 0.f, 0.f};
+            if (seq < a.nseq) {
+                const long long base = (long long)qq[j] * a.outer_stride + (long long)qr[j] * a.inner_stride;
+                vx = *reinterpret_cast<const f32x4*>(a.X + (base + (long long)t * a.t_stride) * 128 + 4 * qc4);
+                if (th >= 0 && th < a.T) vh = *reinterpret_cast<const f32x4*>(a.Hd + (base + (long long)th * a.t_stride) * a.ldh + 4 * qc4);
+            }
+            qv[j][0] = vx; qv[j][1] = vh;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        s0 += WF_R;
+        if (s0 >= a.nseq32) {
+            s0 = 0; ++t;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) seq_split(qrow + 16 * j, qq[j], qr[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { qr[j] += WF_R; while (qr[j] >= a.inner_n) { qr[j] -= a.inner_n; ++qq[j]; } }
+        }
+    };
+    auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
+        unsigned a1, a2, b1, b2;
+        f16_pieces2(c[0], c[1], a1, a2);
+        f16_pieces2(c[2], c[3], b1, b2);
+        lo = (unsigned long long)a1 | ((unsigned long long)b1 << 32);
+        hi = (unsigned long long)a2 | ((unsigned long long)b2 << 32);
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+        char* const pb = wimg + buf * WFW_BUF;
+        char* const qb = pb + 2 * WF_PPL;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* d = pb + (((kgh + 2 * j) * WG_MB + pcol) << 4);
+            *reinterpret_cast<rg_u32x4*>(d) = rg_u32x4{pv[j][0][0], pv[j][0][1], pv[j][1][0], pv[j][1][1]};
+            *reinterpret_cast<rg_u32x4*>(d + WF_PPL) = rg_u32x4{pv[j][0][2], pv[j][0][3], pv[j][1][2], pv[j][1][3]};
+            if (a.part_b) {                                             // S_g da = p1 + p2: column sum and range (every block holds x)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const unsigned u1 = pv[j][h][w], u2 = pv[j][h][2 + w];
+                        const float v0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u1 & 0xffffu)) +
+                                         (float)__builtin_bit_cast(_Float16, (unsigned short)(u2 & 0xffffu));
+                        const float v1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u1 >> 16)) +
+                                         (float)__builtin_bit_cast(_Float16, (unsigned short)(u2 >> 16));
+                        sat_track(satm, v0, v1);
+                        psum += v0 + v1;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = qrow + 16 * j;
+#pragma unroll
+            for (int src = 0; src < 2; ++src) {
+                unsigned long long lo, hi;
+                pieces4(qv[j][src], F16P_XS, lo, hi);
+                char* d = qb + row * QP + src * 256 + (((unsigned)qc4 ^ wf_swz(row)) << 3);
+                *reinterpret_cast<unsigned long long*>(d) = lo;
+                *reinterpret_cast<unsigned long long*>(d + WFW_QPL) = hi;
+            }
+        }
+    };
+
+    const int g = lane >> 4, l = lane & 15, qqq = l >> 2, pp = l & 3;
+    const unsigned ub = (unsigned)(pp | (qqq << 2) | ((g & 1) << 4));
+    const unsigned pa0 = (unsigned)((g * WG_MB + 64 * wm + l) << 4);     // tile jm: + 256 jm bytes (an immediate)
+    unsigned qa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qa[j] = (unsigned)((8 * g + qqq) * QP + wn * 256) + ((((unsigned)(4 * j)) ^ ub) << 3);
+    auto tr8 = [&](const char* plane, unsigned off) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) wf_s4* lptr;
+        const wf_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off));
+        const wf_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off + 4 * QP));
+        rg_u32x4 out;
+        const unsigned long long a0 = __builtin_bit_cast(unsigned long long, lo), a1 = __builtin_bit_cast(unsigned long long, hi);
+        out[0] = (unsigned)a0; out[1] = (unsigned)(a0 >> 32); out[2] = (unsigned)a1; out[3] = (unsigned)(a1 >> 32);
+        return out;
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int jn = 0; jn < 8; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (r0 < r1) {
+        load();
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long k0 = r0; k0 < r1; k0 += WF_R, buf ^= 1) {
+            const bool more = k0 + WF_R < r1;
+            if (more) { advance(); load(); }
+            const char* const pb = wimg + buf * WFW_BUF;
+            const char* const qb = pb + 2 * WF_PPL;
+#pragma unroll
+            for (int hf = 0; hf < 4; ++hf) {                            // the wave's 128 columns two 16-column tiles at a time: 16 fragment registers
+                rg_u32x4 q1[2], q2[2];
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) { q1[jn] = tr8(qb, qa[2 * hf + jn]); q2[jn] = tr8(qb + WFW_QPL, qa[2 * hf + jn]); }
+#pragma unroll
+                for (int jm = 0; jm < 4; ++jm) {
+                    const rg_u32x4 p1 = *reinterpret_cast<const rg_u32x4*>(pb + pa0 + 256 * jm), p2 = *reinterpret_cast<const rg_u32x4*>(pb + WF_PPL + pa0 + 256 * jm);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        acc[jm][2 * hf + jn] = mfma_f16p(p1, q2[jn], acc[jm][2 * hf + jn]);
+                        acc[jm][2 * hf + jn] = mfma_f16p(p2, q1[jn], acc[jm][2 * hf + jn]);
+                        acc[jm][2 * hf + jn] = mfma_f16p(p1, q1[jn], acc[jm][2 * hf + jn]);
+                    }
+                }
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX * 0.99999f);
+    // acc[jm][jn][e] = dW[m][n], m = 256 mb + 64 wm + 16 jm + 4 g + e, n = 128 wn + 16 jn + l
+    float* const out = a.part + (long long)ks * Mpad * Npad;
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = WG_MB * mb + 64 * wm + 16 * jm + 4 * g + e;
+#pragma unroll
+            for (int jn = 0; jn < 8; ++jn) out[(long long)m * Npad + 128 * wn + 16 * jn + l] = acc[jm][jn][e] * inv;
+        }
+    if (a.part_b) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(wimg);
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 256) a.part_b[(long long)ks * Mpad + WG_MB * mb + tid] = (red[tid] + red[tid + 256]) * (1.f / sg);
+    }
+}
+
+// row ranges of the wide form: two sibling workgroups (gate-row halves) per range, two ranges per CU over the launch
+static void wgrad_lstm_wide_plan(long long rows, long long& splits, long long& per) {
+    splits = num_cus();
+    const long long max_splits = (rows + 63) / 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    per = (rows + splits - 1) / splits;
+    per = (per + 31) / 32 * 32;
+    splits = (rows + per - 1) / per;
+}
+static bool wgrad_lstm_wide() {
+    static const bool on = [] { const char* e = getenv("DPRNN_WGRAD_LSTM_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // dW[m*ldm + n*ldn] = (accumulate ? dW : 0) + sum_s part[s][m][n];  db likewise (two optional destinations: the
 // LSTM's b_ih and b_hh receive the same gradient).  A workgroup of 4 waves sums 64 float4 column groups: wave w adds the
 // partials s = w, w+4, ... (eight independent loads in flight), the four wave sums are added in wave order -- a fixed
@@ -666,6 +879,11 @@ static void wgrad_plan(int M, int N, long long rows, int& mblocks, int& nblocks,
 extern "C" int64_t dprnn_wgrad_workspace_floats(int M, int N, int64_t rows) {
     int mblocks, nblocks; long long splits, per;
     wgrad_plan(M, N, rows > 0 ? rows : 1, mblocks, nblocks, splits, per);
+    if (M == 512 && N == 256) {                        // dprnn_wgrad_lstm_f16's 256 x 256 form splits the rows more finely
+        long long ws, wp;
+        wgrad_lstm_wide_plan(rows > 0 ? rows : 1, ws, wp);
+        if (ws > splits) splits = ws;
+    }
     return splits * ((int64_t)mblocks * WG_MB * nblocks * WG_NB + mblocks * WG_MB);
 }
 
@@ -757,7 +975,9 @@ extern "C" int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, con
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride;
     const long long rows = (long long)T * a.nseq32;
     int mblocks, nblocks; long long splits, per;
-    wgrad_plan(512, 256, rows, mblocks, nblocks, splits, per);
+    const bool wide = wgrad_lstm_wide();
+    if (wide) wgrad_lstm_wide_plan(rows, splits, per);
+    else wgrad_plan(512, 256, rows, mblocks, nblocks, splits, per);
     a.rows_per_split = per; a.splits = (int)splits;
     a.part = workspace;
     a.part_b = (db0 || db1) ? workspace + splits * 512LL * 256 : nullptr;
@@ -765,12 +985,20 @@ extern "C" int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, con
     int attr_dev;
     if (dprnn_attr_needed(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lstm_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WF_BUF);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lstm_f16_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WFW_BUF);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(wgrad_lstm_f16): %s", hipGetErrorString(e)); return -2; }
         dprnn_attr_done(attr_mask, attr_dev);
     }
-    const unsigned grid = (unsigned)(4 * ((splits + 7) / 8 * 8));
-    hipLaunchKernelGGL(wgrad_lstm_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, grad_max, dprnn_sat_ptr());
-    int rc = dprnn_check_launch("wgrad_lstm_f16_kernel");
+    int rc;
+    if (wide) {
+        const unsigned grid = (unsigned)(2 * ((splits + 7) / 8 * 8));
+        hipLaunchKernelGGL(wgrad_lstm_f16_wide_kernel, dim3(grid), dim3(WG_THREADS), 2 * WFW_BUF, (hipStream_t)stream, a, grad_max, dprnn_sat_ptr());
+        rc = dprnn_check_launch("wgrad_lstm_f16_wide_kernel");
+    } else {
+        const unsigned grid = (unsigned)(4 * ((splits + 7) / 8 * 8));
+        hipLaunchKernelGGL(wgrad_lstm_f16_kernel, dim3(grid), dim3(WG_THREADS), 2 * WF_BUF, (hipStream_t)stream, a, grad_max, dprnn_sat_ptr());
+        rc = dprnn_check_launch("wgrad_lstm_f16_kernel");
+    }
     if (rc) return rc;
     const int items = 512 * (256 / 4) + (a.part_b ? 512 / 4 : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, (hipStream_t)stream,
