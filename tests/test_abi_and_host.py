@@ -320,3 +320,47 @@ def test_every_engine_setting_is_classified_for_the_graph_key():
     assert names - listed == set(), f"unclassified settings: {sorted(names - listed)}"
     assert listed - names == set(), f"listed but gone: {sorted(listed - names)}"
     assert not set(engine.LAUNCH_KNOBS) & set(engine.OTHER_SETTINGS)
+
+
+def test_padded_twin_places_every_block_and_scales_every_global_norm():
+    """padded.Twin (CPU: construction and parameter placement only; the arithmetic is checked on the GPU against the narrow goldens): every
+    value of the narrow model appears in the twin exactly once and everything else is zero; gate blocks of the RNN weights, direction
+    blocks of the Linears, speaker blocks of conv2d and the (x | embedding) column blocks land at the built offsets; every global norm
+    carries built / real channels as its element-count correction; the twin follows an in-place parameter update."""
+    import numpy as np
+    import torch
+    from conftest import build_model
+    from tss_with_dprnn_amd import padded
+    tiny = dict(input_size=8, feature_size=16, hidden_size=16, chunk_length=10, kernel_size=2, hop_length=5, n_repeats=2)
+    tspe = dict(tiny, O=16, P=24, embeddings_size=12, num_spks=7)
+    for kind, over in (("bss", tiny), ("bss", dict(tiny, rnn_type="GRU", bidirectional=False)), ("spe", dict(tspe, fusion_type="cat", norm_type="ln")),
+                       ("spe", dict(tspe, fusion_type="film", norm_type="gLN")), ("ira", dict(tspe, fusion_type="att", norm_type="ln"))):
+        m, _, _ = build_model(kind, over, 3, None)
+        tm, tw = padded.twin_of(m)
+        assert tw is not None and tm.cfg["input_size"] == 64 and tm.cfg["feature_size"] == 128 and tm.cfg["hidden_size"] == 128
+        tsd = tm.state_dict()
+        for k, v in m.state_dict().items():
+            a, b = v.double(), tsd[k].double()
+            assert abs(a.sum().item() - b.sum().item()) <= 1e-9 * max(1.0, a.abs().sum().item()), k
+            assert abs(a.abs().sum().item() - b.abs().sum().item()) <= 1e-9 * max(1.0, a.abs().sum().item()), k
+        scales = {mod.__dict__["_dprnn_count_scale"] for mod in tm.modules() if "_dprnn_count_scale" in mod.__dict__}
+        assert scales == {8.0}, scales                                  # 64 / 8 for the norms over N, 128 / 16 for those over F
+        assert padded.twin_of(m)[1] is tw                               # built once
+    m, _, _ = build_model("bss", tiny, 3, None)
+    tm, tw = padded.twin_of(m)
+    blk, tblk = m.separation.dprnn_blocks[0], tm.separation.dprnn_blocks[0]
+    w, W = blk.intra_rnn.rnn.weight_ih_l0, tblk.intra_rnn.rnn.weight_ih_l0
+    for g in range(4):                                                  # gate blocks i, f, g, o
+        assert torch.equal(W[128 * g: 128 * g + 16, :16], w[16 * g: 16 * (g + 1)]) and float(W[128 * g + 16: 128 * (g + 1)].abs().sum()) == 0.0
+    lw, LW = blk.intra_linear.weight, tblk.intra_linear.weight        # [F, 2H]: forward | backward columns
+    assert torch.equal(LW[:16, :16], lw[:, :16]) and torch.equal(LW[:16, 128:144], lw[:, 16:]) and float(LW[16:].abs().sum()) == 0.0
+    c, C = m.separation.conv2d.weight, tm.separation.conv2d.weight    # [2F, F, 1, 1]: speaker blocks
+    assert torch.equal(C[:16, :16], c[:16]) and torch.equal(C[128:144, :16], c[16:])
+    with torch.no_grad():
+        blk.intra_norm.weight.mul_(3.0)
+    tm2, _ = padded.twin_of(m)
+    assert tm2 is tm and torch.equal(tblk.intra_norm.weight[:16], blk.intra_norm.weight) and float(tblk.intra_norm.weight[16:].abs().sum()) == 0.0
+    big = dict(tiny, feature_size=256, hidden_size=256, input_size=64)
+    mb, _, _ = build_model("bss", big, 3, None)
+    with pytest.raises(NotImplementedError, match="above the kernels' build"):
+        padded.twin_of(mb)
