@@ -181,6 +181,66 @@ def test_lstm_backward_f16_pieces_flags_gradients_beyond_their_scale():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("path,B,S,K", [("intra", 3, 9, 23), ("inter", 2, 11, 70)])
+def test_lstm_backward_packed_gate_tape(path, B, S, K):
+    """The f16-pieces training forward can leave the gates as 24-bit fixed point (gemm_mode 3 | 0x100: three words per (row, unit)
+    instead of four, csrc/common.h tape_pack) for the f16-pieces BPTT launched with the same flag: dX and the gate gradients dG
+    are those of the fp32 tape to ~1e-7 (a gate is held to 2^-25 / 2^-24 absolute) and dX matches autograd of nn.LSTM like the
+    fp32 tape does.  The flag is refused outside that pair of kernels."""
+    rng = np.random.default_rng(B * 100 + S)
+    lstm = _cpu_lstm(7)
+    X = torch.from_numpy(rng.standard_normal((B, S, K, 128)).astype(np.float32))
+    dH = torch.from_numpy(rng.standard_normal((B, S, K, 256)).astype(np.float32))
+    Xr = X.clone().requires_grad_(True)
+    if path == "intra":
+        out = lstm(Xr.reshape(B * S, K, 128))[0].reshape(B, S, K, 256)
+    else:
+        out = lstm(Xr.permute(0, 2, 1, 3).reshape(B * K, S, 128))[0].reshape(B, K, S, 256).permute(0, 2, 1, 3)
+    out.backward(dH)
+    st = _st()
+    lib = st.lib
+    w = [_t(getattr(lstm, n).detach()) for n in NAMES] + [_t(getattr(lstm, n + "_reverse").detach()) for n in NAMES]
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), device=DEV)
+    rows = B * S * K
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    Xd, dHd = _t(X), _t(dH)
+    hmax = torch.full((1,), float(dH.abs().max()), device=DEV)
+    st.call("dprnn_rnn_pack_ex", 3, 0, *[_p(t) for t in w], _p(packed), _p(bsum))
+    st.call("dprnn_rnn_pack_bwd_ex", 3, 0, _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(packedT))
+    res = {}
+    for flag in (0, 0x100):
+        tape = torch.full((lib.dprnn_lstm_tape_floats(addr[0], addr[1], 2),), float("nan"), device=DEV)
+        H = torch.full((rows, 256), float("nan"), device=DEV)
+        dXd = torch.full((2, rows, 128), float("nan"), device=DEV)
+        dG = torch.zeros(lib.dprnn_rnn_bwd_dg_floats(0, 3, addr[0], addr[1], 2), device=DEV)
+        st.call("dprnn_rnn_fwd_train_ex", 3 | flag, 0, _p(Xd), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), _p(tape), *addr, 2)
+        st.call("dprnn_rnn_bwd_ex", 3 | flag, _p(hmax), 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2)
+        torch.cuda.synchronize()
+        res[flag] = (H.cpu().numpy(), (dXd[0] + dXd[1]).cpu().numpy(), dG.view(torch.int32).cpu().numpy(), tape)
+    assert np.array_equal(res[0][0], res[0x100][0])                      # the forward itself is untouched
+    ref = Xr.grad.numpy().reshape(rows, 128)
+    e_plain, e_packed = rel_l2(res[0][1], ref), rel_l2(res[0x100][1], ref)
+    e_pair = rel_l2(res[0x100][1], res[0][1])
+    print(f"packed tape {path}: dX vs autograd: fp32 tape {e_plain:.2e}, packed {e_packed:.2e}; packed vs fp32 tape {e_pair:.2e}")
+    assert np.isfinite(res[0x100][1]).all() and e_packed < 5e-6 and e_pair < 1e-6
+    # the gate gradients as the f16 piece pairs the weight-gradient GEMM reads: first pieces differ in their last bits at most
+    a, b = res[0][2], res[0x100][2]
+    first = lambda v: np.ascontiguousarray(v.reshape(-1, 4)[:, :2]).view(np.float16).astype(np.float32)    # words {p1, p1, p2, p2} per quad
+    assert float(np.abs(first(a) - first(b)).max()) <= 2.0 ** -9 * max(1.0, float(np.abs(first(a)).max()))
+    # slot 3 of the packed tape is never written (the NaN fill survives)
+    assert bool(torch.isnan(res[0x100][3].view(-1, 5, 256)[:, 3]).all())
+    assert not bool(torch.isnan(res[0][3].view(-1, 5, 256)[:, 3]).all())
+    # the flag outside its pair of kernels
+    tape = res[0][3]
+    assert lib.dprnn_rnn_fwd_train_ex(0x100, 0, _p(Xd), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), _p(tape), *addr, 2, st.stream) == -1
+    assert b"packed gate tape" in lib.dprnn_last_error()
+    assert lib.dprnn_rnn_bwd_ex(0x100, 0, 0, _p(dHd), _p(tape), _p(packedT), _p(dXd), _p(dG), rows, *addr, 2, st.stream) == -1
+    assert b"packed gate tape" in lib.dprnn_last_error()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rows", [1256, 198, 22, 1])
 @pytest.mark.parametrize("kd,nd", [(128, 256), (128, 128), (64, 128), (256, 128), (128, 64)])
 def test_dgrad_matches_matmul(kd, nd, rows):

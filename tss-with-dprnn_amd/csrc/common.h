@@ -190,6 +190,29 @@ __device__ __forceinline__ void sat_commit(int* flags, int slot, unsigned m, flo
     }
 }
 
+// ---- packed LSTM gate tape (training, f16-pieces forward + f16-pieces BPTT; flag bit on the gemm_mode argument of
+// dprnn_rnn_fwd_train_ex / dprnn_rnn_bwd_ex).  The tape is the largest stream of a training step (5 floats per row, direction
+// and hidden unit, written once and read once).  The activated gates live in [0, 1] (i, f, o) and [-1, 1] (g), so 24-bit fixed
+// point holds them to 2^-25 (i, f, o: exact above 1/2) / 2^-24 (g) ABSOLUTE -- what fp32 gives near 1, which is where the gate
+// derivatives i(1-i), 1-g^2 lose their bits anyway -- and the four of a (sequence, unit) fit three words instead of four:
+//   w0 = qi | o[7:0] << 24,  w1 = qf | o[15:8] << 24,  w2 = qg | o[23:16] << 24;  qg = (g + 1) 2^23.   c stays fp32.
+constexpr int DPRNN_TAPE_PACKED = 0x100;
+__device__ __forceinline__ void tape_pack(float i, float f, float g, float o, unsigned& w0, unsigned& w1, unsigned& w2) {
+    const unsigned qi = min((unsigned)__builtin_rintf(i * 16777216.f), 0xffffffu);
+    const unsigned qf = min((unsigned)__builtin_rintf(f * 16777216.f), 0xffffffu);
+    const unsigned qo = min((unsigned)__builtin_rintf(o * 16777216.f), 0xffffffu);
+    const unsigned qg = min((unsigned)__builtin_rintf(__builtin_fmaf(g, 8388608.f, 8388608.f)), 0xffffffu);
+    w0 = qi | (qo << 24);
+    w1 = qf | ((qo << 16) & 0xff000000u);
+    w2 = qg | ((qo << 8) & 0xff000000u);
+}
+__device__ __forceinline__ void tape_unpack(unsigned w0, unsigned w1, unsigned w2, float& i, float& f, float& g, float& o) {
+    i = (float)(w0 & 0xffffffu) * 0x1p-24f;
+    f = (float)(w1 & 0xffffffu) * 0x1p-24f;
+    g = __builtin_fmaf((float)(w2 & 0xffffffu), 0x1p-23f, -1.f);
+    o = (float)((w0 >> 24) | ((w1 >> 16) & 0xff00u) | ((w2 >> 8) & 0xff0000u)) * 0x1p-24f;
+}
+
 // ---- adaptive activation scale of the f16-pieces arithmetic (round 4; api.hip: dprnn_scale_begin / _slot / _update).
 // Activations are multiplied by 2^s before they are split into f16 pieces; s was the constant 4 (|x| <= 4062).  A model whose
 // residual stream runs higher (norm gains are unbounded, dprnn.py:76-77) would saturate on EVERY forward and pay the range-free

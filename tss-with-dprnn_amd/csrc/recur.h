@@ -29,6 +29,7 @@ struct RecurArgs {
     long long rows_per_utt;
     int cell;                                         // 0 LSTM, 1 GRU, 2 Elman RNN (tanh)
     float* tape;                                      // training forward only: activated gates + cell state per step
+    int tape_packed;                                  // f16-pieces training forward: gates as 24-bit fixed point in tape slots 0-2 (common.h: tape_pack), c in slot 4
     // ---- ragged batches (utterances of different lengths in one launch; bf16-split eight-wave kernel only)
     const int* wg_desc;                               // per workgroup of a direction: {row0 lo, row0 hi, T, sequences, utterance, 0, 0, 0}:
                                                       // its sequences are rows row0 + j * inner_stride, it runs T steps (inter-chunk path)

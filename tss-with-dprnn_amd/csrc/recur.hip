@@ -757,6 +757,12 @@ static int rnn_fwd_train(int mode, int cell, const float* X, const float* Z, con
                                    int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride,
                                    int64_t t_stride, int ndir, void* stream) {
     if (!tape) { dprnn_set_error("dprnn_lstm_fwd_train: tape is null"); return -1; }
+    const bool tape_packed = (mode & DPRNN_TAPE_PACKED) != 0;
+    mode &= ~DPRNN_TAPE_PACKED;
+    if (tape_packed && !(mode == 3 && cell == 0)) {
+        dprnn_set_error("dprnn_rnn_fwd_train: the packed gate tape (mode | 0x100) exists for the f16-pieces LSTM forward (mode 3, cell 0) only");
+        return -1;
+    }
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_fwd_train: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
     if (mode != 0 && !(mode == 3 && cell == 0)) {
         dprnn_set_error("dprnn_rnn_fwd_train: the training forward runs in gate-GEMM mode 0 (any cell) or 3 (LSTM), not %d", mode);
@@ -766,7 +772,7 @@ static int rnn_fwd_train(int mode, int cell, const float* X, const float* Z, con
     a.X = X; a.Wp = packed; a.bsum = bsum; a.H = H; a.nseq = nseq; a.T = T; a.inner_n = inner_n; a.ndir = ndir;
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = cell;
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
-    a.rows_per_utt = rows_per_utt; a.Xout = Xout; a.tape = tape;
+    a.rows_per_utt = rows_per_utt; a.Xout = Xout; a.tape = tape; a.tape_packed = tape_packed ? 1 : 0;
     if (!a.X || !a.Wp || !a.bsum || !a.H) { dprnn_set_error("dprnn_lstm_fwd_train: null pointer"); return -1; }
     if (a.nseq <= 0 || a.T <= 0 || a.inner_n <= 0 || (a.ndir != 1 && a.ndir != 2)) {
         dprnn_set_error("dprnn_lstm_fwd_train: bad sizes nseq=%d T=%d inner_n=%d ndir=%d", a.nseq, a.T, a.inner_n, a.ndir);

@@ -500,9 +500,22 @@ void bilstm_split8_kernel(RecurArgs a) {
                 const int wg_b = 2 * blockIdx.x + (nt >> 1);           // the 32-sequence workgroup of the tape layout
                 const __amdgpu_buffer_rsrc_t trs = rsrc_at(a.tape + (((size_t)dir * nwg_b + wg_b) * T + step) * 20480);
                 const unsigned live = wg_b < nwg_b ? toff + (unsigned)((nt & 1) * 10 * 1024) : OOB;
+                if (a.tape_packed) {                                   // wave-uniform: three words of fixed-point gates + c
+                    u32x4 pk[3];
 #pragma unroll
-                for (int x = 0; x < 5; ++x)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[x]), trs, live + (unsigned)(x * 1024), 0, 0);   // soffset stays 0: see the store hazard note in recur.hip
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned w0, w1, w2;
+                        tape_pack(sv[0][e], sv[1][e], sv[2][e], sv[3][e], w0, w1, w2);
+                        pk[0][e] = w0; pk[1][e] = w1; pk[2][e] = w2;
+                    }
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) __builtin_amdgcn_raw_buffer_store_b128(pk[x], trs, live + (unsigned)(x * 1024), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[4]), trs, live + 4096u, 0, 0);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 5; ++x)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[x]), trs, live + (unsigned)(x * 1024), 0, 0);   // soffset stays 0: see the store hazard note in recur.hip
+                }
             }
         }
         fence();

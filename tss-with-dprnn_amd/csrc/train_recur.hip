@@ -325,7 +325,7 @@ extern "C" int dprnn_get_bwd_gemm_mode(void) { return g_bwd_gemm_mode; }
 int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r, const float* w_hh_r, float* packedT, hipStream_t st);
 int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packedT, float* dX, float* dG, long long rows_total,
                          int nseq, int T, int inner_n, long long outer_stride, long long inner_stride, long long t_stride, int ndir,
-                         bool fast, const float* dhmax, hipStream_t st);
+                         bool fast, const float* dhmax, bool tape_packed, hipStream_t st);
 // One-shot selector: the NEXT dprnn_rnn_bwd launch in mode 3 takes max|dH| from *slot (device float, e.g. written by the dprnn_dgrad
 // call that produced dH: dprnn_dgrad_store_absmax) instead of measuring it with a pass over dH.  Ignored by the fp32 kernel.
 // (dprnn_rnn_bwd_ex takes it as an argument.)
@@ -396,7 +396,13 @@ static int rnn_bwd(int mode, const float* dhmax, int cell, const float* dH, cons
                    int64_t rows_total, int nseq, int T, int inner_n, int64_t outer_stride,
                    int64_t inner_stride, int64_t t_stride, int ndir, void* stream) {
     if (cell < 0 || cell > 2) { dprnn_set_error("dprnn_rnn_bwd: cell must be 0 (LSTM), 1 (GRU) or 2 (RNN tanh)"); return -1; }
+    const bool tape_packed = (mode & DPRNN_TAPE_PACKED) != 0;           // the tape dprnn_rnn_fwd_train_ex(3 | 0x100, ...) wrote
+    mode &= ~DPRNN_TAPE_PACKED;
     if (mode != 0 && mode != 3) { dprnn_set_error("dprnn_rnn_bwd: backward gemm mode must be 0 or 3 (got %d)", mode); return -1; }
+    if (tape_packed && !(cell == 0 && mode == 3)) {
+        dprnn_set_error("dprnn_rnn_bwd: a packed gate tape (mode | 0x100) is read by the f16-pieces LSTM backward (mode 3, cell 0) only");
+        return -1;
+    }
     if (cell != 0) mode = 0;
     if (!dH || !tape || !packedT || !dX || !dG) { dprnn_set_error("dprnn_rnn_bwd: null pointer"); return -1; }
     if (nseq <= 0 || T <= 0 || inner_n <= 0 || (ndir != 1 && ndir != 2) || rows_total < (int64_t)nseq * T) {
@@ -411,10 +417,10 @@ static int rnn_bwd(int mode, const float* dhmax, int cell, const float* dH, cons
         return -1;
     }
     if (int rc = dprnn_pack_expect(packedT, DPRNN_PACK_BWD, cell, mode, ndir, "dprnn_rnn_bwd")) return rc;
-    if (cell == 0 && mode == 3 && !g_bwd_stamps)
+    if (cell == 0 && mode == 3 && (!g_bwd_stamps || tape_packed))
         return recur_bwd_f16_launch(dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, (long long)outer_stride,
                                     (long long)inner_stride, (long long)t_stride, ndir, dprnn_fast_activations_enabled() != 0,
-                                    dhmax, (hipStream_t)stream);
+                                    dhmax, tape_packed, (hipStream_t)stream);
     BwdArgs a{dH, tape, packedT, dX, dG, (long long)rows_total, nseq, T, inner_n, ndir,
               (long long)outer_stride, (long long)inner_stride, (long long)t_stride, g_bwd_stamps};
     if (g_bwd_stamps && cell == 0) {            // diagnostic twin: same kernel with cycle stamps of wave 0 per workgroup

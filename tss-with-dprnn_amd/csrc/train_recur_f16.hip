@@ -120,7 +120,9 @@ struct Bwd16Args {
     long long outer_stride, inner_stride, t_stride;
 };
 
-template <bool FAST>
+// PACKED: the forward left the gates as three words of 24-bit fixed point per (sequence, unit) in tape slots 0-2 (common.h:
+// tape_pack) -- 4 KB instead of 5 KB of tape per row and direction, unpacked where the gate derivatives need them.
+template <bool FAST, bool PACKED = false>
 __global__ __launch_bounds__(512, 2)
 void lstm_bwd8_f16_kernel(Bwd16Args a) {
     constexpr int NSR = 64, NT = 4, KG = 512, NSL = 16;
@@ -188,7 +190,7 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs[nt >> 1], base + (unsigned)(((nt & 1) * 10 + slot) * 1024), 0, SAUX));
     };
 
-    f32x4 gi[NT], gf[NT], gg[NT], go[NT], cc[NT], cp[NT], dho[NT];
+    f32x4 gi[NT], gf[NT], gg[NT], go[PACKED ? 1 : NT], cc[NT], cp[NT], dho[NT];     // PACKED: gi / gf / gg hold the packed words
     f32x4 dh[NT], dc[NT];
     auto load_step = [&](int fs) __attribute__((always_inline)) {      // gates of step fs, c of step fs-1, dH of step fs
         const int fq = fs > 0 ? fs - 1 : 0;
@@ -197,7 +199,8 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
         const __amdgpu_buffer_rsrc_t dhs = rsrc_at(a.dH + (row0 + t_of(fs) * a.t_stride) * hpitch);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            gi[nt] = tape_ld(trs, nt, 0); gf[nt] = tape_ld(trs, nt, 1); gg[nt] = tape_ld(trs, nt, 2); go[nt] = tape_ld(trs, nt, 3);
+            gi[nt] = tape_ld(trs, nt, 0); gf[nt] = tape_ld(trs, nt, 1); gg[nt] = tape_ld(trs, nt, 2);
+            if constexpr (!PACKED) go[nt] = tape_ld(trs, nt, 3);
             const f32x4 c1 = tape_ld(tqs, nt, 4);
             cp[nt] = fs > 0 ? c1 : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -254,7 +257,17 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             fence();
             const f32x4 one = {1.f, 1.f, 1.f, 1.f};
             const f32x4 dht = dho[nt] + dh[nt];
-            const f32x4 i_ = gi[nt], f_ = gf[nt], g_ = gg[nt], o_ = go[nt];
+            f32x4 i_, f_, g_, o_;
+            if constexpr (PACKED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float vi, vf, vg, vo;
+                    tape_unpack(__float_as_uint(gi[nt][e]), __float_as_uint(gf[nt][e]), __float_as_uint(gg[nt][e]), vi, vf, vg, vo);
+                    i_[e] = vi; f_[e] = vf; g_[e] = vg; o_[e] = vo;
+                }
+            } else {
+                i_ = gi[nt]; f_ = gf[nt]; g_ = gg[nt]; o_ = go[nt];
+            }
             const f32x2 t01 = tanh_f2<FAST>(f32x2{cc[nt][0], cc[nt][1]}), t23 = tanh_f2<FAST>(f32x2{cc[nt][2], cc[nt][3]});
             const f32x4 tc = {t01[0], t01[1], t23[0], t23[1]};
             const f32x4 dct = dc[nt] + dht * o_ * (one - tc * tc);
@@ -355,7 +368,7 @@ int recur_bwd_f16_pack(const float* w_ih, const float* w_hh, const float* w_ih_r
 
 int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packedT, float* dX, float* dG, long long rows_total,
                          int nseq, int T, int inner_n, long long outer_stride, long long inner_stride, long long t_stride, int ndir,
-                         bool fast, const float* dhmax, hipStream_t st) {
+                         bool fast, const float* dhmax, bool tape_packed, hipStream_t st) {
     float* extra = const_cast<float*>(packedT) + (size_t)ndir * BWD_PACK_WORDS_PER_DIR;
     const long long n4 = rows_total * ndir * HD / 4;
     if (dhmax) {                                         // measured by dH's producer (dprnn_rnn_bwd_use_gradmax): 4 bytes instead of a pass
@@ -367,13 +380,15 @@ int recur_bwd_f16_launch(const float* dH, const float* tape, const float* packed
     Bwd16Args a{dH, tape, reinterpret_cast<const unsigned*>(packedT), extra, dX, dG, rows_total, nseq, T, inner_n, ndir,
                 outer_stride, inner_stride, t_stride};
     const size_t lds = (size_t)2 * 64 * 512 * 2 + 3 * 64 * 4;
-    auto kern = fast ? &lstm_bwd8_f16_kernel<true> : &lstm_bwd8_f16_kernel<false>;
-    static std::atomic<unsigned long long> attr_mask[2];
+    auto kern = tape_packed ? (fast ? &lstm_bwd8_f16_kernel<true, true> : &lstm_bwd8_f16_kernel<false, true>)
+                            : (fast ? &lstm_bwd8_f16_kernel<true> : &lstm_bwd8_f16_kernel<false>);
+    static std::atomic<unsigned long long> attr_mask[4];
     int attr_dev;
-    if (dprnn_attr_needed(attr_mask[fast], &attr_dev)) {
+    const int ki = (tape_packed ? 2 : 0) + (fast ? 1 : 0);
+    if (dprnn_attr_needed(attr_mask[ki], &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lstm_bwd8_f16): %s", hipGetErrorString(e)); return -2; }
-        dprnn_attr_done(attr_mask[fast], attr_dev);
+        dprnn_attr_done(attr_mask[ki], attr_dev);
     }
     hipLaunchKernelGGL(kern, dim3((nseq + 63) / 64, ndir), dim3(512), lds, st, a);
     return dprnn_check_launch("lstm_bwd8_f16_kernel");

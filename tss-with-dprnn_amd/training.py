@@ -48,6 +48,10 @@ TRAIN_BWD_GEMM_MODE = int(os.environ.get("DPRNN_TRAIN_BWD_GEMM_MODE", "3"))
 # ... and, with mode 3, the gradient GEMMs of the Linear after each recurrence (dZ @ W, dZ^T H) in f16 pieces, dZ scaled from its own
 # maximum (DPRNN_TRAIN_WGRAD_F16=0: fp32 MFMA for those).  Mask-head and bottleneck gradients are always fp32 MFMA.
 TRAIN_WGRAD_F16 = os.environ.get("DPRNN_TRAIN_WGRAD_F16", "1") != "0"
+# f16-pieces forward AND f16-pieces BPTT of an LSTM: the gate tape holds i, f, g, o as 24-bit fixed point (three words per (row, unit)
+# instead of four; csrc/common.h: tape_pack) -- a fifth less of the step's largest HBM stream.  DPRNN_TRAIN_TAPE_PACKED=0: fp32 gates.
+TAPE_PACKED = os.environ.get("DPRNN_TRAIN_TAPE_PACKED", "1") != "0"
+TAPE_PACKED_FLAG = 0x100             # on the gemm_mode argument of dprnn_rnn_fwd_train_ex / dprnn_rnn_bwd_ex
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 _TLS = threading.local()
 
@@ -143,7 +147,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
                                  gemm_mode=fwd_mode)
     Y_keep = Y if (keep and fusion.get("row_scale") is not None) else None        # 'att': the backward needs W a' = (Y - b) / rs
     X = [torch.empty(rows, F_BUILT, **f32)]
-    Z, H, tapes = [], [], []
+    Z, H, tapes, tape_flags = [], [], [], []
     st.call("dprnn_segment_fwd", _p(Y), _p(X[0]), B, L, K, P, S)
     del Y
     packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, **f32)
@@ -164,12 +168,14 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
             addr = _addr(geo, intra)
             Hp = torch.empty(rows, ndir * F_BUILT, **f32)
             tape = torch.empty(lib.dprnn_rnn_tape_floats(cell, addr[0], addr[1], ndir), **f32)
+            # the backward of THIS forward runs in the modes of this thread now (ctx.modes carries them)
+            tflag = TAPE_PACKED_FLAG if (TAPE_PACKED and fwd_mode == 3 and cell == 0 and train_modes()[1] == 3) else 0
             if pending is None:
-                st.call("dprnn_rnn_fwd_train_ex", fwd_mode, cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
+                st.call("dprnn_rnn_fwd_train_ex", fwd_mode | tflag, cell, _p(X[p]), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
             else:               # X[p] = X[p-1] + norm(Z[p-1]) on the fly
                 Zq, sq, gq, bq, eq = pending
                 Xn = torch.empty(rows, F_BUILT, **f32)
-                st.call("dprnn_rnn_fwd_train_ex", fwd_mode, cell, _p(X[p - 1]), _p(Zq), _p(sq), _p(gq), _p(bq), eq, S if intra else K, S * K, _p(Xn),
+                st.call("dprnn_rnn_fwd_train_ex", fwd_mode | tflag, cell, _p(X[p - 1]), _p(Zq), _p(sq), _p(gq), _p(bq), eq, S if intra else K, S * K, _p(Xn),
                         _p(packed), _p(bsum), _p(Hp), _p(tape), *addr, ndir)
                 X.append(Xn)
                 if not keep:
@@ -192,7 +198,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
                 if not keep:
                     X[p] = None
             if keep:
-                Z.append(Zp); H.append(Hp); tapes.append(tape)
+                Z.append(Zp); H.append(Hp); tapes.append(tape); tape_flags.append(tflag)
     finally:
         lib.dprnn_set_gemm_mode(0)
     R = B * L * 2
@@ -218,7 +224,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
     out = engine.decode(st, taps, geo, 2)
     if not keep:
         return out, None
-    saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, U=U, V=V, TG=TG, mask=mask,
+    saved = dict(geo=geo, wav=wav, stats=stats, sc=sc, sh=sh, X=X, Z=Z, H=H, tapes=tapes, tape_flags=tape_flags, U=U, V=V, TG=TG, mask=mask,
                  fusion=fusion, Y=Y_keep, d0=d0)
     return out, saved
 
@@ -378,7 +384,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         # fp32 kernel: dG [rows][ndir * kg]; f16 BPTT: the quad layout [dir][t][seq / 4][512][4] that dprnn_wgrad_lstm_f16 reads
         dG = torch.empty(lib.dprnn_rnn_bwd_dg_floats(cell, bm, addr[0], addr[1], ndir), **f32)
         st.call("dprnn_rnn_pack_bwd_ex", bm, cell, _p(fw[0]), _p(fw[1]), _p(bw[0]), _p(bw[1]), _p(packedT))
-        st.call("dprnn_rnn_bwd_ex", bm, hmax.data_ptr() if bptt_f16 else 0, cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG),
+        st.call("dprnn_rnn_bwd_ex", bm | saved["tape_flags"][p], hmax.data_ptr() if bptt_f16 else 0, cell, _p(dH), _p(tapes[p]), _p(packedT), _p(dXd), _p(dG),
                 rows, *addr, ndir)
         del dH
         pre = f"{blk}_rnn.rnn."
