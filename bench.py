@@ -732,15 +732,21 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
     from tss_with_dprnn_amd import training as _tr
     f16_bwd, f16_fwd = _tr.train_modes()[1] == 3, _tr.train_modes()[0] == 3
     # BPTT in f16 pieces is bound by its HBM streams, not by the matrix pipe: per slab row and both directions it reads the
-    # tape (2 x 128 units x 5 floats) and dH (256) and writes dG (1024) and dX (2 x 128): 11 264 bytes
+    # tape (2 x 128 units x 5 floats; x 4 words with the gates packed to 24-bit fixed point, training.TAPE_PACKED) and dH (256) and
+    # writes dG (1024) and dX (2 x 128): 11 264 bytes (10 240 packed)
     geo = engine.make_geometry(B, SAMPLES, 64, 250, 125, 2, 1)
-    bwd_gb_per_step = 12 * geo.rows * 11264 / 1e9
+    tape_packed = bool(_tr.TAPE_PACKED and f16_bwd and f16_fwd)
+    bwd_gb_per_step = 12 * geo.rows * (10240 if tape_packed else 11264) / 1e9
     hbm = bwd_gb_per_step * args.steps / (union_ms * 1e-3) / 1e3 if union_ms > 0 else float("nan")
     traffic, traffic_src = None, None
-    for cand in ("profiles/r04_pmc_traffic_train_f16.json", "profiles/r02_pmc_traffic_train_f16.json"):     # the newest PMC passes of this kernel
+    # the newest PMC passes of this kernel in the tape format of this run
+    for cand in ("profiles/r04_pmc_traffic_train_f16_packed_tape.json", "profiles/r04_pmc_traffic_train_f16.json"):
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), cand)) as fh:
-                traffic, traffic_src = json.load(fh)["lstm_bwd8_f16_kernel"]["traffic_GB_per_launch"], cand
+                rec = json.load(fh)["lstm_bwd8_f16_kernel"]
+            if (rec.get("tape_bytes_per_row", 5120) == 4096) != tape_packed:
+                continue
+            traffic, traffic_src = rec["traffic_GB_per_launch"], cand
             break
         except (OSError, KeyError, ValueError):
             continue
@@ -748,7 +754,7 @@ def bench_train(args, model, dev, world, rank, dist, sync, lstm_flop_per_step, m
         roof = {"bound": "hbm", "kernel": "lstm_bwd8_f16_kernel (dprnn_rnn_bwd_ex, BPTT, step GEMM in f16 pieces)", "achieved": hbm,
                 "peak": 8.0, "unit": "TB/s", "frac": hbm / 8.0, "traffic": traffic,
                 "traffic_unit": f"GB per launch of one 32-utterance micro-batch (PMC, {traffic_src}); algorithmic {bwd_gb_per_step / 24:.2f}",
-                "algorithmic_gb_per_step": bwd_gb_per_step, "matrix_tflops_algorithmic": achieved,
+                "algorithmic_gb_per_step": bwd_gb_per_step, "gate_tape": "24-bit fixed point, 4096 B per row" if tape_packed else "fp32, 5120 B per row", "matrix_tflops_algorithmic": achieved,
                 "matrix_frac_of_f16_pieces_ceiling": achieved / (2500.0 / 3)}
     else:
         roof = {"bound": "mfma", "kernel": "lstm_bwd_kernel (dprnn_rnn_bwd_ex, BPTT, fp32 MFMA)", "achieved": achieved,

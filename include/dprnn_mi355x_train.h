@@ -99,7 +99,14 @@ int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, const float* X
                          int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
                          float* dWcat, float* db0, float* db1, float* workspace, void* stream);
 /* the same with every selector as an argument (no per-thread state involved): gemm modes as in dprnn_mi355x.h / above;
- * dh_absmax = device float holding max|dH| (NULL: dprnn_rnn_bwd measures it with a pass over dH; mode 3 only) */
+ * dh_absmax = device float holding max|dH| (NULL: dprnn_rnn_bwd measures it with a pass over dH; mode 3 only).
+ * Packed gate tape: gemm_mode 3 | DPRNN_TAPE_PACKED on dprnn_rnn_fwd_train_ex (LSTM) writes the activated gates i, f, g, o of a
+ * (sequence, unit, step) as 24-bit fixed point in three words (tape slots 0-2; slot 3 stays unwritten, c stays fp32 in slot 4)
+ * instead of four floats -- a gate is held to 2^-25 (i, f, o) / 2^-24 (g) absolute, the spacing of fp32 near 1 -- and
+ * dprnn_rnn_bwd_ex must then be called with bwd_gemm_mode 3 | DPRNN_TAPE_PACKED on that tape.  The tape is the largest stream of a
+ * training step: 4 KB instead of 5 KB per slab row (both directions), written once and read once.  Same buffer size
+ * (dprnn_rnn_tape_floats); any other mode / cell with the flag returns -1. */
+#define DPRNN_TAPE_PACKED 0x100
 int dprnn_rnn_fwd_train_ex(int gemm_mode, int cell, const float* X, const float* Z, const double* stats, const float* gamma,
                            const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
                            const float* packed, const float* bsum, float* H, float* tape,

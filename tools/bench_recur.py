@@ -129,8 +129,12 @@ def run_train(st, nwg, T, ndir=2, iters=3):
     st.call("dprnn_rnn_pack", 0, *[p(t) for t in w], *[p(t) for t in w], p(packed), p(bsum))
     st.call("dprnn_rnn_pack_bwd", 0, p(w[0]), p(w[1]), p(w[0]), p(w[1]), p(packedT))      # layout follows dprnn_set_bwd_gemm_mode
     addr = (nseq, T, nseq, 0, T, 1, ndir)
-    calls = {"fwd_train": ("dprnn_rnn_fwd_train", (0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), p(tape), *addr)),
-             "bwd": ("dprnn_rnn_bwd", (0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr))}
+    mode, bmode = lib.dprnn_get_gemm_mode(), lib.dprnn_get_bwd_gemm_mode()
+    flag = 0x100 if (mode == 3 and bmode == 3 and os.environ.get("DPRNN_TRAIN_TAPE_PACKED", "1") != "0") else 0      # the product's pairing
+    calls = {"fwd_train": ("dprnn_rnn_fwd_train_ex", (mode | flag, 0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), p(tape), *addr)),
+             "bwd": ("dprnn_rnn_bwd_ex", (bmode | flag, 0, 0, p(dH), p(tape), p(packedT), p(dX), p(dG), rows, *addr))}
+    if mode == 3:       # the inference kernel on the same grid (64-sequence tiles, h as fp32): what the tape and the sequence-major cell cost
+        calls["fwd (inference kernel)"] = ("dprnn_rnn_fwd", (0, p(X), 0, 0, 0, 0, 0.0, 1, 1, 0, p(packed), p(bsum), p(H), *addr, 2064))
     flops = nseq * T * ndir * 2 * 256 * 512
     out = {}
     for k, (fn, args) in calls.items():

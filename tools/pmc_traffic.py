@@ -68,11 +68,15 @@ def main():
         # training step: the BPTT launch of one 32-utterance micro-batch (bench.py --mode train: 64 utterances as 2 x 32), for
         # bench.py's training roofline.traffic.  Algorithmic bytes per slab row and both directions: tape 2 x 128 units x 5 floats,
         # dH 256 floats in; dG 1024 four-byte elements (f16 piece pairs in the quad layout) and dX 2 x 128 floats out = 11 264 B
+        # (packed gate tape, kernel <.., true>: 2 x 128 units x 4 words = 4096 B of tape, 10 240 B in all)
         n = sum(v["launches"] for v in bw.values())
         traffic = sum(v["launches"] * (v["hbm_read_GB"] + v["hbm_write_GB"]) for v in bw.values()) / n
-        algo = 32 * 48500 * 11264 / 1e9
+        packed = all(re.match(r"lstm_bwd8_f16_kernel<\w+, true>", k) for k in bw)
+        tape = 4096 if packed else 5120
+        algo = 32 * 48500 * (tape + 6144) / 1e9
         out["lstm_bwd8_f16_kernel"] = {"group_batch": 32, "traffic_GB_per_launch": round(traffic, 4), "algorithmic_GB_per_launch": round(algo, 4),
-                                       "note": f"mean over {n} BPTT launches; per slab row and both directions: tape 5120 B + dH 1024 B in, dG 4096 B + "
+                                       "tape_bytes_per_row": tape,
+                                       "note": f"mean over {n} BPTT launches; per slab row and both directions: tape {tape} B + dH 1024 B in, dG 4096 B + "
                                                f"dX 1024 B out; traffic / algorithmic = {traffic / algo:.3f}"}
     json.dump(out, sys.stdout, indent=1)
 

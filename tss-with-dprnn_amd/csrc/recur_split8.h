@@ -495,8 +495,8 @@ void bilstm_split8_kernel(RecurArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv[e]), hrs, rowoff_h[16 * nt + 4 * q + e] + hcol, 0, 0);
-            if constexpr (SAVE) {
+                if (!diag(512)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv[e]), hrs, rowoff_h[16 * nt + 4 * q + e] + hcol, 0, 0);
+            if constexpr (SAVE && !diag(256)) {                        // (probes 256 / 512: no tape / h stores -- what the stores cost)
                 const int wg_b = 2 * blockIdx.x + (nt >> 1);           // the 32-sequence workgroup of the tape layout
                 const __amdgpu_buffer_rsrc_t trs = rsrc_at(a.tape + (((size_t)dir * nwg_b + wg_b) * T + step) * 20480);
                 const unsigned live = wg_b < nwg_b ? toff + (unsigned)((nt & 1) * 10 * 1024) : OOB;
