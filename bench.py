@@ -458,8 +458,9 @@ def main():
                 # the data-sheet peak assumes 2.4 GHz; this forward runs at the board's power limit, which holds the shader clock
                 # lower (the line's `power` object), and a register-only f16 MFMA loop reaches 2024 TFLOP/s on this chip for the
                 # same reason (profiles/r03_power_bound.txt): frac against `peak` cannot exceed ~0.8
-                "peak_at_power_limit_note": None if mode == 0 else "2024 TFLOP/s dense f16 MFMA measured with operands in registers "
-                "(tools/probes/mfma_f16_coexec.hip) = 675 algorithmic; the forward holds the socket at ~1380 W (see `power`)",
+                "peak_at_power_limit_note": None if mode == 0 else "1852 TFLOP/s dense f16 MFMA sustained for 4 s with operands in registers, "
+                "0.70 pJ/FLOP, 1.93 GHz at ~1300 W (tools/probes/mfma_shape_energy.hip, profiles/r04_mfma_shape_energy.txt; short bursts 2024: "
+                "mfma_f16_coexec.hip) = 617 algorithmic; the forward holds the socket at ~1380 W (see `power`)",
                 # the kernel runs at the board's power limit, so time = energy: where the joules of a step go (MFMAs 46-56 %, HBM traffic
                 # 19 %, weight stream from L2 8-12 %, cell arithmetic 9-11 %), measured with the socket's energy counter
                 "energy_budget": None if mode == 0 else "profiles/r04_energy_budget.txt",
