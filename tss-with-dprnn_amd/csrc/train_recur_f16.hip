@@ -112,6 +112,14 @@ void dh_absmax_kernel(const float* __restrict__ dH, long long n4, float* __restr
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
 }
 
+// Probe builds (tools/build_diag_libs.sh with SRC=train_recur_f16; results are wrong by construction, time and energy are valid):
+// 1 no LDS image writes, 2 no dG stores, 4 the first k-slab only (1/16 of the MFMAs, weight stream and image reads), 8 no tape / dH loads
+// after the first step, 16 no dX stores, 32 no gate-derivative arithmetic (da = dh)
+#ifndef DPRNN_BWD16_DIAG
+#define DPRNN_BWD16_DIAG 0
+#endif
+constexpr bool bdiag(int bit) { return (DPRNN_BWD16_DIAG & bit) != 0; }
+
 struct Bwd16Args {
     const float* dH; const float* tape; const unsigned* Wp; const float* extra;
     float* dX; float* dG;
@@ -272,11 +280,16 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
             const f32x4 tc = {t01[0], t01[1], t23[0], t23[1]};
             const f32x4 dct = dc[nt] + dht * o_ * (one - tc * tc);
             f32x4 da[4];
+            if constexpr (bdiag(32)) {
+                da[0] = dht; da[1] = dht + i_; da[2] = dht + f_; da[3] = dht + g_ + o_ + cp[nt];
+                dc[nt] = dht;
+            } else {
             da[3] = dht * tc * o_ * (one - o_);
             da[0] = dct * g_ * i_ * (one - i_);
             da[1] = dct * cp[nt] * f_ * (one - f_);
             da[2] = dct * i_ * (one - g_ * g_);
             dc[nt] = dct * f_;
+            }
             cc[nt] = cp[nt];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -289,18 +302,22 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
                     split2_pair_f16(s0, s1, w1, w2);
                     qw[p2] = w1; qw[2 + p2] = w2;
                     char* const d0 = img + nt * 16384 + g * 256, *const d1 = d0;
-                    *reinterpret_cast<unsigned short*>(d0 + wb[0][2 * p2]) = (unsigned short)w1;
-                    *reinterpret_cast<unsigned short*>(d1 + wb[0][2 * p2 + 1]) = (unsigned short)(w1 >> 16);
-                    *reinterpret_cast<unsigned short*>(d0 + wb[1][2 * p2]) = (unsigned short)w2;
-                    *reinterpret_cast<unsigned short*>(d1 + wb[1][2 * p2 + 1]) = (unsigned short)(w2 >> 16);
+                    if constexpr (!bdiag(1)) {
+                        *reinterpret_cast<unsigned short*>(d0 + wb[0][2 * p2]) = (unsigned short)w1;
+                        *reinterpret_cast<unsigned short*>(d1 + wb[0][2 * p2 + 1]) = (unsigned short)(w1 >> 16);
+                        *reinterpret_cast<unsigned short*>(d0 + wb[1][2 * p2]) = (unsigned short)w2;
+                        *reinterpret_cast<unsigned short*>(d1 + wb[1][2 * p2 + 1]) = (unsigned short)(w2 >> 16);
+                    }
                 }
                 // rows 4 q .. 4 q + 3 of the tile are one quad of sequences (a quad whose first sequence exists is stored whole: the
                 // gate gradients of sequences beyond nseq are zero, their tape and dH lanes read as zero)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, dgs, off_g[16 * nt + 4 * q] + gcol + (unsigned)(g * 2048), 0, SAUX);
+                if constexpr (!bdiag(2))
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, dgs, off_g[16 * nt + 4 * q] + gcol + (unsigned)(g * 2048), 0, SAUX);
+                else asm volatile("" :: "v"(qw[0]), "v"(qw[1]), "v"(qw[2]), "v"(qw[3]));
             }
         }
         fence();
-        if (fs > 0) load_step(fs - 1);                   // in flight during the GEMM below
+        if (fs > 0 && !(bdiag(8) && fs < T - 1)) load_step(fs - 1);                   // in flight during the GEMM below
         fence();
         __syncthreads();                                 // the image of this step is complete
 
@@ -308,6 +325,7 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
         f32x4 acc[NT][2];
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
+            if (bdiag(4) && s > 0) break;
             fence();
             u32x4 P[NT], Q[NT];
 #pragma unroll
@@ -347,7 +365,9 @@ void lstm_bwd8_f16_kernel(Bwd16Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 dh[nt][e] = acc[nt][1][e] * inv;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][0][e] * inv), dxs, off_x[16 * nt + 4 * q + e] + xcol, 0, SAUX);
+                if constexpr (!bdiag(16))
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][0][e] * inv), dxs, off_x[16 * nt + 4 * q + e] + xcol, 0, SAUX);
+                else asm volatile("" :: "v"(acc[nt][0][e]));
             }
         }
     }
