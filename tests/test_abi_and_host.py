@@ -308,6 +308,25 @@ def test_utterance_groups_partition_the_batch_and_leave_one_pipeline_only_while_
     assert engine.plan_groups(9, 3) == 2 and engine.plan_groups(64, 3) == 2 and engine.plan_groups(64, 0) == 4
 
 
+def test_wide_recurrence_tiles_need_a_clear_predicted_advantage():
+    """engine.split_tile (round 4, profiles/r04_inter_tile_sweep.txt): with two pipelines the 64-sequence tile is taken only when the
+    cost model predicts it at least SPLIT_WIDE_TILE_MARGIN better than the 16-sequence resident-weights tile (measured: predicted
+    4 % / 11 % / 17 % better at 13 / 14 / 15 utterances per pipeline, measured 3 % worse / 1 % worse / 1.5 % better), and once taken
+    it stays taken as the pipeline grows; a lone pipeline is not affected."""
+    from tss_with_dprnn_amd import engine
+    K, ncu = 250, 256
+    tiles = [engine.split_tile(n * K, 2, ncu, 2, 3) for n in range(1, 33)]
+    assert tiles[12 - 1] == 2016 and tiles[13 - 1] == 2016 and tiles[14 - 1] == 2016 and tiles[15 - 1] == 2064
+    first_wide = tiles.index(2064)
+    assert all(t == 2064 for t in tiles[first_wide:]) and all(t == 2016 for t in tiles[:first_wide])
+    old = engine.SPLIT_WIDE_TILE_MARGIN
+    try:
+        engine.SPLIT_WIDE_TILE_MARGIN = 1.0
+        assert engine.split_tile(13 * K, 2, ncu, 2, 3) == 2064                    # the bare cost model's choice
+    finally:
+        engine.SPLIT_WIDE_TILE_MARGIN = old
+
+
 def test_every_engine_setting_is_classified_for_the_graph_key():
     """engine.LAUNCH_KNOBS (part of every captured graph's key) and engine.OTHER_SETTINGS together name every upper-case module-level
     setting of engine.py: a knob added later and forgotten fails here instead of replaying a graph captured under another value."""

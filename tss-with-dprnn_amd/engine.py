@@ -604,7 +604,10 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     if cell != 0 and tile > 32:
         tile = 32
     if cell == 0 and g.mode != 0:
-        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(addr[0], ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
+        # every pipeline of a forward takes the tile of the LARGEST one: pipelines on different tiles finish apart, and the forward
+        # waits for the slower (B = 25 as 12 + 13 utterances: 32.4 ms mixed against 30.9 / 31.9 ms on either tile for both)
+        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
     # f16 pieces: the recurrence hands the projection its operand (H as piece quads, dprnn_rnn_fwd_hp_ex) -- unless someone wants to see h
     hp = H_PIECES and g.mode == 3 and cell == 0 and dbg is None and tile >= 2000
     rnn_fwd = "dprnn_rnn_fwd_hp_ex" if hp else "dprnn_rnn_fwd_ex"
@@ -647,10 +650,13 @@ SPLIT_GROUPS = 2             # utterance groups (streams) in the bf16-split mode
 SPLIT_STEP_US_F16 = {2016: 3.8, 2032: 13.2, 2064: 11.6, 2080: 15.3}   # 2016: first weight pieces resident in registers (few utterances)
 
 
+SPLIT_WIDE_TILE_MARGIN = 1.13
+
+
 def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1) -> int:
     """seq_tile code for the split recurrence over nseq sequences x ndir directions: the form whose grid takes the
     least time, rounds x cost of a step (64 x 3 s in two groups: 194 / 250 workgroups of 64 sequences per launch)."""
-    best, best_t = None, None
+    best, best_t, t16 = None, None, None
     for tile, us in (SPLIT_STEP_US_F16 if mode == 3 else SPLIT_STEP_US).items():
         wgs = ndir * -(-nseq // (tile % 1000))
         two_per_cu = tile % 1000 == 32
@@ -661,8 +667,15 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 
         t = rounds * us
         if two_per_cu and wgs * concurrent <= ncu:     # one 32-sequence workgroup per CU runs at the MFMA's pace, not the L2's
             t *= 0.6
+        if tile == 2016:
+            t16 = t
         if best_t is None or t < best_t - 1e-9:
             best, best_t = tile, t
+    # The wider tiles' step costs were measured on a full grid; inside a forward with two pipelines their advantage over the
+    # 16-sequence resident-weights tile is smaller than this model says (profiles/r04_inter_tile_sweep.txt: predicted 4 % / 11 % /
+    # 17 % better at 13 / 14 / 15 utterances per pipeline, measured 3 % worse / 1 % worse / 1.5 % better): switch from 13 % up.
+    if best != 2016 and t16 is not None and concurrent > 1 and t16 <= SPLIT_WIDE_TILE_MARGIN * best_t:
+        best = 2016
     return best
 
 
@@ -787,6 +800,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     for g in groups:
         g.n_concurrent = len(groups)
+        g.plan_B = max(b1 - b0 for b0, b1 in parts)
         g.mode = mode
         g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
@@ -1896,7 +1910,7 @@ class _Graphed:
 # upper-case name is left out): LAUNCH_KNOBS change the launch sequence of a forward -- which kernels, tiles, streams, arithmetic --
 # and are therefore part of every captured graph's key; the others are constants, bookkeeping, or policy applied outside a capture.
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
-LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE",
+LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
                 "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
                 "SATURATION_CHECK")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
