@@ -78,6 +78,8 @@ def parse_args(argv=None):
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
     ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
+    ap.add_argument("--serial-tile-intra", type=int, default=0, help="seq_tile of the direction-serial launches (engine.SEQ_TILE['serial_intra'])")
+    ap.add_argument("--serial-tile-inter", type=int, default=0)
     ap.add_argument("--seq-tile-inter", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -308,6 +310,7 @@ def main():
     if args.rowgemm_grid is not None:
         lib.dprnn_set_rowgemm_grid(args.rowgemm_grid)
     engine.SEQ_TILE["intra"], engine.SEQ_TILE["inter"] = args.seq_tile_intra, args.seq_tile_inter
+    engine.SEQ_TILE["serial_intra"], engine.SEQ_TILE["serial_inter"] = args.serial_tile_intra, args.serial_tile_inter
     if args.groups is not None:
         engine.STREAM_GROUPS = args.groups
     if args.min_group is not None:

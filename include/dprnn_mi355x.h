@@ -104,6 +104,15 @@ int dprnn_scale_init(void* record, void* stream);
 int dprnn_scale_begin(void* record);
 int dprnn_scale_slot(int slot);
 int dprnn_scale_update(void* record, void* stream);
+/* The same with a working copy per forward (what the Python host does): the record is float32[4 * DPRNN_SCALE_SLOTS] (sticky maxima,
+ * unused, low-streak length, low-streak maximum; dprnn_scale_init fills all of it), `work` float32[2 * DPRNN_SCALE_SLOTS] owned by
+ * the forward.  dprnn_scale_fork(record, work, stream) snapshots the sticky maxima into `work` and registers `work` for this thread's
+ * launches (instead of dprnn_scale_begin(record)); dprnn_scale_join(record, work, stream) at the end folds the forward's maxima in
+ * with atomics; then dprnn_scale_begin(NULL).  Forwards of one model on several threads / streams then never see the scale change
+ * between their pack call and the launches that read the pack, and the record comes down again: a site whose forward maximum stays
+ * 16 x below its sticky maximum for 8 consecutive forwards falls back to the largest value of that streak (at least 256). */
+int dprnn_scale_fork(const void* record, void* work, void* stream);
+int dprnn_scale_join(void* record, const void* work, void* stream);
 
 /* packed weights of the split modes: ndir * 196608 u32 (three bf16 piece planes in B-fragment order; the f16 form uses
  * two planes and keeps its scale 2^e, and 1 / (2^4 2^e), in words 512 and 513 of the third) */
@@ -249,6 +258,44 @@ int dprnn_rnn_fwd_hp_ex(int gemm_mode, int cell, const float* X, const float* Z,
  * form with utterance u owning rows [utt_starts[u], utt_starts[u+1])) */
 int dprnn_proj_stats_hp_fwd(const float* Hp, const float* W, const float* bias, float* Z, double* stats,
                             int64_t M, int64_t rows_per_utt, const int64_t* utt_starts, int n_utt, int kdim, void* stream);
+
+/* Direction-serial BiLSTM with the Linear that follows it folded in (gate-GEMM mode 3, LSTM, inference; replaces dprnn.py:86 + :88 and
+ * :95 + :96 -- SingleRNN and intra_linear / inter_linear of one path -- for callers that do not need h itself).  One launch runs ONE
+ * direction and multiplies every h_t with that direction's half of the Linear while h_t is the next step's operand in LDS, so h never
+ * reaches HBM and the projection kernel disappears: a path moves 7 slab rows of 512 B per row instead of 10.
+ *   dprnn_lin_pack_f16: W [F][ndir H] row-major (intra_linear.weight / inter_linear.weight) -> lin_packed, dprnn_lin_pack_floats() floats.
+ *   dprnn_rnn_lin_fwd, phase 1 (dir 0 of a bidirectional LSTM): X (+ the pending norm Z, stats, gamma, beta, eps -> x' to Xout, as
+ *       dprnn_rnn_fwd_ex) -> P [rows][F] = W[:, :H] h_fwd, fp32.
+ *   phase 2 (dir 1; or dir 0 of a unidirectional LSTM with P == NULL): X (x' of phase 1 when a norm was pending: pass Z = NULL) and
+ *       P -> Zout [rows][F] = P + W[:, dir H:] h + bias, and stats_out [utterances][2] += (sum, sum of squares) of each utterance's
+ *       rows in fp64.  P may be Zout, and may be the buffer phase 1 read its pending Z from (every row is consumed before it is
+ *       rewritten).
+ * packed / bsum: dprnn_rnn_pack_ex in mode 3; addressing arguments as dprnn_rnn_fwd_ex; seq_tile 0 (= 2064), 2032, 2048 or 2064;
+ * seqs_per_utt / rows_per_utt are always required (phase 2 maps sequences to utterances with them). */
+int64_t dprnn_lin_pack_floats(void);
+int dprnn_lin_pack_f16(const float* W, int ndir, void* lin_packed, void* stream);
+/* The same fold with BOTH directions in every launch: the path is cut in time at M = T / 2 instead of by direction, so a launch
+ * has twice the workgroups (one per direction and sequence tile) and two pipelines pack the chip as the unfolded launches do.
+ *   phase 1: the forward direction walks steps [0, M) (rows t < M), the reverse direction steps [0, T - M) (rows t >= M); each applies
+ *       the pending norm to the rows it meets (Z, stats, gamma, beta, eps -> x' to Xout; Z == NULL: X is used as it is), leaves its
+ *       partial product in P [rows][F] (P must not be Z) and its cell state + h image in `state`
+ *       (dprnn_rnn_lin_state_floats(nseq, seq_tile) floats).
+ *   phase 2 (pass X = the x' of phase 1, or the same X when nothing was pending; Z = NULL): both directions continue from `state`
+ *       over the rows the other one met in phase 1 and finish them in place: P = P + own half + bias, stats_out += GroupNorm sums.
+ * The kernel boundary between the two launches is the only synchronisation.  7 slab rows of HBM traffic per row and path. */
+int64_t dprnn_rnn_lin_state_floats(int nseq, int seq_tile);
+int dprnn_rnn_lin_split_fwd(int phase, const float* X, const float* Z, const double* stats, const float* gamma,
+                            const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                            const float* packed, const float* bsum, const void* lin_packed, const float* lin_bias,
+                            float* P, double* stats_out, float* state,
+                            int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
+                            int seq_tile, void* stream);
+int dprnn_rnn_lin_fwd(int phase, int dir, const float* X, const float* Z, const double* stats, const float* gamma,
+                      const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
+                      const float* packed, const float* bsum, int ndir, const void* lin_packed, const float* lin_bias,
+                      float* P, float* Zout, double* stats_out,
+                      int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
+                      int seq_tile, void* stream);
 
 /* diagnostic twin of dprnn_bilstm_fwd (seq_tile 32 or 64, fast activations): stamps[workgroup][8] u64 =
  * {shader cycles, 100 MHz ticks, k-loop cycles, cell-phase cycles, start tick, end tick, XCC id, HW id}; in the split modes (seq_tile 2064)

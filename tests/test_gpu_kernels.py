@@ -545,6 +545,180 @@ def test_h_as_piece_quads_feeds_the_projection_bit_for_bit(seq_tile, ndir, ragge
     assert np.abs(h - out[False][0].astype(np.float64)).max() < 2.0 ** -22
 
 
+@pytest.mark.parametrize("seq_tile", [2032, 2048, 2064])
+@pytest.mark.parametrize("path,fused", [("intra", False), ("inter", False), ("intra", True), ("inter", True)])
+@pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (37.0, 0.02)])
+def test_direction_serial_bilstm_with_the_linear_folded_in(seq_tile, path, fused, wscale, xscale):
+    """dprnn_rnn_lin_fwd (recur_split8.h PJ): direction 0 leaves x' and the partial products W[:, :H] h_fwd IN THE BUFFER ITS PENDING Z
+    CAME FROM, direction 1 turns them into z = Linear(cat(h_fwd, h_bwd)) in place and accumulates the GroupNorm sums -- against the
+    numpy oracle's SingleRNN + Linear (dprnn.py:86-88 / 95-96), on both addressing forms, with partial last tiles and utterance
+    boundaries inside tiles, with and without a pending norm, and with weights / activations far from unit scale."""
+    B, S, K = 3, 37, 41
+    rng = np.random.default_rng(seq_tile + int(10 * wscale) + (7 if fused else 0))
+    X = (xscale * rng.standard_normal((B, S, K, 128))).astype(np.float32)
+    sd, p = _lstm_sd(46)
+    sd = {k: (v * np.float32(wscale) if ".rnn.weight_" in k else v) for k, v in sd.items()}
+    W = (rng.standard_normal((128, 256)) / 16.0).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    Xn = X
+    if fused:
+        Zr = (rng.standard_normal((B, S, K, 128)) * 1.3 + 0.2).astype(np.float32)
+        gamma = (xscale * (1 + 0.1 * rng.standard_normal(128))).astype(np.float32)
+        beta = (xscale * 0.1 * rng.standard_normal(128)).astype(np.float32)
+        zb = Zr.reshape(B, -1).astype(np.float64)
+        mean, var = zb.mean(1)[:, None, None, None], zb.var(1)[:, None, None, None]
+        Xn = (X + ((Zr - mean) / np.sqrt(var + 1e-5)) * gamma + beta).astype(np.float32)
+    if path == "intra":
+        h = onp.single_rnn(sd, p, Xn.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    else:
+        h = onp.single_rnn(sd, p, Xn.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
+        h = h.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    want = h.astype(np.float64) @ W.T.astype(np.float64) + b
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    linp = torch.empty(st.lib.dprnn_lin_pack_floats(), device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    st.call("dprnn_rnn_pack_ex", 3, 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    Wd, bd_ = _t(W), _t(b)
+    st.call("dprnn_lin_pack_f16", Wd.data_ptr(), 2, linp.data_ptr())
+    Xd = _t(X)
+    Xo = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    spu = S if path == "intra" else K
+    ZP = torch.full((B, S, K, 128), float("nan"), device=DEV)          # pending z -> partial products -> new z, one buffer
+    norm = (0, 0, 0, 0, 0.0)
+    if fused:
+        ZP.copy_(torch.from_numpy(Zr))
+        stats_in = _t(np.stack([zb.sum(1), (zb ** 2).sum(1)], axis=1))
+        gd, bd = _t(gamma), _t(beta)
+        norm = (ZP.data_ptr(), stats_in.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5)
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_rnn_lin_fwd", 1, 0, Xd.data_ptr(), *norm, spu, S * K, Xo.data_ptr() if fused else 0, packed.data_ptr(), bsum.data_ptr(), 2,
+            linp.data_ptr(), 0, ZP.data_ptr(), 0, 0, *addr, seq_tile)
+    st.call("dprnn_rnn_lin_fwd", 2, 1, (Xo if fused else Xd).data_ptr(), 0, 0, 0, 0, 0.0, spu, S * K, 0, packed.data_ptr(), bsum.data_ptr(), 2,
+            linp.data_ptr(), bd_.data_ptr(), ZP.data_ptr(), ZP.data_ptr(), stats.data_ptr(), *addr, seq_tile)
+    torch.cuda.synchronize()
+    got = ZP.cpu().numpy()
+    assert np.isfinite(got).all()
+    if fused:
+        assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
+    # yardstick: the separate kernels of the same arithmetic (both directions in one launch, then the f16-pieces projection)
+    H = torch.empty(B, S, K, 256, device=DEV)
+    Z2 = torch.empty(B, S, K, 128, device=DEV)
+    stats2 = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_rnn_fwd_ex", 3, 0, _t(Xn).data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, seq_tile)
+    st.lib.dprnn_set_gemm_mode(3)
+    st.call("dprnn_proj_stats_fwd", H.data_ptr(), Wd.data_ptr(), bd_.data_ptr(), Z2.data_ptr(), stats2.data_ptr(), B * S * K, S * K, 256)
+    st.lib.dprnn_set_gemm_mode(0)
+    torch.cuda.synchronize()
+    e_new, e_old = rel_l2(got, want), rel_l2(Z2.cpu().numpy(), want)
+    assert e_new < max(1e-6, 2 * e_old), f"tile {seq_tile} {path} fused={fused}: folded {e_new:.2e}, separate kernels {e_old:.2e}"
+    # the sums are those of the rows actually written (fp32 partial sums of 128 elements, fp64 beyond) ...
+    sg = stats.cpu().numpy()
+    gb = got.astype(np.float64).reshape(B, -1)
+    assert np.allclose(sg[:, 0], gb.sum(1), rtol=1e-9, atol=1e-6 * np.abs(gb).sum(1).max())
+    assert np.allclose(sg[:, 1], (gb ** 2).sum(1), rtol=1e-6)
+    # ... and the oracle's, as far as the rows are (x 37 weights saturate the cell: both kernel forms sit ~1e-4 from the oracle there)
+    wb = want.reshape(B, -1)
+    tol = max(1e-6, 4 * e_new)
+    assert np.allclose(sg[:, 0], wb.sum(1), rtol=0, atol=tol * np.abs(wb).sum(1).max()), (e_new, e_old)
+    assert np.allclose(sg[:, 1], (wb ** 2).sum(1), rtol=4 * tol), (e_new, e_old)
+    print(f"tile {seq_tile} {path} fused={fused} w x{wscale}: folded {e_new:.2e}, separate {e_old:.2e}")
+
+
+@pytest.mark.parametrize("seq_tile", [2032, 2048, 2064])
+@pytest.mark.parametrize("path,fused,dims", [("intra", False, (3, 37, 41)), ("inter", False, (3, 37, 41)), ("intra", True, (3, 37, 41)),
+                                             ("inter", True, (3, 37, 41)), ("intra", True, (2, 5, 1)), ("inter", True, (2, 2, 6)),
+                                             ("inter", False, (1, 3, 4))])
+def test_time_split_bilstm_with_the_linear_folded_in(seq_tile, path, fused, dims):
+    """dprnn_rnn_lin_split_fwd (recur_split8.h: split_m): both directions in both launches, every sequence cut at M = T / 2 -- phase 1
+    leaves x', the partial products of the rows each direction meets and the cell state; phase 2 finishes every row from the other
+    side -- against the numpy oracle's SingleRNN + Linear (dprnn.py:86-88 / 95-96): odd and even T, T = 1, 2, 3 (a direction without
+    a step in one phase), partial tiles, utterance boundaries inside tiles, with and without a pending norm."""
+    B, S, K = dims
+    rng = np.random.default_rng(seq_tile + B * 100 + S * 10 + K + (7 if fused else 0))
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(46)
+    W = (rng.standard_normal((128, 256)) / 16.0).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    Xn = X
+    if fused:
+        Zr = (rng.standard_normal((B, S, K, 128)) * 1.3 + 0.2).astype(np.float32)
+        gamma = (1 + 0.1 * rng.standard_normal(128)).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(128)).astype(np.float32)
+        zb = Zr.reshape(B, -1).astype(np.float64)
+        mean, var = zb.mean(1)[:, None, None, None], zb.var(1)[:, None, None, None]
+        Xn = (X + ((Zr - mean) / np.sqrt(var + 1e-5)) * gamma + beta).astype(np.float32)
+    if path == "intra":
+        h = onp.single_rnn(sd, p, Xn.reshape(B * S, K, 128), "LSTM", True).reshape(B, S, K, 256)
+    else:
+        h = onp.single_rnn(sd, p, Xn.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", True)
+        h = h.reshape(B, K, S, 256).transpose(0, 2, 1, 3)
+    want = h.astype(np.float64) @ W.T.astype(np.float64) + b
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    linp = torch.empty(st.lib.dprnn_lin_pack_floats(), device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names] + [_t(sd[f"{p}.rnn.{n}_reverse"]) for n in names]
+    st.call("dprnn_rnn_pack_ex", 3, 0, *[t.data_ptr() for t in w], packed.data_ptr(), bsum.data_ptr())
+    Wd, bd_ = _t(W), _t(b)
+    st.call("dprnn_lin_pack_f16", Wd.data_ptr(), 2, linp.data_ptr())
+    Xd = _t(X)
+    Xo = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    spu = S if path == "intra" else K
+    state = torch.full((st.lib.dprnn_rnn_lin_state_floats(addr[0], seq_tile),), float("nan"), device=DEV)
+    P = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    norm = (0, 0, 0, 0, 0.0)
+    if fused:
+        stats_in = _t(np.stack([zb.sum(1), (zb ** 2).sum(1)], axis=1))
+        Zd, gd, bd = _t(Zr), _t(gamma), _t(beta)
+        norm = (Zd.data_ptr(), stats_in.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5)
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    tail = (packed.data_ptr(), bsum.data_ptr(), linp.data_ptr())
+    st.call("dprnn_rnn_lin_split_fwd", 1, Xd.data_ptr(), *norm, spu, S * K, Xo.data_ptr() if fused else 0, *tail, 0, P.data_ptr(), 0,
+            state.data_ptr(), *addr, seq_tile)
+    st.call("dprnn_rnn_lin_split_fwd", 2, (Xo if fused else Xd).data_ptr(), 0, 0, 0, 0, 0.0, spu, S * K, 0, *tail, bd_.data_ptr(), P.data_ptr(),
+            stats.data_ptr(), state.data_ptr(), *addr, seq_tile)
+    torch.cuda.synchronize()
+    got = P.cpu().numpy()
+    assert np.isfinite(got).all()
+    if fused:
+        assert rel_l2(Xo.cpu().numpy(), Xn) < 1e-6
+    H = torch.empty(B, S, K, 256, device=DEV)
+    Z2 = torch.empty(B, S, K, 128, device=DEV)
+    stats2 = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_rnn_fwd_ex", 3, 0, _t(Xn).data_ptr(), 0, 0, 0, 0, 0.0, 1, 1, 0, packed.data_ptr(), bsum.data_ptr(), H.data_ptr(), *addr, 2, seq_tile)
+    st.lib.dprnn_set_gemm_mode(3)
+    st.call("dprnn_proj_stats_fwd", H.data_ptr(), Wd.data_ptr(), bd_.data_ptr(), Z2.data_ptr(), stats2.data_ptr(), B * S * K, S * K, 256)
+    st.lib.dprnn_set_gemm_mode(0)
+    torch.cuda.synchronize()
+    e_new, e_old = rel_l2(got, want), rel_l2(Z2.cpu().numpy(), want)
+    assert e_new < max(1e-6, 2 * e_old), f"tile {seq_tile} {path} fused={fused} {dims}: folded {e_new:.2e}, separate kernels {e_old:.2e}"
+    sg = stats.cpu().numpy()
+    gb = got.astype(np.float64).reshape(B, -1)
+    assert np.allclose(sg[:, 0], gb.sum(1), rtol=1e-9, atol=1e-6 * np.abs(gb).sum(1).max())
+    assert np.allclose(sg[:, 1], (gb ** 2).sum(1), rtol=1e-6)
+    wb = want.reshape(B, -1)
+    assert np.allclose(sg[:, 0], wb.sum(1), rtol=0, atol=4e-6 * np.abs(wb).sum(1).max())
+    assert np.allclose(sg[:, 1], (wb ** 2).sum(1), rtol=2e-5)
+
+
+def test_direction_serial_form_refuses_what_it_does_not_do():
+    st = _st()
+    z = torch.zeros(64, device=DEV)
+    args = lambda phase, dir_, Z=0, P=z.data_ptr(), Zout=z.data_ptr(), so=z.data_ptr(), lb=z.data_ptr(), tile=0: (
+        phase, dir_, z.data_ptr(), Z, z.data_ptr(), z.data_ptr(), z.data_ptr(), 1e-5, 1, 1, z.data_ptr() + 4, z.data_ptr(), z.data_ptr(), 2,
+        z.data_ptr(), lb, P, Zout, so, 1, 1, 1, 1, 1, 1, tile)
+    for bad, msg in ((args(3, 0), "phase"), (args(1, 2), "direction"), (args(1, 0, P=0), "partial"), (args(2, 1, so=0), "stats_out"),
+                     (args(2, 1, Z=z.data_ptr()), "pending norm"), (args(1, 0, tile=2016), "seq_tile")):
+        with pytest.raises(RuntimeError, match=msg):
+            st.call("dprnn_rnn_lin_fwd", *bad)
+
+
 @pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("kdim", [256, 128])
 def test_proj_stats_ragged(kdim, mode):

@@ -241,7 +241,7 @@ def test_headline_batch_b64_full_size():
     batch-of-one forward, which takes the small-batch tiles on a single stream (tolerance 2e-6: the two differ only in
     the grouping of the fp64 GroupNorm sums and the MFMA tile a sequence lands in)."""
     from tss_with_dprnn_amd import engine
-    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
+    assert not any(engine.SEQ_TILE.values()) and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
     model, sd, cfg = build_model("bss", dict(), 0, _dev())
     B, T = 64, 24000
     x = make_mixture(B, T, seed=1234)
@@ -496,6 +496,32 @@ def test_narrow_models_run_as_zero_padded_twins_and_follow_their_parameters():
     with pytest.raises(NotImplementedError, match="zero-padded twin"):
         model(*args)
     engine.drop_graphs()
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_narrow_twin_with_several_utterance_groups(mode):
+    """A zero-padded twin's GroupNorm sums are rescaled by built / real channels (engine._count_scale).  With more than one utterance
+    group (13 utterances: two pipelines on side streams in every mode) that factor has to be applied on the group's own stream, after
+    its sums exist and before its next reader, and to that group's utterances only -- round 4 applied it on the main stream to the
+    rest of the batch (silently wrong norms from B = 9 / 11 up).  Eager and graph replay, against the CPU oracle."""
+    over = dict(input_size=48, feature_size=64, hidden_size=64, chunk_length=16, hop_length=8, n_repeats=2, norm_type="ln")
+    model, sd, cfg = build_model("bss", over, 65, _dev())
+    B = 13
+    mix = make_mixture(B, 700, seed=11)
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(mix)).numpy()
+    x = torch.from_numpy(mix).to(_dev())
+    assert len(engine.group_parts(B, mode)) > 1
+    old = engine.GRAPHS
+    try:
+        for graphs in (False, True):
+            engine.GRAPHS = graphs
+            with torch.no_grad(), engine.use_gemm_mode(mode):
+                outs = [model(x).cpu().numpy() for _ in range(3 if graphs else 1)]
+            for o in outs:
+                _close(o, want, f"narrow BSS twin, B = {B}, mode {mode}, graphs {graphs}")
+    finally:
+        engine.GRAPHS = old
+        engine.drop_graphs()
 
 
 def test_in_range_forwards_do_not_fall_back():

@@ -333,7 +333,7 @@ def test_spe_cat_batch_b64_full_size():
     from conftest import build_model, rel_l2
     from oracle import dprnn_torch_cpu as otc
     from tss_with_dprnn_amd import engine
-    assert engine.SEQ_TILE == {"intra": 0, "inter": 0} and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
+    assert not any(engine.SEQ_TILE.values()) and engine.GEMM_MODE == engine.DEFAULT_GEMM_MODE and engine.GROUP_SIZES is None
     model, sd, cfg = build_model("spe", dict(norm_type="ln", fusion_type="cat"), 3, DEV)
     B, T = 64, 24000
     x, a = make_mixture(B, T, seed=1234), make_mixture(B, T, seed=1235)

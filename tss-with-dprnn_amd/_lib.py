@@ -43,6 +43,11 @@ SIGNATURES = {
     "dprnn_rnn_fwd_hp_ex": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i64, c_i64,
                             c_i64, c_i, c_i, c_fp],
     "dprnn_proj_stats_hp_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_fp, c_i, c_i, c_fp],
+    "dprnn_lin_pack_f16": [c_fp, c_i, c_fp, c_fp],
+    "dprnn_rnn_lin_fwd": [c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp,
+                          c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_rnn_lin_split_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_rnn_fwd_ragged_hp_ex": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
     "dprnn_lstm_pack_f16": [c_fp] * 10 + [c_fp],
@@ -57,6 +62,8 @@ SIGNATURES = {
     "dprnn_att_row_scale_rows": [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_scale_init": [c_fp, c_fp],
     "dprnn_scale_update": [c_fp, c_fp],
+    "dprnn_scale_fork": [c_fp, c_fp, c_fp],
+    "dprnn_scale_join": [c_fp, c_fp, c_fp],
     "dprnn_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i64, c_fp],
     "dprnn_head_conv_ola_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_head_conv_ola_norm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -149,6 +156,8 @@ _SPECIAL = {
     "dprnn_get_fast_head_activations": ([], c_i),
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
+    "dprnn_lin_pack_floats": ([], c_i64),
+    "dprnn_rnn_lin_state_floats": ([c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
     "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),
     "dprnn_rnn_bwd_dg_floats": ([c_i, c_i, c_i, c_i, c_i], c_i64),

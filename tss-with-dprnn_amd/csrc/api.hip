@@ -69,7 +69,7 @@ __global__ void scale_update_kernel(float* state, int init) {
     const int i = threadIdx.x;
     if (i >= DPRNN_SCALE_SLOTS) return;
     unsigned* track = reinterpret_cast<unsigned*>(state) + DPRNN_SCALE_SLOTS;
-    if (init) state[i] = 256.f;
+    if (init) { state[i] = 256.f; track[DPRNN_SCALE_SLOTS + i] = 0u; track[2 * DPRNN_SCALE_SLOTS + i] = 0u; }     // 4 x SLOTS words (dprnn_scale_join)
     else {
         const float seen = __uint_as_float(track[i]);                  // NaN / Inf patterns (a non-finite input) leave the record alone
         if (seen < 3.0e38f && seen > state[i]) state[i] = seen;
@@ -85,6 +85,54 @@ extern "C" int dprnn_scale_update(void* state, void* stream) {
     if (!state) { dprnn_set_error("dprnn_scale_update: null pointer"); return -1; }
     hipLaunchKernelGGL(scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<float*>(state), 0);
     return dprnn_check_launch("scale_update_kernel");
+}
+
+// Per-forward working copy (round 5).  The sticky maxima of a model are shared by every forward of it, and a forward reads its
+// scale more than once (the pack kernel folds 2^(4 - s) into W_ih, the recurrence splits x by 2^s): a second thread's update
+// between the two would give W_ih and x different scales, silently.  So a forward FORKS the record -- `work` (2 x SLOTS words, its
+// own) receives a snapshot of the sticky maxima, which is what its launches read, and collects its maxima -- and JOINS at its end:
+// sticky = max(sticky, seen) with an atomic, and the record can come DOWN again: a site whose forward maximum stays 16 x (four
+// exponents) below the sticky one for DPRNN_SCALE_DECAY_FORWARDS consecutive forwards falls back to the largest value of that
+// streak (never below 256, the default range) -- one outlier forward no longer costs every later forward four bits of its
+// second f16 piece.  state: 4 x SLOTS words {sticky, (single-record tracking), low-streak length, low-streak maximum}.
+constexpr int DPRNN_SCALE_DECAY_FORWARDS = 8;
+__global__ void scale_fork_kernel(const float* state, float* work) {
+    const int i = threadIdx.x;
+    if (i >= DPRNN_SCALE_SLOTS) return;
+    work[i] = state[i];
+    reinterpret_cast<unsigned*>(work)[DPRNN_SCALE_SLOTS + i] = 0u;
+}
+__global__ void scale_join_kernel(float* state, const float* work) {
+    const int i = threadIdx.x;
+    if (i >= DPRNN_SCALE_SLOTS) return;
+    const float seen = __uint_as_float(reinterpret_cast<const unsigned*>(work)[DPRNN_SCALE_SLOTS + i]);
+    if (!(seen > 0.f && seen < 3.0e38f)) return;                          // site unused in this forward, or a non-finite input
+    unsigned* sticky = reinterpret_cast<unsigned*>(state) + i;            // positive floats order like their bit patterns
+    unsigned* streak = reinterpret_cast<unsigned*>(state) + 2 * DPRNN_SCALE_SLOTS + i;
+    unsigned* smax = reinterpret_cast<unsigned*>(state) + 3 * DPRNN_SCALE_SLOTS + i;
+    const float cur = __uint_as_float(atomicMax(sticky, __float_as_uint(seen)));
+    if (seen * 16.f < cur) {
+        atomicMax(smax, __float_as_uint(seen));
+        if (atomicAdd(streak, 1u) + 1u >= (unsigned)DPRNN_SCALE_DECAY_FORWARDS) {
+            const float m = fmaxf(__uint_as_float(atomicExch(smax, 0u)), 256.f);
+            atomicExch(sticky, __float_as_uint(m));
+            atomicExch(streak, 0u);
+        }
+    } else {
+        atomicExch(streak, 0u);
+        atomicExch(smax, 0u);
+    }
+}
+extern "C" int dprnn_scale_fork(const void* state, void* work, void* stream) {
+    if (!state || !work) { dprnn_set_error("dprnn_scale_fork: null pointer"); return -1; }
+    hipLaunchKernelGGL(scale_fork_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<const float*>(state), static_cast<float*>(work));
+    g_scale_state = static_cast<float*>(work); g_scale_slot = 0;
+    return dprnn_check_launch("scale_fork_kernel");
+}
+extern "C" int dprnn_scale_join(void* state, const void* work, void* stream) {
+    if (!state || !work) { dprnn_set_error("dprnn_scale_join: null pointer"); return -1; }
+    hipLaunchKernelGGL(scale_join_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<float*>(state), static_cast<const float*>(work));
+    return dprnn_check_launch("scale_join_kernel");
 }
 
 // ---- packed-weight formats, keyed by device address (common.h)

@@ -40,7 +40,33 @@ struct RecurArgs {
     int* sat;                                         // f16-pieces kernels: saturation flags of the calling thread (common.h), may be null
     const float* xs_src;                              // f16-pieces kernels: the record word the x scale 2^s is chosen from (common.h: act_scale), null: 2^4
     unsigned* xmax_dst;                               // ... and where the launch leaves the largest |x| it converted, null: nowhere
+    // ---- direction-serial form with the Linear folded in (dprnn_rnn_lin_fwd; f16-pieces eight-wave kernels, recur_split8.h: PJ).
+    // One launch runs ONE direction (dir0; the grid has no direction axis) and multiplies every h_t it forms, while it is the
+    // operand of the next step's gate GEMM in LDS, with this direction's half of the Linear that follows the BiLSTM
+    // (dprnn.py:88,96): phase 1 leaves the partial products W[:, dir H : (dir + 1) H] h_t as fp32 rows in P, phase 2 adds its
+    // own half and the bias to them, writes z to Zout (may be P: every element is read and rewritten by one lane) and adds the
+    // GroupNorm sums of z to stats_out.  H is not written: h never leaves the CU.
+    int proj;                                         // 0: none; 1: partial products -> P; 2: P (may be null) + own half + bias -> Zout, sums -> stats_out
+    int dir0;                                         // direction this launch runs when proj != 0 (weights, bias, time order)
+    const void* Lp;                                   // packed Linear (dprnn_lin_pack_f16): f16 piece fragments per direction + the scale words
+    const float* lbias;                               // Linear bias [F] (phase 2)
+    float* P;
+    float* Zout;
+    double* stats_out;                                // [utterances][2], accumulated (atomics)
+    int proj_dirs;                                    // directions dir0 .. dir0 + proj_dirs - 1 in one launch (2: the split form below)
+    // ---- the same fold with BOTH directions in every launch (dprnn_rnn_lin_split_fwd): the path is cut in time instead of by direction.
+    // split_m = M >= 0: phase 1 runs the forward direction's steps [0, M) and the reverse direction's [0, T - M) (rows [0, M) and
+    // [M, T): each row met by exactly one direction, which leaves x' and its partial product), phase 2 the remaining steps of both
+    // (each row met by the other direction, which finishes z).  state: [dir][tile][512 x NT x 4 floats of c | the h image] carried
+    // across the kernel boundary.  -1: no split.
+    int split_m;
+    float* state;
 };
+
+// packed Linear of the direction-serial form: [dir][wave 8][k-slab 4][piece 2][lane 64] 16-byte fragments, then the scale words
+constexpr int LINP_FRAG_FLOATS = 2 * 8 * 4 * 2 * 64 * 4;      // both directions
+constexpr int LINP_SCALE_WORD = LINP_FRAG_FLOATS;             // S_w, then 1 / (2^4 S_w)
+constexpr int LINP_FLOATS = LINP_FRAG_FLOATS + 64;
 
 // The recurrence kernels address every tensor as (scalar row of the step) + (32-bit per-lane byte offset of the lane's
 // sequence inside its tile); offsets at or above 2^31 mean "no such sequence".  True when the widest tile (64 sequences)

@@ -48,10 +48,19 @@ constexpr int split8_lds_resident_slabs(int nsr, bool f16) { return (f16 && nsr 
 // SAVE (training forward, dprnn_rnn_fwd_train in gate-GEMM mode 3): every step also writes the activated gates and the cell
 // state to a.tape in the layout of the fp32 training kernel (recur.hip: [dir][32-sequence workgroup][step][wave][nt][u][slot]
 // [lane] float4 over four sequences), which is what the backward kernels read: a 64-sequence tile is two of those workgroups.
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false>
+// PJ (direction-serial form, RecurArgs::proj; dprnn_rnn_lin_fwd): the launch runs one direction and carries a FIFTH weight set through
+// the h half of the gate GEMM -- this direction's half of the Linear that follows the BiLSTM, 16 output columns per wave.  The A
+// fragments are the ones the h half reads anyway (h_{t-1} as f16 pieces in the LDS image), so the fold costs 12 MFMAs per 16
+// sequences, wave and step (+12.5 %), 8 KB of weight pieces per wave and step from L2, and no LDS traffic; the product for time
+// t is complete after step t + 1's h half and leaves in that step's cell phase (one more h half after the loop for the last one).
+// PJ = 1 writes the partial product (fp32, unscaled) to a.P; PJ = 2 starts its accumulators from a.P (x 2^4 S_w: exact), adds the
+// bias, writes z to a.Zout and keeps the GroupNorm sums: fp32 over 8 steps x 4 columns x 4 lanes (128 elements, as in
+// proj_f16_kernel), then fp64 per (wave, sequence) in LDS, one fp64 atomic pair per utterance of the tile at the end.
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false, int PJ = 0>
 __global__ __launch_bounds__(512, 2)
 void bilstm_split8_kernel(RecurArgs a) {
     static_assert(!SAVE || NSR == 64, "the tape layout is written for 64-sequence tiles");
+    static_assert(PJ == 0 || (F16 && F16_UNITS_CONTIGUOUS && !SAVE && !STAMP && NP == 3), "the folded Linear exists in the f16-pieces inference kernels");
     static_assert(NSR % 16 == 0 && NSR >= 16 && NSR <= 96, "whole 16-row tiles");
     static_assert(NP == 6 || (F16 && NP == 3), "three bf16 pieces / six products, or two f16 pieces / three products");
     constexpr int NT = NSR / 16;
@@ -81,6 +90,11 @@ void bilstm_split8_kernel(RecurArgs a) {
     float* const gb = musig + 2 * NSR;
     constexpr int LRES = split8_lds_resident_slabs(NSR, F16);       // second pieces of k-slabs NSLAB - LRES .. NSLAB - 1 in LDS
     char* const wlds = reinterpret_cast<char*>(gb + 256);                 // [slab][w4][gate*2 + wu][lane] 16-byte fragments
+    double* const pstat = reinterpret_cast<double*>(wlds + LRES * 32768);     // PJ == 2: [wave][NSR][2] sums of z
+    // PJ: the (pre-scaled) gate biases and the Linear's bias live in LDS instead of 20 registers -- the fifth accumulator set and its
+    // weight fragments take their place (kernel_resources.sh: 11 spilled registers otherwise)
+    constexpr bool BIAS_LDS = PJ != 0;
+    float* const bias_l = reinterpret_cast<float*>(pstat + (PJ == 2 ? 8 * NSR * 2 : 0));      // [gate][HD], then [F] of the Linear
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -88,7 +102,8 @@ void bilstm_split8_kernel(RecurArgs a) {
 #if DPRNN_SPLIT8_PRIO
     if (DB && wave < 4) __builtin_amdgcn_s_setprio(DPRNN_SPLIT8_PRIO);     // one wave of every SIMD pair runs ahead through the MFMAs
 #endif
-    const int dir = blockIdx.y;
+    const int dir = PJ ? a.dir0 + (int)blockIdx.y : (int)blockIdx.y;
+    const bool split = PJ != 0 && a.split_m >= 0;      // both directions per launch, the path cut in time (below: sb, se)
     const int seq0 = blockIdx.x * NSR;
     constexpr unsigned OOB = 0x80000000u;
 
@@ -101,7 +116,8 @@ void bilstm_split8_kernel(RecurArgs a) {
     const int T = __builtin_amdgcn_readfirstlane(desc ? desc[2] : a.T);
     const int nhere = desc ? desc[3] : (a.nseq - seq0 < NSR ? a.nseq - seq0 : NSR);      // sequences that exist in this tile
     const long long row0 = desc ? (((long long)desc[1] << 32) | (unsigned)desc[0]) : rowbase(seq0);
-    const int hpitch = a.ndir * HD;
+    const int hpitch = PJ ? F : a.ndir * HD;           // PJ: rowoff_h addresses the rows of P / Zout
+    if constexpr (PJ == 2) for (int i = tid; i < 8 * NSR * 2; i += 512) pstat[i] = 0.0;
     for (int j = tid; j < NSR; j += 512) {
         const bool valid = j < nhere;
         const int seq = valid ? seq0 + j : seq0;
@@ -124,14 +140,26 @@ void bilstm_split8_kernel(RecurArgs a) {
     auto tbase = [&](long long t) { return (row0 + t * a.t_stride); };
     const int unit0 = TRANS ? 32 * w4 + 16 * wu + 4 * q : UC ? 32 * w4 + 16 * wu + r : 32 * w4 + 2 * r + wu;   // this lane's (first) hidden unit
 
-    float bias[4][TRANS ? 4 : 1];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < (TRANS ? 4 : 1); ++e) {
-            const float b = a.bsum[dir * 4 * HD + g * HD + unit0 + e];
-            bias[g][e] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+    float bias[4][(TRANS && !BIAS_LDS) ? 4 : 1];
+    if constexpr (BIAS_LDS) {
+        for (int i = tid; i < 4 * HD; i += 512) {
+            const float b = a.bsum[dir * 4 * HD + i];
+            bias_l[i] = FAST ? b * ((i >> 7) == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
         }
+        if (PJ == 2 && tid < F) bias_l[4 * HD + tid] = a.lbias[tid];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < (TRANS ? 4 : 1); ++e) {
+                const float b = a.bsum[dir * 4 * HD + g * HD + unit0 + e];
+                bias[g][e] = FAST ? b * (g == 2 ? 2.8853900817779268f : -1.4426950408889634f) : b;
+            }
+    }
+    auto bget = [&](int g) __attribute__((always_inline)) {        // TRANS forms: the four units' bias of gate g
+        if constexpr (BIAS_LDS) return *reinterpret_cast<const f32x4*>(bias_l + g * HD + unit0);
+        else return f32x4{bias[g][0], bias[g][TRANS ? 1 : 0], bias[g][TRANS ? 2 : 0], bias[g][TRANS ? 3 : 0]};
+    };
     // f16 form: the accumulators are S_x S_w times the gate pre-activations; inv = 1 / (S_x S_w) rides on the multiply the
     // nonlinearity starts with anyway
     const float inv = F16 ? a.Wp[F16_SCALE_WORD + 1] : 1.f;
@@ -192,7 +220,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                     const f32x4 gam = *reinterpret_cast<const f32x4*>(gb + 4 * c4), bet = *reinterpret_cast<const f32x4*>(gb + 128 + 4 * c4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zv[i][e] - mu) * rs * gam[e] + bet[e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo[i] : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo[i] : OOB, 0, 0);
                 }
                 unsigned pa[3], pb[3];
                 if constexpr (F16) {
@@ -244,7 +272,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
                 const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
-                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && dir == 0) ? xo : OOB, 0, 0);
+                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo : OOB, 0, 0);
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
@@ -265,13 +293,30 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
 
     __syncthreads();                                   // row tables are in place
-    const long long tfirst = dir ? (T - 1) : 0;
-    if constexpr (XPF) { x_issue(tfirst); x_finish(tfirst, 0, true); }
-    else x_stage(tfirst, 0, true);
-    for (int i = tid; i < REG / 4; i += 512) reinterpret_cast<unsigned*>(hreg)[i] = 0u;
+    // Steps [sb, se) of this direction's T.  PJ with a split point M = a.split_m (dprnn_rnn_lin_split_fwd): the path runs as two launches of
+    // BOTH directions -- phase 1 the first M (forward) / T - M (reverse) steps, phase 2 the rest -- so every row is met first by one
+    // direction in phase 1 (partial product) and then by the other in phase 2 (finished z), with the kernel boundary between them as
+    // the only synchronisation; the cell state and the h image cross it through a.state.
+    const int nfirst = split ? (dir ? T - a.split_m : a.split_m) : 0;
+    const int sb = (split && PJ == 2) ? nfirst : 0, se = (split && PJ == 1) ? nfirst : T;
+    const int xb0 = DB ? (sb & 1) : 0;                 // image buffers the first step reads
+    const long long tfirst = dir ? (T - 1 - sb) : sb;
+    if (se > sb) {                                     // (a direction may have no step at all in one of the phases: T = 1)
+        if constexpr (XPF) { x_issue(tfirst); x_finish(tfirst, xb0, true); }
+        else x_stage(tfirst, xb0, true);
+    }
     f32x4 c[NT];
+    float* const state = (PJ != 0 && split) ? a.state + ((size_t)dir * gridDim.x + blockIdx.x) * (size_t)(512 * NT * 4 + REG / 4) : nullptr;
+    if (PJ == 2 && split) {                            // phase 2: where phase 1 stopped
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) c[nt] = *reinterpret_cast<const f32x4*>(state + ((size_t)nt * 512 + tid) * 4);
+        const u32x4* src = reinterpret_cast<const u32x4*>(state + 512 * NT * 4);
+        for (int i = tid; i < REG / 16; i += 512) reinterpret_cast<u32x4*>(hreg + xb0 * REG)[i] = src[i];
+    } else {
+        for (int i = tid; i < REG / 4; i += 512) reinterpret_cast<unsigned*>(hreg)[i] = 0u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // A fragments: lane (r, q) of tile nt reads row 16 nt + r, chunk (4 s4 + q) ^ r of the region
     const int abase = r * 256 + ((q ^ (r & 3)) << 4);
@@ -314,6 +359,30 @@ void bilstm_split8_kernel(RecurArgs a) {
         for (int pc = WRES ? 1 : 0; pc < NPC; ++pc) bw[g][pc] = wload(0, g, pc);       // slab 0 is resident whenever any is
     f32x4 acc[NT][4];
     u32x4 fa[NT], fb[NT];
+    // ---- PJ: the Linear's fragments of this wave (16 output columns), one k-slab of two pieces in registers
+    const float inv_l = PJ ? reinterpret_cast<const float*>(a.Lp)[LINP_SCALE_WORD + 1] : 1.f;      // 1 / (2^4 S_w)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.Lp) + (size_t)(PJ ? (dir * 8 + __builtin_amdgcn_readfirstlane(wave)) * 4 * 2 * 64 : 0)),
+        0, PJ ? 0x7fffffff : 0, 0x00020000);
+    auto pload = [&](int s4, int pc) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(prs, lane16, (unsigned)((s4 * 2 + pc) * 1024), 0);
+    };
+    u32x4 bp[2];
+    f32x4 pacc[PJ ? NT : 1];
+    float ps1[PJ == 2 ? NT : 1], ps2[PJ == 2 ? NT : 1];
+    if constexpr (PJ != 0) {
+        bp[0] = pload(0, 0); bp[1] = pload(0, 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (PJ == 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { ps1[nt] = 0.f; ps2[nt] = 0.f; }
+    }
+    auto ppass = [&](const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pacc[nt] = mfma_f16(bp[wpc], af[nt], (first && PJ == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : pacc[nt]);
+    };
     auto pass = [&](f32x4 (&ac)[NT][4], const u32x4 (&af)[NT], int wpc, bool first) __attribute__((always_inline)) {
         if (diag(4) && (wpc != 1 || !first)) return;   // energy probe: one product of the first k-slab only (results are wrong)
 #pragma unroll
@@ -345,7 +414,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     };
     // k-slab s4 of region reg (weights of global slab `s` are in bw; those of slab `sn` are requested as pieces die)
     auto slab = [&](f32x4 (&ac)[NT][4], const char* reg, u32x4 (&P)[NT], u32x4 (&Q)[NT], int s4, int sn, bool have_p, bool prefetch,
-                    bool first) __attribute__((always_inline)) {
+                    bool first, bool pj = false) __attribute__((always_inline)) {
         fence();
         if (!have_p) aload(P, reg, 0, s4);
         aload(Q, reg, 1, s4);
@@ -361,16 +430,20 @@ void bilstm_split8_kernel(RecurArgs a) {
             pass(ac, P, 0, false); wreload(sn, 0); fence();
         } else {
             const int sc = (sn + NSLAB - 1) & (NSLAB - 1);      // the slab in progress
-            pass(ac, P, 1, first); wreload(sn, 1); fence();
+            pass(ac, P, 1, first);
+            if (PJ && pj) { ppass(P, 1, s4 == 0); bp[1] = pload((s4 + 1) & 3, 1); }      // h half: k-slab s4 of the Linear rides along
+            wreload(sn, 1); fence();
             if (WRES && sc < RES) pass_res(ac, P, sc); else pass(ac, P, 0, false);
+            if (PJ && pj) ppass(P, 0, false);
             fence();
             if (prefetch) aload(P, reg, 0, s4 + 1);
             if (WRES && sc < RES) pass_res(ac, Q, sc); else pass(ac, Q, 0, false);
+            if (PJ && pj) { ppass(Q, 0, false); bp[0] = pload((s4 + 1) & 3, 0); }
             wreload(sn, 0); fence();
         }
     };
     // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end
-    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0) __attribute__((always_inline)) {
+    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0, bool pj = false) __attribute__((always_inline)) {
         if constexpr (NP == 6) {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
             slab(ac, reg, fb, fa, 1, s0 + 2, true, true, false);
@@ -378,11 +451,85 @@ void bilstm_split8_kernel(RecurArgs a) {
             if (xhook) x_issue(tx);
             slab(ac, reg, fb, fa, 3, (s0 + 4) & 7, true, false, false);
         } else {
-            slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
-            slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false);
-            slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false);
+            slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first, pj);
+            slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false, pj);
+            slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false, pj);
             if (xhook) x_issue(tx);
-            slab(ac, reg, fa, fb, 3, (s0 + 4) & 7, true, false, false);
+            slab(ac, reg, fa, fb, 3, (s0 + 4) & 7, true, false, false, pj);
+        }
+    };
+    // PJ: the Linear alone over the h image `reg` (after the last step: its h has no gate GEMM to ride on)
+    auto phalf = [&](const char* reg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            fence();
+            aload(fa, reg, 0, s4);
+            aload(fb, reg, 1, s4);
+            fence();
+            ppass(fa, 1, s4 == 0);
+            if (s4 < 3) bp[1] = pload(s4 + 1, 1);
+            ppass(fa, 0, false);
+            ppass(fb, 0, false);
+            if (s4 < 3) bp[0] = pload(s4 + 1, 0);
+            fence();
+        }
+    };
+    // PJ: the finished products of time tp leave (phase 1: partial rows; phase 2: z = product + bias, sums), and phase 2 asks
+    // for the partial rows of time tnext straight into the accumulators (scaled when the next h half begins)
+    const unsigned zcol = (unsigned)(16 * wave + 4 * q) * 4u;
+    auto pout = [&](long long tp, bool store, long long tnext, bool load) __attribute__((always_inline)) {
+        fence();
+        if (store) {
+            const __amdgpu_buffer_rsrc_t ors = rsrc_at((PJ == 2 ? a.Zout : a.P) + tbase(tp) * F);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v;
+                if constexpr (PJ == 2) {
+                    const f32x4 lbv = *reinterpret_cast<const f32x4*>(bias_l + 4 * HD + 16 * wave + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaf(pacc[nt][e], inv_l, lbv[e]);
+                        ps1[nt] += v[e]; ps2[nt] = fmaf(v[e], v[e], ps2[nt]);
+                    }
+                } else {
+                    v = pacc[nt] * f32x4{inv_l, inv_l, inv_l, inv_l};
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, rowoff_h[16 * nt + r] + zcol, 0, 0);
+            }
+        }
+        if constexpr (PJ == 2) {
+            if (load && a.P) {
+                const __amdgpu_buffer_rsrc_t irs = rsrc_at(a.P + tbase(tnext) * F);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    pacc[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, rowoff_h[16 * nt + r] + zcol, 0, 0));
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) pacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        fence();
+    };
+    auto pscale = [&]() __attribute__((always_inline)) {      // phase 2: partial rows -> the accumulators' scale 2^4 S_w (a power of two)
+        if constexpr (PJ == 2) {
+            const float sl = reinterpret_cast<const float*>(a.Lp)[LINP_SCALE_WORD] * F16_XS;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) pacc[nt] = pacc[nt] * f32x4{sl, sl, sl, sl};
+        }
+    };
+    auto pflush = [&]() __attribute__((always_inline)) {      // phase 2: fp32 sums of the last steps -> this wave's fp64 row of the table
+        if constexpr (PJ == 2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float r1 = ps1[nt], r2 = ps2[nt];
+                r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
+                r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
+                if (q == 0) {
+                    double* d = pstat + ((size_t)wave * NSR + 16 * nt + r) * 2;
+                    d[0] += (double)r1; d[1] += (double)r2;
+                }
+                ps1[nt] = 0.f; ps2[nt] = 0.f;
+            }
         }
     };
     // LSTM cell of this wave's 16 units for every row, h -> image (3 pieces) and HBM
@@ -402,6 +549,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             if constexpr (TRANS) {
                 unsigned w1[2], w2[2];
                 f32x2 cn2[2], hh[2];
+                const f32x4 bl[4] = {bget(0), bget(1), bget(2), bget(3)};
                 bool separate = true;                                  // the five-reciprocal forms (libm build, or the guard below)
                 if constexpr (diag(8)) {                               // energy probe: no cell arithmetic (results are wrong)
                     separate = false;
@@ -418,10 +566,10 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2) {
                         const f32x2 kk = f32x2{ksig, ksig};
-                        const f32x2 ai = f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]} * kk + f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]};
-                        const f32x2 af = f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]} * kk + f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]};
-                        const f32x2 ag = f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]} * f32x2{ktanh, ktanh} + f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]};
-                        const f32x2 ao = f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]} * kk + f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]};
+                        const f32x2 ai = f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]} * kk + f32x2{bl[0][2 * p2], bl[0][2 * p2 + 1]};
+                        const f32x2 af = f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]} * kk + f32x2{bl[1][2 * p2], bl[1][2 * p2 + 1]};
+                        const f32x2 ag = f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]} * f32x2{ktanh, ktanh} + f32x2{bl[2][2 * p2], bl[2][2 * p2 + 1]};
+                        const f32x2 ao = f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]} * kk + f32x2{bl[3][2 * p2], bl[3][2 * p2 + 1]};
                         lstm_cell_shared2(ai, af, ag, ao, f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]}, cn2[p2], hh[p2], dmax);
                     }
                     // a denominator beyond 2^100 (a pre-activation below -60 or so; Inf included: the comparison fails) leaves the range in
@@ -431,10 +579,10 @@ void bilstm_split8_kernel(RecurArgs a) {
                 if (separate) {
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2) {
-                        const f32x2 ig = sigmoid_k2v<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, f32x2{bias[0][2 * p2], bias[0][2 * p2 + 1]});
-                        const f32x2 fg = sigmoid_k2v<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, f32x2{bias[1][2 * p2], bias[1][2 * p2 + 1]});
-                        const f32x2 gg = tanh_k2v<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, f32x2{bias[2][2 * p2], bias[2][2 * p2 + 1]});
-                        const f32x2 og = sigmoid_k2v<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, f32x2{bias[3][2 * p2], bias[3][2 * p2 + 1]});
+                        const f32x2 ig = sigmoid_k2v<FAST>(f32x2{ac[nt][0][2 * p2], ac[nt][0][2 * p2 + 1]}, ksig, f32x2{bl[0][2 * p2], bl[0][2 * p2 + 1]});
+                        const f32x2 fg = sigmoid_k2v<FAST>(f32x2{ac[nt][1][2 * p2], ac[nt][1][2 * p2 + 1]}, ksig, f32x2{bl[1][2 * p2], bl[1][2 * p2 + 1]});
+                        const f32x2 gg = tanh_k2v<FAST>(f32x2{ac[nt][2][2 * p2], ac[nt][2][2 * p2 + 1]}, ktanh, f32x2{bl[2][2 * p2], bl[2][2 * p2 + 1]});
+                        const f32x2 og = sigmoid_k2v<FAST>(f32x2{ac[nt][3][2 * p2], ac[nt][3][2 * p2 + 1]}, ksig, f32x2{bl[3][2 * p2], bl[3][2 * p2 + 1]});
                         cn2[p2] = fg * f32x2{c[nt][2 * p2], c[nt][2 * p2 + 1]} + ig * gg;
                         hh[p2] = og * tanh_f2<FAST>(cn2[p2]);
                     }
@@ -451,7 +599,7 @@ void bilstm_split8_kernel(RecurArgs a) {
                 // h_pieces: the next kernel is the f16-pieces projection, which would split 2^4 h into exactly these words again
                 const u32x4 hout = a.h_pieces ? u32x4{w1[0], w1[1], w2[0], w2[1]}
                                               : u32x4{__float_as_uint(hv[0]), __float_as_uint(hv[1]), __float_as_uint(hv[2]), __float_as_uint(hv[3])};
-                if (!diag(32)) __builtin_amdgcn_raw_buffer_store_b128(hout, hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
+                if (!diag(32) && PJ == 0) __builtin_amdgcn_raw_buffer_store_b128(hout, hrs, rowoff_h[16 * nt + r] + hcol, 0, 0);
                 continue;
             }
 #pragma unroll
@@ -525,23 +673,65 @@ void bilstm_split8_kernel(RecurArgs a) {
     {
         __syncthreads();
         if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-        for (int step = 0; step < T; ++step) {
+        for (int step = sb; step < se; ++step) {
             unsigned long long st_a = 0, st_b = 0;
             if constexpr (STAMP) { fence(); st_a = __builtin_amdgcn_s_memtime(); fence(); }
             const long long t = dir ? (T - 1 - step) : step;
-            const bool more = step + 1 < T;
+            const bool more = step + 1 < se;
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
             half(acc, xreg + rb * REG, 0, true);
-            half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn);
+            pscale();
+            half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn, PJ != 0);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             if constexpr (!DB) __syncthreads();        // single-buffered: every wave is done reading the image of this step
+            if constexpr (PJ != 0) {                   // the Linear of h_{step-1} is complete: out; phase 2 asks for time t's partial rows
+                pout(dir ? t + 1 : t - 1, step > sb, t, true);
+                if (PJ == 2 && (step & 7) == 0) pflush();
+            }
             cell(acc, t, step, hreg + wb * REG);
             if constexpr (diag(16)) { }                // energy probe: the image keeps the first step's x (results are wrong)
             else if constexpr (XPF) x_finish(tn, wb, more);
             else x_stage(tn, wb, more);
             if constexpr (STAMP) { fence(); st_p2 += __builtin_amdgcn_s_memtime() - st_b; fence(); }
             __syncthreads();
+        }
+    }
+    if constexpr (PJ != 0) {                           // the last step's h: the Linear alone, then the sums of the tile
+        const char* const hlast = hreg + (DB ? (se & 1) : 0) * REG;
+        if (se > sb) {
+            pscale();
+            phalf(hlast);
+            pout(dir ? T - se : se - 1, true, 0, false);
+        }
+        if (PJ == 1 && split) {                        // phase 1: the state phase 2 continues from (ordered by the kernel boundary)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(state + ((size_t)nt * 512 + tid) * 4) = c[nt];
+            u32x4* dst = reinterpret_cast<u32x4*>(state + 512 * NT * 4);
+            for (int i = tid; i < REG / 16; i += 512) dst[i] = reinterpret_cast<const u32x4*>(hlast)[i];
+        }
+        if constexpr (PJ == 2) {
+            pflush();
+            __syncthreads();
+            if (tid < ((NSR + 63) / 64) * 64) {        // whole waves: thread j = sequence j of the tile
+                const int j = tid;
+                double d1 = 0.0, d2 = 0.0;
+                const bool valid = j < nhere;
+                int b = -1;
+                if (valid) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { d1 += pstat[((size_t)w * NSR + j) * 2]; d2 += pstat[((size_t)w * NSR + j) * 2 + 1]; }
+                    const int seq = seq0 + j;
+                    b = desc ? desc[4] : (a.seq_utt ? a.seq_utt[seq] : seq / a.seqs_per_utt);
+                }
+                const int b0 = __builtin_amdgcn_readfirstlane(b);
+                if (__builtin_amdgcn_ballot_w64(valid && b != b0) == 0ull && b0 >= 0) {      // one utterance (lane 0 is valid whenever any lane is)
+                    const double s1 = wave_sum(d1), s2 = wave_sum(d2);
+                    if (lane == 0) { atomicAdd(&a.stats_out[2 * b0], s1); atomicAdd(&a.stats_out[2 * b0 + 1], s2); }
+                } else if (valid) {
+                    atomicAdd(&a.stats_out[2 * b], d1); atomicAdd(&a.stats_out[2 * b + 1], d2);
+                }
+            }
         }
     }
     if constexpr (F16) sat_commit(a.sat, DPRNN_SAT_RECUR_X, satm, F16_XMAX / xs, a.xmax_dst);
@@ -557,20 +747,21 @@ void bilstm_split8_kernel(RecurArgs a) {
     }
 }
 
-template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false>
+template <int NSR, int NP, bool FAST, bool FUSE, bool STAMP = false, bool F16 = false, bool SAVE = false, int PJ = 0>
 int launch_split8(const RecurArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(split8_double_buffered(NSR, F16) ? 4 : 2) * (NP == 6 ? 3 : 2) * NSR * 256 +
-                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4 + (size_t)split8_lds_resident_slabs(NSR, F16) * 32768;
+                       (size_t)(NSR + NSR + 2 * NSR + 256) * 4 + (size_t)split8_lds_resident_slabs(NSR, F16) * 32768 +
+                       (PJ == 2 ? (size_t)8 * NSR * 2 * 8 : 0) + (PJ ? (size_t)(4 * 128 + 128) * 4 : 0);
     static std::atomic<unsigned long long> attr_mask{0};
     int attr_dev;
     if (dprnn_attr_needed(attr_mask, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE, PJ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(bilstm_split8): %s", hipGetErrorString(e)); return -2; }
         dprnn_attr_done(attr_mask, attr_dev);
     }
-    dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
-    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE>), grid, dim3(512), lds, st, a);
+    dim3 grid(a.wg_desc ? a.nseq : (a.nseq + NSR - 1) / NSR, PJ ? (a.proj_dirs > 1 ? a.proj_dirs : 1) : a.ndir);          // ragged inter-chunk launches pass their tile count in nseq
+    hipLaunchKernelGGL((bilstm_split8_kernel<NSR, NP, FAST, FUSE, STAMP, F16, SAVE, PJ>), grid, dim3(512), lds, st, a);
     return dprnn_check_launch("bilstm_split8_kernel");
 }
 

@@ -32,7 +32,7 @@ H_PIECES = os.environ.get("DPRNN_H_PIECES", "1") != "0"     # mode 3: the recurr
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}       # dprnn_rnn_pack / dprnn_rnn_fwd cell codes
 
 # process-wide tuning knob: sequences per workgroup in the recurrence kernel (0 = library default)
-SEQ_TILE = {"intra": 0, "inter": 0}
+SEQ_TILE = {"intra": 0, "inter": 0, "serial_intra": 0, "serial_inter": 0}
 
 # utterance groups run on separate HIP streams (0/1 = everything on the current stream).  Utterances are
 # independent, so each group is a complete pipeline of its own: while one group's recurrence kernel drains
@@ -129,7 +129,7 @@ def _scale_tensor(owner, dev):
         if getattr(_TLS, "capturing", False):
             raise DprnnError("activation-scale record created inside a graph capture (the first forward of a key runs eagerly)")
         lib = load_library()
-        rec = torch.empty(2 * SCALE_SLOTS, device=dev, dtype=torch.float32)
+        rec = torch.empty(4 * SCALE_SLOTS, device=dev, dtype=torch.float32)       # sticky maxima | unused | low-streak length | low-streak maximum
         check(lib, lib.dprnn_scale_init(rec.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_scale_init")
         recs[str(dev)] = rec
     return rec
@@ -137,17 +137,21 @@ def _scale_tensor(owner, dev):
 
 @contextlib.contextmanager
 def _scale_record(owner, dev):
-    """Registers `owner`'s record with the library for the launches of this block (this thread, mode 3 only); yields the record
-    or None.  The caller ends its forward with dprnn_scale_update on the record."""
+    """Forks `owner`'s record for the launches of this block (this thread, mode 3 only): the forward reads its scales from its OWN
+    snapshot of the sticky maxima and collects its maxima there (csrc/api.hip: dprnn_scale_fork), so another thread's forward of the
+    same model cannot change a scale between this one's pack call and the launches that read the pack; a captured forward's
+    snapshot lives in the graph's pool and is taken again on every replay.  Yields (record, working copy) or None; the caller ends
+    its forward with _scale_end, which joins the working copy into the record."""
     if owner is None or not ADAPTIVE_SCALE or current_mode() != 3 or getattr(_TLS, "scale_depth", 0) > 0:
         yield None
         return
     lib = load_library()
     rec = _scale_tensor(owner, dev)
-    lib.dprnn_scale_begin(rec.data_ptr())
+    work = torch.empty(2 * SCALE_SLOTS, device=dev, dtype=torch.float32)
+    check(lib, lib.dprnn_scale_fork(rec.data_ptr(), work.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_scale_fork")
     _TLS.scale_depth = 1
     try:
-        yield rec
+        yield (rec, work)
     finally:
         _TLS.scale_depth = 0
         lib.dprnn_scale_begin(0)
@@ -169,9 +173,18 @@ def scale_exponents(owner, dev=None):
 
 
 def _scale_end(st, rec) -> None:
-    """Last launch of a forward that ran under a record: the forward's maxima become part of the sticky ones."""
+    """Last launch of a forward that ran under a record: the forward's maxima become part of the sticky ones (and a site that has
+    stayed far below its sticky maximum for eight forwards comes down again)."""
     if rec is not None:
-        st.call("dprnn_scale_update", rec.data_ptr())
+        st.call("dprnn_scale_join", rec[0].data_ptr(), rec[1].data_ptr())
+
+
+def reset_scale(owner) -> None:
+    """Forget what a model's activations have looked like so far: every conversion site starts from the default range again."""
+    for dev, rec in getattr(owner, "_dprnn_scale_records", {}).items():
+        lib = load_library()
+        with torch.cuda.device(rec.device):
+            check(lib, lib.dprnn_scale_init(rec.data_ptr(), torch.cuda.current_stream(rec.device).cuda_stream), "dprnn_scale_init")
 
 
 def unpin(owner) -> None:
@@ -416,12 +429,16 @@ def check_supported(cfg: dict) -> None:
         raise NotImplementedError("DPRNN MI355X path: unsupported configuration: " + "; ".join(bad))
 
 
-def _count_scale(stats_slot: torch.Tensor, norm) -> None:
+def _count_scale(stats_slot: torch.Tensor, norm, st: "Stage", n: int) -> None:
     """Zero-padded twins of narrow models (padded.py): the kernels divide a global norm's sums by rows x BUILT channels; scaling
-    (sum, sum of squares) by built / real channels makes that rows x REAL channels for the mean and the second moment alike."""
+    (sum, sum of squares) by built / real channels makes that rows x REAL channels for the mean and the second moment alike.
+    The factor is applied ON THE STREAM THAT PRODUCED THE SUMS (an utterance group's side stream: torch's current stream is
+    neither ordered after that group's projection nor before its next reader) and to that launch's n utterances only (the slot
+    handed to a group runs on to the end of the batch)."""
     f = norm.__dict__.get("_dprnn_count_scale", 1.0)
     if f != 1.0:
-        stats_slot.mul_(f)
+        with torch.cuda.stream(st.tstream):
+            stats_slot[:n].mul_(f)
 
 
 def _norm_params(norm: torch.nn.Module):
@@ -458,7 +475,7 @@ def bottleneck_affine(st: Stage, wav, enc_w, bott_norm, geo: Geometry, stats_slo
     dev = wav.device
     gamma, beta, eps = _norm_params(bott_norm)
     st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_slot), geo.B, geo.T, geo.L, geo.N, geo.ks, geo.stride)
-    _count_scale(stats_slot, bott_norm)
+    _count_scale(stats_slot, bott_norm, st, geo.B)
     sc = torch.empty(geo.B, geo.N, device=dev, dtype=torch.float32)
     sh = torch.empty_like(sc)
     st.call("dprnn_bottleneck_prep", _p(stats_slot), _p(_param(gamma, "norm.weight", dev)),
@@ -579,7 +596,36 @@ class _Group:
         self.buffers += [self.X2, zh]
 
 
-def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool, scale_slot: int = SLOT_PATH0):
+# Direction-serial form (csrc/recur_split8_f16_lin.hip, round 5): in mode 3 a bidirectional LSTM path runs as two launches -- direction 0
+# leaves x' and its half of the following Linear's product, direction 1 finishes z and the GroupNorm sums -- so h never reaches HBM and
+# the projection kernel disappears: 7 slab rows of HBM traffic per row and path instead of 10.  Each launch has half the workgroups
+# and the path twice the serial steps, so the form is taken when a launch still covers SERIAL_MIN_FILL of the CUs (counting the
+# pipelines in flight together) and left to the concurrent-direction form below that (few utterances: latency).
+# LIN_FOLD (round 5): how the Linear after a bidirectional LSTM is folded into the recurrence in mode 3.
+#   "split"  (default) both directions in every launch, the path cut in time: phase 1 walks the first half of every sequence in each
+#            direction (x', partial products), phase 2 the second halves (z, GroupNorm sums) -- csrc/recur_split8_f16_lin.hip,
+#            dprnn_rnn_lin_split_fwd.  7 slab rows of HBM traffic per row and path instead of 10, no projection kernel, and launches of
+#            2 x tiles workgroups like the unfolded form, so two pipelines still pack the chip.
+#   "serial" one direction per launch (dprnn_rnn_lin_fwd): the same traffic, but a launch has one workgroup per tile -- 194 / 250 for
+#            64 x 3 s on 256 CUs; measured 3 % SLOWER than no fold at B = 64 (profiles/r05_serial_vs_concurrent.txt), wins when a
+#            launch fills the chip twice over.
+#   "off"    recurrence + projection kernel (rounds 2-4).
+LIN_FOLD = os.environ.get("DPRNN_LIN_FOLD", "split")
+SERIAL_DIRS = LIN_FOLD == "serial" or os.environ.get("DPRNN_SERIAL_DIRS", "0") == "1"
+SERIAL_MIN_FILL = float(os.environ.get("DPRNN_SERIAL_MIN_FILL", "0.6"))
+SERIAL_TILES = (2032, 2048, 2064)
+SERIAL_STAGGER = os.environ.get("DPRNN_SERIAL_STAGGER", "0") == "1"      # experiment: pipeline g starts its first path when pipeline g - 1 has finished its own
+
+
+def _serial_tile(nplan: int, ncu: int, concurrent: int) -> int:
+    """seq_tile of the direction-serial form for launches of nplan sequences (one direction each), 0: keep the concurrent form."""
+    if -(-nplan // 64) * concurrent < SERIAL_MIN_FILL * ncu:
+        return 0
+    tile = split_tile(nplan, 1, ncu, concurrent, 3, SERIAL_TILES)
+    return tile if tile in SERIAL_TILES else 0
+
+
+def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool, scale_slot: int = SLOT_PATH0, linp=None):
     st, geo, Z, Hbuf = g.st, g.geo, g.Z, g.H
     _set_slot(st.lib, scale_slot)            # the record word this path's pack call ran under
     dev = Z.device
@@ -608,6 +654,76 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         # waits for the slower (B = 25 as 12 + 13 utterances: 32.4 ms mixed against 30.9 / 31.9 ms on either tile for both)
         nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
         tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
+    w = _param(lin.weight, "linear.weight", dev)
+    if w.shape != (F_BUILT, ndir * F_BUILT):
+        raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+    gamma, beta, eps = _norm_params(norm)
+    gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
+    if LIN_FOLD == "split" and not SERIAL_DIRS and linp is not None and g.mode == 3 and cell == 0 and ndir == 2 and dbg is None and fuse:
+        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
+        stile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, 2, st.lib.dprnn_num_cus(), g.n_concurrent, 3)
+        if stile in SERIAL_TILES:
+            spu, rpu = (S if intra else K), S * K
+            if getattr(g, "Z2", None) is None:      # the partial products / the new z: the pending z is read while they are written
+                g.Z2 = torch.empty_like(Z)
+                g.lin_state = torch.empty(max(st.lib.dprnn_rnn_lin_state_floats(n_, t_) for n_ in (B * S, B * K) for t_ in SERIAL_TILES),
+                                          device=dev, dtype=torch.float32)
+                g.buffers += [g.Z2, g.lin_state]
+            tail = (_p(packed), _p(bsum), _p(linp))
+            lb = _p(_param(lin.bias, "linear.bias", dev))
+            if g.pending is None:
+                st.call("dprnn_rnn_lin_split_fwd", 1, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, 0, _p(g.Z2), 0, _p(g.lin_state), *addr, stile)
+            else:
+                pstats, pg, pb, peps = g.pending
+                st.call("dprnn_rnn_lin_split_fwd", 1, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *tail, 0, _p(g.Z2),
+                        0, _p(g.lin_state), *addr, stile)
+                g.X, g.X2 = g.X2, g.X
+            st.call("dprnn_rnn_lin_split_fwd", 2, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, lb, _p(g.Z2), _p(stats_slot), _p(g.lin_state),
+                    *addr, stile)
+            g.Z, g.Z2 = g.Z2, g.Z
+            _count_scale(stats_slot, norm, st, B)
+            g.pending = (stats_slot, gamma, beta, eps)
+            return
+    if SERIAL_DIRS and linp is not None and g.mode == 3 and cell == 0 and ndir == 2 and dbg is None and fuse:
+        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
+        stile = SEQ_TILE["serial_intra" if intra else "serial_inter"] or _serial_tile(nplan, st.lib.dprnn_num_cus(), g.n_concurrent)
+        if stile and os.environ.get("DPRNN_PROBE_MEET") == "1":
+            # TIMING PROBE (results are wrong): what a forward costs when both directions run in one launch and each leaves the
+            # products of its half of the Linear -- the launch structure of a "meet in the middle" fold, minus its hand-shake
+            spu, rpu = (S if intra else K), S * K
+            common = (_p(packed), _p(bsum), 2, _p(linp))
+            if getattr(g, "Z2", None) is None:
+                g.Z2 = torch.empty_like(Z)
+                g.buffers.append(g.Z2)
+            Pbuf = g.Z2
+            if g.pending is None:
+                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common, 0, _p(Pbuf), 0, 0, *addr, 2064)
+            else:
+                pstats, pg, pb, peps = g.pending
+                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *common,
+                        0, _p(Pbuf), 0, 0, *addr, 2064)
+                g.X, g.X2 = g.X2, g.X
+            with torch.cuda.stream(st.tstream):
+                stats_slot[:B, 0] = 0.0
+                stats_slot[:B, 1] = float(rpu * F_BUILT)
+            g.Z, g.Z2 = g.Z2, g.Z                       # the products are the next path's pending z
+            g.pending = (stats_slot, gamma, beta, eps)
+            return
+        if stile:
+            spu, rpu = (S if intra else K), S * K
+            common = (_p(packed), _p(bsum), 2, _p(linp))
+            if g.pending is None:
+                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common, 0, _p(Z), 0, 0, *addr, stile)
+            else:       # the pending z is consumed row by row ahead of the partial products that replace it
+                pstats, pg, pb, peps = g.pending
+                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *common,
+                        0, _p(Z), 0, 0, *addr, stile)
+                g.X, g.X2 = g.X2, g.X
+            st.call("dprnn_rnn_lin_fwd", 2, 1, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common,
+                    _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(Z), _p(stats_slot), *addr, stile)
+            _count_scale(stats_slot, norm, st, B)
+            g.pending = (stats_slot, gamma, beta, eps)
+            return
     # f16 pieces: the recurrence hands the projection its operand (H as piece quads, dprnn_rnn_fwd_hp_ex) -- unless someone wants to see h
     hp = H_PIECES and g.mode == 3 and cell == 0 and dbg is None and tile >= 2000
     rnn_fwd = "dprnn_rnn_fwd_hp_ex" if hp else "dprnn_rnn_fwd_ex"
@@ -621,18 +737,13 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
         g.pending = None
     if dbg is not None:
         dbg.append(Hbuf[: geo.rows * ndir * F_BUILT].view(B, S, K, ndir * F_BUILT).clone())
-    w = _param(lin.weight, "linear.weight", dev)
-    if w.shape != (F_BUILT, ndir * F_BUILT):
-        raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
     if hp:
         st.call("dprnn_proj_stats_hp_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
                 geo.rows, S * K, 0, 0, ndir * F_BUILT)
     else:
         st.call("dprnn_proj_stats_fwd", _p(Hbuf), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats_slot),
                 geo.rows, S * K, ndir * F_BUILT)
-    _count_scale(stats_slot, norm)
-    gamma, beta, eps = _norm_params(norm)
-    gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
+    _count_scale(stats_slot, norm, st, B)
     if fuse:
         g.pending = (stats_slot, gamma, beta, eps)
     else:
@@ -653,11 +764,13 @@ SPLIT_STEP_US_F16 = {2016: 3.8, 2032: 13.2, 2064: 11.6, 2080: 15.3}   # 2016: fi
 SPLIT_WIDE_TILE_MARGIN = 1.13
 
 
-def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1) -> int:
+def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1, only=None) -> int:
     """seq_tile code for the split recurrence over nseq sequences x ndir directions: the form whose grid takes the
     least time, rounds x cost of a step (64 x 3 s in two groups: 194 / 250 workgroups of 64 sequences per launch)."""
     best, best_t, t16 = None, None, None
     for tile, us in (SPLIT_STEP_US_F16 if mode == 3 else SPLIT_STEP_US).items():
+        if only is not None and tile not in only:
+            continue
         wgs = ndir * -(-nseq // (tile % 1000))
         two_per_cu = tile % 1000 == 32
         slots = ncu * (2 if two_per_cu else 1)
@@ -774,12 +887,16 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     # pack every LSTM once, on the caller's stream, before the groups fork
     packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
     bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+    serial = (SERIAL_DIRS or LIN_FOLD == "split") and mode == 3 and debug is None and FUSE_NORM
+    linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32) if serial else None
     for i, blk in enumerate(blocks):
-        for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
-            _, fw, bw = _rnn_tensors(rnn, dev)
+        for j, (rnn, lin) in enumerate(((blk.intra_rnn, blk.intra_linear), (blk.inter_rnn, blk.inter_linear))):
+            ndir, fw, bw = _rnn_tensors(rnn, dev)
             _set_slot(st.lib, path_slot(i, j == 1))     # the pack folds the path's x scale into W_ih
             st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
                     _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
+            if serial and ndir == 2 and rnn.rnn.mode == "LSTM":
+                st.call("dprnn_lin_pack_f16", _p(_param(lin.weight, "linear.weight", dev)), 2, _p(linp[2 * i + j]))
 
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
@@ -818,9 +935,16 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
                 (blk.inter_rnn, blk.inter_linear, blk.inter_norm)
             slot = 1 + 2 * i + (0 if intra else 1)
             dbg = [] if debug is not None else None
+            prev_done = None
             for g in groups:            # interleaved submission: every group advances one path at a time
+                if SERIAL_STAGGER and i == 0 and intra and prev_done is not None:
+                    g.st.tstream.wait_event(prev_done)
                 _run_path(g, rnn, lin, norm, stats[slot][g.b0:], packed[2 * i + (0 if intra else 1)],
-                          bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse, path_slot(i, not intra))
+                          bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse, path_slot(i, not intra),
+                          None if linp is None else linp[2 * i + (0 if intra else 1)])
+                if SERIAL_STAGGER and i == 0 and intra and len(groups) > 1:
+                    prev_done = torch.cuda.Event()
+                    prev_done.record(g.st.tstream)
             if debug is not None:
                 debug[f"block{i}." + ("intra_rnn" if intra else "inter_rnn")] = dbg[0]
                 debug[f"block{i}" + (".mid" if intra else "")] = groups[0].X.view(B, S, K, F_BUILT).clone()
@@ -1105,7 +1229,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
                                      want_masked=True)
             # second embedding from the first estimate d0 = mask0 * enc  (dprnn_spe_ira.py:79-92)
             st.call("dprnn_rows_stats", _p(d0), _p(stats[-2]), B, geo.L, N)
-            _count_scale(stats[-2], se[0])
+            _count_scale(stats[-2], se[0], st, B)
             g0, b0, _ = _norm_params(se[0])
             sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
             sh_d = torch.empty_like(sc_d)
@@ -1188,7 +1312,7 @@ def _rows_affine(st: Stage, x_cl, norm, B: int, L: int, N: int):
     dev = x_cl.device
     stats = torch.zeros(B, 2, device=dev, dtype=torch.float64)
     st.call("dprnn_rows_stats", _p(x_cl), _p(stats), B, L, N)
-    _count_scale(stats, norm)
+    _count_scale(stats, norm, st, B)
     gamma, beta, eps = _norm_params(norm)
     sc = torch.empty(B, N, device=dev, dtype=torch.float32)
     sh = torch.empty_like(sc)
@@ -1647,7 +1771,7 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             else:
                 st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
                         total, _p(utt_starts), n, ndir * F_BUILT)
-            _count_scale(stats[slot], norm)
+            _count_scale(stats[slot], norm, st, n)
             gamma, beta, eps = _norm_params(norm)
             pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
 
@@ -1760,7 +1884,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             def second(sg, u):
                 geo = geos[u]
                 sg.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
-                _count_scale(stats[u, 2], se[0])
+                _count_scale(stats[u, 2].view(1, 2), se[0], sg, 1)
                 sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
                 sh_d = torch.empty_like(sc_d)
                 sg.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
@@ -1912,7 +2036,7 @@ class _Graphed:
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
 LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
                 "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
-                "SATURATION_CHECK")
+                "SATURATION_CHECK", "SERIAL_DIRS", "SERIAL_MIN_FILL", "SERIAL_TILES", "SERIAL_STAGGER", "LIN_FOLD")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",
                   "GRAPHS", "GRAPH_CACHE_MAX", "GRAPH_STATS", "SLOT_BOTTLENECK", "SLOT_AUX_BOTTLENECK", "SLOT_HEAD_CONV", "SLOT_HEAD_GATE",
