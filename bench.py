@@ -346,7 +346,9 @@ def main():
 
     x = torch.from_numpy(make_mixture(B, SAMPLES, seed=1234 + rank)).to(dev)     # resident in HBM before timing
     REC = "dprnn_rnn_fwd_ex"            # the recurrence launches (the dominant kernel) ...
-    REC_NAMES = {REC, "dprnn_rnn_fwd_hp_ex"}     # ... under either entry point (mode 3 hands h to the projection as f16 piece quads)
+    FOLD = "dprnn_rnn_lin_split_fwd"    # ... with the following Linear folded in (round 5, the default in mode 3): two launches per path, each
+    #                                     half the steps of both directions (csrc/recur_split8_f16_lin.hip)
+    REC_NAMES = {REC, "dprnn_rnn_fwd_hp_ex", FOLD, "dprnn_rnn_lin_fwd"}     # ... under any entry point
 
     def host_state():
         """What can stall the enqueueing host: the caching allocator going back to the driver (segments allocated / freed, retries) and
@@ -429,16 +431,25 @@ def main():
         kern_ms, union_ms, conc, n_ev = _launch_stats([ev for nm in sorted(REC_NAMES) for ev in prof["events"].get(nm, [])], t_ref)
         engine.GEMM_MODE = mode
         n_groups = len(engine.group_parts(B, engine.effective_gemm_mode(B)))
-        flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
+        folded = bool(prof["events"].get(FOLD))
+        if folded:
+            # a launch meets every row of its pipeline ONCE (half the steps of both directions): the gate GEMM [x | h] @ [W_ih | W_hh]^T of
+            # one direction plus that direction's half of the Linear 256 -> 128
+            flop_per_launch = geo.rows / n_groups * (2 * 256 * 512 + 2 * 128 * 128)
+            flop_chip = geo.rows * 2 * (2 * 256 * 512 + 2 * 128 * 128) * 2 * cfg["n_repeats"]
+        else:
+            flop_per_launch = geo.rows / n_groups * 2 * (2 * 256 * 512)          # rows * 2 dirs * (2*256*512)
+            flop_chip = lstm_flop_per_step
         per_launch = flop_per_launch / (kern_ms * 1e-3) / 1e12
-        chip = lstm_flop_per_step * steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
+        chip = flop_chip * steps / (union_ms * 1e-3) / 1e12 if union_ms > 0 else float("nan")
         products = PRODUCTS[mode]
         peak = PEAK_F32_MFMA_TFLOPS if mode == 0 else BF16_PEAK / products
         piece = "f16" if mode == 3 else "bf16"
         traffic, traffic_src = None, None
         try:
             names, key = {0: (["r01_pmc_traffic.json"], "bilstm_kernel"), 1: (["r02_pmc_traffic.json"], "bilstm_split8_kernel"),
-                          3: (["r04_pmc_traffic_f16.json", "r03_pmc_traffic_f16.json", "r02_pmc_traffic_f16.json"], "bilstm_split8_kernel_f16")}[mode]
+                          3: ((["r05_pmc_traffic_f16.json"] if folded else ["r05_pmc_traffic_f16_unfolded_same_box.json", "r04_pmc_traffic_f16.json"]),
+                              "bilstm_split8_kernel_f16")}[mode]
             name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)[key]
@@ -448,7 +459,9 @@ def main():
             pass
         return {"bound": "mfma",
                 "kernel": "bilstm_kernel (dprnn_rnn_fwd_ex, LSTM cell, exact fp32 MFMA)" if mode == 0 else
-                f"bilstm_split8_kernel (dprnn_rnn_fwd_ex, LSTM cell, fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)",
+                ("bilstm_split8_kernel<.., PJ> (dprnn_rnn_lin_split_fwd: LSTM cell + the following Linear folded in, both directions per launch, the "
+                 f"path cut in time into two launches; fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)" if folded else
+                 f"bilstm_split8_kernel (dprnn_rnn_fwd_ex, LSTM cell, fp32 operands as {piece} pieces, {products} products on the {piece} MFMA)"),
                 # achieved: algorithmic FLOPs of one launch / the MEAN duration of a launch (HIP events on the launch streams,
                 # = rocprofv3 --stats' per-kernel average).  The utterance groups' launches overlap on the chip, so this includes
                 # the time a launch waits for CUs the other group's launch still holds.
@@ -473,9 +486,13 @@ def main():
                 "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                 # slab units per launch: read X per direction (2) + write H (2) [+ read Z per direction (2) + write x' (1) when
                 # the previous norm is folded in: all launches of a forward but the first]
+                # folded: phase 1 reads x, z and writes x', partial products (4; the first path has no pending norm: 2), phase 2 reads x',
+                # partial products and writes z (3): 7 units per path where rounds 2-4 moved 10 (profiles/r05_pmc_traffic_f16.json: 7.49 measured)
                 "algorithmic_gb_per_launch": geo.rows / n_groups * 128 * 4 *
-                ((4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
-                "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": 2 * cfg["n_repeats"] * n_groups,
+                (((4 + 3) * (2 * cfg["n_repeats"] - 1) + (2 + 3)) / (4 * cfg["n_repeats"]) if folded else
+                 (4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
+                "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": (4 if folded else 2) * cfg["n_repeats"] * n_groups,
+                "linear_folded_in": folded,
                 "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / steps,
                 # the same FLOPs over the UNION of the launch intervals: the chip-level rate while any recurrence launch is in flight
                 "chip_level_tflops": chip, "chip_level_frac": chip / peak, "mean_concurrency": conc,
@@ -610,7 +627,7 @@ def bench_other_configs(args, dev, mode):
     products = {0: 1, 1: 6, 3: 3}[mode]
     peak = PEAK_F32_MFMA_TFLOPS if mode == 0 else 2500.0 / products
     engine.GEMM_MODE = mode
-    rec_names = {"dprnn_rnn_fwd_ex", "dprnn_rnn_fwd_hp_ex", "dprnn_rnn_fwd_ragged_ex", "dprnn_rnn_fwd_ragged_hp_ex"}
+    rec_names = {"dprnn_rnn_fwd_ex", "dprnn_rnn_fwd_hp_ex", "dprnn_rnn_fwd_ragged_ex", "dprnn_rnn_fwd_ragged_hp_ex", "dprnn_rnn_lin_split_fwd"}
 
     def build(kind, cls):
         cfg = full_cfg(norm_type="ln", fusion_type="cat")
@@ -642,8 +659,13 @@ def bench_other_configs(args, dev, mode):
             prof, engine.PROFILE = engine.PROFILE, None
         ev = [e for n in sorted(rec_names) for e in prof["events"].get(n, [])]
         kern_ms, union_ms, conc, n_ev = _launch_stats(ev, t_ref)
-        per_launch = flop_per_launch_of(n_ev) / (kern_ms * 1e-3) / 1e12
+        flop = flop_per_launch_of(n_ev)
+        folded = bool(prof["events"].get("dprnn_rnn_lin_split_fwd"))
+        if folded:          # a launch meets every row once: one direction's gate GEMM + its half of the Linear (see the headline's roofline)
+            flop *= (2 * 256 * 512 + 2 * 128 * 128) / (2 * (2 * 256 * 512))
+        per_launch = flop / (kern_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "the fused BiLSTM recurrence (bilstm_split8_kernel / bilstm_kernel), as in the headline's roofline",
+                "linear_folded_in": folded,
                 "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)", "frac": per_launch / peak,
                 "traffic": None, "kernel_ms": kern_ms, "launches_timed": n_ev, "mean_concurrency": conc,
                 "whole_forward_tflops": whole_tflops, "whole_forward_frac": whole_tflops / peak,

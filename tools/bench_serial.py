@@ -77,6 +77,20 @@ def main():
                 st.call("dprnn_rnn_lin_fwd", 2, 1, X2.data_ptr(), 0, 0, 0, 0, 0.0, per, S * K, 0, packed.data_ptr(), bsum.data_ptr(), 2,
                         linp.data_ptr(), b.data_ptr(), Z.data_ptr(), Z.data_ptr(), stats.data_ptr(), *addr, a.tile)
 
+            state = torch.empty(lib.dprnn_rnn_lin_state_floats(addr[0], a.tile), device="cuda")
+            Z2 = torch.empty_like(Z)
+
+            def sp1():
+                st.call("dprnn_rnn_lin_split_fwd", 1, X.data_ptr(), *norm, per, S * K, X2.data_ptr(), packed.data_ptr(), bsum.data_ptr(), linp.data_ptr(),
+                        0, Z2.data_ptr(), 0, state.data_ptr(), *addr, a.tile)
+
+            def sp2():
+                st.call("dprnn_rnn_lin_split_fwd", 2, X2.data_ptr(), 0, 0, 0, 0, 0.0, per, S * K, 0, packed.data_ptr(), bsum.data_ptr(), linp.data_ptr(),
+                        b.data_ptr(), Z2.data_ptr(), stats.data_ptr(), state.data_ptr(), *addr, a.tile)
+
+            ts = {k: timed(f, a.iters) for k, f in (("split 1", sp1), ("split 2", sp2))}
+            print(f"B={B} {name}: time-split fold (both directions per launch, {2 * wgs} workgroups): phase 1 {ts['split 1']:.3f} + phase 2 {ts['split 2']:.3f} = "
+                  f"{ts['split 1'] + ts['split 2']:.3f} ms; us per step {ts['split 1'] / (T / 2) * 1e3:.2f} / {ts['split 2'] / (T / 2) * 1e3:.2f}", flush=True)
             t = {k: timed(f, a.iters) for k, f in (("concurrent recurrence", rec_conc), ("projection", proj), ("phase 1", ph1), ("phase 2", ph2))}
             conc, ser = t["concurrent recurrence"] + t["projection"], t["phase 1"] + t["phase 2"]
             print(f"B={B} {name}: {addr[0]} sequences x {T} steps, {wgs} workgroups per direction | concurrent {t['concurrent recurrence']:.3f} + "

@@ -59,10 +59,33 @@ def main():
         # the first launch of a forward has no pending norm: X per direction + H = 4 units
         fused = sum(v["launches"] for k, v in rec.items() if re.match(r"bilstm_split8_kernel<\d+, \d+, \w+, true", k))
         algo = (7 * fused + 4 * (n - fused)) * unit / n
+        note = (f"mean over the {n} recurrence launches of the profiled forwards ({fused} with the pending norm folded in: 7 slab "
+                f"units of {unit:.3f} GB, the others 4)")
+        # Linear folded in (round 5; template argument 8 = PJ): a launch meets every row once -- phase 1 reads x (+ z: pending norm) and
+        # writes (x' and) the partial products: 4 / 2 units; phase 2 reads x' and the partial products and writes z: 3 units
+        def units(k):
+            m = re.match(r"bilstm_split8_kernel<\d+, \d+, \w+, (\w+), \w+, \w+, \w+, (\d)>", k)
+            if not m or m.group(2) == "0":
+                return None
+            return 3 if m.group(2) == "2" else (4 if m.group(1) == "true" else 2)
+        if any(units(k) for k in rec):
+            algo = sum(v["launches"] * (units(k) or 0) for k, v in rec.items()) * unit / n
+            note = (f"mean over the {n} launches of the recurrence with the Linear folded in (phase 1: x, z in, x' and partial products out = 4 slab "
+                    f"units of {unit:.3f} GB, 2 without a pending norm; phase 2: x', partial products in, z out = 3)")
         out[key] = {"group_batch": group_batch, "traffic_GB_per_launch": round(traffic, 4), "algorithmic_GB_per_launch": round(algo, 4),
-                    "note": f"mean over the {n} recurrence launches of the profiled forwards ({fused} with the pending norm folded in: 7 slab "
-                            f"units of {unit:.3f} GB, the others 4); the packed weight pieces come from L2.  traffic / algorithmic = "
-                            f"{traffic / algo:.3f}"}
+                    "note": note + f"; the packed weight pieces come from L2.  traffic / algorithmic = {traffic / algo:.3f}"}
+    if len(sys.argv) > 7:
+        # whole forward: FORWARDS = forwards in the profiled run (bench.py --steps 1 --warmup 1: two), PATHS = DPRNN paths per forward
+        # (12).  Slab units of 512 B per row and path = (traffic of the recurrence + projection kernels) / (paths x rows x 512 B).
+        forwards, paths = int(sys.argv[7]), int(sys.argv[8]) if len(sys.argv) > 8 else 12
+        total = sum(v["launches"] * (v["hbm_read_GB"] + v["hbm_write_GB"]) for v in out["per_launch"].values()) / forwards
+        path_k = {k: v for k, v in out["per_launch"].items() if k.startswith(("bilstm_split8_kernel", "bilstm_kernel", "proj_f16_kernel"))}
+        path_gb = sum(v["launches"] * (v["hbm_read_GB"] + v["hbm_write_GB"]) for v in path_k.values()) / forwards
+        batch_rows = int(sys.argv[6]) * (64 // int(sys.argv[5]))
+        out["forward"] = {"forwards_profiled": forwards, "total_GB_per_forward": round(total, 2), "dprnn_paths_GB_per_forward": round(path_gb, 2),
+                          "slab_units_per_row_and_path": round(path_gb * 1e9 / (paths * batch_rows * 512), 3),
+                          "note": "recurrence (+ projection) kernels only in the path figure; SURVEY.md section 8(d) counts 4 units per path with ideal "
+                                  "fusion, rounds 2-4 moved 10 (x, z read per direction; x', h per direction, z written; h read back)"}
     bw = {k: v for k, v in out["per_launch"].items() if k.startswith("lstm_bwd8_f16_kernel")}
     if bw:
         # training step: the BPTT launch of one 32-utterance micro-batch (bench.py --mode train: 64 utterances as 2 x 32), for

@@ -53,7 +53,7 @@ struct RecurArgs {
     float* P;
     float* Zout;
     double* stats_out;                                // [utterances][2], accumulated (atomics)
-    int proj_dirs;                                    // directions dir0 .. dir0 + proj_dirs - 1 in one launch (2: the split form below)
+    int proj_dirs;                                    // directions dir0 .. dir0 + proj_dirs - 1 in one launch (2: the time-split form below)
     // ---- the same fold with BOTH directions in every launch (dprnn_rnn_lin_split_fwd): the path is cut in time instead of by direction.
     // split_m = M >= 0: phase 1 runs the forward direction's steps [0, M) and the reverse direction's [0, T - M) (rows [0, M) and
     // [M, T): each row met by exactly one direction, which leaves x' and its partial product), phase 2 the remaining steps of both

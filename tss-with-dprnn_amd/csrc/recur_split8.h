@@ -31,7 +31,12 @@ namespace rsplit {
 #endif                                                 //   1 no weight stream from L2 | 2 a quarter of the LDS fragment reads | 4 one MFMA product of the first k-slab only (1 / 24)
                                                        //   8 no cell arithmetic (h = clamp(scaled sum of the four gate accumulators)) | 16 no x staging at all (HBM loads, norm, split, LDS writes, x' store)
                                                        //   32 no h store to HBM | 64 no x' store | 128 the x / z loads of every step read step 0's rows: L2 hits instead of HBM reads
+                                                       //   1024 (PJ) no store of the folded Linear's rows | 2048 (PJ = 2) no load of the partial products
 constexpr bool diag(int bit) { return (DPRNN_SPLIT8_DIAG & bit) != 0; }
+#ifndef DPRNN_SPLIT8_NT
+#define DPRNN_SPLIT8_NT 1                              // experiment: non-temporal cache policy (aux bit 1) on the activation streams of the PJ forms:
+#endif                                                 //   1 x / z loads | 2 x' stores | 4 stores of the folded Linear's rows | 8 loads of the partial products
+constexpr int nt_aux(int bit) { return (DPRNN_SPLIT8_NT & bit) ? 2 : 0; }
 #ifndef DPRNN_CELL_SHARED_RCP
 #define DPRNN_CELL_SHARED_RCP 1                        // hardware-activation builds of the TRANS forms: two reciprocals per unit-step instead of five
 #endif
@@ -255,8 +260,8 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
             const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
-            xq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0));
-            if (FUSE) zq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo, 0, 0));
+            xq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, PJ ? nt_aux(1) : 0));
+            if (FUSE) zq[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, xo, 0, PJ ? nt_aux(1) : 0));
         }
         fence();
     };
@@ -272,7 +277,7 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
                 const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
-                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo : OOB, 0, 0);
+                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo : OOB, 0, PJ ? nt_aux(2) : 0);
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
@@ -494,15 +499,15 @@ void bilstm_split8_kernel(RecurArgs a) {
                 } else {
                     v = pacc[nt] * f32x4{inv_l, inv_l, inv_l, inv_l};
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, rowoff_h[16 * nt + r] + zcol, 0, 0);
+                if (!diag(1024)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, rowoff_h[16 * nt + r] + zcol, 0, nt_aux(4));
             }
         }
         if constexpr (PJ == 2) {
-            if (load && a.P) {
+            if (load && a.P && !diag(2048)) {
                 const __amdgpu_buffer_rsrc_t irs = rsrc_at(a.P + tbase(tnext) * F);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    pacc[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, rowoff_h[16 * nt + r] + zcol, 0, 0));
+                    pacc[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, rowoff_h[16 * nt + r] + zcol, 0, nt_aux(8)));
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) pacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};

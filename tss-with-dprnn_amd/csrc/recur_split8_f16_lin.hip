@@ -108,7 +108,7 @@ extern "C" int dprnn_rnn_lin_fwd(int phase, int dir, const float* X, const float
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = 0;
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
     a.rows_per_utt = rows_per_utt; a.Xout = Xout;
-    { const char* e = getenv("DPRNN_PROBE_MEET"); a.proj_dirs = (e && atoi(e) == 1 && phase == 1) ? 2 : 1; }      // timing probe: both directions leave partial products (results are WRONG)
+    a.proj_dirs = 1;
     a.split_m = -1;
     a.proj = phase; a.dir0 = dir; a.Lp = lin_packed; a.lbias = lin_bias; a.P = P; a.Zout = Zout; a.stats_out = stats_out;
     if (!tile_offsets_fit(inner_n, outer_stride, inner_stride, t_stride, F)) {

@@ -596,33 +596,74 @@ class _Group:
         self.buffers += [self.X2, zh]
 
 
-# Direction-serial form (csrc/recur_split8_f16_lin.hip, round 5): in mode 3 a bidirectional LSTM path runs as two launches -- direction 0
-# leaves x' and its half of the following Linear's product, direction 1 finishes z and the GroupNorm sums -- so h never reaches HBM and
-# the projection kernel disappears: 7 slab rows of HBM traffic per row and path instead of 10.  Each launch has half the workgroups
-# and the path twice the serial steps, so the form is taken when a launch still covers SERIAL_MIN_FILL of the CUs (counting the
-# pipelines in flight together) and left to the concurrent-direction form below that (few utterances: latency).
-# LIN_FOLD (round 5): how the Linear after a bidirectional LSTM is folded into the recurrence in mode 3.
-#   "split"  (default) both directions in every launch, the path cut in time: phase 1 walks the first half of every sequence in each
-#            direction (x', partial products), phase 2 the second halves (z, GroupNorm sums) -- csrc/recur_split8_f16_lin.hip,
-#            dprnn_rnn_lin_split_fwd.  7 slab rows of HBM traffic per row and path instead of 10, no projection kernel, and launches of
-#            2 x tiles workgroups like the unfolded form, so two pipelines still pack the chip.
-#   "serial" one direction per launch (dprnn_rnn_lin_fwd): the same traffic, but a launch has one workgroup per tile -- 194 / 250 for
-#            64 x 3 s on 256 CUs; measured 3 % SLOWER than no fold at B = 64 (profiles/r05_serial_vs_concurrent.txt), wins when a
-#            launch fills the chip twice over.
+# LIN_FOLD (round 5): the Linear after a bidirectional LSTM folded into the recurrence (mode 3; csrc/recur_split8_f16_lin.hip): every h_t
+# is multiplied with its direction's half of the Linear while it is the next step's operand in LDS, so h never reaches HBM and the
+# projection kernel disappears -- 7 slab rows of HBM traffic per row and path instead of 10 (profiles/r05_pmc_traffic_f16.json: 7.49
+# measured against 10.43).  The two halves of a row's product have to meet; two launch structures do that without any
+# synchronisation inside a kernel:
+#   "split"  both directions in every launch, the path cut in TIME (dprnn_rnn_lin_split_fwd): phase 1 walks the first half of every
+#            sequence in each direction (x', partial products), phase 2 the second halves (z, GroupNorm sums).  Launches of 2 x tiles
+#            workgroups like the unfolded form, so two pipelines still pack the chip: +3 % at 64 x 3 s.
+#   "serial" one direction per launch (dprnn_rnn_lin_fwd): a launch has ONE workgroup per tile -- 194 / 250 for 64 x 3 s on 256 CUs, 85 %
+#            of the chip on average: 3 % SLOWER than no fold there, 4 % faster at 128 x 3 s, where a launch fills the chip 1.5 x over
+#            (profiles/r05_linear_fold.txt).
 #   "off"    recurrence + projection kernel (rounds 2-4).
-LIN_FOLD = os.environ.get("DPRNN_LIN_FOLD", "split")
-SERIAL_DIRS = LIN_FOLD == "serial" or os.environ.get("DPRNN_SERIAL_DIRS", "0") == "1"
-SERIAL_MIN_FILL = float(os.environ.get("DPRNN_SERIAL_MIN_FILL", "0.6"))
-SERIAL_TILES = (2032, 2048, 2064)
-SERIAL_STAGGER = os.environ.get("DPRNN_SERIAL_STAGGER", "0") == "1"      # experiment: pipeline g starts its first path when pipeline g - 1 has finished its own
+#   "auto"   (default) per path, by how far the launches of the pipelines in flight cover the chip: serial from FOLD_SERIAL_MIN_FILL,
+#            split from FOLD_SPLIT_MIN_FILL, else off -- a folded step costs 13-21 % more than an unfolded one (+12.5 % MFMAs, the
+#            weight pieces of the Linear, a second set of stores), which pays only when the projection kernel it replaces would have
+#            had to queue for CUs (profiles/r05_batch_sweep_fold.txt: below ~29 utterances the unfolded form is 1-2 % faster).
+LIN_FOLD = os.environ.get("DPRNN_LIN_FOLD", "auto")
+FOLD_SPLIT_MIN_FILL = float(os.environ.get("DPRNN_FOLD_SPLIT_MIN_FILL", "0.98"))
+FOLD_SERIAL_MIN_FILL = float(os.environ.get("DPRNN_FOLD_SERIAL_MIN_FILL", "1.5"))
+FOLD_TILES = (2032, 2048, 2064)
 
 
-def _serial_tile(nplan: int, ncu: int, concurrent: int) -> int:
-    """seq_tile of the direction-serial form for launches of nplan sequences (one direction each), 0: keep the concurrent form."""
-    if -(-nplan // 64) * concurrent < SERIAL_MIN_FILL * ncu:
-        return 0
-    tile = split_tile(nplan, 1, ncu, concurrent, 3, SERIAL_TILES)
-    return tile if tile in SERIAL_TILES else 0
+def fold_plan(nplan: int, ncu: int, concurrent: int, intra: bool):
+    """(form, seq_tile) of one DPRNN path whose launches cover nplan sequences per pipeline, `concurrent` pipelines in flight:
+    ("off", 0), ("split", tile) or ("serial", tile)."""
+    if LIN_FOLD == "off":
+        return "off", 0
+    key = "intra" if intra else "inter"
+    tiles = lambda t: -(-nplan // (t % 1000))
+    if LIN_FOLD in ("serial", "auto"):
+        tile = SEQ_TILE["serial_" + key] or split_tile(nplan, 1, ncu, concurrent, 3, FOLD_TILES)
+        if tile in FOLD_TILES and (LIN_FOLD == "serial" or concurrent * tiles(tile) >= FOLD_SERIAL_MIN_FILL * ncu):
+            return "serial", tile
+    if LIN_FOLD in ("split", "auto"):
+        tile = SEQ_TILE[key] or split_tile(nplan, 2, ncu, concurrent, 3)
+        if tile in FOLD_TILES and (LIN_FOLD == "split" or 2 * concurrent * tiles(tile) >= FOLD_SPLIT_MIN_FILL * ncu):
+            return "split", tile
+    return "off", 0
+
+
+def _path_folded(g: "_Group", form: str, tile: int, lin, stats_slot, packed, bsum, linp, intra: bool, addr, dev):
+    """One bidirectional LSTM path with its Linear folded in (mode 3): two launches; leaves the new z in g.Z and its sums in stats_slot."""
+    st, geo = g.st, g.geo
+    spu, rpu = (geo.S if intra else geo.K), geo.S * geo.K
+    lb = _p(_param(lin.bias, "linear.bias", dev))
+    norm = (0, 0, 0, 0, 0.0)
+    xout = 0
+    if g.pending is not None:
+        pstats, pg, pb, peps = g.pending
+        norm, xout = (_p(g.Z), _p(pstats), _p(pg), _p(pb), peps), _p(g.X2)
+    if form == "split":
+        if getattr(g, "Z2", None) is None:      # the partial products / the new z: the pending z is still read while they are written
+            g.Z2 = torch.empty_like(g.Z)
+            g.lin_state = torch.empty(max(st.lib.dprnn_rnn_lin_state_floats(n_, t_) for n_ in (geo.B * geo.S, geo.B * geo.K) for t_ in FOLD_TILES),
+                                      device=dev, dtype=torch.float32)
+            g.buffers += [g.Z2, g.lin_state]
+        tail = (_p(packed), _p(bsum), _p(linp))
+        st.call("dprnn_rnn_lin_split_fwd", 1, _p(g.X), *norm, spu, rpu, xout, *tail, 0, _p(g.Z2), 0, _p(g.lin_state), *addr, tile)
+        if g.pending is not None:
+            g.X, g.X2 = g.X2, g.X
+        st.call("dprnn_rnn_lin_split_fwd", 2, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, lb, _p(g.Z2), _p(stats_slot), _p(g.lin_state), *addr, tile)
+        g.Z, g.Z2 = g.Z2, g.Z
+    else:       # serial: the pending z is consumed row by row ahead of the partial products that replace it, in the same buffer
+        tail = (_p(packed), _p(bsum), 2, _p(linp))
+        st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), *norm, spu, rpu, xout, *tail, 0, _p(g.Z), 0, 0, *addr, tile)
+        if g.pending is not None:
+            g.X, g.X2 = g.X2, g.X
+        st.call("dprnn_rnn_lin_fwd", 2, 1, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, lb, _p(g.Z), _p(g.Z), _p(stats_slot), *addr, tile)
 
 
 def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, dbg, fuse: bool, scale_slot: int = SLOT_PATH0, linp=None):
@@ -649,78 +690,20 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     cell = CELL_ID[rnn.rnn.mode]
     if cell != 0 and tile > 32:
         tile = 32
+    nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
     if cell == 0 and g.mode != 0:
         # every pipeline of a forward takes the tile of the LARGEST one: pipelines on different tiles finish apart, and the forward
         # waits for the slower (B = 25 as 12 + 13 utterances: 32.4 ms mixed against 30.9 / 31.9 ms on either tile for both)
-        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
         tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
     w = _param(lin.weight, "linear.weight", dev)
     if w.shape != (F_BUILT, ndir * F_BUILT):
         raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
     gamma, beta, eps = _norm_params(norm)
     gamma, beta = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
-    if LIN_FOLD == "split" and not SERIAL_DIRS and linp is not None and g.mode == 3 and cell == 0 and ndir == 2 and dbg is None and fuse:
-        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
-        stile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, 2, st.lib.dprnn_num_cus(), g.n_concurrent, 3)
-        if stile in SERIAL_TILES:
-            spu, rpu = (S if intra else K), S * K
-            if getattr(g, "Z2", None) is None:      # the partial products / the new z: the pending z is read while they are written
-                g.Z2 = torch.empty_like(Z)
-                g.lin_state = torch.empty(max(st.lib.dprnn_rnn_lin_state_floats(n_, t_) for n_ in (B * S, B * K) for t_ in SERIAL_TILES),
-                                          device=dev, dtype=torch.float32)
-                g.buffers += [g.Z2, g.lin_state]
-            tail = (_p(packed), _p(bsum), _p(linp))
-            lb = _p(_param(lin.bias, "linear.bias", dev))
-            if g.pending is None:
-                st.call("dprnn_rnn_lin_split_fwd", 1, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, 0, _p(g.Z2), 0, _p(g.lin_state), *addr, stile)
-            else:
-                pstats, pg, pb, peps = g.pending
-                st.call("dprnn_rnn_lin_split_fwd", 1, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *tail, 0, _p(g.Z2),
-                        0, _p(g.lin_state), *addr, stile)
-                g.X, g.X2 = g.X2, g.X
-            st.call("dprnn_rnn_lin_split_fwd", 2, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *tail, lb, _p(g.Z2), _p(stats_slot), _p(g.lin_state),
-                    *addr, stile)
-            g.Z, g.Z2 = g.Z2, g.Z
-            _count_scale(stats_slot, norm, st, B)
-            g.pending = (stats_slot, gamma, beta, eps)
-            return
-    if SERIAL_DIRS and linp is not None and g.mode == 3 and cell == 0 and ndir == 2 and dbg is None and fuse:
-        nplan = addr[0] // g.geo.B * max(g.geo.B, getattr(g, "plan_B", 0))
-        stile = SEQ_TILE["serial_intra" if intra else "serial_inter"] or _serial_tile(nplan, st.lib.dprnn_num_cus(), g.n_concurrent)
-        if stile and os.environ.get("DPRNN_PROBE_MEET") == "1":
-            # TIMING PROBE (results are wrong): what a forward costs when both directions run in one launch and each leaves the
-            # products of its half of the Linear -- the launch structure of a "meet in the middle" fold, minus its hand-shake
-            spu, rpu = (S if intra else K), S * K
-            common = (_p(packed), _p(bsum), 2, _p(linp))
-            if getattr(g, "Z2", None) is None:
-                g.Z2 = torch.empty_like(Z)
-                g.buffers.append(g.Z2)
-            Pbuf = g.Z2
-            if g.pending is None:
-                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common, 0, _p(Pbuf), 0, 0, *addr, 2064)
-            else:
-                pstats, pg, pb, peps = g.pending
-                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *common,
-                        0, _p(Pbuf), 0, 0, *addr, 2064)
-                g.X, g.X2 = g.X2, g.X
-            with torch.cuda.stream(st.tstream):
-                stats_slot[:B, 0] = 0.0
-                stats_slot[:B, 1] = float(rpu * F_BUILT)
-            g.Z, g.Z2 = g.Z2, g.Z                       # the products are the next path's pending z
-            g.pending = (stats_slot, gamma, beta, eps)
-            return
-        if stile:
-            spu, rpu = (S if intra else K), S * K
-            common = (_p(packed), _p(bsum), 2, _p(linp))
-            if g.pending is None:
-                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common, 0, _p(Z), 0, 0, *addr, stile)
-            else:       # the pending z is consumed row by row ahead of the partial products that replace it
-                pstats, pg, pb, peps = g.pending
-                st.call("dprnn_rnn_lin_fwd", 1, 0, _p(g.X), _p(Z), _p(pstats), _p(pg), _p(pb), peps, spu, rpu, _p(g.X2), *common,
-                        0, _p(Z), 0, 0, *addr, stile)
-                g.X, g.X2 = g.X2, g.X
-            st.call("dprnn_rnn_lin_fwd", 2, 1, _p(g.X), 0, 0, 0, 0, 0.0, spu, rpu, 0, *common,
-                    _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(Z), _p(stats_slot), *addr, stile)
+    if linp is not None and g.mode == 3 and cell == 0 and ndir == 2 and dbg is None and fuse:
+        form, ftile = fold_plan(nplan, st.lib.dprnn_num_cus(), g.n_concurrent, intra)
+        if form != "off":
+            _path_folded(g, form, ftile, lin, stats_slot, packed, bsum, linp, intra, addr, dev)
             _count_scale(stats_slot, norm, st, B)
             g.pending = (stats_slot, gamma, beta, eps)
             return
@@ -887,7 +870,14 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     # pack every LSTM once, on the caller's stream, before the groups fork
     packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
     bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
-    serial = (SERIAL_DIRS or LIN_FOLD == "split") and mode == 3 and debug is None and FUSE_NORM
+    fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
+    parts = _split(B) if debug is None else [(0, B)]
+    if mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
+        parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
+    plan_B = max(b1 - b0 for b0, b1 in parts)
+    # the Linears are packed for the folded launches only when some path of this forward will take them (fold_plan: batch-size dependent)
+    serial = mode == 3 and fuse and any(fold_plan(plan_B * (S if intra else K), st.lib.dprnn_num_cus(), len(parts), intra)[0] != "off"
+                                        for intra in (True, False))
     linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32) if serial else None
     for i, blk in enumerate(blocks):
         for j, (rnn, lin) in enumerate(((blk.intra_rnn, blk.intra_linear), (blk.inter_rnn, blk.inter_linear))):
@@ -901,10 +891,6 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
 
-    fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
-    parts = _split(B) if debug is None else [(0, B)]
-    if mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
-        parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
     if len(parts) == 1:
         groups = [_Group(st, geo, 0, B, dev)]
     else:
@@ -917,7 +903,7 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
 
     for g in groups:
         g.n_concurrent = len(groups)
-        g.plan_B = max(b1 - b0 for b0, b1 in parts)
+        g.plan_B = plan_B
         g.mode = mode
         g.st.call("dprnn_segment_fwd", _p(Y[g.b0:]), _p(g.X), g.geo.B, L, K, P, S)
     if debug is not None:
@@ -935,16 +921,10 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
                 (blk.inter_rnn, blk.inter_linear, blk.inter_norm)
             slot = 1 + 2 * i + (0 if intra else 1)
             dbg = [] if debug is not None else None
-            prev_done = None
             for g in groups:            # interleaved submission: every group advances one path at a time
-                if SERIAL_STAGGER and i == 0 and intra and prev_done is not None:
-                    g.st.tstream.wait_event(prev_done)
                 _run_path(g, rnn, lin, norm, stats[slot][g.b0:], packed[2 * i + (0 if intra else 1)],
                           bsum[2 * i + (0 if intra else 1)], intra, dbg, fuse, path_slot(i, not intra),
                           None if linp is None else linp[2 * i + (0 if intra else 1)])
-                if SERIAL_STAGGER and i == 0 and intra and len(groups) > 1:
-                    prev_done = torch.cuda.Event()
-                    prev_done.record(g.st.tstream)
             if debug is not None:
                 debug[f"block{i}." + ("intra_rnn" if intra else "inter_rnn")] = dbg[0]
                 debug[f"block{i}" + (".mid" if intra else "")] = groups[0].X.view(B, S, K, F_BUILT).clone()
@@ -2036,7 +2016,7 @@ class _Graphed:
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
 LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
                 "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
-                "SATURATION_CHECK", "SERIAL_DIRS", "SERIAL_MIN_FILL", "SERIAL_TILES", "SERIAL_STAGGER", "LIN_FOLD")
+                "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",
                   "GRAPHS", "GRAPH_CACHE_MAX", "GRAPH_STATS", "SLOT_BOTTLENECK", "SLOT_AUX_BOTTLENECK", "SLOT_HEAD_CONV", "SLOT_HEAD_GATE",
