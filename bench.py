@@ -557,6 +557,20 @@ def main():
     if world == 1 and not args.no_other_configs and not args.no_optional_modes:
         t_oc = time.perf_counter()
         others = bench_other_configs(args, dev, args.gemm_mode)
+        # BASELINE.json configs[3]'s per-GPU share: the training step (forward with tape, PIT SI-SDR loss, backward, clip, Adam) on a copy of
+        # the model, 5 warm-ups + 10 steps, with its own roofline object (bench_train: what `--mode train` prints as a line of its own)
+        import argparse
+        import copy
+        engine.drop_graphs()
+        del out, ref_out
+        torch.cuda.empty_cache()
+        targs = argparse.Namespace(**dict(vars(args), steps=10, warmup=5, no_power=True))
+        tmodel = copy.deepcopy(model)
+        try:
+            others["train_b64"] = bench_train(targs, tmodel, dev, world, rank, None, sync, lstm_flop_per_step, make_sources)
+        finally:
+            del tmodel
+            torch.cuda.empty_cache()
         others["seconds_spent"] = time.perf_counter() - t_oc
         others["note"] = ("timed after the headline region on the same GPU, same arithmetic as `value` (dtype), inputs resident in HBM; "
                           "NOT part of `value`")

@@ -25,8 +25,10 @@
 extern "C" {
 #endif
 
-#define DPRNN_ABI_VERSION   2   /* dprnn_abi_version(): 2 since dprnn_adam_multi takes its betas as double and the *_ex,
-                                 * saturation and pack-format entry points exist; hosts compare it when they load the library */
+#define DPRNN_ABI_VERSION   3   /* dprnn_abi_version(): 2 since dprnn_adam_multi takes its betas as double and the *_ex, saturation and
+                                 * pack-format entry points exist; 3 (round 5) with the piece-quad H / packed gate tape entry points of
+                                 * round 4, the folded Linear (dprnn_lin_pack_f16, dprnn_rnn_lin_fwd, dprnn_rnn_lin_split_fwd) and the forked
+                                 * activation-scale record (4 x DPRNN_SCALE_SLOTS words).  Hosts compare it when they load the library */
 #define DPRNN_OK            0
 #define DPRNN_EINVAL       -1   /* unsupported size / null pointer */
 #define DPRNN_ELAUNCH      -2   /* HIP launch error */

@@ -13,6 +13,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: redundant-by-design repetitions of a covered case (every tiny / narrow golden in the opt-in "
+                                       "gate-GEMM modes, ...): skipped unless the marker expression names it -- `-m \"gpu and slow\"`")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (the driver's run, 900 s limit) leaves the `slow` repetitions out; `-m "gpu and slow"` or DPRNN_TEST_SLOW=1 runs them."""
+    if "slow" in (config.getoption("-m") or "") or os.environ.get("DPRNN_TEST_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow repetition: run with -m \"gpu and slow\" (or DPRNN_TEST_SLOW=1)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 def load_golden(name):

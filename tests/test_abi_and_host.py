@@ -59,7 +59,7 @@ def test_binding_table_has_one_argtype_per_header_parameter():
 
 def test_library_loads_and_reports_abi(lib_path):
     lib = pkg.load_library()
-    assert lib.dprnn_abi_version() == 2
+    assert lib.dprnn_abi_version() == 3
     assert lib.dprnn_last_error() is not None
 
 
@@ -325,6 +325,72 @@ def test_wide_recurrence_tiles_need_a_clear_predicted_advantage():
         assert engine.split_tile(13 * K, 2, ncu, 2, 3) == 2064                    # the bare cost model's choice
     finally:
         engine.SPLIT_WIDE_TILE_MARGIN = old
+
+
+def test_the_exported_capture_lock_is_the_one_the_engine_captures_under():
+    """INTEGRATION.md, "Other graphs in the same process": engine.capture_lock() hands a host the very lock the engine holds while it
+    evicts, captures and first-launches a graph; it is re-entrant (a capture may run inside the host's own critical section) and
+    excludes other threads."""
+    import threading
+    from tss_with_dprnn_amd import engine
+    got = []
+    with engine.capture_lock():
+        assert engine._CAPTURE_LOCK._is_owned()
+        with engine.capture_lock():                        # re-entrant
+            pass
+        t = threading.Thread(target=lambda: got.append(engine._CAPTURE_LOCK.acquire(blocking=False)))
+        t.start(); t.join()
+        assert got == [False]                              # another thread cannot capture / destroy meanwhile
+    assert not engine._CAPTURE_LOCK._is_owned()
+    t = threading.Thread(target=lambda: (got.append(engine._CAPTURE_LOCK.acquire(blocking=False)), engine._CAPTURE_LOCK.release()))
+    t.start(); t.join()
+    assert got == [False, True]
+
+
+def test_evicted_graphs_are_destroyed_under_the_capture_lock_and_only_when_idle():
+    """engine._retire: dropping the cache's reference does not destroy a graph another thread is still replaying; such a
+    graph is parked and destroyed by a later call -- always by the holder of the capture lock."""
+    from tss_with_dprnn_amd import engine
+
+    class Fake:
+        def __init__(self):
+            self.users, self.destroyed_under_lock = 0, None
+
+        def destroy(self):
+            self.destroyed_under_lock = engine._CAPTURE_LOCK._is_owned()
+    busy, idle = Fake(), Fake()
+    busy.users = 1
+    with engine.capture_lock():
+        engine._retire([busy, idle])
+    assert idle.destroyed_under_lock is True and busy.destroyed_under_lock is None and busy in engine._GRAPH_RETIRED
+    busy.users = 0
+    with engine.capture_lock():
+        engine._retire()
+    assert busy.destroyed_under_lock is True and not engine._GRAPH_RETIRED
+
+
+def test_the_linear_fold_is_taken_where_the_launches_cover_the_chip(monkeypatch):
+    """engine.fold_plan (profiles/r05_linear_fold.txt): per DPRNN path, the time-split fold from where the two pipelines' launches
+    (2 directions x tiles each) cover the CUs, the direction-serial fold where one direction's launches cover them 1.5 times, neither
+    below -- and the explicit settings."""
+    from tss_with_dprnn_amd import engine
+    S, K, ncu = 194, 250, 256
+
+    def plan(B):
+        parts = engine.group_parts(B, 3)
+        pB = max(b - a for a, b in parts)
+        return [engine.fold_plan(pB * n, ncu, len(parts), intra) for n, intra in ((S, True), (K, False))]
+    monkeypatch.setattr(engine, "LIN_FOLD", "auto")
+    assert plan(1) == plan(8) == plan(28) == [("off", 0), ("off", 0)]
+    assert plan(31) == [("off", 0), ("split", 2064)] and plan(40)[0] == ("off", 0)
+    assert plan(41) == plan(64) == plan(96) == [("split", 2064), ("split", 2064)]
+    assert plan(128) == [("serial", 2064), ("serial", 2064)]
+    monkeypatch.setattr(engine, "LIN_FOLD", "off")
+    assert plan(64) == [("off", 0), ("off", 0)]
+    monkeypatch.setattr(engine, "LIN_FOLD", "serial")
+    assert plan(64) == [("serial", 2064), ("serial", 2064)]
+    monkeypatch.setattr(engine, "LIN_FOLD", "split")
+    assert plan(64) == [("split", 2064), ("split", 2064)] and plan(2) == [("off", 0), ("off", 0)]      # 16-sequence tiles have no folded form
 
 
 def test_every_engine_setting_is_classified_for_the_graph_key():

