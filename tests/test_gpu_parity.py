@@ -204,7 +204,7 @@ def test_stream_groups_do_not_change_results():
     assert torch.equal(again, outs[2]), "multi-stream forward is not run-to-run deterministic"
 
 
-@pytest.mark.parametrize("B,T", [(1, 2), (2, 3), (1, 100), (3, 251), (2, 1000), (65, 600), (2, 111920)])
+@pytest.mark.parametrize("B,T", [(1, 2), (2, 3), (1, 100), (3, 251), (2, 1000), (65, 600), (1, 111920)])
 def test_edge_lengths_and_batches_vs_cpu_oracle(B, T):
     """Utterances shorter than a chunk (L < K, a single frame), odd lengths, and a batch that splits unevenly
     into stream groups (65), and the longest Libri2Mix-test utterance (111 920 samples, 898 chunks: SURVEY.md 8d)
@@ -275,9 +275,9 @@ FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_")]
 # In the opt-in modes 0 and 1 a representative third runs by default -- every full-size golden, the wide ones that differ in kernel path
 # (cells, fusions, norms, trained-like weights, BatchNorm in train mode) -- and the tiny / narrow twins and the remaining wide variants
 # are marked `slow` (the same kernels at other shapes; they all run in the default mode 3): the driver's `pytest -m gpu` has a time limit.
-OPT_IN_MODE_GOLDENS = {"bss_full_b2", "bss_full_trained_rms1", "bss_wide_small", "bss_wide_small_gln_relu", "bss_wide_hop5", "bss_wide_trained_small",
-                       "bss_narrow64_small", "spe_full_b1", "spe_full_att_b1", "spe_wide_small_film", "spe_wide_small_cat_bntrain", "ira_full_b1",
-                       "ira_wide_trained_small", "bss_tiny_b1"}
+OPT_IN_MODE_GOLDENS = {"bss_full_b2", "bss_wide_small", "bss_wide_small_gln_relu", "bss_wide_hop5", "bss_wide_k250", "bss_narrow64_small",
+                       "spe_full_b1", "spe_full_att_b1", "spe_wide_small_film", "spe_wide_small_cat_bntrain", "spe_narrow_att_bntrain",
+                       "ira_full_b1", "ira_wide_small_cat", "bss_tiny_b1"}        # (the trained-like goldens have their own tests)
 assert OPT_IN_MODE_GOLDENS <= set(FORWARD_GOLDENS)
 
 
@@ -399,7 +399,7 @@ def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
     from tss_with_dprnn_amd.synthetic import make_mixture
     over = dict(chunk_length=50, hop_length=25, n_repeats=2)
     key = "separation.dprnn_blocks.0.intra_norm.weight" if where == "residual_stream" else "separation.bottleneck.0.weight"
-    xs = [make_mixture(6, 6000, seed=40 + i) for i in range(10)]
+    xs = [make_mixture(4, 6000, seed=40 + i) for i in range(10)]
 
     def timed_forwards(model):
         outs, ts = [], []

@@ -909,23 +909,16 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     if debug is not None:
         debug["segmented"] = groups[0].X.view(B, S, K, F_BUILT).clone()
     if owned:
-        if len(groups) > 1:
-            # The frames' block is released below and (bottleneck_frames sizes it for that) becomes the FIRST pipeline's X2, which that
-            # pipeline writes from its second recurrence on -- while another pipeline's segmentation may still be reading the frames.
-            # Eagerly record_stream() makes the allocator wait; inside a capture there is no such bookkeeping, so every pipeline
-            # waits for every segmentation explicitly (short kernels: nothing is lost).
-            seg_done = []
+        # The frames' block is released here and (bottleneck_frames sizes it for that) becomes the FIRST pipeline's X2, which that pipeline
+        # writes from its second recurrence on -- while another pipeline's segmentation may still be reading the frames.  Eagerly
+        # record_stream() makes the allocator wait for every reader.  Inside a capture there is no such bookkeeping (and cross-waits
+        # between the forked streams crashed hipStreamEndCapture with three pipelines: gpurun_out/r05n_call.log), so a captured forward
+        # with several pipelines keeps the frames until its join instead -- one block more in the graph pool (0.8 GB at 64 x 3 s).
+        if len(groups) > 1 and getattr(_TLS, "capturing", False):
+            groups[0].buffers.append(Y)
+        elif len(groups) > 1:
             for g in groups:
-                ev = torch.cuda.Event()
-                ev.record(g.st.tstream)
-                seg_done.append(ev)
-            for i, g in enumerate(groups):
-                for j, ev in enumerate(seg_done):
-                    if j != i:
-                        g.st.tstream.wait_event(ev)
-            if not getattr(_TLS, "capturing", False):
-                for g in groups:
-                    Y.record_stream(g.st.tstream)   # read by the groups' streams: the allocator waits for them before it reuses the block
+                Y.record_stream(g.st.tstream)       # read by the groups' streams: the allocator waits for them before it reuses the block
         del Y
     for g in groups:
         g.alloc_rest()
