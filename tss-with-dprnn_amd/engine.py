@@ -630,7 +630,7 @@ def fold_plan(nplan: int, ncu: int, concurrent: int, intra: bool):
         if tile in FOLD_TILES and (LIN_FOLD == "serial" or concurrent * tiles(tile) >= FOLD_SERIAL_MIN_FILL * ncu):
             return "serial", tile
     if LIN_FOLD in ("split", "auto"):
-        tile = SEQ_TILE[key] or split_tile(nplan, 2, ncu, concurrent, 3)
+        tile = SEQ_TILE[key] or split_tile(nplan, 2, ncu, concurrent, 3, path=key)
         if tile in FOLD_TILES and (LIN_FOLD == "split" or 2 * concurrent * tiles(tile) >= FOLD_SPLIT_MIN_FILL * ncu):
             return "split", tile
     return "off", 0
@@ -694,7 +694,8 @@ def _run_path(g: _Group, rnn, lin, norm, stats_slot, packed, bsum, intra: bool, 
     if cell == 0 and g.mode != 0:
         # every pipeline of a forward takes the tile of the LARGEST one: pipelines on different tiles finish apart, and the forward
         # waits for the slower (B = 25 as 12 + 13 utterances: 32.4 ms mixed against 30.9 / 31.9 ms on either tile for both)
-        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode)
+        tile = SEQ_TILE["intra" if intra else "inter"] or split_tile(nplan, ndir, st.lib.dprnn_num_cus(), g.n_concurrent, g.mode,
+                                                                     path="intra" if intra else "inter")
     w = _param(lin.weight, "linear.weight", dev)
     if w.shape != (F_BUILT, ndir * F_BUILT):
         raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
@@ -747,7 +748,15 @@ SPLIT_STEP_US_F16 = {2016: 3.8, 2032: 13.2, 2064: 11.6, 2080: 15.3}   # 2016: fi
 SPLIT_WIDE_TILE_MARGIN = 1.13
 
 
-def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1, only=None) -> int:
+# A launch of 64-sequence tiles whose workgroups -- all pipelines' together -- exceed the CUs by a few per cent leaves those few waiting a
+# whole launch for a free CU; the pipeline they belong to falls behind the other one and finishes the forward alone on half the chip
+# (round 5, profiles/r05_tile_zone.txt: -3 .. -5 % at 33-37 and 43-46 utterances, the "steps" of rounds 3 and 4).  The 16-sequence tile has
+# four times the workgroups and packs such batches; the wide tile is taken when everything fits one round (fill <= 1) or from the
+# fill where its lower cost per sequence wins again -- measured: 1.14 on the intra-chunk path, 1.33 on the inter-chunk path.
+WIDE_TILE_MIN_FILL = {"intra": 1.14, "inter": 1.33}
+
+
+def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 1, only=None, path=None) -> int:
     """seq_tile code for the split recurrence over nseq sequences x ndir directions: the form whose grid takes the
     least time, rounds x cost of a step (64 x 3 s in two groups: 194 / 250 workgroups of 64 sequences per launch)."""
     best, best_t, t16 = None, None, None
@@ -772,6 +781,10 @@ def split_tile(nseq: int, ndir: int, ncu: int, concurrent: int = 1, mode: int = 
     # 17 % better at 13 / 14 / 15 utterances per pipeline, measured 3 % worse / 1 % worse / 1.5 % better): switch from 13 % up.
     if best != 2016 and t16 is not None and concurrent > 1 and t16 <= SPLIT_WIDE_TILE_MARGIN * best_t:
         best = 2016
+    if path is not None and mode == 3 and best is not None and best != 2016 and t16 is not None and concurrent > 1 and best % 1000 >= 48:
+        fill = concurrent * ndir * -(-nseq // (best % 1000)) / ncu          # one workgroup per CU at these tiles
+        if 1.0 < fill < WIDE_TILE_MIN_FILL[path]:
+            best = 2016
     return best
 
 
@@ -819,7 +832,10 @@ def _even_parts(B: int, n: int):
 # split modes run two groups from 9 utterances up (was: from 32), the exact mode two from 11 (was: from 24), three from 40, four from 56.
 def plan_groups(B: int, gemm_mode: int) -> int:
     if gemm_mode != 0:
-        return 1 if B <= 8 else SPLIT_GROUPS
+        # 21 .. 24 utterances (round 5, profiles/r05_tile_zone.txt): as two pipelines the larger one's intra-chunk launch of 16-sequence
+        # tiles (2 x 134 workgroups from 11 utterances) no longer fits the CUs and that pipeline falls behind: three pipelines of 7-8,
+        # +1.9 % at 21; from 29 on the inter-chunk path takes 64-sequence tiles, which two pipelines of <= 16 fill exactly
+        return 1 if B <= 8 else 3 if 21 <= B <= 24 and SPLIT_GROUPS == 2 else SPLIT_GROUPS
     return 1 if B <= 10 else 2 if B < 40 else 3 if B < 56 else min(4, STREAM_GROUPS)
 
 
@@ -2056,7 +2072,7 @@ class _Graphed:
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
 LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
                 "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
-                "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES")
+                "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES", "WIDE_TILE_MIN_FILL")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",
                   "GRAPHS", "GRAPH_CACHE_MAX", "GRAPH_STATS", "SLOT_BOTTLENECK", "SLOT_AUX_BOTTLENECK", "SLOT_HEAD_CONV", "SLOT_HEAD_GATE",
