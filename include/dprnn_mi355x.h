@@ -292,6 +292,13 @@ int dprnn_rnn_lin_split_fwd(int phase, const float* X, const float* Z, const dou
                             float* P, double* stats_out, float* state,
                             int nseq, int T, int inner_n, int64_t outer_stride, int64_t inner_stride, int64_t t_stride,
                             int seq_tile, void* stream);
+/* ... and for ragged batches (utterances of different lengths in one launch; addressing arguments as dprnn_rnn_fwd_ragged: utt_rows,
+ * seq_utt (intra-chunk, T = K) or wg_desc (inter-chunk: every workgroup is cut at the middle of its own T = S_u), 64-sequence tiles;
+ * state: dprnn_rnn_lin_state_floats(64 * tiles, 2064) floats with tiles = ceil(n_items / 64) or n_items). */
+int dprnn_rnn_lin_split_ragged_fwd(int phase, const float* X, const float* Z, const double* stats, const float* gamma,
+                                   const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                                   int n_items, float* Xout, const float* packed, const float* bsum, const void* lin_packed,
+                                   const float* lin_bias, float* P, double* stats_out, float* state, int T, int K, void* stream);
 int dprnn_rnn_lin_fwd(int phase, int dir, const float* X, const float* Z, const double* stats, const float* gamma,
                       const float* beta, float eps, int seqs_per_utt, int64_t rows_per_utt, float* Xout,
                       const float* packed, const float* bsum, int ndir, const void* lin_packed, const float* lin_bias,

@@ -103,14 +103,18 @@ def split_gate_gemm():
     yield
     engine.GEMM_MODE = old
 
-@pytest.mark.parametrize("kind", ["bss", "spe", "ira", "spe_att_bntrain"])
-def test_ragged_batch_equals_one_by_one(kind, split_gate_gemm):
+@pytest.mark.parametrize("kind", ["bss", "spe", "ira", "spe_att_bntrain", "bss+fold", "ira+fold"])
+def test_ragged_batch_equals_one_by_one(kind, split_gate_gemm, monkeypatch):
     """SURVEY.md 8f-3 / inferencer_spe.py:27-32: utterances of different lengths through ONE launch per DPRNN path must
     give what the reference's one-at-a-time loop gives.  Lengths leave ragged tiles everywhere (chunk counts 11 .. 47,
     K = 40 chunk positions against 64-sequence tiles); the speaker branch keeps batch-of-one BatchNorm statistics."""
     from tss_with_dprnn_amd import engine, inference
     from conftest import build_model
     from oracle.weights import make_mixture
+    if kind.endswith("+fold"):          # the Linear folded into the ragged recurrence launches (dprnn_rnn_lin_split_ragged_fwd: every workgroup cut at
+        kind = kind[:-5]                # the middle of its own T); the one-by-one loop runs 16-sequence tiles, which have no folded form
+        monkeypatch.setattr(engine, "LIN_FOLD", "split")
+        monkeypatch.setattr(engine, "GEMM_MODE", 3)
     over = dict(chunk_length=40, hop_length=20, n_repeats=2)
     if kind != "bss":
         over.update(fusion_type="att" if "att" in kind else "cat", norm_type="ln")

@@ -439,6 +439,44 @@ def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
     engine.drop_graphs()
 
 
+def test_the_activation_scale_comes_down_again_after_an_outlier():
+    """the sticky maxima only ever grew -- one forward with large values cost every later forward of that model up to 12 bits
+    of its second f16 piece.  Round 5 (csrc/api.hip: dprnn_scale_join): a site whose forward maximum stays 16 x below its sticky
+    maximum for eight consecutive forwards falls back to the largest value of that streak (never below the default range); every
+    forward reads its scales from its own snapshot of the record.  A norm gain x 3000 for two forwards, then the normal weights:
+    the exponents are back at 4 after eight more forwards, every output is fp32-class throughout, and engine.reset_scale does the same at once."""
+    import warnings
+    from tss_with_dprnn_amd.synthetic import make_mixture
+    over = dict(chunk_length=50, hop_length=25, n_repeats=2)
+    key = "separation.dprnn_blocks.0.intra_norm.weight"
+    model, sd, cfg = build_model("bss", over, 21, _dev())
+    x = make_mixture(3, 5000, seed=77)
+    xd = torch.from_numpy(x).to(_dev())
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
+    prm = dict(model.named_parameters())[key]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        prm.mul_(3000.0)
+        for _ in range(2):
+            model(xd)
+        assert min(engine.scale_exponents(model).values()) < 4
+        prm.div_(3000.0)
+        outs = [model(xd).cpu().numpy() for _ in range(10)]
+    for i, o in enumerate(outs):
+        _close(o, want, f"forward {i + 1} after the outlier")
+    assert set(engine.scale_exponents(model).values()) == {4}, engine.scale_exponents(model)
+    assert not model.__dict__.get("_dprnn_pin_mode1", False)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        prm.mul_(3000.0)
+        model(xd); model(xd)
+        prm.div_(3000.0)
+    assert min(engine.scale_exponents(model).values()) < 4
+    engine.reset_scale(model)
+    assert set(engine.scale_exponents(model).values()) == {4}
+    engine.drop_graphs()
+
+
 def test_repeated_saturation_pins_the_model_to_mode_1():
     """Values no scale can hold (here a NaN sample: flagged where every forward begins, the record ignores it) saturate every
     forward: after two in a row the model runs in mode 1 directly -- one warning, no further repeats -- until engine.unpin."""

@@ -48,6 +48,8 @@ SIGNATURES = {
                           c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
     "dprnn_rnn_lin_split_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                 c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_fp],
+    "dprnn_rnn_lin_split_ragged_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                       c_i, c_i, c_fp],
     "dprnn_rnn_fwd_ragged_hp_ex": [c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_lstm_pack_split": [c_fp] * 10 + [c_fp],
     "dprnn_lstm_pack_f16": [c_fp] * 10 + [c_fp],

@@ -55,7 +55,7 @@ struct RecurArgs {
     double* stats_out;                                // [utterances][2], accumulated (atomics)
     int proj_dirs;                                    // directions dir0 .. dir0 + proj_dirs - 1 in one launch (2: the time-split form below)
     // ---- the same fold with BOTH directions in every launch (dprnn_rnn_lin_split_fwd): the path is cut in time instead of by direction.
-    // split_m = M >= 0: phase 1 runs the forward direction's steps [0, M) and the reverse direction's [0, T - M) (rows [0, M) and
+    // split_m >= 0 (the cut is M = T / 2 of the workgroup's own T): phase 1 runs the forward direction's steps [0, M) and the reverse direction's [0, T - M) (rows [0, M) and
     // [M, T): each row met by exactly one direction, which leaves x' and its partial product), phase 2 the remaining steps of both
     // (each row met by the other direction, which finishes z).  state: [dir][tile][512 x NT x 4 floats of c | the h image] carried
     // across the kernel boundary.  -1: no split.

@@ -302,7 +302,7 @@ void bilstm_split8_kernel(RecurArgs a) {
     // BOTH directions -- phase 1 the first M (forward) / T - M (reverse) steps, phase 2 the rest -- so every row is met first by one
     // direction in phase 1 (partial product) and then by the other in phase 2 (finished z), with the kernel boundary between them as
     // the only synchronisation; the cell state and the h image cross it through a.state.
-    const int nfirst = split ? (dir ? T - a.split_m : a.split_m) : 0;
+    const int nfirst = split ? (dir ? T - (T >> 1) : (T >> 1)) : 0;       // M = T / 2 of THIS workgroup's T (ragged inter-chunk tiles differ)
     const int sb = (split && PJ == 2) ? nfirst : 0, se = (split && PJ == 1) ? nfirst : T;
     const int xb0 = DB ? (sb & 1) : 0;                 // image buffers the first step reads
     const long long tfirst = dir ? (T - 1 - sb) : sb;

@@ -165,7 +165,7 @@ extern "C" int dprnn_rnn_lin_split_fwd(int phase, const float* X, const float* Z
     a.outer_stride = outer_stride; a.inner_stride = inner_stride; a.t_stride = t_stride; a.cell = 0;
     a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.seqs_per_utt = seqs_per_utt;
     a.rows_per_utt = rows_per_utt; a.Xout = Xout;
-    a.proj = phase; a.dir0 = 0; a.proj_dirs = 2; a.split_m = T / 2; a.state = state;
+    a.proj = phase; a.dir0 = 0; a.proj_dirs = 2; a.split_m = 0; a.state = state;
     a.Lp = lin_packed; a.lbias = lin_bias; a.P = P; a.Zout = P; a.stats_out = stats_out;
     if (!tile_offsets_fit(inner_n, outer_stride, inner_stride, t_stride, F)) {
         dprnn_set_error("dprnn_rnn_lin_split_fwd: a sequence tile spans more than 2 GiB (outer_stride=%lld rows)", (long long)outer_stride);
@@ -180,4 +180,39 @@ extern "C" int dprnn_rnn_lin_split_fwd(int phase, const float* X, const float* Z
         case 48: return launch_lin<48>(a, true, st);
         default: return launch_lin<64>(a, true, st);
     }
+}
+
+// ---- ragged batches (utterances of different lengths in one launch; addressing as dprnn_rnn_fwd_ragged): intra-chunk (wg_desc == NULL):
+// n_items chunks of T = K steps, seq_utt names their utterances; inter-chunk: n_items workgroup descriptors {row0 lo, row0 hi, T = S_u,
+// count <= 64, utterance, 0, 0, 0}, every workgroup cut at the middle of ITS OWN T.  64-sequence tiles.  state:
+// dprnn_rnn_lin_state_floats(64 * tiles, 2064) floats, tiles = ceil(n_items / 64) (intra-chunk) or n_items (inter-chunk).
+extern "C" int dprnn_rnn_lin_split_ragged_fwd(int phase, const float* X, const float* Z, const double* stats, const float* gamma,
+                                              const float* beta, float eps, const int64_t* utt_rows, const int* seq_utt, const int* wg_desc,
+                                              int n_items, float* Xout, const float* packed, const float* bsum, const void* lin_packed,
+                                              const float* lin_bias, float* P, double* stats_out, float* state, int T, int K, void* stream) {
+    if (!X || !packed || !bsum || !lin_packed || !P || !state || !utt_rows || (!wg_desc && !seq_utt)) {
+        dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: null pointer");
+        return -1;
+    }
+    if (phase != 1 && phase != 2) { dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: phase %d (1: first halves, 2: second halves)", phase); return -1; }
+    if (phase == 2 && (!stats_out || !lin_bias)) { dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: phase 2 needs stats_out and the Linear's bias"); return -1; }
+    if (n_items <= 0 || K <= 0 || (!wg_desc && T <= 0)) { dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: bad sizes n_items=%d T=%d K=%d", n_items, T, K); return -1; }
+    if (Z && (phase != 1 || !stats || !gamma || !beta || !Xout || Xout == X || Z == P)) {
+        dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: the pending norm belongs to phase 1 and needs stats, gamma, beta, an Xout different from X and a P different from Z");
+        return -1;
+    }
+    RecurArgs a{};
+    a.X = X; a.Wp = packed; a.bsum = bsum; a.H = nullptr; a.nseq = n_items; a.T = T; a.ndir = 2; a.cell = 0;
+    a.Z = Z; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Xout = Xout;
+    a.seqs_per_utt = 1; a.rows_per_utt = 1; a.utt_rows = reinterpret_cast<const long long*>(utt_rows);
+    a.seq_utt = seq_utt; a.wg_desc = wg_desc;
+    if (wg_desc) { a.inner_n = 1 << 30; a.outer_stride = 0; a.inner_stride = 1; a.t_stride = K; }
+    else { a.inner_n = n_items; a.outer_stride = 0; a.inner_stride = K; a.t_stride = 1; }
+    if ((long long)64 * K * F * 4 >= 0x7fffffffLL) { dprnn_set_error("dprnn_rnn_lin_split_ragged_fwd: chunk_length too large"); return -1; }
+    a.proj = phase; a.dir0 = 0; a.proj_dirs = 2; a.split_m = 0; a.state = state;
+    a.Lp = lin_packed; a.lbias = lin_bias; a.P = P; a.Zout = P; a.stats_out = stats_out;
+    if (int rc = dprnn_pack_expect(packed, DPRNN_PACK_FWD, 0, 3, 2, "dprnn_rnn_lin_split_ragged_fwd")) return rc;
+    a.sat = dprnn_sat_ptr();
+    { const ScaleRef sr = dprnn_scale_ref(); a.xs_src = sr.src; a.xmax_dst = sr.dst; }
+    return launch_lin<64>(a, true, (hipStream_t)stream);
 }

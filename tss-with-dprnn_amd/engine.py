@@ -1745,6 +1745,15 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     arena = torch.empty(3 * m + int(head_off[-1]), device=dev, dtype=torch.float32)
     X, X2, Z, H = arena[:m], arena[m: 2 * m], arena[2 * m: 3 * m], arena[3 * m:]
     stats = torch.zeros(2 * len(blocks), n, 2, device=dev, dtype=torch.float64)
+    # the Linear folded into the recurrence (time-split form, LIN_FOLD above) where the one pipeline's launches cover the chip
+    ncu = st.lib.dprnn_num_cus()
+    tiles_intra, tiles_inter = -(-int(seq_utt.size) // 64), n_tiles
+    covers = lambda tiles: LIN_FOLD == "split" or (LIN_FOLD == "auto" and 2 * tiles >= FOLD_SPLIT_MIN_FILL * ncu)
+    fold = {True: mode == 3 and covers(tiles_intra), False: mode == 3 and covers(tiles_inter)}
+    if any(fold.values()):
+        Z2 = torch.empty(m, device=dev, dtype=torch.float32)
+        lin_state = torch.empty(st.lib.dprnn_rnn_lin_state_floats(64 * max(tiles_intra, tiles_inter), 2064), device=dev, dtype=torch.float32)
+        linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32)
     fan = _Fan(st, n)
     for u in range(n):
         fan.run(u, lambda sg, u=u: sg.call("dprnn_segment_fwd", _p(Ys[u]), _p(X[int(starts[u]) * F_BUILT:]), 1, geos[u].L, K, P,
@@ -1760,14 +1769,29 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
             hp = H_PIECES and mode == 3
             _set_slot(st.lib, path_slot(i, not intra))
+            w = _param(lin.weight, "linear.weight", dev)
+            if w.shape != (F_BUILT, ndir * F_BUILT):
+                raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
+            if fold[intra] and ndir == 2:
+                st.call("dprnn_lin_pack_f16", _p(w), 2, _p(linp[slot]))
+                rag = (_p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d), int(seq_utt.size) if intra else n_tiles)
+                tail = (_p(packed[slot]), _p(bsum[slot]), _p(linp[slot]))
+                st.call("dprnn_rnn_lin_split_ragged_fwd", 1, _p(X), *pn, *rag, 0 if pending is None else _p(X2), *tail, 0, _p(Z2), 0,
+                        _p(lin_state), K if intra else 0, K)
+                if pending is not None:
+                    X, X2 = X2, X
+                st.call("dprnn_rnn_lin_split_ragged_fwd", 2, _p(X), 0, 0, 0, 0, 0.0, *rag, 0, *tail, _p(_param(lin.bias, "linear.bias", dev)),
+                        _p(Z2), _p(stats[slot]), _p(lin_state), K if intra else 0, K)
+                Z, Z2 = Z2, Z
+                _count_scale(stats[slot], norm, st, n)
+                gamma, beta, eps = _norm_params(norm)
+                pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
+                continue
             st.call("dprnn_rnn_fwd_ragged_hp_ex" if hp else "dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
                     int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
                     K if intra else 0, K, ndir)
             if pending is not None:
                 X, X2 = X2, X
-            w = _param(lin.weight, "linear.weight", dev)
-            if w.shape != (F_BUILT, ndir * F_BUILT):
-                raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
             if hp:
                 st.call("dprnn_proj_stats_hp_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
                         total, 1, _p(utt_starts), n, ndir * F_BUILT)
