@@ -864,9 +864,47 @@ def _split(B: int):
     return _even_parts(B, n)
 
 
+def pack_weights(st: Stage, sep, geo: Geometry, debug=None) -> dict:
+    """Everything of a dprnn_process call that depends on the weights and the batch geometry only: the arithmetic mode, the utterance
+    groups, and every LSTM (and, where a path will take the folded form, every Linear) in its kernel's fragment order -- packed on
+    st's stream from the LIVE parameters (an optimizer step between two forwards shows in the next one)."""
+    dev = st.device
+    B, K, S = geo.B, geo.K, geo.S
+    blocks = list(sep.dprnn_blocks)
+    mode = effective_gemm_mode(B, blocks)
+    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
+    bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
+    fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
+    parts = _split(B) if debug is None else [(0, B)]
+    if mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
+        parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
+    plan_B = max(b1 - b0 for b0, b1 in parts)
+    # the Linears are packed for the folded launches only when some path of this forward will take them (fold_plan: batch-size dependent)
+    folds = mode == 3 and fuse and any(fold_plan(plan_B * (S if intra else K), st.lib.dprnn_num_cus(), len(parts), intra)[0] != "off"
+                                       for intra in (True, False))
+    linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32) if folds else None
+    for i, blk in enumerate(blocks):
+        for j, (rnn, lin) in enumerate(((blk.intra_rnn, blk.intra_linear), (blk.inter_rnn, blk.inter_linear))):
+            ndir, fw, bw = _rnn_tensors(rnn, dev)
+            _set_slot(st.lib, path_slot(i, j == 1))     # the pack folds the path's x scale into W_ih
+            st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
+                    _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
+            if folds and ndir == 2 and rnn.rnn.mode == "LSTM":
+                st.call("dprnn_lin_pack_f16", _p(_param(lin.weight, "linear.weight", dev)), 2, _p(linp[2 * i + j]))
+    return dict(mode=mode, packed=packed, bsum=bsum, linp=linp, parts=parts, plan_B=plan_B, fuse=fuse, key=(B, S, K, debug is None))
+
+
+def prepack(st: Stage, sep, geo: Geometry, debug=None) -> dict:
+    """pack_weights for a forward that calls dprnn_process more than once with the same weights (DPRNN-Spe-IRA's two passes share one
+    pack).  (Round 5 also tried packing on a side stream beside the bottleneck -- ~60 small launches, 0.35 ms of the forward's 1.3 ms
+    serial prologue: 0.5 % SLOWER, 886.9 / 886.5 / 881.1 against 891.7 / 891.1 / 890.0 utt/s interleaved on one box, gpurun_out r05u;
+    the fork / join costs more than the launches it hides.)"""
+    return pack_weights(st, sep, geo, debug)
+
+
 @_leaves_exact_mode
 def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, relu_act: bool,
-                  want_masked: bool = False, debug: Optional[dict] = None, masks_out: Optional[torch.Tensor] = None):
+                  want_masked: bool = False, debug: Optional[dict] = None, masks_out: Optional[torch.Tensor] = None, packs=None):
     """Segmentation -> DPRNN blocks -> mask head -> mask*enc -> decoder taps.
 
     reference: dprnn.py:171-186 (== dprnn_spe.py:231-248), dprnn.py:277, encoder_decoder.py:40-42.
@@ -881,28 +919,12 @@ def dprnn_process(st: Stage, sep, Y, wav, enc_w, dec_w, geo: Geometry, stats, re
     B, L, K, P, S = geo.B, geo.L, geo.K, geo.P, geo.S
     blocks = list(sep.dprnn_blocks)
 
-    mode = effective_gemm_mode(B, blocks)
+    if packs is None:
+        packs = pack_weights(st, sep, geo, debug)
+    elif packs["key"] != (B, S, K, debug is None):
+        raise DprnnError("dprnn_process: the packed weights were prepared for another batch geometry")
+    mode, packed, bsum, linp, parts, plan_B, fuse = (packs[k] for k in ("mode", "packed", "bsum", "linp", "parts", "plan_B", "fuse"))
     st.lib.dprnn_set_gemm_mode(mode)            # the row GEMMs of this forward (this thread's default)
-    # pack every LSTM once, on the caller's stream, before the groups fork
-    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
-    bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
-    fuse = FUSE_NORM and debug is None          # debug taps want the residual stream after every path
-    parts = _split(B) if debug is None else [(0, B)]
-    if mode != 0 and GROUP_SIZES is None and SPLIT_ONE_GROUP and debug is None:
-        parts = _split_mode_parts(B)   # few, large pipelines (two: their launches interleave)
-    plan_B = max(b1 - b0 for b0, b1 in parts)
-    # the Linears are packed for the folded launches only when some path of this forward will take them (fold_plan: batch-size dependent)
-    serial = mode == 3 and fuse and any(fold_plan(plan_B * (S if intra else K), st.lib.dprnn_num_cus(), len(parts), intra)[0] != "off"
-                                        for intra in (True, False))
-    linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32) if serial else None
-    for i, blk in enumerate(blocks):
-        for j, (rnn, lin) in enumerate(((blk.intra_rnn, blk.intra_linear), (blk.inter_rnn, blk.inter_linear))):
-            ndir, fw, bw = _rnn_tensors(rnn, dev)
-            _set_slot(st.lib, path_slot(i, j == 1))     # the pack folds the path's x scale into W_ih
-            st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
-                    _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
-            if serial and ndir == 2 and rnn.rnn.mode == "LSTM":
-                st.call("dprnn_lin_pack_f16", _p(_param(lin.weight, "linear.weight", dev)), 2, _p(linp[2 * i + j]))
 
     taps = torch.empty(B, 2, L, geo.ks, device=dev, dtype=torch.float32)
     masked = torch.empty(B, L, geo.N, device=dev, dtype=torch.float32) if want_masked else None
@@ -1028,11 +1050,12 @@ def _tasnet_forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None)
         dec_w = _param(model.decoder.weight, "decoder.weight", dev)
         stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), geo.B, 2, device=dev, dtype=torch.float64)
         first = group_parts(geo.B, effective_gemm_mode(geo.B, list(sep.dprnn_blocks)))[0] if debug is None else (0, geo.B)
+        packs = prepack(st, sep, geo, debug)
         frames = [frames_from_waveform(st, wav, enc_w, sep.bottleneck[0], sep.bottleneck[1], geo, stats[0],
                                        min_floats=(first[1] - first[0]) * geo.S * geo.K * F_BUILT)]
         if debug is not None:
             debug["bottleneck"] = frames[0].clone()
-        taps = dprnn_process(st, sep, frames, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug)
+        taps = dprnn_process(st, sep, frames, wav, enc_w, dec_w, geo, stats, cfg["activation_type"] == "relu", debug=debug, packs=packs)
         out = decode(st, taps, geo, 2)
         _scale_end(st, rec)
         return out
@@ -1203,6 +1226,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
         geo_a = make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
         B = geo.B
         sep = model.separation
+        packs = prepack(st, sep, geo, debug)        # beside the speaker branch and the bottleneck; both IRA passes use the one pack
         enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
         dec_w = _param(model.decoder.weight, "decoder.weight", dev)
         n_blocks = len(sep.dprnn_blocks)
@@ -1226,10 +1250,10 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
         relu_act = cfg["activation_type"] == "relu"
         v_last = v0
         if not ira:
-            taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[: 1 + 2 * n_blocks], relu_act, debug=debug)
+            taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[: 1 + 2 * n_blocks], relu_act, debug=debug, packs=packs)
         else:
             taps, d0 = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[: 1 + 2 * n_blocks], relu_act,
-                                     want_masked=True)
+                                     want_masked=True, packs=packs)
             # second embedding from the first estimate d0 = mask0 * enc  (dprnn_spe_ira.py:79-92)
             st.call("dprnn_rows_stats", _p(d0), _p(stats[-2]), B, geo.L, N)
             _count_scale(stats[-2], se[0], st, B)
@@ -1253,7 +1277,7 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
             row_scale2 = _att_row_scale(st, sep, cfg, wav, enc_w, geo, stats[0], mul2) if cfg["fusion_type"] == "att" else None
             Y = bottleneck_frames(st, wav, enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2)
             taps = dprnn_process(st, sep, Y, wav, enc_w, dec_w, geo, stats[1 + 2 * n_blocks: 2 * (1 + 2 * n_blocks)],
-                                 relu_act, debug=debug)
+                                 relu_act, debug=debug, packs=packs)
             v_last = v1
         logits = _linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last)
         est = decode(st, taps, geo, 1)                    # speaker 0 only (dprnn_spe.py:325)
