@@ -152,6 +152,38 @@ def test_ragged_batch_equals_one_by_one(kind, split_gate_gemm, monkeypatch):
                 assert torch.allclose(v, bn_ragged[k], rtol=1e-5, atol=1e-7), k
 
 
+@pytest.mark.parametrize("kind", ["bss", "ira"])
+def test_several_ragged_batches_run_as_two_pipelines(kind, split_gate_gemm, monkeypatch):
+    """inference.separate_ragged (round 5): more utterances than one ragged batch holds are processed as RAGGED_PIPELINES batches in flight
+    on separate streams (here: batches of 3, so four of them on two streams); every output still equals its batch-of-one forward, and
+    the sequential form (RAGGED_PIPELINES = 1) gives the same."""
+    from tss_with_dprnn_amd import engine, inference
+    from conftest import build_model
+    from oracle.weights import make_mixture
+    over = dict(chunk_length=40, hop_length=20, n_repeats=2)
+    if kind != "bss":
+        over.update(fusion_type="cat", norm_type="ln")
+    model, _, cfg = build_model(kind if kind == "bss" else "ira", over, 84, DEV)
+    lens = [901, 377, 640, 233, 901, 512, 777, 300, 845, 199]
+    wavs = [torch.from_numpy(make_mixture(1, n, seed=800 + i)[0]).to(DEV) for i, n in enumerate(lens)]
+    extra = None
+    if kind != "bss":
+        extra = [(torch.from_numpy(make_mixture(1, 400 + 7 * i, seed=850 + i)[0]).to(DEV), float(400 + 7 * i)) for i in range(len(lens))]
+    monkeypatch.setattr(inference, "RAGGED_MAX_UTTS", 3)
+    assert inference.RAGGED_PIPELINES == 2
+    got = inference.separate_many(model, wavs, extra_inputs=extra, ragged=True)
+    monkeypatch.setattr(inference, "RAGGED_PIPELINES", 1)
+    seq = inference.separate_many(model, wavs, extra_inputs=extra, ragged=True)
+    first = lambda o: o[0] if isinstance(o, tuple) else o
+    with torch.no_grad():
+        for i, w in enumerate(wavs):
+            want = model(w[None])[0] if extra is None else model(w[None], extra[i][0][None], torch.tensor(extra[i][1]))[0][0]
+            for what, o in (("two pipelines", got[i]), ("one pipeline", seq[i])):
+                r = float(((first(o).double() - want.double()).norm() / want.double().norm()).item())
+                assert r <= 2e-6, (what, i, r)
+            assert torch.equal(first(got[i]), first(seq[i]))
+
+
 @pytest.mark.parametrize("hop", [40, 30, 27])
 def test_ragged_batch_with_hops_above_half_a_chunk(hop, split_gate_gemm):
     """hop_length > chunk_length / 2 (the reference's hop_length is a free constructor argument, dprnn.py:128): an utterance's

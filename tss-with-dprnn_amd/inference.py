@@ -26,11 +26,14 @@ from typing import List, Sequence
 
 import torch
 
+import os
+
 from ._lib import DprnnError, check, load_library
 
 
 RAGGED_MIN_UTTS = 8          # fewer utterances than this do not fill the chip through one ragged launch per path
-RAGGED_MAX_UTTS = 64         # utterances per ragged batch (bounds the slab arena: ~0.2 GB per 5-s utterance)
+RAGGED_MAX_UTTS = int(os.environ.get("DPRNN_RAGGED_MAX_UTTS", "64"))         # utterances per ragged batch (bounds the slab arena: ~0.2 GB per 5-s utterance)
+RAGGED_PIPELINES = int(os.environ.get("DPRNN_RAGGED_PIPELINES", "2"))       # ragged batches in flight on separate streams (separate_ragged)
 
 
 def separate_ragged(model, wavs: Sequence[torch.Tensor], extra_inputs=None) -> List:
@@ -44,16 +47,45 @@ def separate_ragged(model, wavs: Sequence[torch.Tensor], extra_inputs=None) -> L
     # recurrence launches order their workgroups by length themselves
     order = list(range(len(wavs)))
     ira = bool(getattr(model, "_ira", False))
+    chunks = [order[c0: c0 + RAGGED_MAX_UTTS] for c0 in range(0, len(order), RAGGED_MAX_UTTS)]
+
+    def forward(idx):
+        if extra_inputs is None:
+            return engine.tasnet_forward_ragged(model, [wavs[i] for i in idx])
+        return engine.spe_forward_ragged(model, [wavs[i] for i in idx], [extra_inputs[i][0] for i in idx],
+                                         [extra_inputs[i][1] for i in idx], ira=ira)
+    module = getattr(model, "separation", None)
+    # Several ragged batches: RAGGED_PIPELINES of them in flight on separate streams.  One ragged batch is ONE pipeline -- a launch of
+    # ~640 workgroups is 2.5 rounds of the 256 CUs and the half-empty third is lost; a second pipeline's launches fill it (the same
+    # effect as the two utterance groups of engine.dprnn_process: 64 x 3 s as one pipeline 800 utt/s, as two 865).  Not with BatchNorm
+    # in train mode (its running statistics are updated utterance by utterance, in order), and not inside a graph capture.
+    pipelined = (len(chunks) > 1 and RAGGED_PIPELINES > 1 and not getattr(engine._TLS, "capturing", False)
+                 and not (module is not None and engine._bn_training(module)))
     with torch.no_grad():
-        for c0 in range(0, len(order), RAGGED_MAX_UTTS):
-            idx = order[c0: c0 + RAGGED_MAX_UTTS]
-            if extra_inputs is None:
-                res = engine.tasnet_forward_ragged(model, [wavs[i] for i in idx])
-            else:
-                res = engine.spe_forward_ragged(model, [wavs[i] for i in idx], [extra_inputs[i][0] for i in idx],
-                                                [extra_inputs[i][1] for i in idx], ira=ira)
-            for i, r in zip(idx, res):
-                outs[i] = r
+        if not pipelined:
+            for idx in chunks:
+                for i, r in zip(idx, forward(idx)):
+                    outs[i] = r
+            return outs
+        dev = wavs[0].device
+        main = torch.cuda.current_stream(dev)
+        pool = engine.bucket_streams(dev, RAGGED_PIPELINES)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for n, idx in enumerate(chunks):
+            s = pool[n % len(pool)]
+            if n < len(pool):
+                s.wait_event(fork)
+            with torch.cuda.stream(s):
+                res = forward(idx)
+                for i, r in zip(idx, res):
+                    outs[i] = r
+                    for t in (r if isinstance(r, tuple) else (r,)):
+                        t.record_stream(main)
+        for s in pool:
+            done = torch.cuda.Event()
+            done.record(s)
+            main.wait_event(done)
     return outs
 
 
