@@ -717,11 +717,11 @@ def bench_other_configs(args, dev, mode):
     run = lambda: inference.separate_many(m, wavs, extra_inputs=aux, ragged=True)
     dt = timed(run, 1, 1)
     rows_total = float(sum(engine.make_geometry(1, int(lens[i]), 64, 250, 125, 2, 1).rows for i in order))
-    n_batches = -(-len(order) // inference.RAGGED_MAX_UTTS)
+    n_batches = len(inference.ragged_chunks(list(range(len(order))), [int(lens[i]) for i in order], dev))
     out["ira_full_length"] = {
         "workload": f"DPRNN-Spe-IRA 2-iteration refined inference, {len(order)} full-length utterances (one rank's length-balanced "
                     "eighth of 3000 drawn from the Libri2Mix-test length distribution, 3 .. 14 s), batch-of-one semantics per utterance, "
-                    f"ragged batches of <= {inference.RAGGED_MAX_UTTS} (BASELINE.json configs[4], one GPU's share)",
+                    f"{n_batches} ragged batch(es) of <= {inference.RAGGED_MAX_SAMPLES / 8000:.0f} s of audio (BASELINE.json configs[4], one GPU's share)",
         "value": len(order) / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": 1, "warmup": 1,
         "step": "one pass over the rank's whole share", "audio_seconds": secs, "times_real_time": secs / dt,
         "algorithmic_gflop_per_step": gflop, "algorithmic_gflop_per_utterance_of_3s": FLOP_PER_UTT_IRA / 1e9,

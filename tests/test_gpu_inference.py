@@ -170,7 +170,7 @@ def test_several_ragged_batches_run_as_two_pipelines(kind, split_gate_gemm, monk
     if kind != "bss":
         extra = [(torch.from_numpy(make_mixture(1, 400 + 7 * i, seed=850 + i)[0]).to(DEV), float(400 + 7 * i)) for i in range(len(lens))]
     monkeypatch.setattr(inference, "RAGGED_MAX_UTTS", 3)
-    assert inference.RAGGED_PIPELINES == 2
+    assert inference.RAGGED_PIPELINES == 2 and len(inference.ragged_chunks(list(range(10)), lens)) == 4
     got = inference.separate_many(model, wavs, extra_inputs=extra, ragged=True)
     monkeypatch.setattr(inference, "RAGGED_PIPELINES", 1)
     seq = inference.separate_many(model, wavs, extra_inputs=extra, ragged=True)

@@ -49,8 +49,18 @@ with torch.no_grad():
         a_all = None if kind == "bss" else [(torch.from_numpy(make_mixture(1, 24000, seed=900 + i)[0]).to(dev), 24000.0) for i in order]
         s_all = float(sum(lens[i] for i in order)) / 8000.0
         dt = timed(lambda: inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True), reps=1)
-        print(f"{kind} ragged, the rank's whole share ({len(order)} utterances sorted by length, {s_all:.0f} s of audio): {dt:.3f} s = "
+        print(f"{kind} ragged, the rank's whole share ({len(order)} utterances sorted by length, {s_all:.0f} s of audio, "
+              f"{len(inference.ragged_chunks(list(range(len(order))), [int(w.numel()) for w in w_all], dev))} ragged batch(es)): {dt:.3f} s = "
               f"{len(order) / dt:6.1f} utt/s, {s_all / dt:5.0f}x real time", flush=True)
+        # parity at THIS size (a slab of > 2^31 floats): the longest, a middle and the shortest utterances against their batch-of-one forwards
+        big = inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True)
+        worst_big = 0.0
+        for j in (0, 1, len(order) // 2, len(order) - 2, len(order) - 1):
+            one = inference.separate_many(m, [w_all[j]], extra_inputs=None if a_all is None else [a_all[j]], ragged=False)[0]
+            x0, y0 = (one[0], big[j][0]) if isinstance(one, tuple) else (one, big[j])
+            worst_big = max(worst_big, float(((x0.double() - y0.double()).norm() / x0.double().norm()).item()))
+        print(f"whole-share ragged batch vs batch-of-one forwards (5 utterances): worst rel-L2 {worst_big:.2e}", flush=True)
+        del big
         dt = timed(lambda: inference.separate_many(m, w_all, max_streams=48, extra_inputs=a_all, ragged=False), reps=1)
         print(f"{kind} streams=48, the rank's whole share (one utterance per pipeline): {dt:.3f} s = {len(order) / dt:6.1f} utt/s, "
               f"{s_all / dt:5.0f}x real time", flush=True)

@@ -32,7 +32,33 @@ from ._lib import DprnnError, check, load_library
 
 
 RAGGED_MIN_UTTS = 8          # fewer utterances than this do not fill the chip through one ragged launch per path
-RAGGED_MAX_UTTS = int(os.environ.get("DPRNN_RAGGED_MAX_UTTS", "64"))         # utterances per ragged batch (bounds the slab arena: ~0.2 GB per 5-s utterance)
+# A ragged batch is as large as memory allows: its launches then span many rounds of the 256 CUs and the half-empty last round stops
+# mattering (round 5, one MI355X, 375 full-length utterances through DPRNN-Spe-IRA: batches of 64: 189 utt/s one at a time, 201 two in
+# flight; 96: 212; 160-256: 215; all 375 in one batch: 223).  Bounds: utterances, and audio samples -- the slab arena of a ragged forward
+# is ~7.2 KB per sample (X, X2, Z, Z2, H x 2 and the mask-head scratch at 2 slab rows of 512 B per sample), so 16 M samples (2000 s at 8 kHz)
+# are ~115 GB of the 288 -- and never more than 60 % of what is free on the device.
+RAGGED_MAX_UTTS = int(os.environ.get("DPRNN_RAGGED_MAX_UTTS", "512"))
+RAGGED_MAX_SAMPLES = int(os.environ.get("DPRNN_RAGGED_MAX_SAMPLES", str(16_000_000)))
+RAGGED_BYTES_PER_SAMPLE = 7200
+
+
+def ragged_chunks(order: Sequence[int], lengths: Sequence[int], device=None) -> List[List[int]]:
+    """Consecutive runs of `order` (indices into lengths, in samples), each one ragged batch."""
+    cap = RAGGED_MAX_SAMPLES
+    if device is not None and torch.cuda.is_available():
+        free, _ = torch.cuda.mem_get_info(device)
+        cap = max(1, min(cap, int(0.6 * free / RAGGED_BYTES_PER_SAMPLE)))
+    chunks, cur, tot = [], [], 0
+    for i in order:
+        n = int(lengths[i])
+        if cur and (len(cur) >= RAGGED_MAX_UTTS or tot + n > cap):
+            chunks.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += n
+    if cur:
+        chunks.append(cur)
+    return chunks
 RAGGED_PIPELINES = int(os.environ.get("DPRNN_RAGGED_PIPELINES", "2"))       # ragged batches in flight on separate streams (separate_ragged)
 
 
@@ -47,7 +73,7 @@ def separate_ragged(model, wavs: Sequence[torch.Tensor], extra_inputs=None) -> L
     # recurrence launches order their workgroups by length themselves
     order = list(range(len(wavs)))
     ira = bool(getattr(model, "_ira", False))
-    chunks = [order[c0: c0 + RAGGED_MAX_UTTS] for c0 in range(0, len(order), RAGGED_MAX_UTTS)]
+    chunks = ragged_chunks(order, [int(w.numel()) for w in wavs], wavs[0].device)
 
     def forward(idx):
         if extra_inputs is None:

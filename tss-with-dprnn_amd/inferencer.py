@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from . import sharding
 from ._lib import DprnnError, check, load_library
-from .inference import RAGGED_MAX_UTTS, pit_si_sdr, separate_many, separate_many_async
+from .inference import pit_si_sdr, ragged_chunks, separate_many, separate_many_async
 
 
 def si_sdr_metric(est: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
@@ -76,14 +76,13 @@ class BatchedInferencer:
         return full
 
     def _pipelined(self, mixes, extra=None):
-        """separate_many over buckets of RAGGED_MAX_UTTS utterances (longest first: a ragged batch then holds utterances of similar
+        """separate_many over buckets as large as memory allows (inference.ragged_chunks; longest first: a ragged batch then holds utterances of similar
         length), two buckets in flight: while the device works on bucket k + 1 the host collects bucket k (its saturation check)
         and the caller's metric kernels queue up behind it -- no host stall between buckets."""
         order = sorted(range(len(mixes)), key=lambda j: -int(mixes[j].numel()))
         outs = [None] * len(mixes)
         pending = None
-        for c0 in range(0, len(order), RAGGED_MAX_UTTS):
-            idx = order[c0: c0 + RAGGED_MAX_UTTS]
+        for idx in ragged_chunks(order, [int(m.numel()) for m in mixes], self.device):
             ticket = separate_many_async(self.model, [mixes[j] for j in idx], self.max_streams,
                                          extra_inputs=None if extra is None else [extra[j] for j in idx])
             if pending is not None:
