@@ -493,6 +493,12 @@ def main():
                  (4 + 7 * (2 * cfg["n_repeats"] - 1)) / (2 * cfg["n_repeats"]) if engine.FUSE_NORM else 4) / 1e9,
                 "kernel_ms": kern_ms, "launches_timed": n_ev, "launches_per_step": (4 if folded else 2) * cfg["n_repeats"] * n_groups,
                 "linear_folded_in": folded,
+                # reading `frac` across rounds: rounds 2-4 timed the recurrence launch alone (813.7 GFLOP in ~4.3 ms between two
+                # pipelines: 0.23) and left the projection kernel that followed it (101.7 GFLOP, ~1.6 ms in the forward) out; the folded
+                # launches carry that work and that time -- like for like, round 4 was (813.7 + 101.7) GFLOP / (4.3 + 1.6) ms = 0.186
+                "frac_note": ("per launch of one phase (half the steps of both directions + their halves of the Linear); a launch shares the chip "
+                              "with the other pipeline's, so its duration is about twice its stand-alone time: chip_level_frac is the rate of "
+                              "the chip while any of them is in flight.  Round 4's 0.23 excluded the projection kernel; with it: 0.186") if folded else None,
                 "concurrent_streams": n_groups, "busy_ms_per_step": union_ms / steps,
                 # the same FLOPs over the UNION of the launch intervals: the chip-level rate while any recurrence launch is in flight
                 "chip_level_tflops": chip, "chip_level_frac": chip / peak, "mean_concurrency": conc,

@@ -36,7 +36,7 @@ PACKT_PER_DIR = 512 * 256
 # Utterances are independent, so a (micro-)batch is processed as TRAIN_STREAM_GROUPS complete forward / backward
 # pipelines on their own HIP streams (as the inference path does): one group's weight-gradient GEMMs and streaming
 # passes fill the CUs another group's serial recurrence launches leave idle.
-TRAIN_STREAM_GROUPS = 0              # 0 = choose from the launch geometry (_auto_groups); n > 0 = up to n groups
+TRAIN_STREAM_GROUPS = int(os.environ.get("DPRNN_TRAIN_STREAM_GROUPS", "0"))              # 0 = choose from the launch geometry (_auto_groups); n > 0 = up to n groups
 MIN_TRAIN_GROUP = 8                  # utterances per group at least (explicit group counts only)
 # Gate-GEMM arithmetic of the training FORWARD (recurrence with tape + the Linear after it + mask head): 3 = two f16 pieces / three
 # products as in inference (LSTM cells only, others fall back), 0 = exact fp32 MFMA.  DPRNN_TRAIN_GEMM_MODE overrides.
