@@ -408,6 +408,16 @@ def test_the_linear_fold_is_taken_where_the_launches_cover_the_chip(monkeypatch)
     assert plan(64) == [("split", 2064), ("split", 2064)] and plan(2) == [("off", 0), ("off", 0)]      # 16-sequence tiles have no folded form
 
 
+def test_no_undefined_names_in_the_package(root):
+    """engine.py is cut into scale / submodules / ragged / graphs (round 5), whose code reads engine-level names through the module object
+    at call time: a name that exists nowhere would only fail on the GPU box, in the branch that uses it.  tools/check_names.py (this image
+    has no pyflakes) resolves every global a function loads and every `E.attribute` against the imported engine."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_names.py")], capture_output=True, text=True, cwd=root)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
 def test_every_engine_setting_is_classified_for_the_graph_key():
     """engine.LAUNCH_KNOBS (part of every captured graph's key) and engine.OTHER_SETTINGS together name every upper-case module-level
     setting of engine.py: a knob added later and forgotten fails here instead of replaying a graph captured under another value."""

@@ -433,8 +433,9 @@ def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
         assert np.isfinite(outs[i]).all() and np.abs(outs[i]).max() > 0
     s = engine.scale_exponents(model)
     assert min(s.values()) < 4 and not model.__dict__.get("_dprnn_pin_mode1", False), s
-    ratio = float(np.median(t_big[2:]) / np.median(t_plain[2:]))
-    assert ratio < 1.1, (ratio, t_big, t_plain)
+    # (a repeat would double or triple the time; forwards of 2 ms carry host jitter, so the fastest of each series is compared)
+    ratio = float(min(t_big[2:]) / min(t_plain[2:]))
+    assert ratio < 1.25, (ratio, t_big, t_plain)
     print(f"{where}: scale exponents {sorted(set(s.values()))}, forwards 3..10 at {ratio:.3f} x the unsaturated time")
     engine.drop_graphs()
 

@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""One-off refactoring tool (round 5): cut tss-with-dprnn_amd/engine.py along its seams into scale.py (saturation guard, activation-scale
+record), submodules.py (separator-level / sub-module forwards), ragged.py (ragged batches) and graphs.py (HIP-graph capture and replay).
+Every UPPER-CASE setting stays in engine.py -- the one namespace bench.py, the tests and the graph key read and assign -- and the moved
+code reads engine-level names through the module object (`E.NAME`) at call time, so `engine.GRAPHS = False` keeps meaning what it meant.
+engine.py re-exports the moved names at its end.  usage: python tools/split_engine.py  (rewrites the package in place; kept for the record)"""
+import ast
+import builtins
+import os
+import re
+import sys
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tss-with-dprnn_amd")
+SRC = os.path.join(PKG, "engine.py")
+text = open(SRC).read()
+lines = text.split("\n")
+tree = ast.parse(text)
+top = tree.body
+
+
+def node_start(n):
+    return min([n.lineno] + [d.lineno for d in getattr(n, "decorator_list", [])])
+
+
+def names_of(n):
+    if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+        return [n.name]
+    if isinstance(n, ast.Assign):
+        return [x.id for t in n.targets for x in ast.walk(t) if isinstance(x, ast.Name)]
+    if isinstance(n, ast.AnnAssign) and isinstance(n.target, ast.Name):
+        return [n.target.id]
+    return []
+
+
+# region boundaries by marker names (first and last top-level symbol of each region)
+REGIONS = {
+    "scale": ("_count", "_guarded_async"),
+    "submodules": ("_no_grad_only", "fusion_forward"),
+    "ragged": ("_Fan", "_spe_forward_ragged_impl"),
+    "graphs": ("_GRAPH_CACHE", "drop_graphs"),
+}
+KEEP_IN_ENGINE = {"_freeze", "launch_knobs", "_TLS", "_STATS_LOCK", "_FAN_POOL"}      # registry helpers; thread-local state shared by everything
+first_line = {names_of(n)[0]: node_start(n) for n in top if names_of(n)}
+region_of = {}
+for reg, (a, b) in REGIONS.items():
+    la, lb = first_line[a], first_line[b]
+    for n in top:
+        nm = names_of(n)
+        if nm and la <= node_start(n) <= lb:
+            region_of[id(n)] = reg
+
+engine_globals = set()
+for n in top:
+    engine_globals.update(names_of(n))
+imported = set()
+for n in top:
+    if isinstance(n, (ast.Import, ast.ImportFrom)):
+        for a in n.names:
+            imported.add((a.asname or a.name).split(".")[0])
+
+moved = {r: [] for r in REGIONS}
+for n in top:
+    reg = region_of.get(id(n))
+    if not reg:
+        continue
+    nm = names_of(n)
+    is_setting = isinstance(n, (ast.Assign, ast.AnnAssign)) and all(x.upper() == x and not x.startswith("_") for x in nm)
+    if is_setting or any(x in KEEP_IN_ENGINE for x in nm):
+        continue
+    moved[reg].append(n)
+
+prev_end = {}
+ordered = sorted(top, key=node_start)
+for i, n in enumerate(ordered):
+    prev_end[id(n)] = ordered[i - 1].end_lineno if i else 0
+
+
+def chunk_span(n):
+    """source lines of n including the comment / blank lines right above it"""
+    s = node_start(n)
+    k = s - 1
+    while k > prev_end[id(n)] and (lines[k - 1].strip().startswith("#") or lines[k - 1].strip() == ""):
+        k -= 1
+    # keep leading blank lines out
+    while k < s - 1 and lines[k].strip() == "":
+        k += 1
+    return k + 1, n.end_lineno
+
+
+class Scope(ast.NodeVisitor):
+    """collects (lineno, col, name) of Name nodes that resolve to module globals"""
+
+    def __init__(self):
+        self.stack = []
+        self.hits = []
+        self.fstrings = []
+
+    def _locals(self, fn):
+        loc = set()
+        a = fn.args
+        for arg in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+            loc.add(arg.arg)
+        body = fn.body if isinstance(fn.body, list) else [fn.body]
+
+        def walk(node):
+            for ch in ast.iter_child_nodes(node):
+                if isinstance(ch, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                    loc.add(ch.name)
+                    continue
+                if isinstance(ch, ast.Lambda):
+                    continue
+                if isinstance(ch, ast.Name) and isinstance(ch.ctx, (ast.Store, ast.Del)):
+                    loc.add(ch.id)
+                if isinstance(ch, (ast.Import, ast.ImportFrom)):
+                    for al in ch.names:
+                        loc.add((al.asname or al.name).split(".")[0])
+                if isinstance(ch, ast.ExceptHandler) and ch.name:
+                    loc.add(ch.name)
+                walk(ch)
+        for st in body:
+            if isinstance(st, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                loc.add(st.name)
+            elif isinstance(st, ast.Name) and isinstance(st.ctx, ast.Store):
+                loc.add(st.id)
+            else:
+                if isinstance(st, ast.AST):
+                    walk(st)
+                    if isinstance(st, (ast.Import, ast.ImportFrom)):
+                        for al in st.names:
+                            loc.add((al.asname or al.name).split(".")[0])
+        return loc
+
+    def visit_FunctionDef(self, n):
+        for d in n.decorator_list:
+            self.visit(d)
+        for d in n.args.defaults + [x for x in n.args.kw_defaults if x is not None]:
+            self.visit(d)
+        self.stack.append(self._locals(n))
+        for st in n.body:
+            self.visit(st)
+        self.stack.pop()
+
+    visit_AsyncFunctionDef = visit_FunctionDef
+
+    def visit_Lambda(self, n):
+        for d in n.args.defaults + [x for x in n.args.kw_defaults if x is not None]:
+            self.visit(d)
+        self.stack.append(self._locals(n))
+        self.visit(n.body)
+        self.stack.pop()
+
+    def visit_ClassDef(self, n):
+        for d in n.decorator_list + n.bases:
+            self.visit(d)
+        self.stack.append({x for st in n.body for x in names_of(st)} | {st.name for st in n.body if isinstance(st, ast.FunctionDef)})
+        for st in n.body:
+            self.visit(st)
+        self.stack.pop()
+
+    def _comp(self, n):
+        loc = set()
+        for g in n.generators:
+            for t in ast.walk(g.target):
+                if isinstance(t, ast.Name):
+                    loc.add(t.id)
+        self.stack.append(loc)
+        self.generic_visit(n)
+        self.stack.pop()
+
+    visit_ListComp = visit_SetComp = visit_DictComp = visit_GeneratorExp = _comp
+
+    def visit_JoinedStr(self, n):
+        self.fstrings.append(n)
+        self.in_f = getattr(self, "in_f", 0) + 1
+        self.generic_visit(n)
+        self.in_f -= 1
+
+    def visit_Name(self, n):
+        if any(n.id in s for s in self.stack):
+            return
+        self.hits.append((n.lineno, n.col_offset, n.id, getattr(self, "in_f", 0) > 0, n))
+
+    def visit_arg(self, n):          # annotations are strings (from __future__ import annotations): leave them alone
+        return
+
+    def visit_AnnAssign(self, n):
+        self.visit(n.target)
+        if n.value:
+            self.visit(n.value)
+
+
+HEADER = '''from __future__ import annotations
+
+import collections
+import contextlib
+import ctypes
+import functools
+import os
+import threading
+import warnings
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import engine as E
+from ._lib import SAT_NAMES, SAT_SLOTS, SCALE_SLOTS, DprnnError, check, load_library
+
+'''
+DOCS = {
+    "scale": '"""Saturation guard and adaptive activation scale of the f16-pieces arithmetic (host side): the per-model scale record and its per-forward\nworking copy, _guarded / _guarded_async / ForwardTicket (a forward whose kernels met a value beyond the f16 range is repeated in a\nrange-free arithmetic), the thread\'s gate-GEMM mode.  Part of the engine: settings live in engine.py and are read through it (`E.NAME`)\nat call time; engine.py re-exports everything defined here."""\n',
+    "submodules": '"""Separator-level and sub-module forwards on the HIP kernels (DPRNN.forward, DPRNNSpe._auxiliary / _fusion, SingleRNN, DPRNNBlock, Encoder,\nDecoder, ResBlock, norms, 1x1 convs, Linears): what code that drives the separator\'s pieces itself calls -- the reference\'s\nDPRNNRawNet (dprnn_rawnet.py:79-105).  Part of the engine (see engine.py); inference only."""\n',
+    "ragged": '"""Ragged batches: utterances of different lengths through one launch per DPRNN path (SURVEY.md section 8f-3; the reference evaluates one\nutterance at a time, inferencer.py:48-78, inferencer_spe.py:20-54).  Part of the engine (see engine.py)."""\n',
+    "graphs": '"""HIP-graph capture and replay of the inference forwards: one engine-owned memory pool per device, graphs created, first-launched and\ndestroyed under one lock (engine.capture_lock), the graph key, eviction.  Part of the engine (see engine.py: DESIGN.md section 6b)."""\n',
+}
+PATCHED = {"_Graphed"}       # names tests monkeypatch on the engine module: always looked up through it
+
+remove = []           # (start, end) line spans leaving engine.py
+exports = {}
+for reg, nodes in moved.items():
+    defined = set()
+    for n in nodes:
+        defined.update(names_of(n))
+    exports[reg] = sorted(defined)
+    out = []
+    for n in nodes:
+        s, e = chunk_span(n)
+        remove.append((s, e))
+        seg = lines[s - 1: e]
+        sc = Scope()
+        sc.visit(n)
+        edits = []
+        for (ln, col, name, in_f, node) in sc.hits:
+            if name in dir(builtins) or name in imported or name == "E":
+                continue
+            inside_own_class = isinstance(n, ast.ClassDef) and name == n.name
+            if name in defined and not (name in PATCHED and not inside_own_class):
+                continue
+            if name not in engine_globals:
+                print("?? unresolved", reg, name, ln, file=sys.stderr)
+                continue
+            if in_f:
+                continue          # handled textually below
+            edits.append((ln, col, name))
+        for (ln, col, name) in sorted(set(edits), reverse=True):
+            i = ln - s
+            assert seg[i][col: col + len(name)] == name, (reg, ln, col, name, seg[i])
+            seg[i] = seg[i][:col] + "E." + seg[i][col:]
+        # f-strings: textual, inside the f-string's own lines only
+        need = {name for (_, _, name, in_f, _) in sc.hits if in_f and name in engine_globals and name not in defined
+                and name not in dir(builtins) and name not in imported}
+        for fs in sc.fstrings:
+            for ln in range(fs.lineno, fs.end_lineno + 1):
+                i = ln - s
+                for name in need:
+                    seg[i] = re.sub(r"(?<![\w.])" + re.escape(name) + r"(?![\w])(?=[^{}]*\})", "E." + name, seg[i])
+        out.append("\n".join(seg))
+    body = "\n\n\n".join(out) + "\n"
+    open(os.path.join(PKG, reg + ".py"), "w").write(DOCS[reg] + HEADER + "\n" + body)
+
+keep = []
+rm = sorted(remove)
+j = 0
+for i, ln in enumerate(lines, 1):
+    while j < len(rm) and i > rm[j][1]:
+        j += 1
+    if j < len(rm) and rm[j][0] <= i <= rm[j][1]:
+        continue
+    keep.append(ln)
+new = "\n".join(keep)
+new = re.sub(r"\n{4,}", "\n\n\n", new).rstrip("\n") + "\n"
+tail = ["", "", "# ---- the rest of the engine (round 5: cut along its seams; every setting above stays the one namespace callers read and assign) ----"]
+for reg in ("scale", "submodules", "ragged", "graphs"):
+    names = exports[reg]
+    tail.append(f"from .{reg} import (  # noqa: E402,F401")
+    row = "    "
+    for nm in names:
+        if len(row) + len(nm) + 2 > 130:
+            tail.append(row.rstrip())
+            row = "    "
+        row += nm + ", "
+    tail.append(row.rstrip())
+    tail.append(")")
+open(SRC, "w").write(new + "\n".join(tail) + "\n")
+for reg in exports:
+    print(reg, len(exports[reg]), "names")

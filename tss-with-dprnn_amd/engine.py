@@ -76,32 +76,6 @@ _STATS_LOCK = threading.Lock()       # SATURATION / GRAPH_STATS are process-wide
 _TLS = threading.local()
 
 
-def _count(stats: dict, key: str, n: int = 1) -> int:
-    with _STATS_LOCK:
-        stats[key] = stats[key] + n
-        return stats[key]
-
-
-def current_mode() -> int:
-    """The mode this thread's forwards run in: engine.GEMM_MODE unless a `use_gemm_mode` block is active on the thread."""
-    m = getattr(_TLS, "mode", None)
-    return GEMM_MODE if m is None else m
-
-
-@contextlib.contextmanager
-def use_gemm_mode(mode: int):
-    """Run the forwards of this block, on this thread, in gate-GEMM mode `mode` (other threads keep theirs: the C library's mode
-    is per thread too, and the packed weights carry their format)."""
-    if mode not in GEMM_MODES:
-        raise DprnnError(f"gate-GEMM mode {mode}: choose one of {GEMM_MODES}")
-    prev = getattr(_TLS, "mode", None)
-    _TLS.mode = mode
-    try:
-        yield
-    finally:
-        _TLS.mode = prev
-
-
 # ---- adaptive activation scale of the f16-pieces arithmetic (include/dprnn_mi355x.h: dprnn_scale_*; csrc/common.h).  One device
 # record per (model, device): the largest |x| every conversion site has met; the kernels of a forward read their scale 2^s from it
 # and leave their maxima in it, all on the device (no host round trip, and the same addresses on every replay of a captured
@@ -111,233 +85,6 @@ ADAPTIVE_SCALE = os.environ.get("DPRNN_ADAPTIVE_SCALE", "1") != "0"
 SLOT_BOTTLENECK, SLOT_AUX_BOTTLENECK, SLOT_HEAD_CONV, SLOT_HEAD_GATE, SLOT_SPK, SLOT_PATH0 = 0, 1, 2, 3, 4, 5
 SAT_NONFINITE = 5              # DPRNN_SAT_NONFINITE (csrc/common.h)
 PIN_AFTER_FALLBACKS = 2          # consecutive saturated forwards after which a model stays in mode 1
-
-
-def path_slot(i_block: int, inter: bool) -> int:
-    """Record slot of DPRNN path (block, intra / inter): its pack call, its recurrence launch."""
-    return SLOT_PATH0 + (2 * i_block + int(inter)) % (SCALE_SLOTS - SLOT_PATH0)
-
-
-def _set_slot(lib, slot: int) -> None:
-    lib.dprnn_scale_slot(slot)
-
-
-def _scale_tensor(owner, dev):
-    recs = owner.__dict__.setdefault("_dprnn_scale_records", {})
-    rec = recs.get(str(dev))
-    if rec is None:
-        if getattr(_TLS, "capturing", False):
-            raise DprnnError("activation-scale record created inside a graph capture (the first forward of a key runs eagerly)")
-        lib = load_library()
-        rec = torch.empty(4 * SCALE_SLOTS, device=dev, dtype=torch.float32)       # sticky maxima | unused | low-streak length | low-streak maximum
-        check(lib, lib.dprnn_scale_init(rec.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_scale_init")
-        recs[str(dev)] = rec
-    return rec
-
-
-@contextlib.contextmanager
-def _scale_record(owner, dev):
-    """Forks `owner`'s record for the launches of this block (this thread, mode 3 only): the forward reads its scales from its OWN
-    snapshot of the sticky maxima and collects its maxima there (csrc/api.hip: dprnn_scale_fork), so another thread's forward of the
-    same model cannot change a scale between this one's pack call and the launches that read the pack; a captured forward's
-    snapshot lives in the graph's pool and is taken again on every replay.  Yields (record, working copy) or None; the caller ends
-    its forward with _scale_end, which joins the working copy into the record."""
-    if owner is None or not ADAPTIVE_SCALE or current_mode() != 3 or getattr(_TLS, "scale_depth", 0) > 0:
-        yield None
-        return
-    lib = load_library()
-    rec = _scale_tensor(owner, dev)
-    work = torch.empty(2 * SCALE_SLOTS, device=dev, dtype=torch.float32)
-    check(lib, lib.dprnn_scale_fork(rec.data_ptr(), work.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_scale_fork")
-    _TLS.scale_depth = 1
-    try:
-        yield (rec, work)
-    finally:
-        _TLS.scale_depth = 0
-        lib.dprnn_scale_begin(0)
-
-
-def scale_exponents(owner, dev=None):
-    """{slot: s} of a model's record (2^s multiplies the activations of that site before the f16 split; 4 = the default): a
-    synchronising read, for tests and diagnostics."""
-    import math
-    recs = getattr(owner, "_dprnn_scale_records", {})
-    if not recs:
-        return {}
-    rec = recs[str(dev)] if dev is not None else next(iter(recs.values()))
-    out = {}
-    for i, v in enumerate(rec[:SCALE_SLOTS].cpu().tolist()):
-        ex = math.frexp(v)[1] if 0.0 < v < 3.0e38 else 9
-        out[i] = max(-8, min(4, 13 - ex))
-    return out
-
-
-def _scale_end(st, rec) -> None:
-    """Last launch of a forward that ran under a record: the forward's maxima become part of the sticky ones (and a site that has
-    stayed far below its sticky maximum for eight forwards comes down again)."""
-    if rec is not None:
-        st.call("dprnn_scale_join", rec[0].data_ptr(), rec[1].data_ptr())
-
-
-def reset_scale(owner) -> None:
-    """Forget what a model's activations have looked like so far: every conversion site starts from the default range again."""
-    for dev, rec in getattr(owner, "_dprnn_scale_records", {}).items():
-        lib = load_library()
-        with torch.cuda.device(rec.device):
-            check(lib, lib.dprnn_scale_init(rec.data_ptr(), torch.cuda.current_stream(rec.device).cuda_stream), "dprnn_scale_init")
-
-
-def unpin(owner) -> None:
-    """Let a model that was pinned to mode 1 after repeated saturation try the default arithmetic again."""
-    owner.__dict__["_dprnn_pin_mode1"] = False
-    owner.__dict__["_dprnn_sat_streak"] = 0
-
-
-def _bn_buffers(module):
-    if module is None:
-        return []
-    return [b for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
-            for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
-
-
-def _guarded(dev, primary, fallback, what: str, module=None, active: Optional[bool] = None, flags: Optional[torch.Tensor] = None,
-             owner=None, begin: bool = True, finite_inputs=None):
-    """primary() with saturation detection on this thread.  If an f16-pieces kernel it launched converted a value beyond the
-    f16 range (or met Inf / NaN), its result is discarded: BatchNorm running buffers primary() updated are restored and
-    fallback() -- the same call in a range-free arithmetic -- supplies the result.  One stream synchronisation per call (the
-    flags come back with a 32-byte copy).  Nested calls are covered by the outermost guard.
-    active: whether detection is needed at all (default: the thread's mode is 3).  flags: the device buffer to register (a captured
-    HIP graph's kernels carry the address of the buffer that was registered when they were captured).  begin=False: primary()
-    clears and registers the flags itself (a graph replay does it inside its serialised section).  finite_inputs: tensors whose
-    NaN / Inf content must raise the non-finite flag here -- the entry points that do not pass through dprnn_bottleneck_prep (where
-    every full forward's input is checked): a float maximum skips NaN and the f16 conversion clamps it, so without this a NaN sample
-    would come back as finite numbers from SingleRNN / DPRNNBlock / _dprnn_process / _auxiliary where the reference returns NaN."""
-    if active is None:
-        active = current_mode() == 3
-    if not active or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
-        return primary()
-    lib = load_library()
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
-        if flags is None:
-            flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
-        bufs = _bn_buffers(module)
-        keep = [b.clone() for b in bufs]
-        if begin:
-            check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
-        _TLS.guard = 1
-        host = (ctypes.c_int32 * SAT_SLOTS)()
-        try:
-            for t in (finite_inputs or ()):              # one reduction per input, OR-ed into the flag record on the device: no extra sync
-                flags[SAT_NONFINITE: SAT_NONFINITE + 1].bitwise_or_(torch.isfinite(t).all().logical_not().to(torch.int32).view(1))
-            out = primary()
-            rc = lib.dprnn_saturation_flags(ctypes.addressof(host), stream.cuda_stream)
-        finally:
-            _TLS.guard = 0
-            lib.dprnn_saturation_begin(0, 0)
-        if rc < 0:
-            check(lib, rc, "dprnn_saturation_flags")
-        _count(SATURATION, "checks")
-        if rc == 0:
-            if owner is not None:
-                owner.__dict__["_dprnn_sat_streak"] = 0
-            return out
-        del out
-        return _saturated(dev, list(host), what, bufs, keep, fallback, owner)
-
-
-class ForwardTicket:
-    """What forward_async / separate_many_async hand back beside the (enqueued, not yet checked) output: result() waits for the
-    forward's saturation flags -- 32 bytes copied to pinned host memory behind the forward's last kernel -- and returns the output, or,
-    when the f16-pieces arithmetic met a value beyond its range, the result of the same call repeated in a range-free arithmetic
-    (exactly what the synchronous call does; a caller that never asks keeps a possibly clamped output: always ask)."""
-
-    def __init__(self, dev, out, host, event, fallback, what, bufs, keep, owner):
-        self.dev, self._out, self._host, self._event = dev, out, host, event
-        self._fallback, self._what, self._bufs, self._keep, self._owner = fallback, what, bufs, keep, owner
-        self._done = host is None
-
-    def ready(self) -> bool:
-        """True once the forward and its flag copy have finished on the device (never blocks)."""
-        return self._done or self._event.query()
-
-    def result(self):
-        if self._done:
-            return self._out
-        self._event.synchronize()
-        self._done = True
-        host = [int(v) for v in self._host.tolist()]
-        _count(SATURATION, "checks")
-        if not any(host):
-            if self._owner is not None:
-                self._owner.__dict__["_dprnn_sat_streak"] = 0
-            return self._out
-        self._out = _saturated(self.dev, host, self._what, self._bufs, self._keep, self._fallback, self._owner)
-        return self._out
-
-
-def _saturated(dev, host, what, bufs, keep, fallback, owner):
-    """A forward's flags came back set: count it, say so (once), restore what the discarded forward changed, run the fall-back."""
-    hit = [SAT_NAMES[i] for i in range(SAT_SLOTS) if host[i]]
-    n_fallbacks = _count(SATURATION, "fallbacks")
-    with _STATS_LOCK:
-        SATURATION["last_flags"], SATURATION["last_what"] = list(host), what
-    msg = (f"{what}: the f16-pieces arithmetic met values beyond its range ({', '.join(hit)}: |x| > 4062 after scaling, or "
-           "Inf / NaN)")
-    if ON_SATURATION == "raise":
-        raise DprnnError(msg + "; DPRNN_ON_SATURATION=raise")
-    if owner is not None:
-        # The activation-scale record has adapted by now (the saturated forward left its maxima): the next forward normally fits.
-        # A model that saturates again and again (values that grow from call to call, Inf / NaN inputs) stops paying twice.
-        streak = owner.__dict__.get("_dprnn_sat_streak", 0) + 1
-        owner.__dict__["_dprnn_sat_streak"] = streak
-        if streak >= PIN_AFTER_FALLBACKS and not owner.__dict__.get("_dprnn_pin_mode1", False):
-            owner.__dict__["_dprnn_pin_mode1"] = True
-            warnings.warn(f"{what}: {streak} consecutive forwards left the range of the f16-pieces arithmetic; this model now runs in "
-                          "gate-GEMM mode 1 (three bf16 pieces, no range assumption) -- engine.unpin(model) returns it to the default",
-                          RuntimeWarning, stacklevel=4)
-    if n_fallbacks == 1:
-        warnings.warn(msg + " -- running the call again in a range-free arithmetic (further fall-backs are counted in "
-                      "engine.SATURATION without a warning)", RuntimeWarning, stacklevel=4)
-    with torch.cuda.device(dev):
-        for b, k in zip(bufs, keep):
-            b.copy_(k)
-        prev = getattr(_TLS, "guard", 0)
-        _TLS.guard = 1                 # the fall-back arithmetic has no range assumption: nothing to detect
-        try:
-            return fallback()
-        finally:
-            _TLS.guard = prev
-
-
-def _guarded_async(dev, primary, fallback, what: str, module=None, flags: Optional[torch.Tensor] = None, owner=None,
-                   begin: bool = True):
-    """_guarded without its stream synchronisation: primary() is enqueued, the flags travel to pinned host memory behind it, and
-    the check (with the repeat, if needed) happens in ForwardTicket.result().  Returns (output, ticket)."""
-    if current_mode() != 3 or not SATURATION_CHECK or getattr(_TLS, "guard", 0) > 0:
-        out = primary()
-        return out, ForwardTicket(dev, out, None, None, None, what, [], [], owner)
-    lib = load_library()
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
-        if flags is None:
-            flags = torch.empty(SAT_SLOTS, dtype=torch.int32, device=dev)
-        bufs = _bn_buffers(module)
-        keep = [b.clone() for b in bufs]
-        host = torch.empty(SAT_SLOTS, dtype=torch.int32).pin_memory()
-        if begin:
-            check(lib, lib.dprnn_saturation_begin(flags.data_ptr(), stream.cuda_stream), "dprnn_saturation_begin")
-        _TLS.guard = 1
-        try:
-            out = primary(host) if not begin else primary()      # a graph replay copies its flags out inside its serialised section
-        finally:
-            _TLS.guard = 0
-            lib.dprnn_saturation_begin(0, 0)
-        if begin:
-            host.copy_(flags, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record(stream)
-        return out, ForwardTicket(dev, out, host, event, fallback, what, bufs, keep, owner)
 
 
 # optional per-kernel timing (bench.py): {"names": set of C-ABI entry points, "events": {name: [(start, end)]}}
@@ -1285,374 +1032,6 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
         return est[:, 0, :], logits
 
 
-# ------------------------------------------------------------------- separation-level entry points (materialised frames)
-# The TasNet wrappers above never materialise the encoder output.  Code that subclasses the SEPARATOR modules and calls
-# their pieces on [B, C, L] tensors -- /root/reference/src/models/dprnn_rawnet.py:79-94 does: self._auxiliary,
-# self.bottleneck[i], self._fusion, self._dprnn_process -- gets the same HIP kernels through these functions
-# (inference only: the backward kernels are wired to the TasNet wrappers).
-def _no_grad_only(what: str, *tensors, module=None) -> None:
-    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor)) or
-                                    (module is not None and any(p.requires_grad for p in module.parameters()))):
-        raise NotImplementedError(
-            f"{what}: the separation-level MI355X entry points are inference-only (call them under torch.no_grad()); "
-            "training goes through DPRNNTasNet / DPRNNSpeTasNet / DPRNNSpeIRATasNet.forward, which own the backward kernels")
-
-
-def _check_frames(x: torch.Tensor, channels: int, what: str) -> torch.Tensor:
-    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[1] != channels:
-        raise DprnnError(f"{what} must be a [batch, {channels}, frames] tensor")
-    if not x.is_cuda:
-        raise DprnnError(f"{what} is on {x.device}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
-    if x.dtype != torch.float32:
-        raise DprnnError(f"{what} must be float32 (got {x.dtype})")
-    return x
-
-
-def _separator_masks_impl(sep, frames: torch.Tensor) -> torch.Tensor:
-    """DPRNN._dprnn_process (dprnn.py:171-186 == dprnn_spe.py:231-248): bottleneck output [B, F, L] -> masks [B, 2, N, L]."""
-    cfg = dict(input_size=sep.input_size, feature_size=sep.feature_size, hidden_size=sep.dprnn_blocks[0].intra_rnn.hidden_size,
-               rnn_type=sep.dprnn_blocks[0].intra_rnn.rnn.mode, kernel_size=1, norm_type=sep.norm_type,
-               activation_type=sep.activation_type, hop_length=sep.hop_length, chunk_length=sep.chunk_length)
-    check_supported(cfg)
-    frames = _check_frames(frames, F_BUILT, "bottleneck output")
-    _no_grad_only("_dprnn_process", frames, module=sep)
-    dev = frames.device
-    B, _, L = frames.shape
-    N = sep.input_size
-    with torch.cuda.device(dev), _scale_record(sep, dev) as rec:
-        st = Stage(dev)
-        Y = frames.transpose(1, 2).contiguous()                       # channels-last frames [B][L][F] (layout plumbing)
-        # the mask kernel also forms decoder taps of mask * encoder(wav); here there is no waveform: a 1-tap all-zero
-        # encoder / decoder over a zero signal of L samples keeps its addressing valid, and the taps are discarded
-        geo = Geometry(B, L, L, sep.chunk_length, sep.hop_length, (L + sep.chunk_length) // sep.hop_length + 1, 1, 1, N)
-        zero_w = torch.zeros(N, device=dev, dtype=torch.float32)
-        zero_x = torch.zeros(B, L, device=dev, dtype=torch.float32)
-        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
-        masks = torch.empty(B, L, 2, N, device=dev, dtype=torch.float32)         # rows (b, l, speaker)
-        dprnn_process(st, sep, Y, zero_x, zero_w, zero_w, geo, stats, sep.activation_type == "relu", masks_out=masks)
-        _scale_end(st, rec)
-        return masks.permute(0, 2, 3, 1).contiguous()                 # [B, 2, N, L] as dprnn.py:185
-
-
-def _rows_affine(st: Stage, x_cl, norm, B: int, L: int, N: int):
-    """Per-utterance affine (sc, sh) of GroupNorm(1, N) / GlobLN over materialised rows [B*L][N]."""
-    dev = x_cl.device
-    stats = torch.zeros(B, 2, device=dev, dtype=torch.float64)
-    st.call("dprnn_rows_stats", _p(x_cl), _p(stats), B, L, N)
-    _count_scale(stats, norm, st, B)
-    gamma, beta, eps = _norm_params(norm)
-    sc = torch.empty(B, N, device=dev, dtype=torch.float32)
-    sh = torch.empty_like(sc)
-    st.call("dprnn_bottleneck_prep", _p(stats), _p(_param(gamma, "norm.weight", dev)), _p(_param(beta, "norm.bias", dev)),
-            eps, 0, 0, _p(sc), _p(sh), B, L, N)
-    return sc, sh
-
-
-def _separator_forward_impl(sep, enc: torch.Tensor) -> torch.Tensor:
-    """DPRNN.forward (dprnn.py:166-187) on a materialised encoder output [B, N, L] -> masks [B, 2, N, L]."""
-    enc = _check_frames(enc, sep.input_size, "separator input")
-    _no_grad_only("DPRNN.forward", enc, module=sep)
-    if sep.input_size != N_BUILT or len(sep.bottleneck) != 2:
-        raise NotImplementedError(f"DPRNN MI355X path: input_size must be {N_BUILT} and norm_type 'ln' or 'gLN'")
-    dev = enc.device
-    B, N, L = enc.shape
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        x_cl = enc.transpose(1, 2).contiguous().view(B * L, N)
-        sc, sh = _rows_affine(st, x_cl, sep.bottleneck[0], B, L, N)
-        conv = sep.bottleneck[1]
-        Y = _pointwise(st, x_cl, B * L, N, conv.weight, conv.bias, F_BUILT, in_scale=sc, in_shift=sh, aff_stride=N,
-                       rows_per_utt=L)
-    return separator_masks(sep, Y.view(B, L, F_BUILT).transpose(1, 2))
-
-
-def _auxiliary_embedding_impl(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
-    """DPRNNSpe._auxiliary (dprnn_spe.py:156-163): encoder output of the reference utterance [B, N, La] -> [B, E]."""
-    aux = _check_frames(aux, sep.input_size, "aux")
-    _no_grad_only("_auxiliary", aux, module=sep.spk_encoder)
-    dev = aux.device
-    B, N, La = aux.shape
-    se = sep.spk_encoder
-    if N != N_BUILT or se[1].out_channels != 128 or se[5].in_channels != 256 or se[5].out_channels != 128:
-        raise NotImplementedError("DPRNN-Spe MI355X path: speaker encoder must be input_size 64, O=128, P=256, embeddings 128")
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        x_cl = aux.transpose(1, 2).contiguous().view(B * La, N)
-        sc, sh = _rows_affine(st, x_cl, se[0], B, La, N)
-        A0 = _pointwise(st, x_cl, B * La, N, se[1].weight, se[1].bias, 128, in_scale=sc, in_shift=sh, aff_stride=N,
-                        rows_per_utt=La)
-        return speaker_embedding(st, sep, A0, B, La, _aux_len_tensor(aux_len, B, dev), sep.kernel_size)
-
-
-# ---- sub-module forwards (inference only).  No shipped caller uses them -- the TasNet wrappers fuse everything from the
-# waveform -- but the reference's classes have them (dprnn.py:33-37,79-99, encoder_decoder.py:25-33,40-49, dprnn_spe.py:31-42), so
-# code that drives a single block / RNN / encoder / decoder / ResBlock on [B, C, ...] tensors gets the same HIP kernels.  Layout
-# changes between the reference's channels-first tensors and the kernels' channels-last rows are torch copies (plumbing).
-def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
-    """SingleRNN.forward (dprnn.py:33-37): [n, T, F] batch-first -> [n, T, ndir*H], zero initial state."""
-    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[2] != F_BUILT or rnn.hidden_size != F_BUILT:
-        raise DprnnError(f"SingleRNN input must be [sequences, steps, {F_BUILT}] with hidden_size {F_BUILT}")
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise DprnnError("SingleRNN runs on float32 HIP tensors only (no CPU fallback)")
-    _no_grad_only("SingleRNN.forward", x, module=rnn)
-    dev = x.device
-    n, T, _ = x.shape
-    if rnn.rnn.mode not in CELL_ID:
-        raise NotImplementedError(f"rnn_type {rnn.rnn.mode!r}")
-
-    def run():
-        with torch.cuda.device(dev), _scale_record(rnn, dev) as rec:
-            st = Stage(dev)
-            _set_slot(st.lib, SLOT_PATH0)
-            xc = x.contiguous()
-            ndir, fw, bw = _rnn_tensors(rnn, dev)
-            cell = CELL_ID[rnn.rnn.mode]
-            mode = current_mode() if cell == 0 else 0
-            if mode == 1 and n < 64:
-                mode = 0
-            packed = torch.empty(2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
-            bsum = torch.empty(2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
-            st.call("dprnn_rnn_pack_ex", mode, cell, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed), _p(bsum))
-            H = torch.empty(n, T, ndir * F_BUILT, device=dev, dtype=torch.float32)
-            tile = 0 if mode == 0 else split_tile(n, ndir, st.lib.dprnn_num_cus(), 1, mode)
-            if cell != 0 and tile > 32:
-                tile = 32
-            st.call("dprnn_rnn_fwd_ex", mode, cell, _p(xc), 0, 0, 0, 0, 0.0, 1, 1, 0, _p(packed), _p(bsum), _p(H), n, T, n, 0, T, 1, ndir, tile)
-            _scale_end(st, rec)
-            return H
-    return _guarded(dev, run, _in_mode(1, run), "SingleRNN.forward", finite_inputs=[x])
-
-
-def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
-    """DPRNNBlock.forward (dprnn.py:79-99): [B, F, K, S] -> [B, F, K, S]."""
-    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != F_BUILT:
-        raise DprnnError(f"DPRNNBlock input must be [batch, {F_BUILT}, chunk_length, chunks]")
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise DprnnError("DPRNNBlock runs on float32 HIP tensors only (no CPU fallback)")
-    if not hasattr(blk, "intra_norm"):
-        raise DprnnError("DPRNNBlock without norms (norm_type neither 'ln' nor 'gLN'): the reference's forward fails too")
-    _no_grad_only("DPRNNBlock.forward", x, module=blk)
-    dev = x.device
-    B, _, K, S = x.shape
-
-    def run():
-        with torch.cuda.device(dev), _scale_record(blk, dev) as rec:
-            st = Stage(dev)
-            import types
-            geo = Geometry(B, 0, 0, K, 1, S, 1, 1, N_BUILT)
-            rows = B * S * K
-            g = types.SimpleNamespace(st=st, geo=geo, b0=0, b1=B, pending=None, n_concurrent=1, mode=0,
-                                      X=torch.empty(rows * F_BUILT, device=dev, dtype=torch.float32), X2=None,
-                                      Z=torch.empty(rows * F_BUILT, device=dev, dtype=torch.float32),
-                                      H=torch.empty(rows * 2 * F_BUILT, device=dev, dtype=torch.float32))
-            g.X.view(B, S, K, F_BUILT).copy_(x.permute(0, 3, 2, 1))          # slab rows (b, s, k)
-            mode = effective_gemm_mode(B, [blk])
-            prev = st.lib.dprnn_get_gemm_mode()
-            st.lib.dprnn_set_gemm_mode(mode)
-            g.mode = mode
-            try:
-                stats = torch.zeros(2, B, 2, device=dev, dtype=torch.float64)
-                packed = torch.empty(2, 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
-                bsum = torch.empty(2, 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
-                for j, (rnn, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
-                                                             (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
-                    _, fw, bw = _rnn_tensors(rnn, dev)
-                    _set_slot(st.lib, path_slot(0, j == 1))
-                    st.call("dprnn_rnn_pack_ex", mode, CELL_ID[rnn.rnn.mode], *[_p(t) for t in fw], *[_p(t) for t in bw],
-                            _p(packed[j]), _p(bsum[j]))
-                    _run_path(g, rnn, lin, norm, stats[j], packed[j], bsum[j], intra, None, False, path_slot(0, j == 1))
-            finally:
-                st.lib.dprnn_set_gemm_mode(prev)
-            _scale_end(st, rec)
-            return g.X.view(B, S, K, F_BUILT).permute(0, 3, 2, 1).contiguous()
-    return _guarded(dev, run, _in_mode(1, run), "DPRNNBlock.forward", finite_inputs=[x])
-
-
-def encoder_forward(enc, wav: torch.Tensor) -> torch.Tensor:
-    """Encoder.forward (encoder_decoder.py:25-33): [B, T] -> relu(conv1d) [B, N, L]."""
-    wav = check_input(wav)
-    dev = wav.device
-    w = _param(enc.conv1d.weight, "encoder.conv1d.weight", dev)
-    N, _, ks = w.shape
-    stride = enc.conv1d.stride[0]
-    if N != N_BUILT or ks > KS_MAX:
-        raise NotImplementedError(f"Encoder MI355X path: output_size must be {N_BUILT}, kernel_size <= {KS_MAX}")
-    _no_grad_only("Encoder.forward", wav, module=enc)
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        geo = make_geometry(wav.shape[0], wav.shape[1], N, 1, 1, ks, stride)
-        one = torch.ones(geo.B, N, device=dev, dtype=torch.float32)
-        zero = torch.zeros_like(one)
-        A = torch.empty(geo.B, geo.L, N, device=dev, dtype=torch.float32)
-        st.call("dprnn_encoder_norm_rows", _p(wav), _p(w), _p(one), _p(zero), _p(A), geo.B, geo.T, geo.L, N, ks, stride)
-        return A.transpose(1, 2).contiguous()
-
-
-def decoder_forward(dec, x: torch.Tensor) -> torch.Tensor:
-    """Decoder.forward (encoder_decoder.py:40-49): [B, N, L] -> [B, T] with the reference's squeeze rule."""
-    if not isinstance(x, torch.Tensor) or x.dim() != 3:
-        raise DprnnError("Decoder input must be [batch, channels, frames]")   # (the reference also accepts 2-D; its wrappers never pass it)
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise DprnnError("Decoder runs on float32 HIP tensors only (no CPU fallback)")
-    _no_grad_only("Decoder.forward", x, module=dec)
-    dev = x.device
-    w = _param(dec.weight, "decoder.weight", dev)
-    N, oc, ks = w.shape
-    stride = dec.stride[0]
-    B, C, L = x.shape
-    if C != N or oc != 1:
-        raise DprnnError(f"Decoder expects {N} channels and one output channel")
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        rows = x.transpose(1, 2).contiguous().view(B * L, N)
-        wt = w[:, 0, :].t().contiguous()                                     # [ks][N]: taps[row][j] = sum_n Wd[n][j] x[row][n]
-        taps = torch.zeros(B, 2, L, ks, device=dev, dtype=torch.float32)     # dprnn_decoder_fwd reads [B][2 speakers][L][ks]
-        taps[:, 0] = _linear_small(st, wt, None, rows).view(B, L, ks)
-        geo = Geometry(B, 0, L, 1, 1, 1, ks, stride, N)
-        out = decode(st, taps, geo, 1)[:, 0, :]
-    from .encoder_decoder import squeeze_like_reference
-    return squeeze_like_reference(out)
-
-
-def resblock_forward(blk, x: torch.Tensor) -> torch.Tensor:
-    """ResBlock.forward (dprnn_spe.py:31-42): [B, C_in, T] -> [B, C_out, T // 3]."""
-    if not isinstance(x, torch.Tensor) or x.dim() != 3:
-        raise DprnnError("ResBlock input must be [batch, channels, frames]")
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise DprnnError("ResBlock runs on float32 HIP tensors only (no CPU fallback)")
-    _no_grad_only("ResBlock.forward", x, module=blk)
-    dev = x.device
-    B, cin, T = x.shape
-    cout = blk.conv1.out_channels
-    if blk.conv1.in_channels != cin or cin not in (128, 256) or cout not in (128, 256):
-        raise NotImplementedError("ResBlock MI355X path: 128 or 256 channels (the reference's speaker encoder: O=128, P=256)")
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        rows = x.transpose(1, 2).contiguous().view(B * T, cin)
-        out, _ = _resblock(st, blk, rows, B, T, cin, cout)
-        return out.transpose(1, 2).contiguous()
-
-
-# ---- the per-frame glue of the separator-level surfaces as HIP kernels (round 4): a subclass of the reference's DPRNNSpe that
-# calls bottleneck[0], _fusion, bottleneck[1], pred_linear itself (src/models/dprnn_rawnet.py:79-105) gets these through the
-# modules of device_modules.py -- no MIOpen / rocBLAS kernel behind a surface INTEGRATION.md calls "on the HIP kernels".
-def _device_f32(x, what: str):
-    if not isinstance(x, torch.Tensor) or not x.is_cuda:
-        raise DprnnError(f"{what}: the DPRNN MI355X path runs only on a HIP device (no CPU fallback)")
-    if x.dtype != torch.float32:
-        raise DprnnError(f"{what} must be float32 (got {x.dtype})")
-    return x
-
-
-def norm_forward(norm, x: torch.Tensor) -> torch.Tensor:
-    """nn.GroupNorm(1, C) / norms.GlobLN on [B, C, ...] (dprnn.py:131-136, norms.py:27-31): per-utterance statistics in fp64
-    (dprnn_rows_stats), affine from dprnn_bottleneck_prep, applied by dprnn_rows_affine_fwd."""
-    x = _device_f32(x, "norm input")
-    _no_grad_only(type(norm).__name__ + ".forward", x, module=norm)
-    if x.dim() < 3:
-        raise DprnnError("norm input must be [batch, channels, ...]")
-    B, C = x.shape[:2]
-    if C % 4:
-        raise NotImplementedError("norm over a channel count that is not a multiple of 4")
-    dev = x.device
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        rows = x.reshape(B, C, -1).transpose(1, 2).contiguous()                # channels-last rows [B][R][C] (layout plumbing)
-        R = rows.shape[1]
-        sc, sh = _rows_affine(st, rows, norm, B, R, C)
-        out = torch.empty_like(rows)
-        st.call("dprnn_rows_affine_fwd", _p(rows), _p(sc), _p(sh), 0, _p(out), B * R, C, R)
-        return out.transpose(1, 2).reshape(x.shape).contiguous()
-
-
-def conv1x1_forward(conv, x: torch.Tensor) -> torch.Tensor:
-    """nn.Conv1d(C_in, C_out, 1) on [B, C_in, L] as a row GEMM (dprnn_pointwise_fwd).  C_in up to 256 (zero-padded to 64 / 128 /
-    256: the 'cat' fusion's 192 channels), C_out a multiple of 128."""
-    x = _device_f32(x, "conv input")
-    _no_grad_only("Conv1d.forward", x, module=conv)
-    if x.dim() != 3 or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1 or conv.padding != (0,):
-        raise NotImplementedError("Conv1d MI355X path: 1x1 convolutions over [batch, channels, frames]")
-    B, cin, L = x.shape
-    cout = conv.out_channels
-    if cin != conv.in_channels or cin > 256 or cout % 128:
-        raise NotImplementedError(f"Conv1d MI355X path: in_channels <= 256 and out_channels a multiple of 128 (got {cin} -> {cout})")
-    dev = x.device
-    kdim = 64 if cin <= 64 else 128 if cin <= 128 else 256
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        w = _param(conv.weight, "conv.weight", dev).reshape(cout, cin)
-        if kdim == cin:
-            rows = x.transpose(1, 2).contiguous().view(B * L, cin)
-        else:                                                                # zero columns: plumbing, no arithmetic
-            rows = torch.zeros(B * L, kdim, device=dev, dtype=torch.float32)
-            rows.view(B, L, kdim)[:, :, :cin] = x.transpose(1, 2)
-            wp = torch.zeros(cout, kdim, device=dev, dtype=torch.float32)
-            wp[:, :cin] = w
-            w = wp
-        out = torch.empty(B * L, cout, device=dev, dtype=torch.float32)
-        bias = _param(conv.bias, "conv.bias", dev) if conv.bias is not None else None
-        for col0 in range(0, cout, 128):
-            st.call("dprnn_pointwise_fwd", _p(rows), kdim, kdim, 0, 0, 0, 0, 0, 0, _p(w), kdim, _p(bias), _p(out), cout, col0, 0, B * L)
-        return out.view(B, L, cout).transpose(1, 2).contiguous()
-
-
-def linear_forward(lin, x: torch.Tensor) -> torch.Tensor:
-    """nn.Linear on [..., in_features] through dprnn_linear_small_fwd (the per-utterance Linears: fusion_linear*, aux_linear,
-    pred_linear; dprnn_spe.py:88-105,123, dprnn_spe_ira.py:51)."""
-    x = _device_f32(x, "linear input")
-    _no_grad_only("Linear.forward", x, module=lin)
-    if x.shape[-1] != lin.in_features:
-        raise DprnnError(f"Linear expects {lin.in_features} input features, got {x.shape[-1]}")
-    dev = x.device
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        flat = x.reshape(-1, lin.in_features).contiguous()
-        out = _linear_small(st, lin.weight, lin.bias, flat)
-        return out.view(*x.shape[:-1], lin.out_features)
-
-
-def fusion_forward(sep, emb: torch.Tensor, output: torch.Tensor, L: int) -> torch.Tensor:
-    """DPRNNSpe._fusion (dprnn_spe.py:165-229) on device tensors: emb [B, E], output [B, N, L] (already normalised) -> the fused
-    [B, C, L].  The per-utterance vectors come from dprnn_linear_small_fwd, the broadcast arithmetic runs in dprnn_rows_affine_fwd,
-    the 'att' scores / softmax / nearest upsampling in dprnn_att_row_scale_rows; 'cat' is a copy."""
-    output = _device_f32(output, "_fusion input")
-    emb = _device_f32(emb, "speaker embedding")
-    _no_grad_only("_fusion", output, emb, module=sep)
-    ft = sep.fusion_type
-    if ft == "cat":
-        return torch.cat((output, emb.unsqueeze(-1).expand(-1, -1, L)), dim=1)
-    B, N, _ = output.shape
-    dev = output.device
-    with torch.cuda.device(dev):
-        st = Stage(dev)
-        rows = output.transpose(1, 2).contiguous()                            # [B][L][N]
-        out = torch.empty_like(rows)
-        lin = lambda m: _linear_small(st, m.weight, m.bias, emb.contiguous())
-        if ft == "film":
-            mul, add = lin(sep.fusion_linear_1), lin(sep.fusion_linear_2)      # (both alive until the launch that reads them is enqueued)
-            st.call("dprnn_rows_affine_fwd", _p(rows), _p(mul), _p(add), 0, _p(out), B * L, N, L)
-        elif ft == "add":
-            add = lin(sep.fusion_linear)
-            st.call("dprnn_rows_affine_fwd", _p(rows), 0, _p(add), 0, _p(out), B * L, N, L)
-        elif ft == "mul":
-            mul = lin(sep.fusion_linear)
-            st.call("dprnn_rows_affine_fwd", _p(rows), _p(mul), 0, 0, _p(out), B * L, N, L)
-        elif ft == "att":
-            a = lin(sep.fusion_linear)
-            ks_a = sep.average.kernel_size[0]
-            if sep.average.stride[0] != ks_a or sep.average.groups != N:
-                raise DprnnError("unexpected averaging conv geometry in the 'att' fusion")
-            La = (L - ks_a) // ks_a + 1
-            scores = torch.empty(B, La, device=dev, dtype=torch.float32)
-            row_scale = torch.empty(B, L, device=dev, dtype=torch.float32)
-            st.call("dprnn_att_row_scale_rows", _p(rows), N, 0, 0, _p(_param(sep.average.weight, "average.weight", dev)),
-                    _p(_param(sep.average.bias, "average.bias", dev)), _p(a), _p(scores), _p(row_scale), B, L, N, ks_a)
-            st.call("dprnn_rows_affine_fwd", _p(rows), _p(a), 0, _p(row_scale), _p(out), B * L, N, L)      # output * a * (att + 1)
-        else:
-            raise DprnnError(f"unknown fusion_type {ft!r}")
-        return out.transpose(1, 2).contiguous()
-
-
 # ------------------------------------------------------------------------------------------------ ragged batches
 # Full-length test utterances differ in length (Libri2Mix test: 3 .. 14 s), and the reference evaluates them one at a time
 # (src/inferencers/inferencer.py:54-58, inferencer_spe.py:27-32): zero-padding to a common length would change the
@@ -1665,309 +1044,6 @@ def fusion_forward(sep, emb: torch.Tensor, output: torch.Tensor, L: int) -> torc
 # batches on streams otherwise (inference.separate_many).
 RAGGED_STREAMS = 8           # side streams for the per-utterance launches around the ragged slab (small kernels: they overlap)
 _FAN_POOL: dict = {}
-
-
-class _Fan:
-    """Independent per-utterance work dealt round-robin over persistent side streams; join() makes the caller's stream wait
-    for all of it (and hands the tensors produced there over to it)."""
-
-    def __init__(self, st: Stage, n_items: int, enable: bool = True):
-        self.main = st
-        n = min(RAGGED_STREAMS, n_items) if enable else 0
-        if n > 1:
-            pool = _persistent_streams(_FAN_POOL, (threading.get_ident(), str(st.device)), st.device, n)
-            fork = torch.cuda.Event()
-            fork.record(st.tstream)
-            self.stages = [Stage(st.device, s) for s in pool]
-            for sg in self.stages:
-                sg.tstream.wait_event(fork)
-        else:
-            self.stages = []
-        self.made = []
-
-    def run(self, u: int, fn):
-        """fn(stage) on the side stream of item u; tensors it returns are kept alive / handed over at join()."""
-        if not self.stages:
-            return fn(self.main)
-        sg = self.stages[u % len(self.stages)]
-        with torch.cuda.stream(sg.tstream):
-            out = fn(sg)
-        self.made.append(out)
-        return out
-
-    def join(self):
-        def walk(o):
-            if isinstance(o, torch.Tensor):
-                o.record_stream(self.main.tstream)
-            elif isinstance(o, (list, tuple)):
-                for v in o:
-                    walk(v)
-        for sg in self.stages:
-            ev = torch.cuda.Event()
-            ev.record(sg.tstream)
-            self.main.tstream.wait_event(ev)
-        walk(self.made)
-        self.made = []
-
-
-def _bn_training(module) -> bool:
-    """BatchNorm in train mode updates its running buffers in place per utterance: such work stays on one stream, in order."""
-    return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in module.modules())
-
-
-def ragged_supported(sep) -> bool:
-    return current_mode() in (1, 3) and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
-
-
-@_leaves_exact_mode
-def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act: bool, want_masked: bool = False):
-    """dprnn_process for utterances of different lengths.  Ys[u]: frames [1][L_u][F]; wavs[u]: [1][T_u]; geos[u]: Geometry
-    with B = 1.  Returns (taps list [1][2][L_u][ks], masked list [1][L_u][N] or None)."""
-    import numpy as np
-    dev = Ys[0].device
-    n = len(Ys)
-    K, P, ks, N = geos[0].K, geos[0].P, geos[0].ks, geos[0].N
-    blocks = list(sep.dprnn_blocks)
-    if not ragged_supported(sep):
-        raise DprnnError("ragged batches need gate-GEMM mode 1 or 3 and LSTM cells")
-    mode = current_mode()
-    st.lib.dprnn_set_gemm_mode(mode)
-    rows = np.array([g.S * K for g in geos], dtype=np.int64)
-    starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    total = int(starts[-1])
-    chunks = np.array([g.S for g in geos], dtype=np.int64)
-    seq_utt = np.repeat(np.arange(n, dtype=np.int32), chunks)
-    desc = []
-    for u in np.argsort(-chunks, kind="stable"):                 # longest utterances first: their workgroups run longest
-        for k0 in range(0, K, 64):
-            r0 = int(starts[u]) + k0
-            desc.append((r0 & 0xFFFFFFFF, r0 >> 32, int(chunks[u]), min(64, K - k0), int(u), 0, 0, 0))
-    desc = np.array(desc, dtype=np.int64).astype(np.uint32).view(np.int32)
-    tables = _upload(torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), seq_utt, desc.reshape(-1)])), dev)
-    o = 0
-    utt_rows = tables[o: o + 2 * n]; o += 2 * n
-    utt_starts = tables[o: o + 2 * (n + 1)]; o += 2 * (n + 1)
-    seq_utt_d = tables[o: o + seq_utt.size]; o += seq_utt.size
-    desc_d = tables[o:]
-    n_tiles = desc.shape[0]
-
-    packed = torch.empty(2 * len(blocks), 2 * PACK_PER_DIR_MAX, device=dev, dtype=torch.float32)
-    bsum = torch.empty(2 * len(blocks), 2 * 4 * F_BUILT, device=dev, dtype=torch.float32)
-    for i, blk in enumerate(blocks):
-        for j, rnn in enumerate((blk.intra_rnn, blk.inter_rnn)):
-            _, fw, bw = _rnn_tensors(rnn, dev)
-            _set_slot(st.lib, path_slot(i, j == 1))
-            st.call("dprnn_rnn_pack_ex", mode, 0, *[_p(t) for t in fw], *[_p(t) for t in bw], _p(packed[2 * i + j]), _p(bsum[2 * i + j]))
-
-    m = total * F_BUILT
-    # H [total][2F] is dead once the last projection has read it; the mask head of utterance u then takes its U [L_u][2F] and
-    # V [2 L_u][F] from the same region.  S_u K rows of 2F floats cover them when hop <= K / 2 (S K >= 2 L); a larger hop needs
-    # more, so every utterance gets max(S_u K 2F, 4 L_u F) floats at its own offset (the non-ragged arena does the same through
-    # dprnn_workspace_bytes).
-    head_need = np.array([max(g.S * K * 2 * F_BUILT, 4 * g.L * F_BUILT) for g in geos], dtype=np.int64)
-    head_off = np.concatenate([[0], np.cumsum(head_need)]).astype(np.int64)
-    arena = torch.empty(3 * m + int(head_off[-1]), device=dev, dtype=torch.float32)
-    X, X2, Z, H = arena[:m], arena[m: 2 * m], arena[2 * m: 3 * m], arena[3 * m:]
-    stats = torch.zeros(2 * len(blocks), n, 2, device=dev, dtype=torch.float64)
-    # the Linear folded into the recurrence (time-split form, LIN_FOLD above) where the one pipeline's launches cover the chip
-    ncu = st.lib.dprnn_num_cus()
-    tiles_intra, tiles_inter = -(-int(seq_utt.size) // 64), n_tiles
-    covers = lambda tiles: LIN_FOLD == "split" or (LIN_FOLD == "auto" and 2 * tiles >= FOLD_SPLIT_MIN_FILL * ncu)
-    fold = {True: mode == 3 and covers(tiles_intra), False: mode == 3 and covers(tiles_inter)}
-    if any(fold.values()):
-        Z2 = torch.empty(m, device=dev, dtype=torch.float32)
-        lin_state = torch.empty(st.lib.dprnn_rnn_lin_state_floats(64 * max(tiles_intra, tiles_inter), 2064), device=dev, dtype=torch.float32)
-        linp = torch.empty(2 * len(blocks), st.lib.dprnn_lin_pack_floats(), device=dev, dtype=torch.float32)
-    fan = _Fan(st, n)
-    for u in range(n):
-        fan.run(u, lambda sg, u=u: sg.call("dprnn_segment_fwd", _p(Ys[u]), _p(X[int(starts[u]) * F_BUILT:]), 1, geos[u].L, K, P,
-                                           geos[u].S))
-    fan.join()
-    pending = None
-    for i, blk in enumerate(blocks):
-        for intra in (True, False):
-            rnn, lin, norm = (blk.intra_rnn, blk.intra_linear, blk.intra_norm) if intra else \
-                (blk.inter_rnn, blk.inter_linear, blk.inter_norm)
-            slot = 2 * i + (0 if intra else 1)
-            ndir = 2 if rnn.rnn.bidirectional else 1
-            pn = (0, 0, 0, 0, 0.0) if pending is None else (_p(Z), _p(pending[0]), _p(pending[1]), _p(pending[2]), pending[3])
-            hp = H_PIECES and mode == 3
-            _set_slot(st.lib, path_slot(i, not intra))
-            w = _param(lin.weight, "linear.weight", dev)
-            if w.shape != (F_BUILT, ndir * F_BUILT):
-                raise DprnnError(f"linear weight shape {tuple(w.shape)} does not match ndir={ndir}")
-            if fold[intra] and ndir == 2:
-                st.call("dprnn_lin_pack_f16", _p(w), 2, _p(linp[slot]))
-                rag = (_p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d), int(seq_utt.size) if intra else n_tiles)
-                tail = (_p(packed[slot]), _p(bsum[slot]), _p(linp[slot]))
-                st.call("dprnn_rnn_lin_split_ragged_fwd", 1, _p(X), *pn, *rag, 0 if pending is None else _p(X2), *tail, 0, _p(Z2), 0,
-                        _p(lin_state), K if intra else 0, K)
-                if pending is not None:
-                    X, X2 = X2, X
-                st.call("dprnn_rnn_lin_split_ragged_fwd", 2, _p(X), 0, 0, 0, 0, 0.0, *rag, 0, *tail, _p(_param(lin.bias, "linear.bias", dev)),
-                        _p(Z2), _p(stats[slot]), _p(lin_state), K if intra else 0, K)
-                Z, Z2 = Z2, Z
-                _count_scale(stats[slot], norm, st, n)
-                gamma, beta, eps = _norm_params(norm)
-                pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
-                continue
-            st.call("dprnn_rnn_fwd_ragged_hp_ex" if hp else "dprnn_rnn_fwd_ragged_ex", mode, _p(X), *pn, _p(utt_rows), _p(seq_utt_d) if intra else 0, 0 if intra else _p(desc_d),
-                    int(seq_utt.size) if intra else n_tiles, 0 if pending is None else _p(X2), _p(packed[slot]), _p(bsum[slot]), _p(H),
-                    K if intra else 0, K, ndir)
-            if pending is not None:
-                X, X2 = X2, X
-            if hp:
-                st.call("dprnn_proj_stats_hp_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
-                        total, 1, _p(utt_starts), n, ndir * F_BUILT)
-            else:
-                st.call("dprnn_proj_stats_ragged_fwd", _p(H), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Z), _p(stats[slot]),
-                        total, _p(utt_starts), n, ndir * F_BUILT)
-            _count_scale(stats[slot], norm, st, n)
-            gamma, beta, eps = _norm_params(norm)
-            pending = (stats[slot], _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev), eps)
-
-    taps, masked = [], []
-    head_w = (_p(_param(sep.prelu.weight, "prelu.weight", dev)), _p(_param(sep.conv2d.weight, "conv2d.weight", dev)),
-              _p(_param(sep.conv2d.bias, "conv2d.bias", dev)))
-    def head(sg, u):
-        g = geos[u]
-        r0 = int(starts[u])
-        Hu = H[int(head_off[u]): int(head_off[u + 1])]                        # this utterance's U | V scratch
-        U, V = Hu[: g.L * 2 * F_BUILT], Hu[g.L * 2 * F_BUILT: 2 * g.L * 2 * F_BUILT]
-        assert V.numel() == g.L * 2 * F_BUILT
-        _set_slot(sg.lib, SLOT_HEAD_CONV)
-        if pending is None:
-            sg.call("dprnn_head_conv_ola_fwd", _p(X[r0 * F_BUILT:]), *head_w, _p(U), 1, g.L, K, P, g.S)
-        else:
-            sg.call("dprnn_head_conv_ola_norm_fwd", _p(X[r0 * F_BUILT:]), _p(Z[r0 * F_BUILT:]), _p(pending[0][u]), _p(pending[1]),
-                    _p(pending[2]), pending[3], *head_w, _p(U), 1, g.L, K, P, g.S)
-        _set_slot(sg.lib, SLOT_HEAD_GATE)
-        sg.call("dprnn_head_gate_fwd", _p(U), _p(_param(sep.out[0].weight, "out.0.weight", dev)),
-                _p(_param(sep.out[0].bias, "out.0.bias", dev)), _p(_param(sep.gate[0].weight, "gate.0.weight", dev)),
-                _p(_param(sep.gate[0].bias, "gate.0.bias", dev)), _p(V), g.L * 2)
-        t = torch.empty(1, 2, g.L, ks, device=dev, dtype=torch.float32)
-        mk = torch.empty(1, g.L, N, device=dev, dtype=torch.float32) if want_masked else None
-        sg.call("dprnn_head_mask_decode_fwd", _p(V), _p(_param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
-                _p(wavs[u]), _p(enc_w), _p(dec_w), _p(t), _p(mk), 1 if relu_act else 0, 1, g.T, g.L, N, ks, g.stride)
-        return t, mk
-
-    fan = _Fan(st, n)
-    res = [fan.run(u, lambda sg, u=u: head(sg, u)) for u in range(n)]
-    fan.join()
-    taps = [r[0] for r in res]
-    masked = [r[1] for r in res]
-    return taps, (masked if want_masked else None)
-
-
-def _tasnet_forward_ragged_impl(model, wavs):
-    """DPRNNTasNet.forward for a list of 1-D waveforms of different lengths -> list of [2, T_out_u] (each equal to the
-    batch-of-one forward of that utterance)."""
-    cfg = model.cfg
-    check_supported(cfg)
-    dev = wavs[0].device
-    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
-        st = Stage(dev)
-        sep = model.separation
-        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
-        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
-        ws = [check_input(w.reshape(1, -1)) for w in wavs]
-        geos = [make_geometry(1, w.shape[1], cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"],
-                              cfg["stride"]) for w in ws]
-        stats0 = torch.zeros(len(ws), 1, 2, device=dev, dtype=torch.float64)
-        fan = _Fan(st, len(ws))
-        Ys = [fan.run(u, lambda sg, u=u: frames_from_waveform(sg, ws[u], enc_w, sep.bottleneck[0], sep.bottleneck[1], geos[u],
-                                                                stats0[u])) for u in range(len(ws))]
-        fan.join()
-        taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, cfg["activation_type"] == "relu")
-        fan = _Fan(st, len(ws))
-        outs = [fan.run(u, lambda sg, u=u: decode(sg, taps[u], geos[u], 2)) for u in range(len(ws))]
-        fan.join()
-        _scale_end(st, rec)
-        return [o[0] for o in outs]
-
-
-def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
-    """DPRNNSpeTasNet / DPRNNSpeIRATasNet forward for lists of mixtures and reference utterances of different lengths ->
-    list of (estimate [T_out_u], logits [num_spks]); every utterance keeps batch-of-one semantics (BatchNorm statistics of
-    the speaker branch included, as the reference's one-at-a-time loop has them)."""
-    cfg = model.cfg
-    check_supported_spe(cfg)
-    dev = wavs[0].device
-    with torch.cuda.device(dev), _scale_record(model, dev) as rec:
-        st = Stage(dev)
-        N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
-        sep = model.separation
-        se = sep.spk_encoder
-        enc_w = _param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
-        dec_w = _param(model.decoder.weight, "decoder.weight", dev)
-        relu_act = cfg["activation_type"] == "relu"
-        n = len(wavs)
-        ws = [check_input(w.reshape(1, -1)) for w in wavs]
-        axs = [check_input(a.reshape(1, -1), "aux") for a in auxs]
-        geos = [make_geometry(1, w.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride) for w in ws]
-        stats = torch.zeros(n, 4, 1, 2, device=dev, dtype=torch.float64)     # per utterance: bottleneck, aux, d0 statistics
-        parallel = not _bn_training(sep)               # train-mode BatchNorm updates its buffers per utterance, in order
-
-        def first(sg, u):
-            geo_a = make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
-            alen = _aux_len_tensor(aux_lens[u], 1, dev)
-            sc_a, sh_a = bottleneck_affine(sg, axs[u], enc_w, se[0], geo_a, stats[u, 1])
-            A0 = bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=SLOT_AUX_BOTTLENECK).view(geo_a.L, F_BUILT)
-            v0 = speaker_embedding(sg, sep, A0, 1, geo_a.L, alen, ks)
-            mul, add, row_bias = _fusion_operands(sg, sep, cfg, v0)
-            sc, sh = bottleneck_affine(sg, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
-            row_scale = _att_row_scale(sg, sep, cfg, ws[u], enc_w, geos[u], stats[u, 0], mul) if cfg["fusion_type"] == "att" else None
-            Y = bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geos[u], row_bias, row_scale)
-            return v0, Y, sc, sh, alen
-
-        fan = _Fan(st, n, parallel)
-        r1 = [fan.run(u, lambda sg, u=u: first(sg, u)) for u in range(n)]
-        fan.join()
-        v0s, Ys = [r[0] for r in r1], [r[1] for r in r1]
-        scs, alens = [(r[2], r[3]) for r in r1], [r[4] for r in r1]
-        v_last = v0s
-        if not ira:
-            taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act)
-        else:
-            taps, d0s = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act, want_masked=True)
-            g0, b0, _ = _norm_params(se[0])
-
-            def second(sg, u):
-                geo = geos[u]
-                sg.call("dprnn_rows_stats", _p(d0s[u]), _p(stats[u, 2]), 1, geo.L, N)
-                _count_scale(stats[u, 2].view(1, 2), se[0], sg, 1)
-                sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
-                sh_d = torch.empty_like(sc_d)
-                sg.call("dprnn_bottleneck_prep", _p(stats[u, 2]), _p(_param(g0, "spk_encoder.0.weight", dev)),
-                        _p(_param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, _p(sc_d), _p(sh_d), 1, geo.L, N)
-                A0d = _pointwise(sg, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
-                                 aff_stride=N, rows_per_utt=geo.L)
-                v1 = speaker_embedding(sg, sep, A0d, 1, geo.L, alens[u], ks)
-                v1 = _linear_small(sg, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous())
-                mul2, add2, row_bias2 = _fusion_operands(sg, sep, cfg, v1)
-                sc, sh = scs[u]
-                if mul2 is not None or add2 is not None:
-                    g, b_, eps = _norm_params(sep.bottleneck[0])
-                    sg.call("dprnn_bottleneck_prep", _p(stats[u, 0]), _p(g), _p(b_), eps, _p(mul2), _p(add2), _p(sc), _p(sh), 1, geo.L, N)
-                row_scale2 = _att_row_scale(sg, sep, cfg, ws[u], enc_w, geo, stats[u, 0], mul2) if cfg["fusion_type"] == "att" else None
-                return v1, bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2)
-
-            fan = _Fan(st, n, parallel)
-            r2 = [fan.run(u, lambda sg, u=u: second(sg, u)) for u in range(n)]
-            fan.join()
-            del Ys, d0s
-            taps, _ = dprnn_process_ragged(st, sep, [r[1] for r in r2], ws, enc_w, dec_w, geos, relu_act)
-            v_last = [r[0] for r in r2]
-
-        def last(sg, u):
-            logits = _linear_small(sg, sep.pred_linear.weight, sep.pred_linear.bias, v_last[u])
-            return decode(sg, taps[u], geos[u], 1), logits
-
-        fan = _Fan(st, n)
-        r3 = [fan.run(u, lambda sg, u=u: last(sg, u)) for u in range(n)]
-        fan.join()
-        _scale_end(st, rec)
-        return [(est[0, 0, :], logits[0]) for est, logits in r3]
 
 
 # ------------------------------------------------------------------------------------------------ HIP graphs
@@ -1992,126 +1068,6 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
 GRAPHS = os.environ.get("DPRNN_GRAPHS", "1") != "0"
 GRAPH_CACHE_MAX = 16
 GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_for_memory": 0}
-_GRAPH_CACHE: "collections.OrderedDict" = collections.OrderedDict()
-_GRAPH_SEEN: "collections.OrderedDict" = collections.OrderedDict()
-_GRAPH_EAGER_KEYS: set = set()            # keys whose capture failed or did not fit: eager from then on
-_GRAPH_RETIRED: list = []                 # evicted graphs: destroyed under _CAPTURE_LOCK once no thread is replaying them (_retire)
-_GRAPH_LOCK = threading.Lock()
-_CAPTURE_LOCK = threading.RLock()        # torch registers generator state per capture, process-wide: one capture at a time; also
-                                         # held by empty_cache() / drop_graphs(): no segment goes back to the driver during a capture
-
-
-class _EnginePool:
-    """The memory pool every captured forward of one device allocates from, and the order of their replays."""
-
-    def __init__(self):
-        self.pool = torch.cuda.MemPool()
-        self.lock = threading.RLock()
-        self.last = None                 # event recorded behind the latest replay
-
-
-_POOLS: dict = {}
-
-
-def _engine_pool(dev) -> _EnginePool:
-    key = str(dev)
-    with _GRAPH_LOCK:
-        ep = _POOLS.get(key)
-        if ep is None:
-            ep = _POOLS[key] = _EnginePool()
-        return ep
-
-
-@contextlib.contextmanager
-def capture_lock():
-    """The lock under which this engine instantiates, first-launches and destroys its HIP graphs.  A host process that owns OTHER
-    graphs (torch.cuda.CUDAGraph of its own, torch.compile's reduce-overhead mode, another library's) must create, first-replay and
-    destroy them inside `with engine.capture_lock():` -- or run the engine with DPRNN_GRAPHS=0.  Why: on this ROCm stack a graph
-    DESTROYED between another graph's instantiation and that graph's first launch faults hipGraphLaunch (round 3's segfault, located
-    in round 4: profiles/r04_graph_churn.txt; no hipFree inside any capture is involved).  The engine keeps its own graphs out of
-    that window with this lock; it cannot see anybody else's.  Re-entrant; also taken by engine.empty_cache() and drop_graphs()."""
-    with _CAPTURE_LOCK:
-        yield
-
-
-def empty_cache() -> None:
-    """torch.cuda.empty_cache() that waits for a capture in progress (use this one beside a serving engine: segments must not go
-    back to the driver while another thread captures a forward)."""
-    with _CAPTURE_LOCK:
-        if torch.cuda.is_available():
-            torch.cuda.empty_cache()
-
-
-def _clone_out(o):
-    if isinstance(o, torch.Tensor):
-        return o.clone()
-    if isinstance(o, (tuple, list)):
-        return type(o)(_clone_out(v) for v in o)
-    return o
-
-
-def _retire(graphs=()) -> None:
-    """Caller holds _CAPTURE_LOCK.  Evicted graphs are DESTROYED here and nowhere else: dropping the cache's reference is not enough
-    when another thread fetched the graph a moment earlier and is still replaying it -- its reference would die outside the lock,
-    possibly between a capture and that graph's first launch.  A graph in use stays on the list until a later call."""
-    with _GRAPH_LOCK:
-        _GRAPH_RETIRED.extend(graphs)
-        idle = [g for g in _GRAPH_RETIRED if g.users == 0]
-        _GRAPH_RETIRED[:] = [g for g in _GRAPH_RETIRED if g.users != 0]
-    for g in idle:
-        g.destroy()
-
-
-class _Graphed:
-    def __init__(self, dev, fn, inputs, ep: _EnginePool):
-        lib = load_library()
-        self.ep, self.dev = ep, dev
-        self.users = 0                   # threads between fetching this graph from the cache and the end of their replay (_GRAPH_LOCK)
-        prev = getattr(_TLS, "guard", 0)
-        _TLS.guard, _TLS.capturing = 1, True
-        # Captured OUTSIDE inference mode whatever the caller's state: tensors created under torch.inference_mode() are inference
-        # tensors -- the static inputs could then not be copied into from a plain no_grad caller, and torch's CUDA generator creates
-        # its graph-safe state tensors at the first capture of a process: made under inference mode they break every later capture
-        # outside it ("Inplace update to inference tensor outside InferenceMode", seen on the MI355X).  One graph serves both states.
-        try:
-            with torch.inference_mode(False), torch.no_grad():
-                self.graph = torch.cuda.CUDAGraph()
-                self.inputs = [t.clone() for t in inputs]           # static inputs and flags: ordinary allocations (a few MB)
-                self.flags = torch.zeros(SAT_SLOTS, dtype=torch.int32, device=dev)
-                torch.cuda.synchronize(dev)
-                check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "dprnn_saturation_begin")
-                with torch.cuda.graph(self.graph, pool=ep.pool.id, capture_error_mode="thread_local"):
-                    self.outputs = fn(*self.inputs)
-        finally:
-            _TLS.guard, _TLS.capturing = prev, False
-            lib.dprnn_saturation_begin(0, 0)
-
-    def destroy(self):
-        """Release the executable graph now (caller holds _CAPTURE_LOCK and has seen users == 0)."""
-        graph, self.graph = self.graph, None
-        if graph is not None:
-            graph.reset()
-        self.outputs = self.inputs = None
-
-    def replay(self, inputs, host_flags=None):
-        ep = self.ep
-        lib = load_library()
-        with ep.lock:                    # graphs of one pool share their workspace addresses: one at a time, in enqueue order
-            cur = torch.cuda.current_stream(self.dev)
-            if ep.last is not None:
-                cur.wait_event(ep.last)
-            # the graph's own flag buffer is cleared (and registered for the read that follows) behind the previous replay
-            check(lib, lib.dprnn_saturation_begin(self.flags.data_ptr(), cur.cuda_stream), "dprnn_saturation_begin")
-            for s_, t in zip(self.inputs, inputs):
-                s_.copy_(t)
-            self.graph.replay()
-            out = _clone_out(self.outputs)
-            if host_flags is not None:
-                host_flags.copy_(self.flags, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            ep.last = ev
-        return out
 
 
 # Every module-level setting of this file is listed in exactly one of these two tuples (tests/test_abi_and_host.py checks that no
@@ -2142,141 +1098,6 @@ def launch_knobs() -> tuple:
     return tuple((k, _freeze(g[k])) for k in LAUNCH_KNOBS) + (
         ("mode", current_mode()), ("fast_act", lib.dprnn_get_fast_activations()), ("fast_head_act", lib.dprnn_get_fast_head_activations()),
         ("rowgemm_grid", lib.dprnn_get_rowgemm_grid()))
-
-
-def _graph_key(kind: str, model, inputs, extra=()):
-    params = tuple(p.data_ptr() for p in model.parameters()) + tuple(b.data_ptr() for b in model.buffers())
-    bn = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
-    knobs = launch_knobs() + (("pinned", bool(model.__dict__.get("_dprnn_pin_mode1", False))),)
-    return (kind, threading.get_ident(), id(model), tuple((tuple(t.shape), str(t.device)) for t in inputs), params, bn, knobs, extra)
-
-
-def _pool_reserved_bytes(ep: _EnginePool) -> int:
-    try:
-        return sum(int(seg.get("total_size", 0)) for seg in torch.cuda.memory_snapshot(ep.pool.id))
-    except Exception:
-        return 0
-
-
-def _keep_eager(key, why: str) -> None:
-    with _GRAPH_LOCK:
-        first = not _GRAPH_EAGER_KEYS
-        _GRAPH_EAGER_KEYS.add(key)
-        while len(_GRAPH_EAGER_KEYS) > 256:
-            _GRAPH_EAGER_KEYS.pop()
-    if first:
-        warnings.warn(f"HIP-graph capture skipped, this forward stays on eager launches: {why} (further ones are counted in "
-                      "engine.GRAPH_STATS without a warning)", RuntimeWarning, stacklevel=4)
-
-
-def _guard_call(dev, primary, fallback, what, module, owner):
-    """_guarded, or -- inside forward_async -- _guarded_async: (output, ticket)."""
-    if getattr(_TLS, "want_ticket", False):
-        return _guarded_async(dev, primary, fallback, what, module, owner=owner)
-    return _guarded(dev, primary, fallback, what, module, owner=owner)
-
-
-def _graphed(kind: str, model, inputs, fn, what: str, module=None, extra=(), need_bytes=None, owner=None):
-    """fn(*inputs) -- an inference forward over device tensors -- eagerly, or through its captured HIP graph (see above); either
-    way under the saturation guard, falling back to an eager forward in mode 1.  need_bytes: device memory the forward allocates
-    (a number or a callable), checked against what is free before capturing."""
-    dev = inputs[0].device
-    eager = lambda: fn(*inputs)
-    usable = (GRAPHS and PROFILE is None and getattr(_TLS, "guard", 0) == 0 and not getattr(_TLS, "capturing", False)
-              and not torch.is_grad_enabled())
-    if not usable:
-        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
-    key = _graph_key(kind, model, inputs, extra)
-    with _GRAPH_LOCK:
-        g = _GRAPH_CACHE.get(key)
-        seen = 0
-        if g is not None:
-            _GRAPH_CACHE.move_to_end(key)
-            g.users += 1
-        elif key not in _GRAPH_EAGER_KEYS:
-            seen = _GRAPH_SEEN.get(key, 0) + 1
-            _GRAPH_SEEN[key] = seen
-            _GRAPH_SEEN.move_to_end(key)
-            while len(_GRAPH_SEEN) > 64:
-                _GRAPH_SEEN.popitem(last=False)
-    if g is None and seen < 2:
-        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
-    with torch.cuda.device(dev):
-        if g is None:
-            ep = _engine_pool(dev)
-            with _CAPTURE_LOCK:
-                with _GRAPH_LOCK:
-                    evicted = []
-                    while len(_GRAPH_CACHE) >= max(1, GRAPH_CACHE_MAX):
-                        evicted.append(_GRAPH_CACHE.popitem(last=False)[1])
-                # nothing of the eager forwards' cached segments is left for the allocator to release while the capture runs
-                torch.cuda.synchronize(dev)
-                _retire(evicted)
-                del evicted
-                torch.cuda.empty_cache()
-                if owner is not None and ADAPTIVE_SCALE and current_mode() == 3:
-                    _scale_tensor(owner, dev)            # the activation-scale record exists before the capture (never allocated inside one)
-                need = need_bytes() if callable(need_bytes) else need_bytes
-                if need is not None:
-                    free, _ = torch.cuda.mem_get_info(dev)
-                    have = free + _pool_reserved_bytes(ep)
-                    if 1.1 * need > have:
-                        _count(GRAPH_STATS, "kept_eager_for_memory")
-                        _keep_eager(key, f"{what} needs about {need / 2**30:.1f} GiB, {have / 2**30:.1f} GiB are free on {dev}")
-                        return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
-                try:
-                    g = _Graphed(dev, fn, inputs, ep)
-                except Exception as exc:          # out of memory in the pool, a synchronising call inside the forward, ...
-                    _count(GRAPH_STATS, "capture_failures")
-                    try:
-                        torch.cuda.synchronize(dev)
-                    except Exception:
-                        pass
-                    _keep_eager(key, f"capture of {what} raised {type(exc).__name__}: {exc}")
-                    g = None
-                if g is not None:
-                    _count(GRAPH_STATS, "captures")
-                    with _GRAPH_LOCK:
-                        _GRAPH_CACHE[key] = g
-                        g.users += 1
-                    # The new graph's FIRST launch happens here, still under the capture lock: graphs are destroyed only under this
-                    # lock (eviction above, drop_graphs), and a graph destroyed between another graph's instantiation and its first
-                    # launch is what crashed hipGraphLaunch in round 3 (DESIGN.md 6b, profiles/r04_graph_churn.txt).
-                    return _replay_guarded(g, dev, inputs, eager, what, module, owner)
-            return _guard_call(dev, eager, _in_mode(1, eager), what, module, owner)
-        return _replay_guarded(g, dev, inputs, eager, what, module, owner)
-
-
-def _replay_guarded(g, dev, inputs, eager, what, module, owner):
-    """Replays g (whose `users` count the caller raised when it took g from the cache) and lets go of it."""
-    def run(host_flags=None):
-        _count(GRAPH_STATS, "replays")
-        return g.replay(inputs, host_flags)
-    try:
-        if getattr(_TLS, "want_ticket", False):
-            return _guarded_async(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
-        return _guarded(dev, run, _in_mode(1, eager), what, module, flags=g.flags, owner=owner, begin=False)
-    finally:
-        with _GRAPH_LOCK:
-            g.users -= 1
-
-
-def drop_graphs(release_pool: bool = True) -> None:
-    """Forget every captured forward; release_pool also hands the engine's graph memory pool back to the driver."""
-    with _CAPTURE_LOCK:                  # never while another thread captures: segments go back to the driver here
-        with _GRAPH_LOCK:
-            dropped = list(_GRAPH_CACHE.values())
-            _GRAPH_CACHE.clear()
-            _GRAPH_SEEN.clear()
-            _GRAPH_EAGER_KEYS.clear()
-            pools = list(_POOLS.values()) if release_pool else []
-            if release_pool:
-                _POOLS.clear()
-        if torch.cuda.is_available() and (dropped or pools or _GRAPH_RETIRED):
-            torch.cuda.synchronize()
-            _retire(dropped)
-            del dropped, pools
-            torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------ guarded entry points
@@ -2415,3 +1236,22 @@ def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
     run = lambda: _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira)
     return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNSpeTasNet ragged forward", model.separation)
 
+
+# ---- the rest of the engine (round 5: cut along its seams; every setting above stays the one namespace callers read and assign) ----
+from .scale import (  # noqa: E402,F401
+    ForwardTicket, _bn_buffers, _count, _guarded, _guarded_async, _saturated, _scale_end, _scale_record, _scale_tensor,
+    _set_slot, current_mode, path_slot, reset_scale, scale_exponents, unpin, use_gemm_mode,
+)
+from .submodules import (  # noqa: E402,F401
+    _auxiliary_embedding_impl, _check_frames, _device_f32, _no_grad_only, _rows_affine, _separator_forward_impl,
+    _separator_masks_impl, block_forward, conv1x1_forward, decoder_forward, encoder_forward, fusion_forward, linear_forward,
+    norm_forward, resblock_forward, single_rnn_forward,
+)
+from .ragged import (  # noqa: E402,F401
+    _Fan, _bn_training, _spe_forward_ragged_impl, _tasnet_forward_ragged_impl, dprnn_process_ragged, ragged_supported,
+)
+from .graphs import (  # noqa: E402,F401
+    _CAPTURE_LOCK, _EnginePool, _GRAPH_CACHE, _GRAPH_EAGER_KEYS, _GRAPH_LOCK, _GRAPH_RETIRED, _GRAPH_SEEN, _Graphed, _POOLS,
+    _clone_out, _engine_pool, _graph_key, _graphed, _guard_call, _keep_eager, _pool_reserved_bytes, _replay_guarded, _retire,
+    capture_lock, drop_graphs, empty_cache,
+)
