@@ -707,6 +707,41 @@ def test_time_split_bilstm_with_the_linear_folded_in(seq_tile, path, fused, dims
     assert np.allclose(sg[:, 1], (wb ** 2).sum(1), rtol=2e-5)
 
 
+@pytest.mark.parametrize("path", ["intra", "inter"])
+def test_folded_linear_of_a_unidirectional_lstm(path):
+    """dprnn_rnn_lin_fwd phase 2 alone (P = NULL): a unidirectional LSTM + its Linear 128 -> 128 in one launch (the reference's inter-chunk RNN
+    may be unidirectional, dprnn.py:68), against the numpy oracle."""
+    B, S, K = 2, 19, 23
+    rng = np.random.default_rng(91)
+    X = rng.standard_normal((B, S, K, 128)).astype(np.float32)
+    sd, p = _lstm_sd(47, bidir=False)
+    W = (rng.standard_normal((128, 128)) / 11.0).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    if path == "intra":
+        h = onp.single_rnn(sd, p, X.reshape(B * S, K, 128), "LSTM", False).reshape(B, S, K, 128)
+    else:
+        h = onp.single_rnn(sd, p, X.transpose(0, 2, 1, 3).reshape(B * K, S, 128), "LSTM", False).reshape(B, K, S, 128).transpose(0, 2, 1, 3)
+    want = h.astype(np.float64) @ W.T.astype(np.float64) + b
+    st = _st()
+    packed = torch.empty(2 * engine.PACK_PER_DIR_MAX, device=DEV)
+    bsum = torch.empty(2 * 512, device=DEV)
+    linp = torch.empty(st.lib.dprnn_lin_pack_floats(), device=DEV)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [_t(sd[f"{p}.rnn.{n}"]) for n in names]
+    st.call("dprnn_rnn_pack_ex", 3, 0, *[t.data_ptr() for t in w], 0, 0, 0, 0, packed.data_ptr(), bsum.data_ptr())
+    st.call("dprnn_lin_pack_f16", _t(W).data_ptr(), 1, linp.data_ptr())
+    addr = (B * S, K, B * S, 0, K, 1) if path == "intra" else (B * K, S, K, S * K, 1, K)
+    Z = torch.full((B, S, K, 128), float("nan"), device=DEV)
+    stats = torch.zeros(B, 2, device=DEV, dtype=torch.float64)
+    st.call("dprnn_rnn_lin_fwd", 2, 0, _t(X).data_ptr(), 0, 0, 0, 0, 0.0, S if path == "intra" else K, S * K, 0, packed.data_ptr(), bsum.data_ptr(), 1,
+            linp.data_ptr(), _t(b).data_ptr(), 0, Z.data_ptr(), stats.data_ptr(), *addr, 2064)
+    torch.cuda.synchronize()
+    got = Z.cpu().numpy()
+    assert np.isfinite(got).all() and rel_l2(got, want) < 1e-6, rel_l2(got, want)
+    gb = got.astype(np.float64).reshape(B, -1)
+    assert np.allclose(stats.cpu().numpy()[:, 1], (gb ** 2).sum(1), rtol=1e-6)
+
+
 def test_direction_serial_form_refuses_what_it_does_not_do():
     st = _st()
     z = torch.zeros(64, device=DEV)

@@ -324,6 +324,42 @@ def test_every_golden_in_every_fp32_class_gate_gemm_mode(name, mode):
     print(f"{name}: rel-L2 vs reference {r:.2e} in gate-GEMM mode {mode}")
 
 
+@pytest.mark.parametrize("form", ["split", "serial"])
+@pytest.mark.parametrize("name", ["bss_full_b2", "bss_wide_small", "bss_wide_hop5", "bss_wide_k250", "bss_narrow64_small", "spe_full_b1",
+                                  "spe_wide_small_film", "ira_full_b1"])
+def test_goldens_with_the_linear_folded_in(name, form, monkeypatch):
+    """The folded launch structures (engine.LIN_FOLD, section 3a of DESIGN.md) are chosen from ~31 utterances up, the reference fixtures
+    hold 1-3: here both forms are FORCED on them (64-sequence tiles, whatever the batch) -- the time-split form (odd and even T, the
+    shipped K = 250 / S = 194 among them) and the direction-serial form against the reference's own outputs, at the golden tolerances."""
+    monkeypatch.setattr(engine, "LIN_FOLD", form)
+    monkeypatch.setattr(engine, "GEMM_MODE", 3)
+    for k in ("intra", "inter", "serial_intra", "serial_inter"):
+        monkeypatch.setitem(engine.SEQ_TILE, k, 2064)
+    g = load_golden(name)
+    m = g["meta"]
+    model, _, _ = build_model(m["kind"], m["cfg"], m["seed"], _dev())
+    calls = []
+    real = engine.Stage.call
+
+    def spy(self, fn, *a):
+        calls.append(fn)
+        return real(self, fn, *a)
+    monkeypatch.setattr(engine.Stage, "call", spy)
+    with torch.no_grad():
+        if m["kind"] == "bss":
+            out, logits = model(torch.from_numpy(g["mix"]).to(_dev())), None
+        else:
+            out, logits = model(torch.from_numpy(g["mix"]).to(_dev()), torch.from_numpy(g["aux"]).to(_dev()), torch.tensor(float(g["aux_len"])))
+    torch.cuda.synchronize()
+    want_fn = "dprnn_rnn_lin_split_fwd" if form == "split" else "dprnn_rnn_lin_fwd"
+    assert want_fn in calls and "dprnn_proj_stats_hp_fwd" not in calls and "dprnn_proj_stats_fwd" not in calls, sorted(set(calls))
+    r = _close(out.cpu().numpy(), g["out"], f"{name} ({form} fold)")
+    if logits is not None:
+        assert rel_l2(logits.cpu().numpy(), g["logits"]) <= REL_TOL
+    print(f"{name}: rel-L2 vs reference {r:.2e} with the Linear folded in ({form})")
+    engine.drop_graphs()
+
+
 @pytest.mark.parametrize("kind", ["bss", "spe"])
 @pytest.mark.parametrize("where", ["residual_stream", "bottleneck", "input_nan"])
 def test_values_beyond_the_f16_range_fall_back_to_bf16_pieces(kind, where):
