@@ -37,6 +37,10 @@ constexpr bool diag(int bit) { return (DPRNN_SPLIT8_DIAG & bit) != 0; }
 #define DPRNN_SPLIT8_NT 1                              // experiment: non-temporal cache policy (aux bit 1) on the activation streams of the PJ forms:
 #endif                                                 //   1 x / z loads | 2 x' stores | 4 stores of the folded Linear's rows | 8 loads of the partial products
 constexpr int nt_aux(int bit) { return (DPRNN_SPLIT8_NT & bit) ? 2 : 0; }
+#ifndef DPRNN_SPLIT8_DEFER_XS
+#define DPRNN_SPLIT8_DEFER_XS 1                        // launches with a pending norm: the x' rows staged at the end of a step are STORED after the first k-slab of
+#endif                                                 // the next step -- behind, not in front of, that step's first weight requests in the in-order vmcnt queue
+                                                       // (round 5: +1.2 % on the forward; 1 = the folded (PJ) forms, 2 = also the unfolded inference forms)
 #ifndef DPRNN_CELL_SHARED_RCP
 #define DPRNN_CELL_SHARED_RCP 1                        // hardware-activation builds of the TRANS forms: two reciprocals per unit-step instead of five
 #endif
@@ -265,8 +269,24 @@ void bilstm_split8_kernel(RecurArgs a) {
         }
         fence();
     };
+    constexpr bool DEFER = FUSE && XPF && !SAVE && !STAMP && F16 && (DPRNN_SPLIT8_DEFER_XS >= 2 || (DPRNN_SPLIT8_DEFER_XS == 1 && PJ != 0));
+    f32x4 xkeep[DEFER ? NT : 1];
+    long long tkeep = 0;
+    bool keep_live = false;
+    auto x_flush = [&]() __attribute__((always_inline)) {
+        if constexpr (DEFER) {
+            if (keep_live) {
+                const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(tkeep) * F);
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xkeep[m]), ors, rowoff_x[xrow0 + 16 * m] + c4 * 16u, 0, nt_aux(2));
+                keep_live = false;
+            }
+        }
+    };
     auto x_finish = [&](long long t, int xb, bool live) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t ors = rsrc_at(a.Xout + tbase(t) * F);
+        if constexpr (DEFER) { tkeep = t; keep_live = live && (dir == 0 || split); }
         fence();
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
@@ -277,7 +297,8 @@ void bilstm_split8_kernel(RecurArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] + ((zq[m][e] - mu) * rs * gam[e] + bet[e]);
                 const unsigned xo = rowoff_x[xrow0 + 16 * m] + c4 * 16u;
-                if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo : OOB, 0, PJ ? nt_aux(2) : 0);
+                if constexpr (DEFER) xkeep[m] = v;
+                else if (!diag(64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (live && (dir == 0 || split)) ? xo : OOB, 0, PJ ? nt_aux(2) : 0);
             }
             unsigned pa[3], pb[3];
             if constexpr (F16) {
@@ -448,7 +469,7 @@ void bilstm_split8_kernel(RecurArgs a) {
         }
     };
     // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end
-    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0, bool pj = false) __attribute__((always_inline)) {
+    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0, bool pj = false, bool flush = false) __attribute__((always_inline)) {
         if constexpr (NP == 6) {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
             slab(ac, reg, fb, fa, 1, s0 + 2, true, true, false);
@@ -457,6 +478,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             slab(ac, reg, fb, fa, 3, (s0 + 4) & 7, true, false, false);
         } else {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first, pj);
+            if (flush) x_flush();                      // (DEFER) last step's x' rows: behind this step's first weight requests
             slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false, pj);
             slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false, pj);
             if (xhook) x_issue(tx);
@@ -685,7 +707,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             const bool more = step + 1 < se;
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
-            half(acc, xreg + rb * REG, 0, true);
+            half(acc, xreg + rb * REG, 0, true, false, 0, false, DEFER);
             pscale();
             half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn, PJ != 0);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
@@ -702,6 +724,7 @@ void bilstm_split8_kernel(RecurArgs a) {
             __syncthreads();
         }
     }
+    x_flush();
     if constexpr (PJ != 0) {                           // the last step's h: the Linear alone, then the sums of the tile
         const char* const hlast = hreg + (DB ? (se & 1) : 0) * REG;
         if (se > sb) {
