@@ -469,7 +469,7 @@ void bilstm_split8_kernel(RecurArgs a) {
         }
     };
     // four slabs of one region: global slabs s0 .. s0 + 3, the weights of slab (s0 + 4) & 7 are in flight at the end
-    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0, bool pj = false, bool flush = false) __attribute__((always_inline)) {
+    auto half = [&](f32x4 (&ac)[NT][4], const char* reg, int s0, bool first, bool xhook = false, long long tx = 0, bool pj = false, int flush = -1) __attribute__((always_inline)) {
         if constexpr (NP == 6) {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first);
             slab(ac, reg, fb, fa, 1, s0 + 2, true, true, false);
@@ -478,11 +478,14 @@ void bilstm_split8_kernel(RecurArgs a) {
             slab(ac, reg, fb, fa, 3, (s0 + 4) & 7, true, false, false);
         } else {
             slab(ac, reg, fa, fb, 0, s0 + 1, false, true, first, pj);
-            if (flush) x_flush();                      // (DEFER) last step's x' rows: behind this step's first weight requests
+            if (flush == 0) x_flush();                 // (DEFER) last step's x' rows: behind this step's weight requests so far
             slab(ac, reg, fa, fb, 1, s0 + 2, true, true, false, pj);
+            if (flush == 1) x_flush();
             slab(ac, reg, fa, fb, 2, s0 + 3, true, true, false, pj);
+            if (flush == 2) x_flush();
             if (xhook) x_issue(tx);
             slab(ac, reg, fa, fb, 3, (s0 + 4) & 7, true, false, false, pj);
+            if (flush == 3) x_flush();
         }
     };
     // PJ: the Linear alone over the h image `reg` (after the last step: its h has no gate GEMM to ride on)
@@ -707,9 +710,12 @@ void bilstm_split8_kernel(RecurArgs a) {
             const bool more = step + 1 < se;
             const long long tn = more ? (dir ? (t - 1) : (t + 1)) : t;
             const int rb = DB ? (step & 1) : 0, wb = DB ? (rb ^ 1) : 0;      // image read in this step / written for the next
-            half(acc, xreg + rb * REG, 0, true, false, 0, false, DEFER);
+#ifndef DPRNN_SPLIT8_DEFER_AT
+#define DPRNN_SPLIT8_DEFER_AT 1                        // k-slab (0 .. 7 over [x | h]) after which the deferred x' rows are stored
+#endif
+            half(acc, xreg + rb * REG, 0, true, false, 0, false, (DEFER && DPRNN_SPLIT8_DEFER_AT < 4) ? DPRNN_SPLIT8_DEFER_AT : -1);
             pscale();
-            half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn, PJ != 0);
+            half(acc, hreg + rb * REG, 4, false, XPF && !diag(16), tn, PJ != 0, (DEFER && DPRNN_SPLIT8_DEFER_AT >= 4) ? DPRNN_SPLIT8_DEFER_AT - 4 : -1);
             if constexpr (STAMP) { fence(); st_b = __builtin_amdgcn_s_memtime(); fence(); st_p1 += st_b - st_a; }
             if constexpr (!DB) __syncthreads();        // single-buffered: every wave is done reading the image of this step
             if constexpr (PJ != 0) {                   // the Linear of h_{step-1} is complete: out; phase 2 asks for time t's partial rows
