@@ -12,6 +12,8 @@ import sys
 
 PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tss-with-dprnn_amd")
 SRC = os.path.join(PKG, "engine.py")
+if os.path.exists(os.path.join(PKG, "graphs.py")):
+    sys.exit("the package is already split (graphs.py exists): this tool is kept for the record of how the cut was made")
 text = open(SRC).read()
 lines = text.split("\n")
 tree = ast.parse(text)
