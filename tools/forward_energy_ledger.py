@@ -61,10 +61,13 @@ def measure_calls(label, call, seconds, ms_hint=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--fold", choices=["off", "auto"], default="auto",
+                    help="the forward and the per-launch items with the Linear folded into the recurrence (time-split, two launches per path) or not")
     a = ap.parse_args()
     import tss_with_dprnn_amd as pkg
     from tss_with_dprnn_amd import engine
     from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_state
+    engine.LIN_FOLD = a.fold
     dev = torch.device("cuda:0")
     ctor = ["input_size", "feature_size", "hidden_size", "chunk_length", "kernel_size", "hop_length", "n_repeats",
             "bidirectional", "rnn_type", "norm_type", "activation_type", "dropout", "stride"]
@@ -117,9 +120,41 @@ def main():
     res["proj"] = measure_calls("projection 256 -> 128 + GroupNorm sums on h piece quads",
                                 lambda: st.call("dprnn_proj_stats_hp_fwd", p(H), p(Wp), p(bp), p(Zo), p(stats2), rows, S * K, 0, 0, 256), a.seconds)
 
-    f = res["forward"]
+    if a.fold != "off":
+        # the folded form (round 5): each path is two launches of both directions, cut in time; the Linear rides in the h half of the gate GEMM
+        linp = torch.empty(st.lib.dprnn_lin_pack_floats(), device="cuda")
+        st.call("dprnn_lin_pack_f16", p(Wp), 2, p(linp))
+        Z2 = torch.empty_like(Z)
+        state = torch.empty(max(st.lib.dprnn_rnn_lin_state_floats(n, 2064) for n in (B * S, B * K)), device="cuda")
+
+        def phase(ph, addr, per, fuse):
+            tail = (p(packed), p(bsum), p(linp))
+            if ph == 1:
+                norm = (p(Z), p(stats), p(gamma), p(beta), 1e-8) if fuse else (0, 0, 0, 0, 0.0)
+                args = (1, p(X), *norm, per, S * K, p(X2) if fuse else 0, *tail, 0, p(Z2), 0, p(state), *addr, 2064)
+            else:
+                args = (2, p(X2), 0, 0, 0, 0, 0.0, per, S * K, 0, *tail, p(bp), p(Z2), p(stats2), p(state), *addr, 2064)
+            return lambda: st.call("dprnn_rnn_lin_split_fwd", *args)
+        # phase 2 needs the state phase 1 of the same path left: run each pair once before timing the second alone
+        for nm, addr, per in (("intra", intra, S), ("inter", inter, K)):
+            phase(1, addr, per, 1)()
+            res[nm + "_p1"] = measure_calls(f"folded {nm}-chunk path, phase 1 (first halves in time; pending norm folded in)", phase(1, addr, per, 1), a.seconds)
+            res[nm + "_p2"] = measure_calls(f"folded {nm}-chunk path, phase 2 (second halves; new z and its sums)", phase(2, addr, per, 0), a.seconds)
+        f = res["forward"]
+        items = [("folded intra paths, phase 1 (12)", 12, res["intra_p1"]), ("folded intra paths, phase 2 (12)", 12, res["intra_p2"]),
+                 ("folded inter paths, phase 1 (12)", 12, res["inter_p1"]), ("folded inter paths, phase 2 (12)", 12, res["inter_p2"])]
+        ledger(f, idle_w, items)
+        print("\n# for comparison, the unfolded launches of the same shapes on this box (not part of this forward):")
+        for k in ("intra", "inter", "proj"):
+            r = res[k]
+            print(f"#   {k:6s} {r['ms_per_call']:.3f} ms, {r['joules_per_call']:.3f} J each")
+        return
     items = [("recurrences, first path (2)", 2, res["intra_first"]), ("recurrences, intra-chunk (10)", 10, res["intra"]),
              ("recurrences, inter-chunk (12)", 12, res["inter"]), ("projections (24)", 24, res["proj"])]
+    ledger(res["forward"], idle_w, items)
+
+
+def ledger(f, idle_w, items):
     print(f"\n# forward: {f['joules_per_call']:.1f} J and {f['ms_per_call']:.2f} ms per 64 utterances at {f['mean_watts']:.0f} W "
           f"(mid-run {f['mid_run_watts_sclk']}); idle {idle_w:.0f} W = {idle_w * f['ms_per_call'] / 1e3:.1f} J of it")
     print(f"{'item':34s} {'launches':>8s} {'ms each':>8s} {'W alone':>8s} {'J each':>7s} {'J total':>8s} {'share of the forward':>22s}")
