@@ -148,6 +148,13 @@ GRAD_CASES = [
     ("grad_bss_wide_gru", dict(WIDE, rnn_type="GRU", n_repeats=1), 2, 211, 69),
     ("grad_bss_wide_gru_unidir", dict(WIDE, rnn_type="GRU", bidirectional=False, norm_type="gLN", n_repeats=2), 3, 211, 70),
     ("grad_bss_wide_rnn", dict(WIDE, rnn_type="RNN", n_repeats=1), 2, 211, 71),
+    # narrower than the kernels' build (round 5: trained on the zero-padded twin, padded.py): a power-of-two width, widths with no power
+    # of two in them (input, feature and hidden size all different; gLN, relu, unidirectional GRU in the second)
+    ("grad_bss_narrow64", dict(WIDE, feature_size=64, hidden_size=64), 2, 300, 72),
+    ("grad_bss_narrow_n40_f96_h80", dict(WIDE, input_size=40, feature_size=96, hidden_size=80, norm_type="gLN", activation_type="relu",
+                                         n_repeats=1), 3, 211, 73),
+    ("grad_bss_narrow_f48_gru_unidir", dict(WIDE, input_size=24, feature_size=48, hidden_size=32, rnn_type="GRU", bidirectional=False,
+                                            n_repeats=1), 2, 211, 74),
 ]
 N_PROJ = 8
 FULL_MAX = 40000          # gradients up to this many elements are stored whole, larger ones as projections

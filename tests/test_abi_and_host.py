@@ -474,3 +474,35 @@ def test_padded_twin_places_every_block_and_scales_every_global_norm():
     mb, _, _ = build_model("bss", big, 3, None)
     with pytest.raises(NotImplementedError, match="above the kernels' build"):
         padded.twin_of(mb)
+
+
+def test_placed_parameters_hand_a_narrow_model_the_real_blocks_of_its_twins_gradient():
+    """Training a narrow model (padded.placed_parameters): the twin's parameters as differentiable functions of the narrow ones.  Values equal
+    the twin's own; a gradient w.r.t. a placed parameter reaches the narrow parameter as exactly the blocks that are real (gate blocks,
+    direction blocks, speaker blocks), and nothing of the padding."""
+    import torch
+    from conftest import build_model
+    from tss_with_dprnn_amd import padded
+    tiny = dict(input_size=8, feature_size=16, hidden_size=16, chunk_length=10, kernel_size=2, hop_length=5, n_repeats=1)
+    m, _, _ = build_model("bss", tiny, 5, None)
+    tm, tw = padded.twin_of(m)
+    placed = padded.placed_parameters(m, tw)
+    twin = dict(tm.named_parameters())
+    gen = torch.Generator().manual_seed(0)
+    up = {k: torch.randn(v.shape, generator=gen) for k, v in twin.items()}
+    total = 0.0
+    for k, v in placed.items():
+        assert torch.equal(v.detach(), twin[k].detach()), k
+        total = total + (v * up[k]).sum()
+    total.backward()
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None and prm.grad.shape == prm.shape, k
+        want = torch.zeros_like(prm)
+        scratch = torch.zeros_like(twin[k])
+        # the inverse of the placement, by placing an index image: element i of the narrow tensor lands where its index lands
+        idx = torch.arange(prm.numel(), dtype=torch.float32).reshape(prm.shape) + 1.0
+        padded._place(scratch, idx, padded._blocks(k, tuple(prm.shape), tw.narrow_cfg))
+        where = scratch.reshape(-1).nonzero().squeeze(1)
+        assert where.numel() == prm.numel(), k
+        want.reshape(-1)[(scratch.reshape(-1)[where] - 1.0).long()] = up[k].reshape(-1)[where]
+        assert torch.equal(prm.grad, want), k

@@ -542,7 +542,7 @@ def test_narrow_models_run_as_zero_padded_twins_and_follow_their_parameters():
     """padded.py: a model narrower than the kernels' build is computed on a twin at the built widths whose extra rows / columns are
     zero.  The twin follows the model (an in-place parameter update shows in the next forward, graph replay included), train-mode
     BatchNorm statistics land in the NARROW model's buffers as torch's own modules would leave them, widths above the build and
-    training a narrow model raise."""
+    training a narrow SPEAKER-CONDITIONED model raise (a narrow DPRNNTasNet trains on its twin: tests/test_gpu_train.py, grad_bss_narrow_*)."""
     import warnings
     from tss_with_dprnn_amd import padded
     over = dict(input_size=48, feature_size=64, hidden_size=64, O=64, P=96, embeddings_size=40, chunk_length=16, hop_length=8, n_repeats=1,

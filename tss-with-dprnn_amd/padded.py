@@ -16,8 +16,11 @@ computed exactly by the built kernels on a zero-padded twin:
 by placing every tensor's blocks -- gate blocks of the RNN weights, direction blocks of the Linears after a recurrence, speaker blocks of
 the mask head's conv2d, the [x | embedding] column blocks of the 'cat' bottleneck and of aux_linear -- at the built offsets, and
 refreshes it in place whenever a parameter of the narrow model changed (``_version`` counters: the addresses the captured graphs
-hold stay valid).  BatchNorm buffers a train-mode forward updates are written back.  Inference only: the backward kernels run on
-the built widths (training a narrow model raises).  Wider than built is not supported.
+hold stay valid).  BatchNorm buffers a train-mode forward updates are written back.  TRAINING (DPRNNTasNet, round 5): the training
+kernels run the twin as well -- the same element-count correction on the two sums of every global norm's backward
+(training._count_scale_red) -- and ``placed_parameters`` makes the twin's parameters differentiable functions of the narrow ones, so
+``loss.backward()`` leaves each narrow parameter the real block of its twin's gradient.  The speaker-conditioned models train at the
+built widths only.  Wider than built is not supported.
 """
 from __future__ import annotations
 
@@ -63,12 +66,30 @@ def _blocks(name: str, shape, cfg: dict):
     return dims
 
 
-def _place(dst: torch.Tensor, src: torch.Tensor, dims) -> None:
+def _place(dst: torch.Tensor, src: torch.Tensor, dims, copy: bool = True) -> None:
     import itertools
     for combo in itertools.product(*dims):
         s_idx = tuple(slice(a, a + n) for a, n, _ in combo)
         d_idx = tuple(slice(b, b + n) for _, n, b in combo)
-        dst[d_idx].copy_(src[s_idx])
+        if copy:
+            dst[d_idx].copy_(src[s_idx])
+        else:
+            dst[d_idx] = src[s_idx]          # index assignment: recorded by autograd when src requires grad
+
+
+def placed_parameters(model, tw: "Twin") -> Dict[str, torch.Tensor]:
+    """The twin's parameters as differentiable functions of the narrow model's (training): every narrow parameter placed into zeros of
+    the built shape with autograd watching, so the gradient of a twin parameter flows back to the blocks that are real."""
+    built = {k: tuple(v.shape) for k, v in tw.model.named_parameters()}
+    out = {}
+    for k, v in model.named_parameters():
+        if built[k] == tuple(v.shape):
+            out[k] = v
+            continue
+        d = v.new_zeros(built[k])
+        _place(d, v, _blocks(k, tuple(v.shape), tw.narrow_cfg), copy=False)
+        out[k] = d
+    return out
 
 
 class Twin:

@@ -187,6 +187,7 @@ def forward_train(model, wav: torch.Tensor, keep: bool = True, fusion: Optional[
             Zp = torch.empty(rows, F_BUILT, **f32)
             st.call("dprnn_proj_stats_fwd", _p(Hp), _p(w), _p(_param(lin.bias, "linear.bias", dev)), _p(Zp), _p(stats[1 + p]),
                     rows, S * K, ndir * F_BUILT)
+            engine._count_scale(stats[1 + p], norm, st, B)      # zero-padded twin of a narrow model: sums over the REAL channel count
             gamma, beta, eps = _norm_params(norm)
             gq, bq = _param(gamma, "norm.weight", dev), _param(beta, "norm.bias", dev)
             if fold and p + 1 < npth:
@@ -245,6 +246,21 @@ class _Scratch:
             self.off[name] = self.top
             self.top += n
         return self.buf.data_ptr() + 8 * self.off[name]
+
+    def view(self, name: str, n: int) -> torch.Tensor:
+        """Slot `name` (already handed out) as a tensor of n doubles."""
+        return self.buf[self.off[name]: self.off[name] + n]
+
+
+def _count_scale_red(scr: "_Scratch", name: str, norm, st: Stage, n: int) -> None:
+    """Zero-padded twin of a narrow model (padded.py): the two per-utterance sums of a global norm's backward (sum of gamma dy, sum of
+    gamma dy x_hat -- the padded channels add nothing to either, their gamma is zero) are divided by rows x BUILT channels in the kernel
+    that uses them; scaled by built / real channels that is the mean over the real element count, as in the forward
+    (engine._count_scale)."""
+    f = norm.__dict__.get("_dprnn_count_scale", 1.0)
+    if f != 1.0:
+        with torch.cuda.stream(st.tstream):
+            scr.view(name, 2 * n).mul_(f)
 
 
 def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch] = None, extras: Optional[dict] = None
@@ -357,6 +373,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         a_red, a_dgb = scr.slot(f"red{p}", 2 * B), scr.slot(f"dgb{p}", 2 * F_BUILT)
         st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
                 _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
+        _count_scale_red(scr, f"red{p}", norm, st, B)
         f16_lin = wgrad_f16                                         # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum,
         st.call("dprnn_gn_bwd_dz_ex", zmax.data_ptr() if f16_lin else 0,      # which the kernel that writes dZ measures
                 _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
@@ -485,6 +502,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     a_red0, a_dgb0 = scr.slot("red_bn", 2 * B), scr.slot("dgb_bn", 2 * N)
     st.call("dprnn_encoder_norm_bwd_stats", _p(wav), _p(enc_w), _p(dA), _p(stats[0]), _p(gamma), eps, a_red0, a_dgb0,
             B, geo.T, L, N, ks, geo.stride)
+    _count_scale_red(scr, "red_bn", sep.bottleneck[0], st, B)
     gname, bname = ("gamma", "beta") if hasattr(sep.bottleneck[0], "gamma") else ("weight", "bias")
     grads[f"separation.bottleneck.0.{gname}"] = to_grad(a_dgb0, gamma)
     grads[f"separation.bottleneck.0.{bname}"] = to_grad(a_dgb0 + 8 * N, beta)
@@ -667,13 +685,23 @@ class _TasNetFunction(torch.autograd.Function):
 
 def tasnet_forward_autograd(model, wav: torch.Tensor) -> torch.Tensor:
     """model(wav) under autograd: differentiable w.r.t. every parameter (not w.r.t. the waveform)."""
-    check_supported_train(model.cfg)
+    from . import padded
     wav = engine.check_input(wav)
     if wav.requires_grad:
         raise NotImplementedError("DPRNN MI355X training path: gradients w.r.t. the input waveform are not computed")
     named = [(n, p) for n, p in model.named_parameters()]
     for n, p in named:
         _param(p, n, wav.device)
+    if padded.needs_twin(model.cfg):
+        # A narrower model trains on its zero-padded twin (padded.py): the kernels run the twin, whose parameters are the narrow ones
+        # placed into zeros -- a differentiable function of them, so autograd hands every narrow parameter the block of the twin's
+        # gradient that belongs to it and drops the padding's.  (Wider than the build: padded.Twin raises.)
+        run, tw = padded.twin_of(model)
+        check_supported_train(run.cfg)
+        wide = padded.placed_parameters(model, tw)
+        with torch.cuda.device(wav.device):
+            return _TasNetFunction.apply(run, wav, tuple(n for n, _ in named), *[wide[n] for n, _ in named])
+    check_supported_train(model.cfg)
     with torch.cuda.device(wav.device):
         return _TasNetFunction.apply(model, wav, tuple(n for n, _ in named), *[p for _, p in named])
 
@@ -793,4 +821,10 @@ class FusedAdam(torch.optim.Optimizer):
                 b1, b2 = group["betas"]
                 st.call("dprnn_adam_multi", _p(table), n, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                         float(group["weight_decay"]), step, float(clip_norm or 0.0), _p(sumsq))
+        # the kernels wrote the parameters through their pointers: tell torch (version counters), as an in-place torch update would --
+        # the zero-padded twin of a narrow model (padded.Twin.sync) and anything else that watches `_version` reads them again
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
         return None
