@@ -225,6 +225,12 @@ int dprnn_encoder_bwd(const float* wav, const float* enc_w, const float* dA, con
 int dprnn_rows64_affine(const float* X, const float* sc, const float* sh, float* A, int B, int L, void* stream);
 int dprnn_rows64_norm_bwd(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
                           double* red, double* dgb, float* dX, int B, int L, void* stream);
+/* The same for the zero-padded twin of a narrower model (padded.py: real channels in the leading columns, zeros behind them, gamma = beta =
+ * 0 there): count_scale = 64 / real channels turns the element count L x 64 of the two sums into L x real.  The other global norms take the
+ * same correction from the host between their two calls (stats and red are plain (sum, sum of squares) / (sum, sum) pairs of doubles: multiply
+ * them by built / real channels -- training._count_scale_red, engine._count_scale). */
+int dprnn_rows64_norm_bwd_ex(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
+                             double* red, double* dgb, float* dX, int B, int L, double count_scale, void* stream);
 
 /* ---- PIT SI-SDR loss = PITLossWrapper(pairwise_neg_sisdr, pit_from='pw_mtx') of asteroid==0.7.0 as called at
  * src/trainers/trainer.py:39,104.  fwd: moments [B][n][n][5], pw [B][n][n] (SI-SDR dB, estimate i vs target j),

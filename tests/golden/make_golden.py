@@ -258,6 +258,13 @@ GRAD_SPE_CASES = [
     ("grad_ira_wide_cat", dict(WIDE, fusion_type="cat", norm_type="ln", n_repeats=1, num_spks=11), 2, 300, 411, 187, True),
     ("grad_ira_wide_att", dict(WIDE, fusion_type="att", norm_type="ln", n_repeats=1, num_spks=11), 3, 211, 300, 488, True),
     ("grad_ira_wide_film_bneval", dict(WIDE, fusion_type="film", norm_type="gLN", n_repeats=1, num_spks=11), 2, 211, 300, 89, False),
+    # narrower than the kernels' build (round 5: trained on the zero-padded twin, padded.py), the speaker encoder narrowed as well
+    ("grad_spe_narrow_cat", dict(WIDE, input_size=48, feature_size=64, hidden_size=64, O=64, P=96, embeddings_size=40, fusion_type="cat",
+                                 norm_type="ln", n_repeats=1, num_spks=11), 3, 300, 411, 90, True),
+    ("grad_spe_narrow_att", dict(WIDE, input_size=40, feature_size=96, hidden_size=80, O=96, P=160, embeddings_size=48, fusion_type="att",
+                                 norm_type="gLN", n_repeats=1, num_spks=11), 2, 301, 411, 91, True),
+    ("grad_ira_narrow_film", dict(WIDE, feature_size=64, hidden_size=96, O=96, P=128, embeddings_size=64, fusion_type="film",
+                                  norm_type="ln", n_repeats=1, num_spks=11), 2, 211, 300, 192, True),
 ]
 
 

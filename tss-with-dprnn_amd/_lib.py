@@ -111,6 +111,7 @@ SIGNATURES = {
     "dprnn_mask_decode_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
     "dprnn_rows64_affine": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp],
     "dprnn_rows64_norm_bwd": [c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_i, c_fp],
+    "dprnn_rows64_norm_bwd_ex": [c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_i, c_i, c_d, c_fp],
     "dprnn_ola_prelu_sum": [c_fp] * 5 + [c_i] * 5 + [c_fp],
     "dprnn_segment_bwd": [c_fp] * 4 + [c_i] * 5 + [c_fp],
     "dprnn_encoder_norm_rows": [c_fp] * 5 + [c_i] * 6 + [c_fp],

@@ -348,6 +348,11 @@ void encoder_rows_kernel(const float* __restrict__ wav, const float* __restrict_
     }
 }
 
+__global__ void scale_f64_kernel(double* __restrict__ x, int n, double f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= f;
+}
+
 __global__ void scratch_to_grad_kernel(const double* __restrict__ s, float* __restrict__ g, int n, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) g[i] = accumulate ? g[i] + (float)s[i] : (float)s[i];
@@ -584,18 +589,30 @@ extern "C" int dprnn_rows64_affine(const float* X, const float* sc, const float*
     return dprnn_check_launch("encoder_rows_kernel<0,mat>");
 }
 
-extern "C" int dprnn_rows64_norm_bwd(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
-                                     double* red, double* dgb, float* dX, int B, int L, void* stream) {
+// count_scale: built / real channels when the 64 columns are the zero-padded twin of a narrower model (the two sums are divided by
+// L x 64 in the second pass; times count_scale that is L x real channels -- the padded columns add nothing to either sum)
+extern "C" int dprnn_rows64_norm_bwd_ex(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
+                                        double* red, double* dgb, float* dX, int B, int L, double count_scale, void* stream) {
     if (!X || !dA || !stats || !gamma || !red || !dgb || !dX || B < 1 || L < 1) { dprnn_set_error("dprnn_rows64_norm_bwd: null pointer / sizes"); return -1; }
+    if (!(count_scale >= 1.0)) { dprnn_set_error("dprnn_rows64_norm_bwd: count_scale must be >= 1 (built / real channels)"); return -1; }
     const Geo geo{B, 0, L, 64, 1, 1};
     const int ch = enc_chunks(B, L);
     hipLaunchKernelGGL((encoder_rows_kernel<1, true>), dim3(B * ch), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, geo, nullptr,
                        nullptr, nullptr, dA, stats, gamma, eps, red, dgb, nullptr, nullptr, ch, X, nullptr);
     int rc = dprnn_check_launch("encoder_rows_kernel<1,mat>");
     if (rc) return rc;
+    if (count_scale != 1.0) {
+        hipLaunchKernelGGL(scale_f64_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, red, 2 * B, count_scale);
+        rc = dprnn_check_launch("scale_f64_kernel");
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((encoder_rows_kernel<2, true>), dim3(B * ch), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, geo, nullptr,
                        nullptr, nullptr, dA, stats, gamma, eps, red, nullptr, nullptr, nullptr, ch, X, dX);
     return dprnn_check_launch("encoder_rows_kernel<2,mat>");
+}
+extern "C" int dprnn_rows64_norm_bwd(const float* X, const float* dA, const double* stats, const float* gamma, float eps,
+                                     double* red, double* dgb, float* dX, int B, int L, void* stream) {
+    return dprnn_rows64_norm_bwd_ex(X, dA, stats, gamma, eps, red, dgb, dX, B, L, 1.0, stream);
 }
 
 extern "C" int dprnn_scratch_to_grad(const double* scratch, float* grad, int n, int accumulate, void* stream) {

@@ -157,7 +157,7 @@ def check_supported(cfg: dict) -> None:
     bad = []
     if cfg["feature_size"] != F_BUILT or cfg["hidden_size"] != F_BUILT:
         bad.append(f"feature_size/hidden_size must be {F_BUILT} here (got {cfg['feature_size']}/{cfg['hidden_size']}; narrower models run "
-                   "through a zero-padded twin, padded.py: inference for every model class, training for DPRNNTasNet)")
+                   "through a zero-padded twin, padded.py)")
     if cfg["input_size"] != N_BUILT:
         bad.append(f"input_size must be {N_BUILT} here (got {cfg['input_size']}; narrower: zero-padded twin, padded.py)")
     if cfg["rnn_type"] not in CELL_ID:

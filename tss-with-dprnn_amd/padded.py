@@ -16,11 +16,11 @@ computed exactly by the built kernels on a zero-padded twin:
 by placing every tensor's blocks -- gate blocks of the RNN weights, direction blocks of the Linears after a recurrence, speaker blocks of
 the mask head's conv2d, the [x | embedding] column blocks of the 'cat' bottleneck and of aux_linear -- at the built offsets, and
 refreshes it in place whenever a parameter of the narrow model changed (``_version`` counters: the addresses the captured graphs
-hold stay valid).  BatchNorm buffers a train-mode forward updates are written back.  TRAINING (DPRNNTasNet, round 5): the training
+hold stay valid).  BatchNorm buffers a train-mode forward updates are written back.  TRAINING (round 5): the training
 kernels run the twin as well -- the same element-count correction on the two sums of every global norm's backward
 (training._count_scale_red) -- and ``placed_parameters`` makes the twin's parameters differentiable functions of the narrow ones, so
-``loss.backward()`` leaves each narrow parameter the real block of its twin's gradient.  The speaker-conditioned models train at the
-built widths only.  Wider than built is not supported.
+``loss.backward()`` leaves each narrow parameter the real block of its twin's gradient (DPRNNTasNet, DPRNNSpeTasNet and
+DPRNNSpeIRATasNet: tests/golden/grad_*_narrow_*.npz hold the reference's gradients).  Wider than built is not supported.
 """
 from __future__ import annotations
 

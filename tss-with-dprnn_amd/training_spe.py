@@ -111,6 +111,7 @@ def _fusion_for(st: Stage, model, wav, emb, geo):
                                           "(dprnn_spe.py:102-103); its gradient is not computed")
         stats_m = torch.zeros(B, 2, device=dev, dtype=torch.float64)
         st.call("dprnn_encoder_stats", _p(wav), _p(enc_w), _p(stats_m), B, geo.T, geo.L, N, ks, stride)
+        engine._count_scale(stats_m, sep.bottleneck[0], st, B)          # zero-padded twin of a narrow model: the real element count
         g_, b_, eps_ = _norm_params(sep.bottleneck[0])
         sc0 = torch.empty(B, N, device=dev, dtype=torch.float32)
         sh0 = torch.empty_like(sc0)
@@ -165,6 +166,7 @@ def spe_forward_train(model, wav, aux, aux_len, ira: bool = False):
     d0 = saved["d0"]
     stats_d = torch.zeros(B, 2, device=dev, dtype=torch.float64)
     st.call("dprnn_rows_stats", _p(d0), _p(stats_d), B, geo.L, N)
+    engine._count_scale(stats_d, se[0], st, B)
     g0, b0, eps0 = _norm_params(se[0])
     sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
     sh_d = torch.empty_like(sc_d)
@@ -387,7 +389,8 @@ def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[tor
         g0, b0, eps0 = _norm_params(se[0])
         a_red, a_dgb = scr.slot("red_d0", 2 * B), scr.slot("dgb_d0", 2 * N)
         dD0 = torch.empty(rows_m, N, **f32)
-        st.call("dprnn_rows64_norm_bwd", _p(d0), _p(dAn), _p(saved["stats_d"]), _p(g0), eps0, a_red, a_dgb, _p(dD0), B, geo.L)
+        st.call("dprnn_rows64_norm_bwd_ex", _p(d0), _p(dAn), _p(saved["stats_d"]), _p(g0), eps0, a_red, a_dgb, _p(dD0), B, geo.L,
+                float(se[0].__dict__.get("_dprnn_count_scale", 1.0)))
         _acc(grads, "separation.spk_encoder.0.weight", _to_grad(st, a_dgb, g0))
         _acc(grads, "separation.spk_encoder.0.bias", _to_grad(st, a_dgb + 8 * N, b0))
         # first separator pass: its decoded output is unused; the gradient enters through d0 (dprnn_spe_ira.py:79-80)
@@ -421,6 +424,7 @@ def spe_backward(model, saved: dict, d_est: torch.Tensor, d_logits: Optional[tor
     a_red, a_dgb = scr.slot("red_spk", 2 * B), scr.slot("dgb_spk", 2 * N)
     st.call("dprnn_encoder_norm_bwd_stats", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, a_dgb,
             B, geo_a.T, geo_a.L, N, ks, geo_a.stride)
+    training._count_scale_red(scr, "red_spk", se[0], st, B)
     _acc(grads, "separation.spk_encoder.0.weight", _to_grad(st, a_dgb, g0))
     _acc(grads, "separation.spk_encoder.0.bias", _to_grad(st, a_dgb + 8 * N, b0))
     st.call("dprnn_encoder_bwd", _p(aux), _p(enc_w), _p(dAn), _p(spk["stats_a"]), _p(g0), eps0, a_red, 0,
@@ -472,7 +476,7 @@ class _SpeFunction(torch.autograd.Function):
 
 def spe_forward_autograd(model, wav, aux, aux_len):
     """model(mix, reference, ref_len) under autograd: differentiable w.r.t. every parameter."""
-    check_supported_spe_train(model.cfg)
+    from . import padded
     wav, aux = engine.check_input(wav), engine.check_input(aux, "aux")
     if aux.shape[0] != wav.shape[0]:
         raise DprnnError("mixture and reference batch sizes differ")
@@ -481,5 +485,17 @@ def spe_forward_autograd(model, wav, aux, aux_len):
     named = [(n, p) for n, p in model.named_parameters()]
     for n, p in named:
         _param(p, n, wav.device)
+    if padded.needs_twin(model.cfg):
+        # a narrower model trains on its zero-padded twin (padded.py, training.tasnet_forward_autograd); the BatchNorm running statistics
+        # the twin's train-mode forward moved go back into the caller's buffers (their real channels), as after an inference forward
+        run, tw = padded.twin_of(model)
+        check_supported_spe_train(run.cfg)
+        wide = padded.placed_parameters(model, tw)
+        with torch.cuda.device(wav.device):
+            out = _SpeFunction.apply(run, wav, aux, aux_len, tuple(n for n, _ in named), *[wide[n] for n, _ in named])
+        if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in model.modules()):
+            tw.write_back_buffers(model)
+        return out
+    check_supported_spe_train(model.cfg)
     with torch.cuda.device(wav.device):
         return _SpeFunction.apply(model, wav, aux, aux_len, tuple(n for n, _ in named), *[p for _, p in named])
