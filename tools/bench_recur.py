@@ -318,9 +318,8 @@ def main():
         bwd_stamps(st, ncu * 2, a.T)        # two per CU: the production occupancy
         return
     if a.train == 3:
-        # BPTT occupancy probe (round 5): the f16 BPTT owns 64 sequences per workgroup, and a 32-utterance micro-batch gives 194 / 250 workgroups
-        # = at most one per CU although two fit (launch bounds (512, 2), 64 KB + 64 KB of LDS).  Same launch at 1, 1.5 and 2 workgroups per
-        # CU: time per workgroup tells whether a second resident workgroup overlaps its memory phase with the first one's GEMM phase.
+        # BPTT grid probe (round 5): the f16 BPTT owns 64 sequences and 128 KB of LDS per workgroup (one per CU); the same launch at 1, 1.5, 2,
+        # 3 and 4 rounds of workgroups: what a round costs, and that a partial round costs a whole one.
         lib.dprnn_set_gemm_mode(3)
         lib.dprnn_set_bwd_gemm_mode(3)
         for per_cu in (1.0, 1.5, 2.0, 3.0, 4.0):
@@ -328,7 +327,7 @@ def main():
             r = run_train(st, nwg32, a.T, iters=5)
             ms, tf = r["bwd"]
             msf, _ = r["fwd_train"]
-            print(f"bwd f16, {per_cu:.1f} 64-sequence workgroups per CU: {ms:.3f} ms = {ms / per_cu:.3f} ms per full round, {tf:.1f} TFLOP/s | "
+            print(f"bwd f16, {per_cu:.1f} rounds of 64-sequence workgroups (one per CU): {ms:.3f} ms = {ms / per_cu:.3f} ms per full round, {tf:.1f} TFLOP/s | "
                   f"fwd_train (32-sequence tiles, {2 * per_cu:.0f} per CU): {msf:.3f} ms = {msf / per_cu:.3f} per round", flush=True)
         lib.dprnn_set_gemm_mode(0); lib.dprnn_set_bwd_gemm_mode(0)
         return
