@@ -196,11 +196,27 @@ int dprnn_head_conv_bwd(const float* dU, const float* W2d, const float* X, const
 int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
                        const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
                        double* red, double* dgb, void* stream);
+/* The same with absmax [B][2] (optional; zeroed by the call): per utterance max |gamma dy| and max |x_hat| as float bits.  With red
+ * they bound the dZ that dprnn_lin_bwd_f16 forms on the fly: |dZ| <= rstd (max|gamma dy| + |red0 / n| + max|x_hat| |red1 / n|). */
+int dprnn_gn_bwd_stats_ex(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
+                          const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
+                          double* red, double* dgb, unsigned* absmax, void* stream);
 int dprnn_gn_bwd_dz(const float* dY, const float* Z, const double* stats, const double* red, const float* gamma,
                     float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
 /* absmax_out as an argument (dprnn_gn_bwd_dz_store_absmax selects it for the next call) */
 int dprnn_gn_bwd_dz_ex(float* absmax_out, const float* dY, const float* Z, const double* stats, const double* red,
                        const float* gamma, float eps, int B, int64_t rows_per_utt, float* dZ, void* stream);
+
+/* ---- Pass 2 of the GroupNorm backward AND the backward of the Linear in front of it (dprnn.py:88-90, 96-98) in one pass over the rows,
+ * in f16 pieces (bidirectional recurrences: H [rows][256], W = linear.weight [128][256]): dZ is formed while dY and Z are staged and never
+ * stored; dH [rows][256] = dZ W, dW [128][256] = dZ^T H, db [128] = column sums of dZ; hmax (optional device float) = max |dH|, the f16
+ * BPTT's gradient scale.  6 slab units of 512 B per row where dprnn_gn_bwd_dz_ex + dprnn_dgrad_ex + dprnn_wgrad_ex move 9.  red / absmax:
+ * from dprnn_gn_bwd_stats_ex (red times built / real channels for a narrow model's twin).  B <= 1024 utterances.
+ * workspace: dprnn_lin_bwd_workspace_floats(B * rows_per_utt) floats. */
+int64_t dprnn_lin_bwd_workspace_floats(int64_t rows);
+int dprnn_lin_bwd_f16(const float* dY, const float* Z, const double* stats, const double* red, const unsigned* absmax,
+                      const float* gamma, float eps, int B, int64_t rows_per_utt, const float* H, const float* W,
+                      float* dH, float* dW, float* db, float* hmax, float* workspace, void* stream);
 
 /* ---- DPRNN._segmentation backward (dprnn.py:189-201): dY[(b,l)] = sum over chunks covering l of (dXn + dXa + dXb) */
 int dprnn_segment_bwd(const float* dXn, const float* dXa, const float* dXb, float* dY,

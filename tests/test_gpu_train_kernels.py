@@ -443,3 +443,60 @@ def test_training_forward_of_the_mask_head_keeps_what_the_backward_needs(ks, str
     assert torch.equal(V0, V1) and torch.equal(taps0, taps1) and torch.equal(m0, m1)
     assert rel_l2(TG.cpu().numpy(), np.concatenate([ta, sg], 1)) < 2e-6
     assert rel_l2(mask.cpu().numpy(), mk) < 2e-6
+
+
+@pytest.mark.parametrize("B,rpu,dyscale,seed", [(3, 1237, 1.0, 0), (2, 48500 // 25, 3e-4, 1), (5, 40, 50.0, 2), (1, 33, 1.0, 3)])
+def test_fused_norm_and_linear_backward_in_one_pass(B, rpu, dyscale, seed):
+    """dprnn_gn_bwd_stats_ex + dprnn_lin_bwd_f16 (round 5): the GroupNorm backward's second pass, the Linear's data gradient and its weight
+    gradient in one pass over the rows, dZ never stored, its f16 scale from a bound the first pass leaves.  Against float64 autograd of
+    y = gamma * (z - mean) / sqrt(var + eps) + beta, z = H W^T + b (dprnn.py:88-90) for an upstream dY: dH, dW, db to f16-pieces
+    accuracy; the bound is above max|dZ| and within a small factor of it; max|dH| lands in the slot; rows not a multiple of the 32-row
+    chunk, utterance boundaries inside a chunk, several utterances per workgroup, gradients of very different magnitude."""
+    rng = np.random.default_rng(seed)
+    rows = B * rpu
+    H = (rng.standard_normal((rows, 256)) * 0.4).astype(np.float32)
+    W = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
+    b = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    gamma = (1.0 + 0.3 * rng.standard_normal(128)).astype(np.float32)
+    dY = (rng.standard_normal((rows, 128)) * dyscale * (1.0 + 4.0 * (rng.random((rows, 1)) < 0.01))).astype(np.float32)
+    eps = 1e-5
+    Ht = torch.from_numpy(H).double().requires_grad_(True)
+    Wt = torch.from_numpy(W).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    z = Ht @ Wt.T + bt
+    zf = z.detach().float()                                     # what the forward left in HBM
+    zb = z.reshape(B, rpu * 128)
+    mean, var = zb.mean(1, keepdim=True), zb.var(1, unbiased=False, keepdim=True)
+    y = ((zb - mean) / torch.sqrt(var + eps)).reshape(rows, 128) * torch.from_numpy(gamma).double()
+    z.retain_grad()
+    (y * torch.from_numpy(dY).double()).sum().backward()
+    st = _st()
+    lib = st.lib
+    Zd, dYd, Hd, Wd, gd = _t(zf), _t(dY), _t(H), _t(W), _t(gamma)
+    z64 = zf.double().reshape(B, -1)
+    stats = _t(torch.stack([z64.sum(1), (z64 * z64).sum(1)], 1))
+    red = torch.zeros(2 * B + 256, device=DEV, dtype=torch.float64)
+    absmax = torch.empty(B, 2, device=DEV, dtype=torch.int32)
+    st.call("dprnn_gn_bwd_stats_ex", _p(dYd), 0, 0, 0, _p(Zd), _p(stats), _p(gd), eps, B, rpu, _p(red), red.data_ptr() + 8 * 2 * B, _p(absmax))
+    dH = torch.empty(rows, 256, device=DEV)
+    dW = torch.empty(128, 256, device=DEV)
+    db = torch.empty(128, device=DEV)
+    hmax = torch.full((1,), -1.0, device=DEV)
+    ws = torch.empty(lib.dprnn_lin_bwd_workspace_floats(rows), device=DEV)
+    st.call("dprnn_lin_bwd_f16", _p(dYd), _p(Zd), _p(stats), _p(red), _p(absmax), _p(gd), eps, B, rpu, _p(Hd), _p(Wd), _p(dH), _p(dW), _p(db),
+            _p(hmax), _p(ws))
+    torch.cuda.synchronize()
+    dz = z.grad.numpy()
+    e_h, e_w, e_b = rel_l2(dH.cpu().numpy(), Ht.grad.numpy()), rel_l2(dW.cpu().numpy(), Wt.grad.numpy()), rel_l2(db.cpu().numpy(), bt.grad.numpy())
+    # the bound the first pass leaves: rstd (max|gamma dy| + |m1| + max|x_hat| |m2|) per utterance
+    am = absmax.view(torch.float32).cpu().double()
+    cnt = rpu * 128.0
+    rs = 1.0 / torch.sqrt(var.detach().reshape(B) + eps)
+    r = red[:2 * B].cpu().reshape(B, 2)
+    bound = float((rs * (am[:, 0] + (r[:, 0] / cnt).abs() + am[:, 1] * (r[:, 1] / cnt).abs())).max())
+    true = float(np.abs(dz).max())
+    print(f"B {B} rows/utt {rpu}: dH {e_h:.2e} dW {e_w:.2e} db {e_b:.2e}; max|dZ| {true:.3e}, bound {bound:.3e} ({bound / true:.2f} x); "
+          f"max|dH| {float(hmax):.4e} vs {float(Ht.grad.abs().max()):.4e}")
+    assert true <= bound * (1 + 1e-5) and bound < 8 * true
+    assert abs(float(hmax) - float(Ht.grad.abs().max())) <= 1e-5 * float(Ht.grad.abs().max())
+    assert max(e_h, e_w, e_b) < 3e-6, (e_h, e_w, e_b)

@@ -106,6 +106,8 @@ SIGNATURES = {
     "dprnn_head_mask_decode_fwd_train": [c_fp] * 8 + [c_i] * 7 + [c_fp],
     "dprnn_head_conv_bwd": [c_fp] * 6 + [c_i] * 5 + [c_fp],
     "dprnn_gn_bwd_stats": [c_fp] * 7 + [c_f, c_i, c_i64, c_fp, c_fp, c_fp],
+    "dprnn_gn_bwd_stats_ex": [c_fp] * 7 + [c_f, c_i, c_i64, c_fp, c_fp, c_fp, c_fp],
+    "dprnn_lin_bwd_f16": [c_fp] * 6 + [c_f, c_i, c_i64] + [c_fp] * 8,
     "dprnn_gn_bwd_dz": [c_fp] * 5 + [c_f, c_i, c_i64, c_fp, c_fp],
     "dprnn_gate_bwd": [c_fp, c_fp, c_fp, c_i64, c_fp],
     "dprnn_mask_decode_bwd": [c_fp] * 5 + [c_i, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp],
@@ -168,6 +170,7 @@ _SPECIAL = {
     "dprnn_scale_begin": ([c_fp], c_i),
     "dprnn_scale_slot": ([c_i], c_i),
     "dprnn_wgrad_workspace_floats": ([c_i, c_i, c_i64], c_i64),
+    "dprnn_lin_bwd_workspace_floats": ([c_i64], c_i64),
     "dprnn_workspace_bytes": ([c_i] * 9 + [ctypes.POINTER(c_i64)], c_i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_VOID) + list(_SPECIAL))

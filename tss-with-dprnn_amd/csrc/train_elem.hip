@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256)
 void gn_bwd_stats_kernel(const float* __restrict__ dXn, const float* __restrict__ dXa, const float* __restrict__ dXb,
                          float* __restrict__ dXo, const float* __restrict__ Z, const double* __restrict__ stats,
                          const float* __restrict__ gamma, float eps, long long rows_per_utt, int chunks_per_utt,
-                         double* __restrict__ red, double* __restrict__ dgb) {
+                         double* __restrict__ red, double* __restrict__ dgb, unsigned* __restrict__ absmax) {
     const int b = blockIdx.x / chunks_per_utt, ch = blockIdx.x % chunks_per_utt;
     const long long per = (rows_per_utt + chunks_per_utt - 1) / chunks_per_utt;
     const long long lo = (long long)b * rows_per_utt + per * ch;
@@ -39,6 +39,7 @@ void gn_bwd_stats_kernel(const float* __restrict__ dXn, const float* __restrict_
     }
     f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
+    float mgd = 0.f, mxh = 0.f;              // max |gamma dy| and max |x_hat| of this thread's elements (absmax)
     double S1 = 0.0, S2 = 0.0;
     int n = 0;
     for (long long row = lo + rr; row < hi; row += 8) {
@@ -60,11 +61,21 @@ void gn_bwd_stats_kernel(const float* __restrict__ dXn, const float* __restrict_
                 const float gd = gm[e] * dy[e];
                 s1 += gd;
                 s2 = fmaf(gd, xh, s2);
+                mgd = fmaxf(mgd, fabsf(gd));
+                mxh = fmaxf(mxh, fabsf(xh));
             }
             if (++n == 64) { S1 += (double)s1; S2 += (double)s2; s1 = 0.f; s2 = 0.f; n = 0; }
         }
     }
     if (!Z) return;
+    if (absmax) {                            // per-utterance maxima as float bits: what bounds |dZ| before dZ exists (dprnn_lin_bwd_f16)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mgd = fmaxf(mgd, __shfl_xor(mgd, o, 64)); mxh = fmaxf(mxh, __shfl_xor(mxh, o, 64)); }
+        if ((threadIdx.x & 63) == 0) {
+            if (mgd > 0.f) atomicMax(absmax + 2 * b, __float_as_uint(mgd));
+            if (mxh > 0.f) atomicMax(absmax + 2 * b + 1, __float_as_uint(mxh));
+        }
+    }
     S1 += (double)s1; S2 += (double)s2;
     __shared__ double sred[2][4];
     __shared__ float cred[8][2][128];
@@ -455,19 +466,30 @@ inline int grid_for(long long items, int cap_mult = 8) {
 
 }  // namespace
 
-extern "C" int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
-                                  const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
-                                  double* red, double* dgb, void* stream) {
-    if (!dXn || (dXa && (!dXb || !dXo)) || (Z && (!stats || !gamma || !red || !dgb)) || B < 1 || rows_per_utt < 1) {
+// absmax (optional, [B][2] words, zeroed here): per utterance max |gamma dy| and max |x_hat| as float bits -- with red they bound |dZ|:
+// |dZ| <= rstd (max|gamma dy| + |red0 / n| + max|x_hat| |red1 / n|), the scale source of dprnn_lin_bwd_f16, which forms dZ on the fly
+extern "C" int dprnn_gn_bwd_stats_ex(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
+                                     const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
+                                     double* red, double* dgb, unsigned* absmax, void* stream) {
+    if (!dXn || (dXa && (!dXb || !dXo)) || (Z && (!stats || !gamma || !red || !dgb)) || B < 1 || rows_per_utt < 1 || (absmax && !Z)) {
         dprnn_set_error("dprnn_gn_bwd_stats: null pointer / sizes"); return -1;
+    }
+    if (absmax) {
+        hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned) * 2 * B, (hipStream_t)stream);
+        if (e != hipSuccess) { dprnn_set_error("dprnn_gn_bwd_stats: %s", hipGetErrorString(e)); return -2; }
     }
     int chunks = (4 * num_cus() + B - 1) / B;
     const long long maxc = (rows_per_utt + 63) / 64;
     if (chunks > maxc) chunks = (int)maxc;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream,
-                       dXn, dXa, dXb, dXo, Z, stats, gamma, eps, (long long)rows_per_utt, chunks, red, dgb);
+                       dXn, dXa, dXb, dXo, Z, stats, gamma, eps, (long long)rows_per_utt, chunks, red, dgb, absmax);
     return dprnn_check_launch("gn_bwd_stats_kernel");
+}
+extern "C" int dprnn_gn_bwd_stats(const float* dXn, const float* dXa, const float* dXb, float* dXo, const float* Z,
+                                  const double* stats, const float* gamma, float eps, int B, int64_t rows_per_utt,
+                                  double* red, double* dgb, void* stream) {
+    return dprnn_gn_bwd_stats_ex(dXn, dXa, dXb, dXo, Z, stats, gamma, eps, B, rows_per_utt, red, dgb, nullptr, stream);
 }
 
 // One-shot selector: the NEXT dprnn_gn_bwd_dz call also leaves max|dZ| in *slot (device float) -- the scale source of the Linear's

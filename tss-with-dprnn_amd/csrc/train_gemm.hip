@@ -867,6 +867,301 @@ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict
     }
 }
 
+
+// ---- The Linear after a recurrence (dprnn.py:88,96): its whole backward, and the GroupNorm backward's second pass in front of it, in ONE
+// pass over the rows (round 5).  Before: gn_bwd_dz (dY, Z -> dZ), the data gradient (dZ -> dH) and the weight gradient (dZ, H -> dW, db)
+// were three launches that moved 9 slab units of 512 B per row (2 R + 1 W, 1 R + 2 W, 1 R + 2 R), each paced by HBM at ~5 TB/s.  Here a
+// workgroup owns a contiguous range of rows and streams dY, Z and H through it once (4 R), forms
+//     dZ = rstd_b (gamma dy - m1_b - x_hat m2_b),   x_hat = (Z - mu_b) rstd_b                        (the norm's second pass; never stored)
+// while it stages the chunk, as two f16 pieces of S_z dZ in a row-major LDS image, and multiplies that image twice:
+//     dW[128][256] += dZ^T H      rows = the MFMA k dimension: ds_read_b64_tr_b16 fragments of the dZ and H images (wgrad_f16_kernel's scheme)
+//     dH[32][256]   = dZ W        rows = the MFMA m dimension: plain 16-byte A fragments of the same dZ image; this wave's 32 columns of W
+//                                 stay in registers as piece fragments for the whole kernel
+// and writes dH (2 W): 6 units.  db = column sums of dZ ride in the staging registers; max|dH| (the BPTT's gradient scale) is followed in
+// the epilogue that stores dH.  S_z: dZ does not exist before this kernel, so its scale comes from a BOUND the first norm pass leaves
+// (dprnn_gn_bwd_stats_ex: per utterance max|gamma dy| and max|x_hat|): |dZ| <= rstd (max|gamma dy| + |m1| + max|x_hat| |m2|), placed at
+// 2^6 like every other gradient -- a bound a few times above the true maximum costs as many of the ~2^-20 relative floor bits.
+constexpr int LB_R = 32;
+constexpr int LB_PPL = LB_R * 128 * 2, LB_QPL = LB_R * 256 * 2;              // bytes of one piece plane of a dZ / H chunk
+constexpr int LB_BUF = 2 * LB_PPL + 2 * LB_QPL;                              // 48 KB
+constexpr int LB_MAXB = 1024;                                                // utterances in the (mu, rstd, m1, m2) table
+
+struct LinBwdArgs {
+    const float* dY; const float* Z; const double* stats; const double* red; const unsigned* absmax; const float* gamma;
+    float eps; int B; long long rows_per_utt;
+    const float* H; const float* W; float* dH;
+    long long rows, rows_per_split; int splits;
+    float* part; float* part_b;                   // [splits][128][256], [splits][128]
+    unsigned* hmax;                               // max |dH| as float bits, or null
+};
+
+__device__ __forceinline__ float lb_pow2_to(float m, int target) {
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+    ex = ex < -100 ? -100 : ex > 100 ? 100 : ex;
+    return ldexpf(1.f, target - ex);
+}
+
+__global__ __launch_bounds__(WG_THREADS, 1)
+void lin_bwd_f16_kernel(LinBwdArgs a, int* sat) {
+    extern __shared__ __attribute__((aligned(16))) char limg[];             // [buf 2][dZ piece 0 | dZ piece 1 | H piece 0 | H piece 1] | table
+    f32x4* const utab = reinterpret_cast<f32x4*>(limg + 2 * LB_BUF);
+    __shared__ float redm[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = blockIdx.x;                                                // one workgroup per row range (grid = splits)
+    const long long r0 = (long long)ks * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > a.rows) r1 = a.rows;
+
+    // ---- per-utterance constants of the norm's backward, the bound on |dZ|, max |W|
+    const double cnt = (double)a.rows_per_utt * 128.0;
+    float zb = 0.f, wmx = 0.f;
+    for (int b = tid; b < a.B; b += WG_THREADS) {
+        const double mean = a.stats[2 * b] / cnt;
+        double var = a.stats[2 * b + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float m1 = (float)(a.red[2 * b] / cnt), m2 = (float)(a.red[2 * b + 1] / cnt);
+        utab[b] = f32x4{mu, rs, m1, m2};
+        zb = fmaxf(zb, rs * (__uint_as_float(a.absmax[2 * b]) + fabsf(m1) + __uint_as_float(a.absmax[2 * b + 1]) * fabsf(m2)));
+    }
+    for (int idx = tid; idx < 128 * 256 / 4; idx += WG_THREADS) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(a.W)[idx];
+        wmx = fmaxf(wmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { zb = fmaxf(zb, __shfl_xor(zb, o, 64)); wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64)); }
+    if (lane == 0) { redm[0][wave] = zb; redm[1][wave] = wmx; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { zb = fmaxf(zb, redm[0][i]); wmx = fmaxf(wmx, redm[1][i]); }
+    const float sz = lb_pow2_to(zb, 6), sw = lb_pow2_to(wmx, 14);
+    const float inv_w = 1.f / (sz * F16P_XS), inv_h = 1.f / (sz * sw);
+
+    // ---- this wave's 32 columns of W as B fragments: lane (l, g) holds W[k = 32 s + 8 g .. + 7][n = 32 wave + 16 nt + l]
+    const int g = lane >> 4, l = lane & 15, qq = l >> 2, pp = l & 3;
+    rg_u32x4 wf[4][2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float* src = a.W + (long long)(32 * s + 8 * g) * 256 + 32 * wave + 16 * nt + l;
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = src[e * 256] * sw; hi[e] = src[(4 + e) * 256] * sw; }
+            f16_pieces8(lo, hi, wf[s][nt][0], wf[s][nt][1]);
+        }
+
+    // ---- staging: dY / Z rows prow + 16 j (j < 2), float4 column chunk pc4; H rows qrow + 8 j (j < 4), chunk qc4
+    const int pc4 = tid & 31, prow = tid >> 5;
+    const int qc4 = tid & 63, qrow = tid >> 6;
+    unsigned poff[2], qoff[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) poff[j] = (unsigned)(((prow + 16 * j) * 128 + 4 * pc4) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qoff[j] = (unsigned)(((qrow + 8 * j) * 256 + 4 * qc4) * 4);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * pc4);
+    // utterance of this thread's two dY / Z rows, advanced by 32 rows per chunk without dividing
+    int ub_[2]; long long rem_[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long long row = r0 + prow + 16 * j;
+        ub_[j] = (int)(row / a.rows_per_utt);
+        rem_[j] = row % a.rows_per_utt;
+    }
+    f32x4 dyv[2], zv[2], qv[4], psum = {0.f, 0.f, 0.f, 0.f};
+    int bcur[2] = {0, 0};
+    bool vcur[2] = {false, false};
+    auto load = [&](long long row0) __attribute__((always_inline)) {
+        const long long leftp = (r1 - row0) * 128LL * 4, leftq = (r1 - row0) * 256LL * 4;
+        const unsigned rp = leftp > 0x7fffffffLL ? 0x7fffffffu : (unsigned)leftp, rq = leftq > 0x7fffffffLL ? 0x7fffffffu : (unsigned)leftq;
+        const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY + row0 * 128), 0, rp, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Z + row0 * 128), 0, rp, 0x00020000);
+        const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H + row0 * 256), 0, rq, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            dyv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ys, poff[j], 0, 0));
+            zv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zs, poff[j], 0, 0));
+            vcur[j] = row0 + prow + 16 * j < r1;
+            bcur[j] = ub_[j] < a.B ? ub_[j] : a.B - 1;
+            rem_[j] += LB_R;                                 // the next chunk's row
+            while (rem_[j] >= a.rows_per_utt) { rem_[j] -= a.rows_per_utt; ++ub_[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hs, qoff[j], 0, 0));
+    };
+    unsigned satm = 0u;
+    auto pieces4 = [&](const f32x4& v, float s, unsigned long long& lo, unsigned long long& hi) __attribute__((always_inline)) {
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e] * s, -F16P_XMAX, F16P_XMAX);
+        unsigned a1, a2, b1, b2;
+        f16_pieces2(c[0], c[1], a1, a2);
+        f16_pieces2(c[2], c[3], b1, b2);
+        lo = (unsigned long long)a1 | ((unsigned long long)b1 << 32);
+        hi = (unsigned long long)a2 | ((unsigned long long)b2 << 32);
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+        char* const pb = limg + buf * LB_BUF;
+        char* const qb = pb + 2 * LB_PPL;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = prow + 16 * j;
+            const f32x4 t = utab[bcur[j]];                   // (mu, rstd, m1, m2)
+            f32x4 dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (zv[j][e] - t[0]) * t[1];
+                const float v = t[1] * (gm[e] * dyv[j][e] - t[2] - xh * t[3]);
+                dz[e] = vcur[j] ? v : 0.f;                   // rows beyond the range read as zero and must stay zero
+                psum[e] += dz[e];
+            }
+            sat_track(satm, dz);
+            unsigned long long lo, hi;
+            pieces4(dz, sz, lo, hi);
+            char* d = pb + row * 256 + (((unsigned)pc4 ^ wf_swz(row)) << 3);
+            *reinterpret_cast<unsigned long long*>(d) = lo;
+            *reinterpret_cast<unsigned long long*>(d + LB_PPL) = hi;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = qrow + 8 * j;
+            unsigned long long lo, hi;
+            pieces4(qv[j], F16P_XS, lo, hi);
+            char* d = qb + row * 512 + (((unsigned)qc4 ^ wf_swz(row)) << 3);
+            *reinterpret_cast<unsigned long long*>(d) = lo;
+            *reinterpret_cast<unsigned long long*>(d + LB_QPL) = hi;
+        }
+    };
+
+    // dW: wave (wm, wn) owns dZ columns 64 wm .. + 63 (M) x H columns 64 wn .. + 63 (N); transposed fragment reads as in wgrad_f16_kernel
+    const int wm = wave >> 2, wn = wave & 3;
+    const unsigned ubx = (unsigned)(pp | (qq << 2) | ((g & 1) << 4));
+    unsigned pa[4], qa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pa[j] = (unsigned)((8 * g + qq) * 256) + ((((unsigned)(16 * wm + 4 * j)) ^ ubx) << 3);
+        qa[j] = (unsigned)((8 * g + qq) * 512) + ((((unsigned)(16 * wn + 4 * j)) ^ ubx) << 3);
+    }
+    auto tr8 = [&](const char* plane, unsigned off, int pitch) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) wf_s4* lptr;
+        const wf_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off));
+        const wf_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(__attribute__((address_space(3))) char*)(plane + off + 4 * pitch));
+        rg_u32x4 out;
+        const unsigned long long a0 = __builtin_bit_cast(unsigned long long, lo), a1 = __builtin_bit_cast(unsigned long long, hi);
+        out[0] = (unsigned)a0; out[1] = (unsigned)(a0 >> 32); out[2] = (unsigned)a1; out[3] = (unsigned)(a1 >> 32);
+        return out;
+    };
+    // dH: A fragment of row tile mt, slab s: lane (l, g) reads the 16 bytes of dZ row 16 mt + l, columns 32 s + 8 g .. + 7 (units 8 s + 2 g, + 1:
+    // the swizzle flips bits 2-4 of the unit index, the pair stays together)
+    auto ha_off = [&](int mt, int s) __attribute__((always_inline)) {
+        return (unsigned)((16 * mt + l) * 256) + ((((unsigned)(8 * s + 2 * g)) ^ wf_swz(16 * mt + l)) << 3);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float hmx = 0.f;
+
+    if (r0 < r1) {
+        load(r0);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long row0 = r0; row0 < r1; row0 += LB_R, buf ^= 1) {
+            const bool more = row0 + LB_R < r1;
+            if (more) load(row0 + LB_R);
+            const char* const pb = limg + buf * LB_BUF;
+            const char* const qb = pb + 2 * LB_PPL;
+            {   // dW += dZ^T H
+                rg_u32x4 q1[4], q2[4];
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) { q1[jn] = tr8(qb, qa[jn], 512); q2[jn] = tr8(qb + LB_QPL, qa[jn], 512); }
+#pragma unroll
+                for (int jm = 0; jm < 4; ++jm) {
+                    const rg_u32x4 p1 = tr8(pb, pa[jm], 256), p2 = tr8(pb + LB_PPL, pa[jm], 256);
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) {
+                        acc[jm][jn] = mfma_f16p(p1, q2[jn], acc[jm][jn]);
+                        acc[jm][jn] = mfma_f16p(p2, q1[jn], acc[jm][jn]);
+                        acc[jm][jn] = mfma_f16p(p1, q1[jn], acc[jm][jn]);
+                    }
+                }
+            }
+            {   // dH = dZ W: rows 16 mt + 4 g + e, columns 32 wave + 16 nt + l
+                f32x4 ah[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) ah[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const unsigned off = ha_off(mt, s);
+                        const rg_u32x4 a1 = *reinterpret_cast<const rg_u32x4*>(pb + off), a2 = *reinterpret_cast<const rg_u32x4*>(pb + LB_PPL + off);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            ah[mt][nt] = mfma_f16p(a1, wf[s][nt][1], ah[mt][nt]);
+                            ah[mt][nt] = mfma_f16p(a2, wf[s][nt][0], ah[mt][nt]);
+                            ah[mt][nt] = mfma_f16p(a1, wf[s][nt][0], ah[mt][nt]);
+                        }
+                    }
+                const long long lefth = (r1 - row0) * 256LL * 4;
+                const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(a.dH + row0 * 256, 0,
+                                                                                    lefth > 0x7fffffffLL ? 0x7fffffffu : (unsigned)lefth, 0x00020000);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const float v = ah[mt][nt][e] * inv_h;
+                            hmx = fmaxf(hmx, fabsf(v));
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ds,
+                                                                  (unsigned)(((16 * mt + 4 * g + e) * 256 + 32 * wave + 16 * nt + l) * 4), 0, 0);
+                        }
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    sat_commit(sat, DPRNN_SAT_WGRAD, satm, F16P_XMAX / sz);
+    if (a.hmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, o, 64));
+        if (lane == 0 && hmx > 0.f) atomicMax(a.hmax, __float_as_uint(hmx));
+    }
+    // acc[jm][jn][e] = dW[m][n], m = 64 wm + 16 jm + 4 g + e, n = 64 wn + 16 jn + l
+    float* const out = a.part + (long long)ks * 128 * 256;
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 64 * wm + 16 * jm + 4 * g + e;
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) out[m * 256 + 64 * wn + 16 * jn + l] = acc[jm][jn][e] * inv_w;
+        }
+    if (a.part_b) {                                      // db: threads tid, tid + 32 j hold the same column chunk
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(limg);
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 32) {
+            f32x4 s = red[tid];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                const f32x4 v = red[tid + 32 * j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += v[e];
+            }
+            *reinterpret_cast<f32x4*>(a.part_b + (long long)ks * 128 + 4 * tid) = s;
+        }
+    }
+}
+
 }  // namespace
 
 // row ranges: about two workgroups per CU, at least 64 rows each
@@ -1009,6 +1304,67 @@ extern "C" int dprnn_wgrad_lstm_f16(const float* grad_max, const float* dG4, con
     const int items = 512 * (256 / 4) + (a.part_b ? 512 / 4 : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        a.part, a.part_b, (int)splits, 512, 256, 512, 256, dWcat, 256LL, 1LL, db0, db1, 0);
+    return dprnn_check_launch("wgrad_reduce_kernel");
+}
+
+
+// ---- dprnn_lin_bwd_f16: GroupNorm backward (second pass) + Linear backward of one DPRNN path in one launch (lin_bwd_f16_kernel above).
+// dY [rows][128] = the gradient of the norm's output (the summed residual gradient), Z the Linear's output as the forward left it, stats
+// its (sum, sum of squares) per utterance, red / absmax what dprnn_gn_bwd_stats_ex left (red possibly scaled by the narrow twin's element
+// count correction), H [rows][256] the BiLSTM output, W [128][256] the Linear's weight.  Writes dH [rows][256], dW [128][256], db [128],
+// and (hmax != NULL) max |dH| as a float for the f16 BPTT's gradient scale.  workspace: dprnn_lin_bwd_workspace_floats(rows) floats.
+static void lin_bwd_plan(long long rows, long long& splits, long long& per) {
+    splits = num_cus();
+    const long long max_splits = (rows + 63) / 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    per = (rows + splits - 1) / splits;
+    per = (per + LB_R - 1) / LB_R * LB_R;
+    splits = (rows + per - 1) / per;
+}
+extern "C" int64_t dprnn_lin_bwd_workspace_floats(int64_t rows) {
+    long long splits, per;
+    lin_bwd_plan(rows > 0 ? rows : 1, splits, per);
+    return splits * (128LL * 256 + 128);
+}
+extern "C" int dprnn_lin_bwd_f16(const float* dY, const float* Z, const double* stats, const double* red, const unsigned* absmax,
+                                 const float* gamma, float eps, int B, int64_t rows_per_utt, const float* H, const float* W,
+                                 float* dH, float* dW, float* db, float* hmax, float* workspace, void* stream) {
+    if (!dY || !Z || !stats || !red || !absmax || !gamma || !H || !W || !dH || !dW || !db || !workspace) {
+        dprnn_set_error("dprnn_lin_bwd_f16: null pointer"); return -1;
+    }
+    if (B < 1 || B > LB_MAXB || rows_per_utt < 1) {
+        dprnn_set_error("dprnn_lin_bwd_f16: 1 <= B <= %d utterances, rows_per_utt >= 1 (got B=%d rows_per_utt=%lld)", LB_MAXB, B, (long long)rows_per_utt);
+        return -1;
+    }
+    const long long rows = (long long)B * rows_per_utt;
+    hipStream_t st = (hipStream_t)stream;
+    LinBwdArgs a{};
+    a.dY = dY; a.Z = Z; a.stats = stats; a.red = red; a.absmax = absmax; a.gamma = gamma; a.eps = eps; a.B = B; a.rows_per_utt = rows_per_utt;
+    a.H = H; a.W = W; a.dH = dH; a.rows = rows;
+    long long splits, per;
+    lin_bwd_plan(rows, splits, per);
+    a.rows_per_split = per; a.splits = (int)splits;
+    a.part = workspace; a.part_b = workspace + splits * 128LL * 256;
+    a.hmax = reinterpret_cast<unsigned*>(hmax);
+    if (hmax) {
+        hipError_t e = hipMemsetAsync(hmax, 0, sizeof(float), st);
+        if (e != hipSuccess) { dprnn_set_error("dprnn_lin_bwd_f16: %s", hipGetErrorString(e)); return -2; }
+    }
+    const int lds = 2 * LB_BUF + LB_MAXB * 16;
+    static std::atomic<unsigned long long> attr_mask{0};
+    int attr_dev;
+    if (dprnn_attr_needed(attr_mask, &attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_bwd_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { dprnn_set_error("hipFuncSetAttribute(lin_bwd_f16): %s", hipGetErrorString(e)); return -2; }
+        dprnn_attr_done(attr_mask, attr_dev);
+    }
+    hipLaunchKernelGGL(lin_bwd_f16_kernel, dim3((unsigned)splits), dim3(WG_THREADS), lds, st, a, dprnn_sat_ptr());
+    int rc = dprnn_check_launch("lin_bwd_f16_kernel");
+    if (rc) return rc;
+    const int items = 128 * (256 / 4) + 128 / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, st,
+                       a.part, a.part_b, (int)splits, 128, 256, 128, 256, dW, 256LL, 1LL, db, static_cast<float*>(nullptr), 0);
     return dprnn_check_launch("wgrad_reduce_kernel");
 }
 

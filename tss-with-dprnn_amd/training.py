@@ -51,6 +51,9 @@ TRAIN_WGRAD_F16 = os.environ.get("DPRNN_TRAIN_WGRAD_F16", "1") != "0"
 # f16-pieces forward AND f16-pieces BPTT of an LSTM: the gate tape holds i, f, g, o as 24-bit fixed point (three words per (row, unit)
 # instead of four; csrc/common.h: tape_pack) -- a fifth less of the step's largest HBM stream.  DPRNN_TRAIN_TAPE_PACKED=0: fp32 gates.
 TAPE_PACKED = os.environ.get("DPRNN_TRAIN_TAPE_PACKED", "1") != "0"
+# The GroupNorm backward's second pass and the Linear's data and weight gradients as ONE launch over the rows (dprnn_lin_bwd_f16: 6 slab units
+# per row instead of 9; bidirectional paths with the Linears' gradients in f16 pieces).  DPRNN_TRAIN_LIN_BWD_FUSED=0: the three launches.
+LIN_BWD_FUSED = os.environ.get("DPRNN_TRAIN_LIN_BWD_FUSED", "1") != "0"
 TAPE_PACKED_FLAG = 0x100             # on the gemm_mode argument of dprnn_rnn_fwd_train_ex / dprnn_rnn_bwd_ex
 _SIDE_STREAMS: Dict[torch.device, List[torch.cuda.Stream]] = {}
 _TLS = threading.local()
@@ -303,7 +306,7 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     shapes = [(N, F_BUILT, R), (2 * F_BUILT, F_BUILT, R), (2 * F_BUILT, F_BUILT, B * L), (F_BUILT, 2 * F_BUILT, rows),
               (4 * F_BUILT, 2 * F_BUILT, rows), (F_BUILT, N, B * L),
               (4 * F_BUILT, 2 * F_BUILT, K * (-(-(B * S) // 32) * 32)), (4 * F_BUILT, 2 * F_BUILT, S * (-(-(B * K) // 32) * 32))]
-    ws = torch.empty(max(lib.dprnn_wgrad_workspace_floats(m_, n_, r_) for m_, n_, r_ in shapes), **f32)
+    ws = torch.empty(max([lib.dprnn_wgrad_workspace_floats(m_, n_, r_) for m_, n_, r_ in shapes] + [lib.dprnn_lin_bwd_workspace_floats(rows)]), **f32)
 
     _, bwd_mode, wgrad_f16 = train_modes()
 
@@ -371,28 +374,38 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
         ndir, fw, bw = _rnn_tensors(rnn, dev)
         gamma, beta, eps = _norm_params(norm)
         a_red, a_dgb = scr.slot(f"red{p}", 2 * B), scr.slot(f"dgb{p}", 2 * F_BUILT)
-        st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
-                _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
-        _count_scale_red(scr, f"red{p}", norm, st, B)
-        f16_lin = wgrad_f16                                         # dZ @ W and dZ^T H in f16 pieces: dZ scaled from its own maximum,
-        st.call("dprnn_gn_bwd_dz_ex", zmax.data_ptr() if f16_lin else 0,      # which the kernel that writes dZ measures
-                _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
-        gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
-        grads[f"{blk}_norm.{gname}"] = to_grad(a_dgb, gamma)
-        grads[f"{blk}_norm.{bname}"] = to_grad(a_dgb + 8 * F_BUILT, beta)
-        # Linear (dprnn.py:88,96)
-        hp = ndir * F_BUILT
-        dH = torch.empty(rows, hp, **f32)
+        f16_lin = wgrad_f16                                         # dZ @ W and dZ^T H in f16 pieces
         cell = engine.CELL_ID[rnn.rnn.mode]
         bptt_f16 = bwd_mode == 3 and cell == 0
-        # the f16 BPTT scales by max|dH|: measured where dH is written
-        st.call("dprnn_dgrad_ex", zmax.data_ptr() if (f16_lin and ndir == 2) else 0, hmax.data_ptr() if bptt_f16 else 0,
-                _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
+        fused = f16_lin and ndir == 2 and LIN_BWD_FUSED and B <= 1024
+        gname, bname = ("gamma", "beta") if hasattr(norm, "gamma") else ("weight", "bias")
+        hp = ndir * F_BUILT
+        dH = torch.empty(rows, hp, **f32)
         gw = torch.empty_like(lin.weight)
         gb = torch.empty_like(lin.bias)
         Hp = H[p]
-        wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
-              F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None, f16_max=zmax.data_ptr() if f16_lin else 0)
+        if fused:
+            # pass 1 also leaves what bounds |dZ| (the scale of its f16 pieces); pass 2, the Linear's data gradient and its weight gradient
+            # are one launch that forms dZ on the fly (dprnn_lin_bwd_f16); max|dH|, the f16 BPTT's scale, is measured where dH is written
+            absmax = torch.empty(B, 2, device=dev, dtype=torch.int32)
+            st.call("dprnn_gn_bwd_stats_ex", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
+                    _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb, _p(absmax))
+            _count_scale_red(scr, f"red{p}", norm, st, B)
+            st.call("dprnn_lin_bwd_f16", _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(absmax), _p(gamma), eps, B, S * K, _p(Hp),
+                    _p(lin.weight), _p(dH), _p(gw), _p(gb), hmax.data_ptr() if bptt_f16 else 0, _p(ws))
+        else:
+            st.call("dprnn_gn_bwd_stats", _p(dX), _p(dXd[0]) if have_dx else 0, _p(dXd[1]) if have_dx else 0,
+                    _p(dX) if have_dx else 0, _p(Z[p]), _p(stats[1 + p]), _p(gamma), eps, B, S * K, a_red, a_dgb)
+            _count_scale_red(scr, f"red{p}", norm, st, B)
+            st.call("dprnn_gn_bwd_dz_ex", zmax.data_ptr() if f16_lin else 0,      # dZ scaled from its own maximum, which the kernel that writes dZ measures
+                    _p(dX), _p(Z[p]), _p(stats[1 + p]), a_red, _p(gamma), eps, B, S * K, _p(dZ))
+            # Linear (dprnn.py:88,96); the f16 BPTT scales by max|dH|: measured where dH is written
+            st.call("dprnn_dgrad_ex", zmax.data_ptr() if (f16_lin and ndir == 2) else 0, hmax.data_ptr() if bptt_f16 else 0,
+                    _p(dZ), F_BUILT, _p(lin.weight), hp, F_BUILT, 0, 0, _p(dH), hp, hp, rows)
+            wgrad(_p(dZ), F_BUILT, F_BUILT, _p(Hp), hp, F_BUILT, 0, (Hp.data_ptr() + 4 * F_BUILT) if ndir == 2 else 0, hp,
+                  F_BUILT if ndir == 2 else 0, 0, rows, 1, 1, gw, hp, 1, gb, None, f16_max=zmax.data_ptr() if f16_lin else 0)
+        grads[f"{blk}_norm.{gname}"] = to_grad(a_dgb, gamma)
+        grads[f"{blk}_norm.{bname}"] = to_grad(a_dgb + 8 * F_BUILT, beta)
         grads[f"{blk}_linear.weight"], grads[f"{blk}_linear.bias"] = gw, gb
         # recurrence (dprnn.py:86,95)
         addr = _addr(geo, intra)
