@@ -361,7 +361,8 @@ def backward(model, saved: dict, d_out: torch.Tensor, scratch: Optional[_Scratch
     del dU
 
     # ---- DPRNN blocks in reverse (dprnn.py:79-99)
-    dXd = torch.zeros(2, rows, F_BUILT, **f32)
+    # the two per-direction dx slabs: a bidirectional BPTT writes every row of both, a unidirectional one leaves the second to the zero_() below
+    dXd = torch.empty(2, rows, F_BUILT, **f32)
     dZ = torch.empty(rows, F_BUILT, **f32)
     packedT = torch.empty(lib.dprnn_rnn_pack_bwd_floats(2), **f32)
     zmax = torch.zeros(1, **f32)
@@ -605,6 +606,12 @@ def _backward_groups(model, saved, d_out):
     return grads
 
 
+def _accumulate(grads: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor]) -> None:
+    """grads[k] += g[k] for every parameter in a few multi-tensor launches instead of one per parameter (170 of them per micro-batch)."""
+    keys = list(g)
+    torch._foreach_add_([grads[k] for k in keys], [g[k] for k in keys])
+
+
 class _TasNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, wav, names, *params):
@@ -675,8 +682,7 @@ class _TasNetFunction(torch.autograd.Function):
                 _, saved = _forward_groups(model, wav[b0:b0 + mb])
                 g = _backward_groups(model, saved, d_out[b0:b0 + mb])
                 del saved
-                for k in g:
-                    grads[k] += g[k]
+                _accumulate(grads, g)
         return grads
 
     @staticmethod
@@ -691,8 +697,7 @@ class _TasNetFunction(torch.autograd.Function):
             if grads is None:
                 grads = g
             else:
-                for k in g:
-                    grads[k] += g[k]
+                _accumulate(grads, g)
         return grads
 
 
