@@ -1043,6 +1043,11 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
 # Needs the bf16-split gate GEMM (the eight-wave 64-sequence kernel) and LSTM cells; callers fall back to per-length
 # batches on streams otherwise (inference.separate_many).
 RAGGED_STREAMS = 8           # side streams for the per-utterance launches around the ragged slab (small kernels: they overlap)
+# Reference utterances of EQUAL length go through the speaker branch as one batch (eval-mode BatchNorm: rows of different utterances never
+# meet), this many at a time (3 KB of intermediates per reference sample: 64 x 3 s = 4.6 GB).  1: one utterance per launch set, as before.
+RAGGED_AUX_BATCH = int(os.environ.get("DPRNN_RAGGED_AUX_BATCH", "64"))
+# The mask head's gate (row-wise) as ONE launch over every utterance of a ragged batch instead of one per utterance.  0: per utterance.
+RAGGED_GATE_BATCHED = os.environ.get("DPRNN_RAGGED_GATE_BATCHED", "1") != "0"
 _FAN_POOL: dict = {}
 
 
@@ -1075,7 +1080,7 @@ GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_f
 # and are therefore part of every captured graph's key; the others are constants, bookkeeping, or policy applied outside a capture.
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
 LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
-                "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS",
+                "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS", "RAGGED_AUX_BATCH", "RAGGED_GATE_BATCHED",
                 "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES", "WIDE_TILE_MIN_FILL")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",

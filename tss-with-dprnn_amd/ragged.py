@@ -172,22 +172,35 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     taps, masked = [], []
     head_w = (E._p(E._param(sep.prelu.weight, "prelu.weight", dev)), E._p(E._param(sep.conv2d.weight, "conv2d.weight", dev)),
               E._p(E._param(sep.conv2d.bias, "conv2d.bias", dev)))
-    def head(sg, u):
+    # The mask head.  conv2d + overlap-add and the decode address an utterance's own geometry and run per utterance on the side streams;
+    # the gate between them (tanh(out(U)) * sigmoid(gate(U)), dprnn.py:157-158,180) is row-wise, so the utterances' U rows sit back to back
+    # and it is ONE launch over all of them -- a per-utterance launch stages its 128 KB of weights for a few hundred rows per workgroup and
+    # ran at a quarter of the batched rate (profiles/r05_ragged_ira_kernel_stats.csv).  U_all [sum L][2F] | V_all [2 sum L][F] in H's region.
+    l_off = np.concatenate([[0], np.cumsum([g.L for g in geos])]).astype(np.int64)
+    sum_l = int(l_off[-1])
+    assert 4 * sum_l * E.F_BUILT <= int(head_off[-1])
+    U_all, V_all = H[: 2 * sum_l * E.F_BUILT], H[2 * sum_l * E.F_BUILT: 4 * sum_l * E.F_BUILT]
+
+    def head_conv(sg, u):
         g = geos[u]
         r0 = int(starts[u])
-        Hu = H[int(head_off[u]): int(head_off[u + 1])]                        # this utterance's U | V scratch
-        U, V = Hu[: g.L * 2 * E.F_BUILT], Hu[g.L * 2 * E.F_BUILT: 2 * g.L * 2 * E.F_BUILT]
-        assert V.numel() == g.L * 2 * E.F_BUILT
+        U = U_all[int(l_off[u]) * 2 * E.F_BUILT: int(l_off[u + 1]) * 2 * E.F_BUILT]
         E._set_slot(sg.lib, E.SLOT_HEAD_CONV)
         if pending is None:
             sg.call("dprnn_head_conv_ola_fwd", E._p(X[r0 * E.F_BUILT:]), *head_w, E._p(U), 1, g.L, K, P, g.S)
         else:
             sg.call("dprnn_head_conv_ola_norm_fwd", E._p(X[r0 * E.F_BUILT:]), E._p(Z[r0 * E.F_BUILT:]), E._p(pending[0][u]), E._p(pending[1]),
                     E._p(pending[2]), pending[3], *head_w, E._p(U), 1, g.L, K, P, g.S)
-        E._set_slot(sg.lib, E.SLOT_HEAD_GATE)
-        sg.call("dprnn_head_gate_fwd", E._p(U), E._p(E._param(sep.out[0].weight, "out.0.weight", dev)),
-                E._p(E._param(sep.out[0].bias, "out.0.bias", dev)), E._p(E._param(sep.gate[0].weight, "gate.0.weight", dev)),
-                E._p(E._param(sep.gate[0].bias, "gate.0.bias", dev)), E._p(V), g.L * 2)
+
+    gate_w = (E._p(E._param(sep.out[0].weight, "out.0.weight", dev)), E._p(E._param(sep.out[0].bias, "out.0.bias", dev)),
+              E._p(E._param(sep.gate[0].weight, "gate.0.weight", dev)), E._p(E._param(sep.gate[0].bias, "gate.0.bias", dev)))
+
+    def head_decode(sg, u):
+        g = geos[u]
+        V = V_all[int(l_off[u]) * 2 * E.F_BUILT: int(l_off[u + 1]) * 2 * E.F_BUILT]
+        if not E.RAGGED_GATE_BATCHED:
+            E._set_slot(sg.lib, E.SLOT_HEAD_GATE)
+            sg.call("dprnn_head_gate_fwd", E._p(U_all[int(l_off[u]) * 2 * E.F_BUILT:]), *gate_w, E._p(V), g.L * 2)
         t = torch.empty(1, 2, g.L, ks, device=dev, dtype=torch.float32)
         mk = torch.empty(1, g.L, N, device=dev, dtype=torch.float32) if want_masked else None
         sg.call("dprnn_head_mask_decode_fwd", E._p(V), E._p(E._param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev)),
@@ -195,7 +208,14 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
         return t, mk
 
     fan = _Fan(st, n)
-    res = [fan.run(u, lambda sg, u=u: head(sg, u)) for u in range(n)]
+    for u in range(n):
+        fan.run(u, lambda sg, u=u: head_conv(sg, u))
+    fan.join()
+    if E.RAGGED_GATE_BATCHED:
+        E._set_slot(st.lib, E.SLOT_HEAD_GATE)
+        st.call("dprnn_head_gate_fwd", E._p(U_all), *gate_w, E._p(V_all), 2 * sum_l)
+    fan = _Fan(st, n)
+    res = [fan.run(u, lambda sg, u=u: head_decode(sg, u)) for u in range(n)]
     fan.join()
     taps = [r[0] for r in res]
     masked = [r[1] for r in res]
@@ -251,12 +271,39 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
         stats = torch.zeros(n, 4, 1, 2, device=dev, dtype=torch.float64)     # per utterance: bottleneck, aux, d0 statistics
         parallel = not _bn_training(sep)               # train-mode BatchNorm updates its buffers per utterance, in order
 
+        # Speaker embeddings of the reference utterances.  Rows of different utterances meet nowhere in the speaker branch but in a
+        # train-mode BatchNorm, so in eval mode the references of EQUAL length run through it as one batch on the caller's stream (19
+        # launches for up to RAGGED_AUX_BATCH utterances instead of 19 small ones each: the per-utterance launches were 20 % of a 48-utterance
+        # ragged forward, profiles/r05_ragged_ira_kernel_stats.csv); the rest -- and everything in train mode -- stays one at a time.
+        emb_of, alen_of = [None] * n, [None] * n
+        if parallel and E.RAGGED_AUX_BATCH > 1:
+            by_len = {}
+            for u in range(n):
+                by_len.setdefault(int(axs[u].shape[1]), []).append(u)
+            for Ta, us in by_len.items():
+                for i in range(0, len(us), E.RAGGED_AUX_BATCH):
+                    grp = us[i: i + E.RAGGED_AUX_BATCH]
+                    if len(grp) < 2:
+                        continue
+                    geo_a = E.make_geometry(len(grp), Ta, N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+                    alen = torch.cat([E._aux_len_tensor(aux_lens[u], 1, dev) for u in grp])
+                    A = torch.cat([axs[u] for u in grp])
+                    st_a = torch.zeros(len(grp), 2, device=dev, dtype=torch.float64)
+                    sc_a, sh_a = E.bottleneck_affine(st, A, enc_w, se[0], geo_a, st_a)
+                    A0 = E.bottleneck_frames(st, A, enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=E.SLOT_AUX_BOTTLENECK).view(len(grp) * geo_a.L, E.F_BUILT)
+                    v = E.speaker_embedding(st, sep, A0, len(grp), geo_a.L, alen, ks)
+                    for j, u in enumerate(grp):
+                        emb_of[u], alen_of[u] = v[j: j + 1], alen[j: j + 1]
+
         def first(sg, u):
-            geo_a = E.make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
-            alen = E._aux_len_tensor(aux_lens[u], 1, dev)
-            sc_a, sh_a = E.bottleneck_affine(sg, axs[u], enc_w, se[0], geo_a, stats[u, 1])
-            A0 = E.bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=E.SLOT_AUX_BOTTLENECK).view(geo_a.L, E.F_BUILT)
-            v0 = E.speaker_embedding(sg, sep, A0, 1, geo_a.L, alen, ks)
+            if emb_of[u] is not None:
+                v0, alen = emb_of[u], alen_of[u]
+            else:
+                geo_a = E.make_geometry(1, axs[u].shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+                alen = E._aux_len_tensor(aux_lens[u], 1, dev)
+                sc_a, sh_a = E.bottleneck_affine(sg, axs[u], enc_w, se[0], geo_a, stats[u, 1])
+                A0 = E.bottleneck_frames(sg, axs[u], enc_w, sc_a, sh_a, se[1], geo_a, scale_slot=E.SLOT_AUX_BOTTLENECK).view(geo_a.L, E.F_BUILT)
+                v0 = E.speaker_embedding(sg, sep, A0, 1, geo_a.L, alen, ks)
             mul, add, row_bias = E._fusion_operands(sg, sep, cfg, v0)
             sc, sh = E.bottleneck_affine(sg, ws[u], enc_w, sep.bottleneck[0], geos[u], stats[u, 0], mul, add)
             row_scale = E._att_row_scale(sg, sep, cfg, ws[u], enc_w, geos[u], stats[u, 0], mul) if cfg["fusion_type"] == "att" else None
