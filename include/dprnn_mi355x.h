@@ -338,6 +338,13 @@ int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W
 int dprnn_head_conv_ola_norm_fwd(const float* X, const float* Z, const double* stats, const float* gamma,
                                  const float* beta, float eps, const float* prelu_w, const float* W2d,
                                  const float* b2d, float* U, int B, int L, int K, int P, int S, void* stream);
+/* The same over a RAGGED batch in one launch (gate-GEMM mode 3): utterance u's slab is rows utt_starts[u] .. utt_starts[u + 1] of X (and Z),
+ * its frames are l_off[u] .. l_off[u + 1] of U; both tables are int64 on the device, n + 1 entries; stats [n][2]; Z may be NULL (no
+ * pending norm).  Replaces one dprnn_head_conv_ola(_norm)_fwd launch per utterance (ragged.py; inferencer_spe.py:20-54 is one at a time). */
+int dprnn_head_conv_ola_ragged_fwd(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                                   float eps, const float* prelu_w, const float* W2d, const float* b2d, float* U,
+                                   const int64_t* utt_starts, const int64_t* l_off, int n, int64_t total_frames, int K, int P,
+                                   void* stream);
 
 /* ---- ragged batches (utterances of DIFFERENT lengths through one launch per DPRNN path; the reference evaluates full-length
  * test utterances one at a time, src/inferencers/inferencer.py:54-58, inferencer_spe.py:27-32, because zero-padding would

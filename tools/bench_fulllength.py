@@ -37,8 +37,9 @@ def timed(fn, reps=2):
 
 with torch.no_grad():
     # one ragged launch per DPRNN path over all utterances (engine.dprnn_process_ragged; bf16-split gate GEMM, the default)
-    dt = timed(lambda: inference.separate_many(m, wavs, extra_inputs=aux, ragged=True))
-    print(f"{kind} ragged batch ({len(mine)} utterances, {secs:.0f} s of audio): {dt:.3f} s = {len(mine) / dt:6.1f} utt/s, {secs / dt:5.0f}x real time", flush=True)
+    if os.environ.get("FL_ONLY") != "share":
+        dt = timed(lambda: inference.separate_many(m, wavs, extra_inputs=aux, ragged=True))
+        print(f"{kind} ragged batch ({len(mine)} utterances, {secs:.0f} s of audio): {dt:.3f} s = {len(mine) / dt:6.1f} utt/s, {secs / dt:5.0f}x real time", flush=True)
     if os.environ.get("FL_ONLY") == "ragged":
         sys.exit(0)
     if os.environ.get("FL_SHARE", "1") == "1":
@@ -49,6 +50,10 @@ with torch.no_grad():
         a_all = None if kind == "bss" else [(torch.from_numpy(make_mixture(1, 24000, seed=900 + i)[0]).to(dev), 24000.0) for i in order]
         s_all = float(sum(lens[i] for i in order)) / 8000.0
         dt = timed(lambda: inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True), reps=1)
+        if os.environ.get("FL_ONLY") == "share":        # for rocprofv3: the whole share twice more, nothing else
+            dt = timed(lambda: inference.separate_many(m, w_all, extra_inputs=a_all, ragged=True), reps=2)
+            print(f"{kind} ragged, whole share: {dt:.3f} s = {len(order) / dt:6.1f} utt/s", flush=True)
+            sys.exit(0)
         print(f"{kind} ragged, the rank's whole share ({len(order)} utterances sorted by length, {s_all:.0f} s of audio, "
               f"{len(inference.ragged_chunks(list(range(len(order))), [int(w.numel()) for w in w_all], dev))} ragged batch(es)): {dt:.3f} s = "
               f"{len(order) / dt:6.1f} utt/s, {s_all / dt:5.0f}x real time", flush=True)

@@ -380,6 +380,96 @@ static int head_conv_ola(const float* X, const float* Z, const double* stats, co
     return launch_rowgemm<128, 256, RT>("head_conv_ola", W2d, 128, 256, nullptr, 0, (long long)B * L, al, ep, (hipStream_t)stream);
 }
 
+// ---- the same for a RAGGED batch (round 5): utterances of different lengths, their slabs back to back in X (utterance u: rows utt_starts[u] ..
+// utt_starts[u + 1] of 128 floats, S_u K of them) and their frames back to back in U (l_off[u] .. l_off[u + 1]).  One launch over all frames: a row
+// finds its utterance by bisection of l_off and then gathers as OlaGather does.  (A launch per utterance stages the 128 KB of conv2d weights in
+// every workgroup for a few hundred rows each: 309 us per utterance where the batched launch needs 37, profiles/r05_ragged_ira_kernel_stats.csv.)
+namespace {
+__device__ __forceinline__ int ragged_utt(const long long* l_off, int n, long long row) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (l_off[mid] <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+template <int RT>
+struct OlaGatherRagged {
+    OlaGather<RT> g; const float* alpha_p; const long long* utt_starts; const long long* l_off; int n;
+    __device__ void init(long long row0, int r, int q, long long M) {
+        g.alpha = *alpha_p;
+        g.q4 = 4 * q;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            long long row = row0 + 16 * rt + r;
+            if (row >= M) row = M - 1;
+            const int u = ragged_utt(l_off, n, row);
+            const int l = (int)(row - l_off[u]);
+            const long long r0 = utt_starts[u];
+            const int S = (int)((utt_starts[u + 1] - r0) / g.K);
+            const int lo = OlaGather<RT>::s_lo(l, g.P), hi = OlaGather<RT>::s_hi(l, g.K, g.P, S);
+            g.nterm[rt] = hi - lo + 1;
+            g.p0[rt] = g.X + (r0 + (long long)lo * g.K + (l + g.K - lo * g.P)) * F + 4 * q;
+            g.mu[rt] = 0.f; g.rs[rt] = 0.f;
+            if (g.Z) {
+                const double cnt = (double)S * (double)g.K * (double)F;
+                const double mean = g.stats[2 * u] / cnt;
+                double var = g.stats[2 * u + 1] / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                g.mu[rt] = (float)mean;
+                g.rs[rt] = (float)(1.0 / sqrt(var + (double)g.eps));
+            }
+        }
+    }
+    __device__ f32x4 load(int rt, int gi) const { return g.load(rt, gi); }
+};
+template <int RT>
+struct EpTHeadConvRagged {      // U[frame][col] = acc + cnt(l) * bias[col], 256 columns; cnt from the frame's own utterance
+    float* U; const float* bias; const long long* utt_starts; const long long* l_off; int n, K, P;
+    __device__ void begin(int tid) {}
+    __device__ void end(int lane) {}
+    __device__ void operator()(f32x4 (&acc)[RT][16], long long row0, int c, int q, long long M, float inv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt + c;
+            if (row >= M) continue;
+            const int u = ragged_utt(l_off, n, row);
+            const int l = (int)(row - l_off[u]);
+            const int S = (int)((utt_starts[u + 1] - utt_starts[u]) / K);
+            const float cnt = (float)(OlaGather<1>::s_hi(l, K, P, S) - OlaGather<1>::s_lo(l, P) + 1);
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * ct + 4 * q);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(cnt, b[e], acc[rt][ct][e] * inv);
+                *reinterpret_cast<f32x4*>(U + row * 256 + 16 * ct + 4 * q) = v;
+            }
+        }
+    }
+};
+}
+
+extern "C" int dprnn_head_conv_ola_ragged_fwd(const float* X, const float* Z, const double* stats, const float* gamma, const float* beta,
+                                              float eps, const float* prelu_w, const float* W2d, const float* b2d, float* U,
+                                              const int64_t* utt_starts, const int64_t* l_off, int n, int64_t total_frames, int K, int P,
+                                              void* stream) {
+    if (!X || !prelu_w || !W2d || !b2d || !U || !utt_starts || !l_off) { dprnn_set_error("dprnn_head_conv_ola_ragged_fwd: null pointer"); return -1; }
+    if (Z && (!stats || !gamma || !beta)) { dprnn_set_error("dprnn_head_conv_ola_ragged_fwd: pending norm needs stats, gamma, beta"); return -1; }
+    if (n < 1 || total_frames < 1 || K < 1 || P < 1 || P > K) {
+        dprnn_set_error("dprnn_head_conv_ola_ragged_fwd: bad sizes n=%d frames=%lld K=%d P=%d", n, (long long)total_frames, K, P);
+        return -1;
+    }
+    if (dprnn_get_gemm_mode() != 3) { dprnn_set_error("dprnn_head_conv_ola_ragged_fwd: gate-GEMM mode 3 (f16 pieces) only"); return -1; }
+    static_assert(sizeof(long long) == sizeof(int64_t), "table element size");
+    const long long* us = reinterpret_cast<const long long*>(utt_starts);
+    const long long* lo = reinterpret_cast<const long long*>(l_off);
+    OlaGatherRagged<HEAD_F16T_RT> al{OlaGather<HEAD_F16T_RT>{X, 0.f, 0, K, P, 0, Z, stats, gamma, beta, eps}, prelu_w, us, lo, n};
+    EpTHeadConvRagged<HEAD_F16T_RT> ep{U, b2d, us, lo, n, K, P};
+    return launch_rowgemm_f16t<128, 256, HEAD_F16T_RT, false>("head_conv_ola_ragged_f16", W2d, 128, 256, nullptr, 0, (long long)total_frames, al, ep,
+                                                              (hipStream_t)stream);
+}
+
 extern "C" int dprnn_head_conv_ola_fwd(const float* X, const float* prelu_w, const float* W2d, const float* b2d,
                                        float* U, int B, int L, int K, int P, int S, void* stream) {
     return head_conv_ola(X, nullptr, nullptr, nullptr, nullptr, 0.f, prelu_w, W2d, b2d, U, B, L, K, P, S, stream);

@@ -853,9 +853,29 @@ def _pointwise(st: Stage, A, rows, kdim, conv_w, conv_b, cout, in_scale=None, in
     return out
 
 
+@contextlib.contextmanager
+def eval_bn_folds(st: Stage, module):
+    """Inside the block, the (scale, shift, mean) of every EVAL-mode BatchNorm of `module` is the one computed here, once, on st's stream --
+    they depend on the layer's parameters and running statistics only.  A ragged batch runs the speaker branch once (or twice) per
+    utterance on side streams forked from st afterwards: six dprnn_bn_prep launches per utterance and pass were a third of its launches."""
+    dev = st.device
+    folds = {id(m): _bn_fold(st, m, None, 1, dev) for m in module.modules()
+             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and not m.training} if RAGGED_BN_FOLDS_ONCE else {}
+    prev = getattr(_TLS, "bn_folds", None)
+    _TLS.bn_folds = folds
+    try:
+        yield
+    finally:
+        _TLS.bn_folds = prev
+
+
 def _bn_fold(st: Stage, bn, col_stats, count, dev):
     if bn.momentum is None:
         raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not supported")
+    if col_stats is None:
+        folds = getattr(_TLS, "bn_folds", None)
+        if folds is not None and id(bn) in folds:
+            return folds[id(bn)]
     C = bn.num_features
     scale = torch.empty(C, device=dev, dtype=torch.float32)
     shift = torch.empty_like(scale)
@@ -1042,12 +1062,16 @@ def _spe_forward_impl(model, wav, aux, aux_len, ira: bool = False, debug: Option
 # bottleneck, speaker branch) and after it (mask head, decoder) is launched per utterance: < 3 % of the work.
 # Needs the bf16-split gate GEMM (the eight-wave 64-sequence kernel) and LSTM cells; callers fall back to per-length
 # batches on streams otherwise (inference.separate_many).
-RAGGED_STREAMS = 8           # side streams for the per-utterance launches around the ragged slab (small kernels: they overlap)
+RAGGED_STREAMS = int(os.environ.get("DPRNN_RAGGED_STREAMS", "8"))           # side streams for the per-utterance launches around the ragged slab (small kernels: they overlap)
 # Reference utterances of EQUAL length go through the speaker branch as one batch (eval-mode BatchNorm: rows of different utterances never
 # meet), this many at a time (3 KB of intermediates per reference sample: 64 x 3 s = 4.6 GB).  1: one utterance per launch set, as before.
 RAGGED_AUX_BATCH = int(os.environ.get("DPRNN_RAGGED_AUX_BATCH", "64"))
 # The mask head's gate (row-wise) as ONE launch over every utterance of a ragged batch instead of one per utterance.  0: per utterance.
 RAGGED_GATE_BATCHED = os.environ.get("DPRNN_RAGGED_GATE_BATCHED", "1") != "0"
+# ... and its conv2d + overlap-add as one launch too (dprnn_head_conv_ola_ragged_fwd, gate-GEMM mode 3).  0: one launch per utterance.
+RAGGED_HEAD_CONV_BATCHED = os.environ.get("DPRNN_RAGGED_HEAD_CONV_BATCHED", "1") != "0"
+# Eval-mode BatchNorm folds of the speaker encoder once per ragged forward instead of once per utterance and pass (eval_bn_folds).  0: per utterance.
+RAGGED_BN_FOLDS_ONCE = os.environ.get("DPRNN_RAGGED_BN_FOLDS_ONCE", "1") != "0"
 _FAN_POOL: dict = {}
 
 
@@ -1080,7 +1104,7 @@ GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_f
 # and are therefore part of every captured graph's key; the others are constants, bookkeeping, or policy applied outside a capture.
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
 LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
-                "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS", "RAGGED_AUX_BATCH", "RAGGED_GATE_BATCHED",
+                "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS", "RAGGED_AUX_BATCH", "RAGGED_GATE_BATCHED", "RAGGED_HEAD_CONV_BATCHED", "RAGGED_BN_FOLDS_ONCE",
                 "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES", "WIDE_TILE_MIN_FILL")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
                   "ON_SATURATION", "SATURATION", "SAT_NONFINITE", "PIN_AFTER_FALLBACKS", "PROFILE", "WS_PARTS", "SKIP_FIRST_STREAM_PAIR",

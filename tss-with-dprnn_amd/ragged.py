@@ -86,10 +86,12 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
             r0 = int(starts[u]) + k0
             desc.append((r0 & 0xFFFFFFFF, r0 >> 32, int(chunks[u]), min(64, K - k0), int(u), 0, 0, 0))
     desc = np.array(desc, dtype=np.int64).astype(np.uint32).view(np.int32)
-    tables = E._upload(torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), seq_utt, desc.reshape(-1)])), dev)
+    l_off = np.concatenate([[0], np.cumsum([g.L for g in geos])]).astype(np.int64)          # frames of the utterances, back to back (mask head)
+    tables = E._upload(torch.from_numpy(np.concatenate([rows.view(np.int32), starts.view(np.int32), l_off.view(np.int32), seq_utt, desc.reshape(-1)])), dev)
     o = 0
     utt_rows = tables[o: o + 2 * n]; o += 2 * n
     utt_starts = tables[o: o + 2 * (n + 1)]; o += 2 * (n + 1)
+    l_off_d = tables[o: o + 2 * (n + 1)]; o += 2 * (n + 1)
     seq_utt_d = tables[o: o + seq_utt.size]; o += seq_utt.size
     desc_d = tables[o:]
     n_tiles = desc.shape[0]
@@ -176,7 +178,6 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
     # the gate between them (tanh(out(U)) * sigmoid(gate(U)), dprnn.py:157-158,180) is row-wise, so the utterances' U rows sit back to back
     # and it is ONE launch over all of them -- a per-utterance launch stages its 128 KB of weights for a few hundred rows per workgroup and
     # ran at a quarter of the batched rate (profiles/r05_ragged_ira_kernel_stats.csv).  U_all [sum L][2F] | V_all [2 sum L][F] in H's region.
-    l_off = np.concatenate([[0], np.cumsum([g.L for g in geos])]).astype(np.int64)
     sum_l = int(l_off[-1])
     assert 4 * sum_l * E.F_BUILT <= int(head_off[-1])
     U_all, V_all = H[: 2 * sum_l * E.F_BUILT], H[2 * sum_l * E.F_BUILT: 4 * sum_l * E.F_BUILT]
@@ -207,10 +208,15 @@ def dprnn_process_ragged(st: Stage, sep, Ys, wavs, enc_w, dec_w, geos, relu_act:
                 E._p(wavs[u]), E._p(enc_w), E._p(dec_w), E._p(t), E._p(mk), 1 if relu_act else 0, 1, g.T, g.L, N, ks, g.stride)
         return t, mk
 
-    fan = _Fan(st, n)
-    for u in range(n):
-        fan.run(u, lambda sg, u=u: head_conv(sg, u))
-    fan.join()
+    if E.RAGGED_HEAD_CONV_BATCHED and mode == 3:       # one launch over every utterance's frames (a row finds its utterance in l_off)
+        E._set_slot(st.lib, E.SLOT_HEAD_CONV)
+        pn_ = (0, 0, 0, 0, 0.0) if pending is None else (E._p(Z), E._p(pending[0]), E._p(pending[1]), E._p(pending[2]), pending[3])
+        st.call("dprnn_head_conv_ola_ragged_fwd", E._p(X), *pn_, *head_w, E._p(U_all), E._p(utt_starts), E._p(l_off_d), n, sum_l, K, P)
+    else:
+        fan = _Fan(st, n)
+        for u in range(n):
+            fan.run(u, lambda sg, u=u: head_conv(sg, u))
+        fan.join()
     if E.RAGGED_GATE_BATCHED:
         E._set_slot(st.lib, E.SLOT_HEAD_GATE)
         st.call("dprnn_head_gate_fwd", E._p(U_all), *gate_w, E._p(V_all), 2 * sum_l)
@@ -256,7 +262,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
     cfg = model.cfg
     E.check_supported_spe(cfg)
     dev = wavs[0].device
-    with torch.cuda.device(dev), E._scale_record(model, dev) as rec:
+    with torch.cuda.device(dev), E._scale_record(model, dev) as rec, E.eval_bn_folds(E.Stage(dev), model.separation):
         st = E.Stage(dev)
         N, ks, stride = cfg["input_size"], cfg["kernel_size"], cfg["stride"]
         sep = model.separation
