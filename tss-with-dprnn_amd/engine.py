@@ -834,10 +834,11 @@ def _linear_small(st: Stage, lin_w, lin_b, x, k0: int = 0, K: Optional[int] = No
 
 
 def _pointwise(st: Stage, A, rows, kdim, conv_w, conv_b, cout, in_scale=None, in_shift=None, aff_stride=0,
-               rows_per_utt=0, in_prelu=None, col_stats=None, in_mean=None):
+               rows_per_utt=0, in_prelu=None, col_stats=None, in_mean=None, out=None):
     dev = A.device
     w = _param(conv_w, "conv.weight", dev)
-    out = torch.empty(rows, cout, device=dev, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(rows, cout, device=dev, dtype=torch.float32)
     # mode 3: the 1x1 convs of the speaker branch run in f16 pieces as well (one activation-scale slot for all of them); a launch that
     # also has to form BatchNorm batch statistics (col_stats) stays on the fp32 kernel inside the library
     prev = st.lib.dprnn_get_gemm_mode()

@@ -46,7 +46,10 @@ def ragged_chunks(order: Sequence[int], lengths: Sequence[int], device=None) -> 
     """Consecutive runs of `order` (indices into lengths, in samples), each one ragged batch."""
     cap = RAGGED_MAX_SAMPLES
     if device is not None and torch.cuda.is_available():
+        # what the next batch's arena can come from: memory the driver still has, and what torch's caching allocator holds unused -- the
+        # previous batch's arena above all (without it a second call on a warm process saw 100+ GB "missing" and cut its batches in three)
         free, _ = torch.cuda.mem_get_info(device)
+        free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
         cap = max(1, min(cap, int(0.6 * free / RAGGED_BYTES_PER_SAMPLE)))
     chunks, cur, tot = [], [], 0
     for i in order:

@@ -259,6 +259,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
     """DPRNNSpeTasNet / DPRNNSpeIRATasNet forward for lists of mixtures and reference utterances of different lengths ->
     list of (estimate [T_out_u], logits [num_spks]); every utterance keeps batch-of-one semantics (BatchNorm statistics of
     the speaker branch included, as the reference's one-at-a-time loop has them)."""
+    import numpy as np
     cfg = model.cfg
     E.check_supported_spe(cfg)
     dev = wavs[0].device
@@ -328,17 +329,67 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             taps, d0s = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act, want_masked=True)
             g0, b0, _ = E._norm_params(se[0])
 
+            # The second speaker pass (dprnn_spe_ira.py:79-92) reads the first estimates d0_u, whose lengths differ.  Everything in it but the
+            # GroupNorm statistics, the max-pools and the time mean is row-wise, so in eval mode the utterances' frames go through the three
+            # ResBlocks and the last conv back to back, RAGGED_AUX_BATCH utterances at a time: every utterance's segment is padded (zero rows)
+            # to a multiple of 27 frames, so that none of the three MaxPool1d(3) stages pools across a boundary and the rows MaxPool1d would drop
+            # (a partial triple at the end, at every stage) land behind the utterance's real outputs, where the time mean does not look.
+            # Per utterance: the statistics and the first conv (its GroupNorm affine is the utterance's own) in front, the time mean behind.
+            v1_of = [None] * n
+            if parallel and E.RAGGED_AUX_BATCH > 1 and n > 1:
+                # groups of up to RAGGED_AUX_BATCH utterances, each on its own side stream from its first launch to its last (as many groups
+                # as there are side streams when the batch allows: the per-utterance launches in front and behind are latency, not work)
+                gsz = min(E.RAGGED_AUX_BATCH, max(8, -(-n // max(1, E.RAGGED_STREAMS))))
+
+                def group(sg, grp):
+                    lp = [-(-geos[u].L // 27) * 27 for u in grp]
+                    off = np.concatenate([[0], np.cumsum(lp)]).astype(np.int64)
+                    A0d_all = torch.zeros(int(off[-1]), E.F_BUILT, device=dev, dtype=torch.float32)
+                    for j, u in enumerate(grp):
+                        geo = geos[u]
+                        sg.call("dprnn_rows_stats", E._p(d0s[u]), E._p(stats[u, 2]), 1, geo.L, N)
+                        E._count_scale(stats[u, 2].view(1, 2), se[0], sg, 1)
+                        sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
+                        sh_d = torch.empty_like(sc_d)
+                        sg.call("dprnn_bottleneck_prep", E._p(stats[u, 2]), E._p(E._param(g0, "spk_encoder.0.weight", dev)),
+                                E._p(E._param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, E._p(sc_d), E._p(sh_d), 1, geo.L, N)
+                        E._pointwise(sg, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
+                                     aff_stride=N, rows_per_utt=geo.L, out=A0d_all[int(off[j]): int(off[j]) + geo.L])
+                    t = int(off[-1])
+                    h, t = E._resblock(sg, se[2], A0d_all, 1, t, 128, 128)
+                    h, t = E._resblock(sg, se[3], h, 1, t, 128, 256)
+                    h, t = E._resblock(sg, se[4], h, 1, t, 256, 256)
+                    Eall = E._pointwise(sg, h.view(t, 256), t, 256, se[5].weight, se[5].bias, 128)
+                    embs = torch.empty(len(grp), 128, device=dev, dtype=torch.float32)
+                    for j, u in enumerate(grp):
+                        t3 = geos[u].L // 27                      # = ((L // 3) // 3) // 3: the rows MaxPool1d(3) x 3 keeps
+                        if t3 < 1:
+                            raise DprnnError("utterance too short for three MaxPool1d(3) stages")
+                        sg.call("dprnn_time_mean_fwd", E._p(Eall[int(off[j]) // 27:]), E._p(alens[u]), 1, E._p(embs[j:]), 1, t3, 128, ks)
+                    return embs
+
+                groups = [list(range(i0, min(n, i0 + gsz))) for i0 in range(0, n, gsz)]
+                fan = _Fan(st, len(groups))
+                outs = [fan.run(gi, lambda sg, grp=grp: group(sg, grp)) for gi, grp in enumerate(groups)]
+                fan.join()
+                for grp, embs in zip(groups, outs):
+                    for j, u in enumerate(grp):
+                        v1_of[u] = embs[j: j + 1]
+
             def second(sg, u):
                 geo = geos[u]
-                sg.call("dprnn_rows_stats", E._p(d0s[u]), E._p(stats[u, 2]), 1, geo.L, N)
-                E._count_scale(stats[u, 2].view(1, 2), se[0], sg, 1)
-                sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
-                sh_d = torch.empty_like(sc_d)
-                sg.call("dprnn_bottleneck_prep", E._p(stats[u, 2]), E._p(E._param(g0, "spk_encoder.0.weight", dev)),
-                        E._p(E._param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, E._p(sc_d), E._p(sh_d), 1, geo.L, N)
-                A0d = E._pointwise(sg, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
-                                 aff_stride=N, rows_per_utt=geo.L)
-                v1 = E.speaker_embedding(sg, sep, A0d, 1, geo.L, alens[u], ks)
+                if v1_of[u] is not None:
+                    v1 = v1_of[u]
+                else:
+                    sg.call("dprnn_rows_stats", E._p(d0s[u]), E._p(stats[u, 2]), 1, geo.L, N)
+                    E._count_scale(stats[u, 2].view(1, 2), se[0], sg, 1)
+                    sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
+                    sh_d = torch.empty_like(sc_d)
+                    sg.call("dprnn_bottleneck_prep", E._p(stats[u, 2]), E._p(E._param(g0, "spk_encoder.0.weight", dev)),
+                            E._p(E._param(b0, "spk_encoder.0.bias", dev)), 1e-5, 0, 0, E._p(sc_d), E._p(sh_d), 1, geo.L, N)
+                    A0d = E._pointwise(sg, d0s[u].view(geo.L, N), geo.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d,
+                                       aff_stride=N, rows_per_utt=geo.L)
+                    v1 = E.speaker_embedding(sg, sep, A0d, 1, geo.L, alens[u], ks)
                 v1 = E._linear_small(sg, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous())
                 mul2, add2, row_bias2 = E._fusion_operands(sg, sep, cfg, v1)
                 sc, sh = scs[u]
