@@ -10,6 +10,20 @@ from . import engine as E
 from ._lib import DprnnError
 
 
+_T0 = [0.0]
+
+
+def _mark(what: str) -> None:
+    """DPRNN_RAGGED_TRACE=1: host-side time of a phase boundary of a ragged forward (ms since the forward began), for reading beside a kernel
+    timeline: where the host was when the GPU went idle."""
+    import os
+    import time
+    if os.environ.get("DPRNN_RAGGED_TRACE") == "1":
+        if what == "begin":
+            _T0[0] = time.perf_counter()
+        print(f"[ragged host] {what:28s} {(time.perf_counter() - _T0[0]) * 1e3:8.1f} ms", flush=True)
+
+
 class _Fan:
     """Independent per-utterance work dealt round-robin over persistent side streams; join() makes the caller's stream wait
     for all of it (and hands the tensors produced there over to it)."""
@@ -260,6 +274,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
     list of (estimate [T_out_u], logits [num_spks]); every utterance keeps batch-of-one semantics (BatchNorm statistics of
     the speaker branch included, as the reference's one-at-a-time loop has them)."""
     import numpy as np
+    _mark("begin")
     cfg = model.cfg
     E.check_supported_spe(cfg)
     dev = wavs[0].device
@@ -317,9 +332,11 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             Y = E.bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geos[u], row_bias, row_scale)
             return v0, Y, sc, sh, alen
 
+        _mark("reference embeddings queued")
         fan = _Fan(st, n, parallel)
         r1 = [fan.run(u, lambda sg, u=u: first(sg, u)) for u in range(n)]
         fan.join()
+        _mark("prologue queued")
         v0s, Ys = [r[0] for r in r1], [r[1] for r in r1]
         scs, alens = [(r[2], r[3]) for r in r1], [r[4] for r in r1]
         v_last = v0s
@@ -327,6 +344,7 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             taps, _ = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act)
         else:
             taps, d0s = dprnn_process_ragged(st, sep, Ys, ws, enc_w, dec_w, geos, relu_act, want_masked=True)
+            _mark("pass 1 + head queued")
             g0, b0, _ = E._norm_params(se[0])
 
             # The second speaker pass (dprnn_spe_ira.py:79-92) reads the first estimates d0_u, whose lengths differ.  Everything in it but the
@@ -399,9 +417,11 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
                 row_scale2 = E._att_row_scale(sg, sep, cfg, ws[u], enc_w, geo, stats[u, 0], mul2) if cfg["fusion_type"] == "att" else None
                 return v1, E.bottleneck_frames(sg, ws[u], enc_w, sc, sh, sep.bottleneck[1], geo, row_bias2, row_scale2)
 
+            _mark("second speaker pass queued")
             fan = _Fan(st, n, parallel)
             r2 = [fan.run(u, lambda sg, u=u: second(sg, u)) for u in range(n)]
             fan.join()
+            _mark("second bottleneck queued")
             del Ys, d0s
             taps, _ = dprnn_process_ragged(st, sep, [r[1] for r in r2], ws, enc_w, dec_w, geos, relu_act)
             v_last = [r[0] for r in r2]
@@ -410,8 +430,10 @@ def _spe_forward_ragged_impl(model, wavs, auxs, aux_lens, ira: bool = False):
             logits = E._linear_small(sg, sep.pred_linear.weight, sep.pred_linear.bias, v_last[u])
             return E.decode(sg, taps[u], geos[u], 1), logits
 
+        _mark("pass 2 + head queued")
         fan = _Fan(st, n)
         r3 = [fan.run(u, lambda sg, u=u: last(sg, u)) for u in range(n)]
         fan.join()
         E._scale_end(st, rec)
+        _mark("everything queued")
         return [(est[0, 0, :], logits[0]) for est, logits in r3]
