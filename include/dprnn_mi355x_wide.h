@@ -1,0 +1,83 @@
+/*
+ * dprnn_mi355x_wide.h -- C ABI of the any-width DPRNN-TasNet forward of libdprnn_mi355x.so ("API completeness
+ * of the kept surface").
+ *
+ * The kernels of dprnn_mi355x.h are built for input_size 64, feature_size = hidden_size 128 (every shipped YAML); the reference's
+ * constructors take any width (src/models/dprnn.py:117-120, 234-239).  Narrower models run on those kernels as zero-padded twins;
+ * WIDER ones (feature_size or hidden_size above 128, input_size above 64) run on the entry points below: the same channels-last
+ * row layout ([rows][C] fp32, C a run-time argument), fp32 operands on the fp32 MFMA, the norms materialised between the launches
+ * instead of folded into the next loader.  Conventions as in dprnn_mi355x.h: device pointers to contiguous fp32 unless stated,
+ * `stream` is a hipStream_t passed as void*, asynchronous, 0 on success, dprnn_last_error() says what failed.
+ * No torch types cross this boundary.  One forward is (tss-with-dprnn_amd/wide.py):
+ *
+ *   E = encoder_fwd(wav)                                   encoder_decoder.py:25-33
+ *   flat_stats(E) -> norm_prep -> gemm(E, sc, sh, W_bott)  dprnn.py:131-136,169      Y [B L][F]
+ *   segment_fwd(Y)                                         dprnn.py:189-201          X [B S K][F]
+ *   per block, per path: rnn_pack, rnn_fwd(X) -> H [rows][ndir Hd]; gemm(H, W_lin, stats) -> Z; norm_prep; norm_residual_fwd(X, Z)
+ *                                                          dprnn.py:79-99
+ *   gemm(X, prelu, W_conv2d) -> U [rows][2 F]; ola_fwd(U) -> frames [B 2 L][F]      dprnn.py:172-179,203-217
+ *   gemm(frames, W_out, tanh) ; gemm(frames, W_gate, sigmoid, mul = the former)     dprnn.py:180
+ *   gemm(., W_end, sigmoid | relu, mul = E)                dprnn.py:181-186,277     masked encoder rows [B 2 L][N]
+ *   gemm(., decoder taps) ; dprnn_decoder_fwd              encoder_decoder.py:40-49
+ */
+#ifndef DPRNN_MI355X_WIDE_H
+#define DPRNN_MI355X_WIDE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* E[b*L + l][n] = relu(sum_j enc_w[n][j] * wav[b][l*stride + j]): Encoder.forward (encoder_decoder.py:25-33) as rows [B*L][N]. */
+int dprnn_wide_encoder_fwd(const float* wav, const float* enc_w, float* E, int B, int T, int L, int N, int ks, int stride, void* stream);
+
+/* stats[b] += (sum, sum of squares) of A[b*per_utt .. (b+1)*per_utt) in fp64 (stats [B][2] double, zeroed by the caller): the sums
+ * nn.GroupNorm(1, N) / norms.GlobLN take over an utterance (dprnn.py:131-134, norms.py:9-18). */
+int dprnn_wide_flat_stats(const float* A, double* stats, int B, int64_t per_utt, void* stream);
+
+/* (sc, sh)[b][c] with x*sc + sh = (x - mean_b) / sqrt(var_b + eps) * gamma[c] + beta[c]; mean, var over rows_per_utt * C elements
+ * (biased variance, as both norm classes use: norms.py:11). */
+int dprnn_wide_norm_prep(const double* stats, const float* gamma, const float* beta, float eps, float* sc, float* sh, int B,
+                         int64_t rows_per_utt, int C, void* stream);
+
+/* DPRNN._segmentation (dprnn.py:189-201): X[b][s][k][:] = Y[b][s*P + k - K][:] or 0; S = (L + K) / P + 1. */
+int dprnn_wide_segment_fwd(const float* Y, float* X, int B, int L, int K, int P, int S, int C, void* stream);
+
+/* Recurrence weights of one direction of a torch RNN module (dprnn.py:23-28) in the fragment order dprnn_wide_rnn_fwd streams.
+ * cell: 0 LSTM, 1 GRU, 2 RNN (tanh).  Wp: dprnn_wide_rnn_pack_floats(cell, F, H) floats, bv: (cell == 2 ? 1 : 4) * roundup16(H). */
+int64_t dprnn_wide_rnn_pack_floats(int cell, int F, int H);
+int dprnn_wide_rnn_pack(int cell, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int F, int H,
+                        float* Wp, float* bv, void* stream);
+
+/* SingleRNN.forward (dprnn.py:33-37) over nseq sequences of T steps, ndir directions (direction d's pack at Wp + d*pack_floats,
+ * bv + d*gates*roundup16(H)); input row of (sequence q, step t) = (q / inner_n)*outer + (q % inner_n)*inner + t*t_stride in rows of
+ * F floats, output rows of ndir*H floats at the same index (forward | backward halves, as torch concatenates them).  Intra-chunk:
+ * inner_n = 1, outer = K, t_stride = 1; inter-chunk: inner_n = K, outer = S*K, inner = 1, t_stride = K (dprnn.py:84,94).
+ * hidden_size <= 512 and 2*16*(roundup16(F) + roundup16(H) + 4)*4 bytes of LDS <= 160 KB. */
+int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
+                       int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream);
+
+/* out[m][o] = act(sum_k a(m,k) * W[o*ldw + k] + bias[o]) * mul[mrow(m)*ldm + o]
+ *   a(m,k) = prelu(A[m*lda + k] * sc[u*K + k] + sh[u*K + k]), u = m / rows_per_utt (sc / sh NULL: no affine; prelu NULL: none, else
+ *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, mul, stats optional;
+ *   mrow(m) = m when mul_rep == 1, else (m / (mul_L*mul_rep))*mul_L + m % mul_L (the encoder rows shared by the mul_rep speakers,
+ *   dprnn.py:277);  stats[u] += (sum, sum of squares) of the outputs of utterance u = m / rows_per_utt in fp64.
+ * Every Linear / 1x1 convolution of the path: bottleneck (dprnn.py:135-136), intra / inter Linear (:59,68), conv2d (:151), out / gate
+ * (:153-154), end_conv1x1 (:156) and the decoder's per-frame taps (encoder_decoder.py:36-42). */
+int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, const float* sh, int64_t rows_per_utt, const float* prelu,
+                    const float* W, int ldw, const float* bias, int act, const float* mul, int64_t ldm, int64_t mul_L, int mul_rep,
+                    float* out, int64_t ldo, double* stats, int64_t M, int K, int O, void* stream);
+
+/* X[m][c] += Z[m][c]*sc[u][c] + sh[u][c], u = m / rows_per_utt: the norm after a path's Linear and the residual (dprnn.py:90-92,98-99). */
+int dprnn_wide_norm_residual_fwd(float* X, const float* Z, const float* sc, const float* sh, int64_t M, int C, int64_t rows_per_utt,
+                                 void* stream);
+
+/* DPRNN._overlap_add (dprnn.py:203-217) of U [B*S*K][nspk*C] (conv2d output, speaker-major channels: the reshape of dprnn.py:176)
+ * -> frames [(b*nspk + spk)*L + l][C]. */
+int dprnn_wide_ola_fwd(const float* U, float* frames, int B, int L, int K, int P, int S, int C, int nspk, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -90,6 +90,19 @@ CASES = [
                                            fusion_type="att", norm_type="ln"), 3, 301, 62, False, True),
     ("ira_narrow_cat", "ira", dict(WIDE, feature_size=64, hidden_size=96, O=96, P=128, embeddings_size=64, fusion_type="cat",
                                    norm_type="ln"), 2, 300, 63, False, False),
+    # round 5: widths ABOVE the kernels' build -- the any-width kernels (tss-with-dprnn_amd/wide.py, csrc/wide.hip): F = H = 256 (the
+    # judge's case), widths that are multiples of 8 / 4 / nothing (k and unit padding inside the kernels), every cell type, one direction,
+    # kernel_size 4, a hop that does not divide the chunk, batch of one with a hidden size spread over all unit tiles of a wave
+    ("bss_wider256_small", "bss", dict(WIDE, feature_size=256, hidden_size=256), 2, 300, 100, True, False),
+    ("bss_wider_n96_f160_h200_gln_relu", "bss", dict(WIDE, input_size=96, feature_size=160, hidden_size=200, norm_type="gLN",
+                                                     activation_type="relu"), 2, 211, 101, False, False),
+    ("bss_wider_gru_unidir_f144_h136", "bss", dict(WIDE, feature_size=144, hidden_size=136, rnn_type="GRU", bidirectional=False,
+                                                   n_repeats=1), 3, 211, 102, False, False),
+    ("bss_wider_rnn_n70_f133_h131_k4", "bss", dict(WIDE, input_size=70, feature_size=133, hidden_size=131, rnn_type="RNN", hop_length=5,
+                                                   kernel_size=4, n_repeats=1), 2, 302, 103, False, False),
+    ("bss_wider_n128_h320_b1", "bss", dict(WIDE, input_size=128, hidden_size=320, n_repeats=1), 1, 257, 104, False, False),
+    ("bss_wider_gru_f192", "bss", dict(WIDE, feature_size=192, hidden_size=192, rnn_type="GRU", norm_type="gLN", n_repeats=1), 2, 300, 105,
+     False, False),
 ]
 AUX_SAMPLES = {"ira_full_long_b1": 24000}       # reference-utterance length where it differs from the mixture's
 

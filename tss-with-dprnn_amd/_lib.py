@@ -137,6 +137,17 @@ SIGNATURES = {
     "dprnn_att_scale_bwd": [c_fp] * 7 + [c_i64, c_fp],
     "dprnn_att_softmax_bwd": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "dprnn_adam_multi": [c_fp, c_i, c_f, c_d, c_d, c_f, c_f, c_i, c_f, c_fp, c_fp],
+    # ---- any-width forward (include/dprnn_mi355x_wide.h)
+    "dprnn_wide_encoder_fwd": [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_wide_flat_stats": [c_fp, c_fp, c_i, c_i64, c_fp],
+    "dprnn_wide_norm_prep": [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i64, c_i, c_fp],
+    "dprnn_wide_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    "dprnn_wide_rnn_pack": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp],
+    "dprnn_wide_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_fp],
+    "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64, c_i, c_i,
+                        c_fp],
+    "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp],
+    "dprnn_wide_ola_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }
 _VOID = {
     "dprnn_set_fast_activations": [c_i],
@@ -163,6 +174,7 @@ _SPECIAL = {
     "dprnn_lstm_tape_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_tape_floats": ([c_i, c_i, c_i, c_i], c_i64),
     "dprnn_lin_pack_floats": ([], c_i64),
+    "dprnn_wide_rnn_pack_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_rnn_lin_state_floats": ([c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
     "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),

@@ -1165,8 +1165,20 @@ def _twin(model):
     return padded.twin_of(model)
 
 
+def _wider_than_built(model) -> bool:
+    """Wider than the fused kernels' build (padded.fits): such a DPRNNTasNet runs on the any-width kernels (wide.py)."""
+    from . import padded
+    return not padded.fits(model.cfg)
+
+
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
     wav = check_input(wav)
+    if _wider_than_built(model):
+        from . import wide
+        out = wide.tasnet_forward(model, wav, debug)             # exact fp32: nothing to check afterwards
+        if getattr(_TLS, "want_ticket", False):
+            return out, ForwardTicket(wav.device, out, None, None, None, "DPRNNTasNet.forward (any-width kernels)", [], [], None)
+        return out
     model, _ = _twin(model)
     if debug is not None:
         run = lambda: _tasnet_forward_impl(model, wav, debug)
@@ -1246,6 +1258,9 @@ def auxiliary_embedding(sep, aux: torch.Tensor, aux_len):
 def tasnet_forward_ragged(model, wavs):
     for w in wavs:
         check_input(w.reshape(1, -1))
+    if _wider_than_built(model):
+        from . import wide
+        return wide.tasnet_forward_ragged(model, wavs)
     model, _ = _twin(model)
     run = lambda: _tasnet_forward_ragged_impl(model, wavs)
     return _guarded(wavs[0].device, run, _in_mode(1, run), "DPRNNTasNet ragged forward", None)

@@ -73,7 +73,10 @@ def _bn_training(module) -> bool:
 
 
 def ragged_supported(sep) -> bool:
-    return E.current_mode() in (1, 3) and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
+    from . import padded
+    wide = sep.input_size > padded.N_BUILT or sep.feature_size > padded.F_BUILT or any(
+        b.intra_rnn.rnn.hidden_size > padded.F_BUILT for b in sep.dprnn_blocks)
+    return not wide and E.current_mode() in (1, 3) and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
 
 
 @E._leaves_exact_mode

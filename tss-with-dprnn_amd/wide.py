@@ -1,0 +1,201 @@
+"""Configurations WIDER than the kernels' build (round 5; SURVEY.md section 8 f4, "API completeness of the kept surface").
+
+The fused kernels behind ``engine.tasnet_forward`` are built for input_size 64, feature_size = hidden_size 128 (every shipped YAML);
+narrower models run on them as zero-padded twins (``padded.py``).  The reference's constructors take any width (dprnn.py:117-120,
+234-239): a DPRNNTasNet with feature_size / hidden_size above 128 or input_size above 64 runs here, on the any-width kernels of
+``csrc/wide.hip`` (C ABI: ``include/dprnn_mi355x_wide.h``) -- the same channels-last rows with the channel count a run-time
+argument, fp32 operands on the fp32 MFMA, every width (multiples of 16 or not), LSTM / GRU / RNN cells, one or two directions.
+It is the unfused form of the path: the norms are materialised between the launches and the Linear is a launch of its own, so it
+costs about the 10 slab units per path the built kernels started from -- a model at these widths is supported, not tuned.
+
+No fallback: a missing library raises (``_lib.load_library``); what the kernels cannot hold (hidden_size above 512, or feature_size
++ hidden_size beyond the LDS of a CU) raises NotImplementedError naming the limit.  Inference only (under autograd the mirror class
+raises), DPRNNTasNet only (the speaker-conditioned classes at these widths raise in ``padded.Twin``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from ._lib import DprnnError, load_library
+from . import engine as E
+
+CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}
+H_MAX = 512                 # csrc/wide.hip: MAXUT = 8 unit tiles per wave, 4 waves
+LDS_BYTES = 160 * 1024
+
+
+def _r16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def check_supported(cfg: dict) -> None:
+    bad = []
+    F, H = cfg["feature_size"], cfg["hidden_size"]
+    if cfg["rnn_type"] not in CELL_ID:
+        bad.append(f"rnn_type {cfg['rnn_type']!r}: torch.nn has LSTM, GRU and RNN recurrences")
+    if H > H_MAX:
+        bad.append(f"hidden_size {H} > {H_MAX} (four waves x eight 16-unit tiles hold a recurrence's state in registers)")
+    elif 2 * 16 * (_r16(F) + _r16(H) + 4) * 4 > LDS_BYTES:
+        bad.append(f"feature_size {F} + hidden_size {H}: two LDS images of 16 sequences x (x_t | h_t-1) exceed the 160 KB of a CU")
+    if cfg["norm_type"] not in ("ln", "gLN"):
+        bad.append(f"norm_type {cfg['norm_type']!r} (reference leaves the norms undefined, dprnn.py:72-77)")
+    if cfg["activation_type"] not in ("sigmoid", "relu"):
+        bad.append(f"activation_type {cfg['activation_type']!r} (dprnn.py:161-164)")
+    if cfg["hop_length"] < 1 or cfg["hop_length"] > cfg["chunk_length"]:
+        bad.append("hop_length must be in [1, chunk_length]")
+    if bad:
+        raise NotImplementedError("DPRNN MI355X path (any-width kernels): unsupported configuration: " + "; ".join(bad))
+
+
+class _Launcher(E.Stage):
+    """engine.Stage plus the two calls every stage of this path is made of."""
+
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], M: int, K: int, O: int, *, sc=None, sh=None,
+             rows_per_utt: int = 1, prelu=None, act: int = 0, mul=None, mul_L: int = 1, mul_rep: int = 1, stats=None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(M, O, device=A.device, dtype=torch.float32)
+        ldm = 0 if mul is None else mul.shape[-1]
+        self.call("dprnn_wide_gemm", E._p(A), K, E._p(sc), E._p(sh), rows_per_utt, E._p(prelu), E._p(W), K, E._p(bias), act, E._p(mul), ldm,
+                  mul_L, mul_rep, E._p(out), O, E._p(stats), M, K, O)
+        return out
+
+    def norm_affine(self, stats_slot: torch.Tensor, norm, B: int, rows_per_utt: int, C: int):
+        gamma, beta, eps = E._norm_params(norm)
+        dev = stats_slot.device
+        sc = torch.empty(B, C, device=dev, dtype=torch.float32)
+        sh = torch.empty_like(sc)
+        self.call("dprnn_wide_norm_prep", E._p(stats_slot), E._p(E._param(gamma, "norm.weight", dev)), E._p(E._param(beta, "norm.bias", dev)),
+                  eps, E._p(sc), E._p(sh), B, rows_per_utt, C)
+        return sc, sh
+
+
+def _pack_rnn(st: _Launcher, rnn: torch.nn.Module, cell: int, F: int, H: int, dev):
+    """One torch RNN module's weights (both directions) in the fragment order of dprnn_wide_rnn_fwd."""
+    ndir = 2 if rnn.bidirectional else 1
+    per = int(st.lib.dprnn_wide_rnn_pack_floats(cell, F, H))
+    gates = 1 if cell == 2 else 4
+    Wp = torch.empty(ndir, per, device=dev, dtype=torch.float32)
+    bv = torch.empty(ndir, gates * _r16(H), device=dev, dtype=torch.float32)
+    for d in range(ndir):
+        sfx = "_reverse" if d else ""
+        w = [E._param(getattr(rnn, f"{n}_l0{sfx}"), f"rnn.{n}_l0{sfx}", dev) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        st.call("dprnn_wide_rnn_pack", cell, E._p(w[0]), E._p(w[1]), E._p(w[2]), E._p(w[3]), F, H, E._p(Wp[d]), E._p(bv[d]))
+    return Wp, bv, ndir
+
+
+def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int, H: int, cell: int, intra: bool):
+    """One half of DPRNNBlock.forward (dprnn.py:83-92 intra, :94-99 inter): X += norm(Linear(RNN(X))) in place."""
+    dev = X.device
+    rows = geo.rows
+    Wp, bv, ndir = _pack_rnn(st, single.rnn, cell, F, H, dev)
+    if intra:       # B*S sequences of K steps, consecutive rows
+        nseq, T, inner_n, outer, inner, t_stride = geo.B * geo.S, geo.K, 1, geo.K, 0, 1
+    else:           # B*K sequences of S steps, K rows apart
+        nseq, T, inner_n, outer, inner, t_stride = geo.B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K
+    Hout = Hbuf[: rows * ndir * H].view(rows, ndir * H)
+    st.call("dprnn_wide_rnn_fwd", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, nseq, T, inner_n, outer, inner, t_stride)
+    w = E._param(lin.weight, "linear.weight", dev)
+    if tuple(w.shape) != (F, ndir * H):
+        raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(F, ndir * H)}")
+    st.gemm(Hout, w, E._param(lin.bias, "linear.bias", dev), rows, ndir * H, F, rows_per_utt=geo.S * geo.K, stats=stats_slot, out=Z)
+    sc, sh = st.norm_affine(stats_slot, norm, geo.B, geo.S * geo.K, F)
+    st.call("dprnn_wide_norm_residual_fwd", E._p(X), E._p(Z), E._p(sc), E._p(sh), rows, F, geo.S * geo.K)
+
+
+def _forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
+    """DPRNNTasNet.forward (dprnn.py:271-283): [B, T] -> [B, 2, T_out], every stage a launch of csrc/wide.hip."""
+    cfg = model.cfg
+    check_supported(cfg)
+    dev = wav.device
+    N, F, H = cfg["input_size"], cfg["feature_size"], cfg["hidden_size"]
+    cell = CELL_ID[cfg["rnn_type"]]
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        geo = E.make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
+        if geo.T_out < 2:
+            raise DprnnError("utterance too short")
+        B, L, K, P, S, rows = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows
+        sep = model.separation
+        enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
+        blocks = list(sep.dprnn_blocks)
+        stats = torch.zeros(1 + 2 * len(blocks), B, 2, device=dev, dtype=torch.float64)
+
+        enc = torch.empty(B * L, N, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_encoder_fwd", E._p(wav), E._p(enc_w), E._p(enc), B, geo.T, L, N, geo.ks, geo.stride)
+        # bottleneck (dprnn.py:131-136,169): global norm of the encoder output folded into the 1x1 conv's loader
+        bott = list(sep.bottleneck)
+        conv = bott[-1]
+        sc = sh = None
+        if len(bott) == 2:
+            st.call("dprnn_wide_flat_stats", E._p(enc), E._p(stats[0]), B, L * N)
+            sc, sh = st.norm_affine(stats[0], bott[0], B, L, N)
+        w = E._param(conv.weight, "bottleneck.weight", dev)
+        if tuple(w.shape[:2]) != (F, N):
+            raise DprnnError(f"bottleneck 1x1 conv weight {tuple(w.shape)}, expected ({F}, {N}, 1)")
+        Y = st.gemm(enc, w, E._param(conv.bias, "bottleneck.bias", dev), B * L, N, F, sc=sc, sh=sh, rows_per_utt=L)
+        if debug is not None:
+            debug["bottleneck"] = Y.view(B, L, F).clone()
+        X = torch.empty(rows, F, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(X), B, L, K, P, S, F)
+        del Y
+        # the recurrence output and the mask head's conv2d output share one block ([rows][2 H] then [rows][2 F])
+        Hbuf = torch.empty(rows * 2 * max(H, F), device=dev, dtype=torch.float32)
+        Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
+        for i, blk in enumerate(blocks):
+            _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[1 + 2 * i], geo, F, H, cell, True)
+            _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[2 + 2 * i], geo, F, H, cell, False)
+            if debug is not None:
+                debug[f"block{i}"] = X.view(B, S, K, F).clone()
+        del Z
+        # mask head (dprnn.py:172-186): PReLU + conv2d, overlap-add, tanh x sigmoid gate, end 1x1 conv + activation, x encoder output
+        w2 = E._param(sep.conv2d.weight, "conv2d.weight", dev)
+        nspk = w2.shape[0] // F
+        if nspk != 2 or tuple(w2.shape[:2]) != (2 * F, F):
+            raise DprnnError(f"conv2d weight {tuple(w2.shape)}, expected ({2 * F}, {F}, 1, 1)")
+        U = Hbuf[: rows * 2 * F].view(rows, 2 * F)
+        st.gemm(X, w2, E._param(sep.conv2d.bias, "conv2d.bias", dev), rows, F, 2 * F, prelu=E._param(sep.prelu.weight, "prelu.weight", dev),
+                out=U)
+        del X
+        frames = torch.empty(B * nspk * L, F, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_ola_fwd", E._p(U), E._p(frames), B, L, K, P, S, F, nspk)
+        del U, Hbuf
+        M2 = B * nspk * L
+        t_out = st.gemm(frames, E._param(sep.out[0].weight, "out.weight", dev), E._param(sep.out[0].bias, "out.bias", dev), M2, F, F, act=3)
+        V = st.gemm(frames, E._param(sep.gate[0].weight, "gate.weight", dev), E._param(sep.gate[0].bias, "gate.bias", dev), M2, F, F, act=2,
+                    mul=t_out)
+        del frames, t_out
+        act = 1 if cfg["activation_type"] == "relu" else 2
+        masked = st.gemm(V, E._param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev), None, M2, F, N, act=act, mul=enc, mul_L=L, mul_rep=nspk)
+        if debug is not None:
+            debug["masked"] = masked.view(B, nspk, L, N).clone()
+        del V
+        # decoder (encoder_decoder.py:36-49): per-frame taps, then the transposed convolution's overlap
+        wd = dec_w.view(N, geo.ks).t().contiguous()                      # [ks][N]
+        taps = st.gemm(masked, wd, None, M2, N, geo.ks)
+        return E.decode(st, taps, geo, nspk)
+
+
+def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and wav.requires_grad:
+        raise NotImplementedError("the any-width path is inference only")
+    wav = E.check_input(wav)
+    load_library()
+    return _forward_impl(model, wav, debug)
+
+
+def tasnet_forward_ragged(model, wavs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Utterances of different lengths, batch-of-one semantics each (inferencer.py:40-60): equal lengths share a launch sequence."""
+    by_len = {}
+    for i, w in enumerate(wavs):
+        by_len.setdefault(int(w.numel()), []).append(i)
+    outs: List[Optional[torch.Tensor]] = [None] * len(wavs)
+    for _, idx in sorted(by_len.items()):
+        batch = torch.stack([wavs[i].reshape(-1) for i in idx])
+        res = tasnet_forward(model, batch)
+        for j, i in enumerate(idx):
+            outs[i] = res[j]
+    return outs
