@@ -465,7 +465,8 @@ def main():
                 # achieved: algorithmic FLOPs of one launch / the MEAN duration of a launch (HIP events on the launch streams,
                 # = rocprofv3 --stats' per-kernel average).  The utterance groups' launches overlap on the chip, so this includes
                 # the time a launch waits for CUs the other group's launch still holds.
-                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)", "frac": per_launch / peak,
+                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)",
+                "frac": per_launch / peak if per_launch is not None else None,
                 "traffic": traffic, "traffic_unit": f"GB per launch (PMC, profiles/{traffic_src})",
                 "peak_note": "157.3 = fp32 MFMA peak" if mode == 0 else
                 f"{BF16_PEAK:.0f} TFLOP/s dense {piece} MFMA / {products} products per algorithmic FLOP; the fp32 MFMA peak is "
@@ -647,7 +648,8 @@ def bench_other_configs(args, dev, mode):
     products = {0: 1, 1: 6, 3: 3}[mode]
     peak = PEAK_F32_MFMA_TFLOPS if mode == 0 else 2500.0 / products
     engine.GEMM_MODE = mode
-    rec_names = {"dprnn_rnn_fwd_ex", "dprnn_rnn_fwd_hp_ex", "dprnn_rnn_fwd_ragged_ex", "dprnn_rnn_fwd_ragged_hp_ex", "dprnn_rnn_lin_split_fwd"}
+    folded_names = {"dprnn_rnn_lin_split_fwd", "dprnn_rnn_lin_split_ragged_fwd"}
+    rec_names = {"dprnn_rnn_fwd_ex", "dprnn_rnn_fwd_hp_ex", "dprnn_rnn_fwd_ragged_ex", "dprnn_rnn_fwd_ragged_hp_ex"} | folded_names
 
     def build(kind, cls):
         cfg = full_cfg(norm_type="ln", fusion_type="cat")
@@ -679,14 +681,15 @@ def bench_other_configs(args, dev, mode):
             prof, engine.PROFILE = engine.PROFILE, None
         ev = [e for n in sorted(rec_names) for e in prof["events"].get(n, [])]
         kern_ms, union_ms, conc, n_ev = _launch_stats(ev, t_ref)
-        flop = flop_per_launch_of(n_ev)
-        folded = bool(prof["events"].get("dprnn_rnn_lin_split_fwd"))
-        if folded:          # a launch meets every row once: one direction's gate GEMM + its half of the Linear (see the headline's roofline)
-            flop *= (2 * 256 * 512 + 2 * 128 * 128) / (2 * (2 * 256 * 512))
-        per_launch = flop / (kern_ms * 1e-3) / 1e12
+        # a folded launch meets every row once: one direction's gate GEMM + its half of the Linear (see the headline's roofline)
+        folded = any(prof["events"].get(n) for n in folded_names)
+        per_launch = flop_per_launch_of(n_ev, folded) / (kern_ms * 1e-3) / 1e12 if n_ev else None
+        if not n_ev:
+            kern_ms = None
         return {"bound": "mfma", "kernel": "the fused BiLSTM recurrence (bilstm_split8_kernel / bilstm_kernel), as in the headline's roofline",
                 "linear_folded_in": folded,
-                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)", "frac": per_launch / peak,
+                "achieved": per_launch, "peak": peak, "unit": "TFLOP/s (algorithmic = fp32-equivalent)",
+                "frac": per_launch / peak if per_launch is not None else None,
                 "traffic": None, "kernel_ms": kern_ms, "launches_timed": n_ev, "mean_concurrency": conc,
                 "whole_forward_tflops": whole_tflops, "whole_forward_frac": whole_tflops / peak,
                 "timed_in": "one eager pass after the timed steps (HIP events on the launch streams)"}
@@ -707,7 +710,8 @@ def bench_other_configs(args, dev, mode):
                     "batch=64 (BASELINE.json configs[2])",
         "value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warm,
         "algorithmic_gflop_per_utterance": FLOP_PER_UTT_SPE / 1e9,
-        "roofline": rec_roofline(lambda: m(x, a, ln), lambda n_ev: geo.rows / n_groups * 2 * (2 * 256 * 512), B / dt * FLOP_PER_UTT_SPE / 1e12)}
+        "roofline": rec_roofline(lambda: m(x, a, ln), lambda n_ev, folded: geo.rows / n_groups * ((2 * 256 * 512 + 2 * 128 * 128) if folded else 2 * (2 * 256 * 512)),
+                                 B / dt * FLOP_PER_UTT_SPE / 1e12)}
     del m, x, a
     engine.drop_graphs()
     # ---- configs[4]: DPRNN-Spe-IRA, full-length utterances (this rank's eighth of the 3000-utterance test-set length distribution)
@@ -731,11 +735,47 @@ def bench_other_configs(args, dev, mode):
         "value": len(order) / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": 1, "warmup": 1,
         "step": "one pass over the rank's whole share", "audio_seconds": secs, "times_real_time": secs / dt,
         "algorithmic_gflop_per_step": gflop, "algorithmic_gflop_per_utterance_of_3s": FLOP_PER_UTT_IRA / 1e9,
-        # launches of a pass: 2 DPRNN passes x 12 paths per ragged batch; mean FLOPs per launch = all slab rows x 2 dirs x 2*256*512 x 24 / launches
-        "roofline": rec_roofline(run, lambda n_ev: rows_total * 2 * (2 * 256 * 512) * 24 / max(n_ev, 1), gflop / dt / 1e3),
+        # launches of a pass: 2 DPRNN passes x 12 paths (x 2 time phases when the Linear is folded in) per ragged batch; mean FLOPs per
+        # launch = all slab rows x (2 dirs x 2*256*512 [+ the Linear's 2*256*128]) x 24 / launches
+        "roofline": rec_roofline(run, lambda n_ev, folded: rows_total * (2 * (2 * 256 * 512) + (2 * 256 * 128 if folded else 0)) * 24 / max(n_ev, 1),
+                                 gflop / dt / 1e3),
         "ragged_batches_per_step": n_batches}
     del m, wavs, aux
     engine.drop_graphs()
+    # ---- beyond BASELINE.json's widths: a DPRNN-TasNet at feature_size = hidden_size = 256 (the reference constructor takes any width,
+    # dprnn.py:117-120) on the any-width kernels (wide.py, csrc/wide.hip: exact fp32 MFMA arithmetic whatever the mode), 64 x 3 s
+    F2 = H2 = 256
+    cfg = full_cfg(feature_size=F2, hidden_size=H2)
+    m = pkg.DPRNNTasNet(**{k: cfg[k] for k in CTOR}).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state("bss", cfg, 0).items()}, strict=True)
+    m = m.to(dev)
+    x = torch.from_numpy(make_mixture(B, SAMPLES, seed=2)).to(dev)
+    dt = timed(lambda: m(x), 1, 3)
+    R = cfg["n_repeats"]
+    rec_flop = geo.rows * 2 * (2 * (F2 + H2) * 4 * H2)                 # one launch: both directions of one path over the whole batch
+    flop = (geo.rows * R * 2 * (2 * (2 * (F2 + H2) * 4 * H2) + 2 * 2 * H2 * F2) + geo.rows * 2 * F2 * 2 * F2
+            + B * 2 * geo.L * 2 * (2 * F2 * F2 + F2 * 64) + B * geo.L * 2 * 64 * F2)
+    engine.PROFILE = {"names": {"dprnn_wide_rnn_fwd"}, "events": {}}
+    t_ref = torch.cuda.Event(enable_timing=True)
+    t_ref.record()
+    try:
+        with torch.no_grad():
+            m(x)
+        torch.cuda.synchronize(dev)
+    finally:
+        prof, engine.PROFILE = engine.PROFILE, None
+    kern_ms, _, _, n_ev = _launch_stats(prof["events"].get("dprnn_wide_rnn_fwd", []), t_ref)
+    out["tasnet_f256_h256_b64"] = {
+        "workload": "DPRNN-TasNet BSS inference at feature_size = hidden_size = 256 (wider than every shipped YAML), synthetic 3 s @ 8 kHz, "
+                    "batch=64, on the any-width kernels",
+        "value": B / dt, "unit": "utt/s", "ms_per_step": 1e3 * dt, "steps": 3, "warmup": 1, "dtype": "f32 (fp32 MFMA, any gate-GEMM mode)",
+        "algorithmic_gflop_per_utterance": flop / B / 1e9,
+        "roofline": {"bound": "mfma", "kernel": "wide_rnn_kernel (dprnn_wide_rnn_fwd: LSTM cell, x_t | h_t-1 in LDS, weights streamed from L2)",
+                     "achieved": rec_flop / (kern_ms * 1e-3) / 1e12 if n_ev else None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": rec_flop / (kern_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_ev else None, "traffic": None,
+                     "kernel_ms": kern_ms if n_ev else None, "launches_timed": n_ev,
+                     "whole_forward_tflops": flop / dt / 1e12, "whole_forward_frac": flop / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+    del m, x
     return out
 
 

@@ -291,3 +291,28 @@ def test_limits_raise_and_name_themselves():
     spe = dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1).to(dev)
     with torch.no_grad(), pytest.raises(NotImplementedError, match="speaker-conditioned"):
         spe(x, x, torch.tensor(400.0))
+
+
+# ------------------------------------------------------------------------------------------------ separation-level entry points
+@pytest.mark.parametrize("over", [dict(feature_size=256, hidden_size=256), dict(input_size=96, feature_size=160, hidden_size=200, norm_type="gLN",
+                                                                                activation_type="relu"),
+                                  dict(feature_size=64, hidden_size=64), dict(input_size=40, feature_size=96, hidden_size=80, rnn_type="GRU")])
+def test_separator_level_forwards_at_any_width(over):
+    """DPRNN.forward (dprnn.py:166-187) and DPRNN._dprnn_process (:171-186) on materialised [B, C, L] tensors, as the reference's
+    DPRNNRawNet drives them (dprnn_rawnet.py:79-105): every width that is not exactly the fused kernels' build -- wider or narrower --
+    runs on the any-width kernels."""
+    from oracle import dprnn_numpy as onp
+    model, sd, cfg = build_model("bss", dict(chunk_length=16, hop_length=8, n_repeats=2, **over), 73, _dev())
+    enc = onp.encoder(sd, cfg, make_mixture(3, 333, seed=8))                                   # [B, N, L]
+    want = onp.separator(sd, cfg, enc)
+    with torch.no_grad():
+        got = model.separation(torch.from_numpy(enc).to(_dev()))
+    assert got.shape == want.shape == (3, 2, cfg["input_size"], 332)
+    assert rel_l2(got.cpu().numpy(), want) <= REL_TOL
+    x = onp.channel_norm(sd, "separation.bottleneck.0", enc, cfg["norm_type"])
+    x = onp.conv1x1(sd["separation.bottleneck.1.weight"], sd["separation.bottleneck.1.bias"], x)   # [B, F, L]
+    with torch.no_grad():
+        got2 = model.separation._dprnn_process(torch.from_numpy(np.ascontiguousarray(x)).to(_dev()), 3, 332)
+    assert rel_l2(got2.cpu().numpy(), want) <= REL_TOL
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        model.separation(torch.from_numpy(enc).to(_dev()))

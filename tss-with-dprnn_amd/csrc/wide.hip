@@ -103,52 +103,80 @@ __global__ __launch_bounds__(256) void wide_ola_kernel(const float* __restrict__
 }
 
 // ---- out[m][o] = act(sum_k a(m,k) W[o][k] + bias[o]) * mul[mrow(m)][o],  a(m,k) = prelu(A[m][k] sc[u][k] + sh[u][k]), u = m / rows_per_utt
-// 64 x 64 output tile per workgroup, four waves of 16 rows x 64 columns; k in blocks of 16 through LDS; the MFMA's k index inside a
-// block is permuted (step s of lane group kk takes k = 4 kk + s) so that every lane reads its operands as one 16-byte LDS word.
+// 64 x (64 NB) output tile per workgroup, four waves of 16 rows x 64 NB columns; k in blocks of 16 through LDS; the MFMA's k index inside
+// a block is permuted (step s of lane group kk takes k = 4 kk + s) so that every lane reads its operands as one 16-byte LDS word.
+// NB = 4 (256 columns per workgroup) for the wide outputs: a 64-column tile does 16 FLOPs per byte it stages and would re-read the A rows
+// from HBM once per column tile (9.8 TB/s at the fp32 MFMA peak); at 256 columns the rows are read once and W (L2-resident) paces nothing.
 constexpr int GP = 20;          // LDS pitch of a 16-float k block (floats): 16-byte aligned, conflict-free for ds_read_b128
+template <int NB>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, long long rows_per_utt, const float* __restrict__ prelu,
                                                         const float* __restrict__ W, int ldw, const float* __restrict__ bias, int act,
                                                         const float* __restrict__ mul, long long ldm, long long mul_L, int mul_rep,
                                                         float* __restrict__ out, long long ldo, double* __restrict__ stats,
-                                                        long long M, int K, int O) {
+                                                        long long M, int K, int O, int vec) {
     __shared__ __attribute__((aligned(16))) float As[64 * GP];
-    __shared__ __attribute__((aligned(16))) float Ws[64 * GP];
+    __shared__ __attribute__((aligned(16))) float Ws[64 * NB * GP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
     const long long m0 = (long long)blockIdx.x * 64;
-    const int o0 = blockIdx.y * 64;
-    const int lr = tid >> 2, lk = (tid & 3) * 4;                  // this thread stages (row lr, k lk .. lk+3) of both tiles
+    const int o0 = blockIdx.y * (64 * NB);
+    const int lr = tid >> 2, lk = (tid & 3) * 4;                  // this thread stages (row lr [+ 64 i], k lk .. lk+3) of the tiles
     const long long am = m0 + lr;
     const bool a_ok = am < M;
     const long long au = a_ok ? am / rows_per_utt : 0;
     const float pw = prelu ? prelu[0] : 0.f;
-    const int wo = o0 + lr;
-    const bool w_ok = wo < O;
-    f32x4 acc[4];
+    f32x4 acc[4 * NB];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4 * NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < K; k0 += 16) {
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv[NB];
+        const int kq = k0 + lk;
+        if (vec) {                                                // K, lda, ldw multiples of 4 and 16-byte aligned bases: whole 16-byte words
+            if (a_ok && kq < K) {
+                av = *reinterpret_cast<const f32x4*>(A + am * lda + kq);
+                if (sc) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + au * K + kq), h4 = *reinterpret_cast<const f32x4*>(sh + au * K + kq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + lk + e;
-            if (k < K) {
-                if (a_ok) {
-                    float v = A[am * lda + k];
-                    if (sc) v = fmaf(v, sc[au * K + k], sh[au * K + k]);
-                    if (prelu) v = v >= 0.f ? v : pw * v;
-                    av[e] = v;
+                    for (int e = 0; e < 4; ++e) av[e] = fmaf(av[e], s4[e], h4[e]);
                 }
-                if (w_ok) wv[e] = W[(long long)wo * ldw + k];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int wo = o0 + lr + 64 * i;
+                wv[i] = (wo < O && kq < K) ? *reinterpret_cast<const f32x4*>(W + (long long)wo * ldw + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) wv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kq + e;
+                if (k < K) {
+                    if (a_ok) {
+                        const float v = A[am * lda + k];
+                        av[e] = sc ? fmaf(v, sc[au * K + k], sh[au * K + k]) : v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int wo = o0 + lr + 64 * i;
+                        if (wo < O) wv[i][e] = W[(long long)wo * ldw + k];
+                    }
+                }
             }
         }
+        if (prelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = av[e] >= 0.f ? av[e] : pw * av[e];
+        }
+        if (sc && !(a_ok)) av = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                          // the previous block's reads are done
         *reinterpret_cast<f32x4*>(&As[lr * GP + lk]) = av;
-        *reinterpret_cast<f32x4*>(&Ws[lr * GP + lk]) = wv;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Ws[(lr + 64 * i) * GP + lk]) = wv[i];
         __syncthreads();
         const f32x4 a = *reinterpret_cast<const f32x4*>(&As[(16 * w + j) * GP + 4 * kk]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 4 * NB; ++t) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(16 * t + j) * GP + 4 * kk]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[t] = mfma16(a[s], b[s], acc[t]);
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict_
         long long mrow = m;
         if (mul && mul_rep > 1) mrow = (m / (mul_L * mul_rep)) * mul_L + m % mul_L;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 4 * NB; ++t) {
             const int o = o0 + 16 * t + j;
             if (o >= O) continue;
             float v = acc[t][r] + (bias ? bias[o] : 0.f);
@@ -421,9 +449,15 @@ extern "C" int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, con
     }
     const long long gm = (M + 63) / 64;
     if (gm > 0x7fffffffLL) { dprnn_set_error("dprnn_wide_gemm: M too large"); return -1; }
-    hipLaunchKernelGGL(wide_gemm_kernel, dim3((unsigned)gm, (O + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, sc, sh,
-                       (long long)rows_per_utt, prelu, W, ldw, bias, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo, stats,
-                       (long long)M, K, O);
+    const int vec = (K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)sc | (uintptr_t)sh) & 15) == 0) ? 1 : 0;
+    if (O > 128)
+        hipLaunchKernelGGL(wide_gemm_kernel<4>, dim3((unsigned)gm, (O + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, sc, sh,
+                           (long long)rows_per_utt, prelu, W, ldw, bias, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
+                           stats, (long long)M, K, O, vec);
+    else
+        hipLaunchKernelGGL(wide_gemm_kernel<1>, dim3((unsigned)gm, (O + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, sc, sh,
+                           (long long)rows_per_utt, prelu, W, ldw, bias, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
+                           stats, (long long)M, K, O, vec);
     return dprnn_check_launch("wide_gemm_kernel");
 }
 

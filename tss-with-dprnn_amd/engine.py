@@ -1237,13 +1237,24 @@ def forward_async(model, *inputs):
     return res
 
 
+def _sep_off_build(sep) -> bool:
+    """A separator whose widths are not exactly the fused kernels' build: its separation-level forwards run on the any-width kernels."""
+    return (sep.input_size, sep.feature_size, sep.dprnn_blocks[0].intra_rnn.hidden_size) != (N_BUILT, F_BUILT, F_BUILT)
+
+
 def separator_masks(sep, frames: torch.Tensor):
+    if _sep_off_build(sep):
+        from . import wide
+        return wide.separator_masks(sep, frames)
     frames = _check_frames(frames, F_BUILT, "bottleneck output")
     run = lambda: _separator_masks_impl(sep, frames)
     return _guarded(frames.device, run, _in_mode(1, run), "DPRNN._dprnn_process", None, finite_inputs=[frames])
 
 
 def separator_forward(sep, enc: torch.Tensor):
+    if _sep_off_build(sep):
+        from . import wide
+        return wide.separator_forward(sep, enc)
     enc = _check_frames(enc, sep.input_size, "separator input")
     run = lambda: _separator_forward_impl(sep, enc)
     return _guarded(enc.device, run, _in_mode(1, run), "DPRNN.forward", None)

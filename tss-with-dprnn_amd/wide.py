@@ -105,78 +105,132 @@ def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int,
     st.call("dprnn_wide_norm_residual_fwd", E._p(X), E._p(Z), E._p(sc), E._p(sh), rows, F, geo.S * geo.K)
 
 
+def _sep_cfg(sep) -> dict:
+    rnn = sep.dprnn_blocks[0].intra_rnn
+    return dict(input_size=sep.input_size, feature_size=sep.feature_size, hidden_size=rnn.hidden_size, rnn_type=rnn.rnn.mode.split("_")[0],
+                norm_type=sep.norm_type, activation_type=sep.activation_type, hop_length=sep.hop_length, chunk_length=sep.chunk_length)
+
+
+def _frames_from_rows(st: _Launcher, sep, enc: torch.Tensor, B: int, L: int, stats_slot: torch.Tensor) -> torch.Tensor:
+    """sep.bottleneck (dprnn.py:131-136,169) on encoder rows [B*L][N] -> frames [B*L][F]: the global norm folded into the 1x1 conv's loader."""
+    dev = enc.device
+    N, F = sep.input_size, sep.feature_size
+    bott = list(sep.bottleneck)
+    conv = bott[-1]
+    sc = sh = None
+    if len(bott) == 2:
+        st.call("dprnn_wide_flat_stats", E._p(enc), E._p(stats_slot), B, L * N)
+        sc, sh = st.norm_affine(stats_slot, bott[0], B, L, N)
+    w = E._param(conv.weight, "bottleneck.weight", dev)
+    if tuple(w.shape[:2]) != (F, N):
+        raise DprnnError(f"bottleneck 1x1 conv weight {tuple(w.shape)}, expected ({F}, {N}, 1)")
+    return st.gemm(enc, w, E._param(conv.bias, "bottleneck.bias", dev), B * L, N, F, sc=sc, sh=sh, rows_per_utt=L)
+
+
+def _masks_from_frames(st: _Launcher, sep, Y: torch.Tensor, geo, stats: torch.Tensor, mul_enc: Optional[torch.Tensor] = None,
+                       debug: Optional[dict] = None) -> torch.Tensor:
+    """DPRNN._dprnn_process (dprnn.py:171-186) on frames [B*L][F] -> mask rows [(b*2 + spk)*L + l][N], times the encoder rows
+    [B*L][N] when given (dprnn.py:277)."""
+    cfg = _sep_cfg(sep)
+    check_supported(cfg)
+    dev = Y.device
+    N, F, H = cfg["input_size"], cfg["feature_size"], cfg["hidden_size"]
+    cell = CELL_ID[cfg["rnn_type"]]
+    B, L, K, P, S, rows = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows
+    blocks = list(sep.dprnn_blocks)
+    X = torch.empty(rows, F, device=dev, dtype=torch.float32)
+    st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(X), B, L, K, P, S, F)
+    # the recurrence output and the mask head's conv2d output share one block ([rows][2 H] then [rows][2 F])
+    Hbuf = torch.empty(rows * 2 * max(H, F), device=dev, dtype=torch.float32)
+    Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
+    for i, blk in enumerate(blocks):
+        _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[1 + 2 * i], geo, F, H, cell, True)
+        _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[2 + 2 * i], geo, F, H, cell, False)
+        if debug is not None:
+            debug[f"block{i}"] = X.view(B, S, K, F).clone()
+    del Z
+    # mask head (dprnn.py:172-186): PReLU + conv2d, overlap-add, tanh x sigmoid gate, end 1x1 conv + activation
+    w2 = E._param(sep.conv2d.weight, "conv2d.weight", dev)
+    nspk = w2.shape[0] // F
+    if nspk != 2 or tuple(w2.shape[:2]) != (2 * F, F):
+        raise DprnnError(f"conv2d weight {tuple(w2.shape)}, expected ({2 * F}, {F}, 1, 1)")
+    U = Hbuf[: rows * 2 * F].view(rows, 2 * F)
+    st.gemm(X, w2, E._param(sep.conv2d.bias, "conv2d.bias", dev), rows, F, 2 * F, prelu=E._param(sep.prelu.weight, "prelu.weight", dev), out=U)
+    del X
+    frames = torch.empty(B * nspk * L, F, device=dev, dtype=torch.float32)
+    st.call("dprnn_wide_ola_fwd", E._p(U), E._p(frames), B, L, K, P, S, F, nspk)
+    del U, Hbuf
+    M2 = B * nspk * L
+    t_out = st.gemm(frames, E._param(sep.out[0].weight, "out.weight", dev), E._param(sep.out[0].bias, "out.bias", dev), M2, F, F, act=3)
+    V = st.gemm(frames, E._param(sep.gate[0].weight, "gate.weight", dev), E._param(sep.gate[0].bias, "gate.bias", dev), M2, F, F, act=2, mul=t_out)
+    del frames, t_out
+    act = 1 if cfg["activation_type"] == "relu" else 2
+    return st.gemm(V, E._param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev), None, M2, F, N, act=act, mul=mul_enc, mul_L=L, mul_rep=nspk)
+
+
+def _sep_geometry(sep, B: int, L: int):
+    K, P = sep.chunk_length, sep.hop_length
+    return E.Geometry(B, L, L, K, P, (L + K) // P + 1, 1, 1, sep.input_size)
+
+
+def separator_masks(sep, frames: torch.Tensor) -> torch.Tensor:
+    """DPRNN._dprnn_process (dprnn.py:171-186) at any width: bottleneck output [B, F, L] -> masks [B, 2, N, L]."""
+    E._check_frames(frames, sep.feature_size, "bottleneck output")
+    E._no_grad_only("_dprnn_process", frames, module=sep)
+    dev = frames.device
+    B, F, L = frames.shape
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        Y = frames.transpose(1, 2).contiguous().view(B * L, F)          # channels-last rows (layout plumbing)
+        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
+        rows = _masks_from_frames(st, sep, Y, _sep_geometry(sep, B, L), stats)
+        return rows.view(B, 2, L, sep.input_size).permute(0, 1, 3, 2).contiguous()
+
+
+def separator_forward(sep, enc: torch.Tensor) -> torch.Tensor:
+    """DPRNN.forward (dprnn.py:166-187) at any width: encoder output [B, N, L] -> masks [B, 2, N, L]."""
+    E._check_frames(enc, sep.input_size, "separator input")
+    E._no_grad_only("DPRNN.forward", enc, module=sep)
+    dev = enc.device
+    B, N, L = enc.shape
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        rows_in = enc.transpose(1, 2).contiguous().view(B * L, N)
+        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
+        Y = _frames_from_rows(st, sep, rows_in, B, L, stats[0])
+        rows = _masks_from_frames(st, sep, Y, _sep_geometry(sep, B, L), stats)
+        return rows.view(B, 2, L, N).permute(0, 1, 3, 2).contiguous()
+
+
 def _forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
     """DPRNNTasNet.forward (dprnn.py:271-283): [B, T] -> [B, 2, T_out], every stage a launch of csrc/wide.hip."""
     cfg = model.cfg
     check_supported(cfg)
     dev = wav.device
-    N, F, H = cfg["input_size"], cfg["feature_size"], cfg["hidden_size"]
-    cell = CELL_ID[cfg["rnn_type"]]
+    N, F = cfg["input_size"], cfg["feature_size"]
     with torch.cuda.device(dev):
         st = _Launcher(dev)
         geo = E.make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
         if geo.T_out < 2:
             raise DprnnError("utterance too short")
-        B, L, K, P, S, rows = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows
+        B, L = geo.B, geo.L
         sep = model.separation
         enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
         dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
-        blocks = list(sep.dprnn_blocks)
-        stats = torch.zeros(1 + 2 * len(blocks), B, 2, device=dev, dtype=torch.float64)
-
+        stats = torch.zeros(1 + 2 * len(sep.dprnn_blocks), B, 2, device=dev, dtype=torch.float64)
         enc = torch.empty(B * L, N, device=dev, dtype=torch.float32)
         st.call("dprnn_wide_encoder_fwd", E._p(wav), E._p(enc_w), E._p(enc), B, geo.T, L, N, geo.ks, geo.stride)
-        # bottleneck (dprnn.py:131-136,169): global norm of the encoder output folded into the 1x1 conv's loader
-        bott = list(sep.bottleneck)
-        conv = bott[-1]
-        sc = sh = None
-        if len(bott) == 2:
-            st.call("dprnn_wide_flat_stats", E._p(enc), E._p(stats[0]), B, L * N)
-            sc, sh = st.norm_affine(stats[0], bott[0], B, L, N)
-        w = E._param(conv.weight, "bottleneck.weight", dev)
-        if tuple(w.shape[:2]) != (F, N):
-            raise DprnnError(f"bottleneck 1x1 conv weight {tuple(w.shape)}, expected ({F}, {N}, 1)")
-        Y = st.gemm(enc, w, E._param(conv.bias, "bottleneck.bias", dev), B * L, N, F, sc=sc, sh=sh, rows_per_utt=L)
+        Y = _frames_from_rows(st, sep, enc, B, L, stats[0])
         if debug is not None:
             debug["bottleneck"] = Y.view(B, L, F).clone()
-        X = torch.empty(rows, F, device=dev, dtype=torch.float32)
-        st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(X), B, L, K, P, S, F)
+        masked = _masks_from_frames(st, sep, Y, geo, stats, mul_enc=enc, debug=debug)          # masks x encoder output (dprnn.py:277)
         del Y
-        # the recurrence output and the mask head's conv2d output share one block ([rows][2 H] then [rows][2 F])
-        Hbuf = torch.empty(rows * 2 * max(H, F), device=dev, dtype=torch.float32)
-        Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
-        for i, blk in enumerate(blocks):
-            _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[1 + 2 * i], geo, F, H, cell, True)
-            _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[2 + 2 * i], geo, F, H, cell, False)
-            if debug is not None:
-                debug[f"block{i}"] = X.view(B, S, K, F).clone()
-        del Z
-        # mask head (dprnn.py:172-186): PReLU + conv2d, overlap-add, tanh x sigmoid gate, end 1x1 conv + activation, x encoder output
-        w2 = E._param(sep.conv2d.weight, "conv2d.weight", dev)
-        nspk = w2.shape[0] // F
-        if nspk != 2 or tuple(w2.shape[:2]) != (2 * F, F):
-            raise DprnnError(f"conv2d weight {tuple(w2.shape)}, expected ({2 * F}, {F}, 1, 1)")
-        U = Hbuf[: rows * 2 * F].view(rows, 2 * F)
-        st.gemm(X, w2, E._param(sep.conv2d.bias, "conv2d.bias", dev), rows, F, 2 * F, prelu=E._param(sep.prelu.weight, "prelu.weight", dev),
-                out=U)
-        del X
-        frames = torch.empty(B * nspk * L, F, device=dev, dtype=torch.float32)
-        st.call("dprnn_wide_ola_fwd", E._p(U), E._p(frames), B, L, K, P, S, F, nspk)
-        del U, Hbuf
-        M2 = B * nspk * L
-        t_out = st.gemm(frames, E._param(sep.out[0].weight, "out.weight", dev), E._param(sep.out[0].bias, "out.bias", dev), M2, F, F, act=3)
-        V = st.gemm(frames, E._param(sep.gate[0].weight, "gate.weight", dev), E._param(sep.gate[0].bias, "gate.bias", dev), M2, F, F, act=2,
-                    mul=t_out)
-        del frames, t_out
-        act = 1 if cfg["activation_type"] == "relu" else 2
-        masked = st.gemm(V, E._param(sep.end_conv1x1.weight, "end_conv1x1.weight", dev), None, M2, F, N, act=act, mul=enc, mul_L=L, mul_rep=nspk)
         if debug is not None:
-            debug["masked"] = masked.view(B, nspk, L, N).clone()
-        del V
+            debug["masked"] = masked.view(B, 2, L, N).clone()
         # decoder (encoder_decoder.py:36-49): per-frame taps, then the transposed convolution's overlap
         wd = dec_w.view(N, geo.ks).t().contiguous()                      # [ks][N]
-        taps = st.gemm(masked, wd, None, M2, N, geo.ks)
-        return E.decode(st, taps, geo, nspk)
+        taps = st.gemm(masked, wd, None, B * 2 * L, N, geo.ks)
+        return E.decode(st, taps, geo, 2)
 
 
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
