@@ -130,11 +130,13 @@ def test_recurrence_against_torch(kind, F, H, bidir, intra):
     assert _rel(out.view(B, S, K, -1), want.contiguous()) <= 3e-6
 
 
-def test_recurrence_with_32_sequence_tiles():
-    """Enough sequences for the 32-sequence workgroups (nseq x ndir >= 32 x CUs), and a count that is no multiple of 32."""
+def test_recurrence_with_32_sequence_tiles(monkeypatch):
+    """The 32-sequence workgroups (DPRNN_WIDE_NT=2: half the weight stream, one workgroup per CU; the default is 16), and a count that
+    is no multiple of 32."""
     from tss_with_dprnn_amd import wide
+    monkeypatch.setenv("DPRNN_WIDE_NT", "2")
     st = _stage()
-    n = 32 * st.lib.dprnn_num_cus() // 2 + 37
+    n = 32 * 5 + 37
     F = H = 144
     T = 5
     rnn = _torch_rnn("LSTM", F, H, True, 6)

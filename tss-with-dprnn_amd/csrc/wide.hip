@@ -5,6 +5,7 @@
 #include "common.h"
 #include "dprnn_mi355x.h"
 #include "dprnn_mi355x_wide.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void wide_rnn_pack_kernel(int cell, const floa
 // w, w+4, ...: the four gates of one (sequence, unit) meet in one lane, c / h state stays in registers.  Weights stream from L2
 // every step as 16-byte fragments (1 KB per wave instruction).
 constexpr int MAXUT = 8;        // unit tiles per wave: hidden_size <= 4 * 8 * 16 = 512
-template <int NT, int G>
+template <int NT, int G, bool FAST>
 __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __restrict__ X, const float* __restrict__ WpAll,
                                                        const float* __restrict__ bvAll, float* __restrict__ Hout, int F, int H, int nseq, int T,
                                                        long long inner_n, long long outer, long long inner, long long t_stride, int ldh,
@@ -324,19 +325,31 @@ __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __
 #pragma unroll
                     for (int g = 0; g < G; ++g) acc[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long long)ut * nkb * G) * 64 + lane;
-                for (int kb = 0; kb < nkb; ++kb) {
-                    f32x4 a[NT];
+                const float* ap = cur + j * pitch + 4 * kk;
+                // two k blocks in flight: the next block's weight fragments (L2) and A words (LDS) are requested before this block's MFMAs
+                f32x4 a0[NT], b0[G], a1[NT], b1[G];
+                auto fetch = [&](f32x4 (&a)[NT], f32x4 (&b)[G], int kb) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4*>(&cur[(nt * 16 + j) * pitch + kb * 16 + 4 * kk]);
+                    for (int g = 0; g < G; ++g) b[g] = wp[((long long)kb * G + g) * 64];
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const f32x4 b = wp[g * 64];
+                    for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * pitch + kb * 16);
+                };
+                auto mma = [&](const f32x4 (&a)[NT], const f32x4 (&b)[G]) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < 4; ++s)                    // consecutive MFMAs on different accumulators: NT x G between dependent ones
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) acc[nt][g] = mfma16(a[nt][s], b[s], acc[nt][g]);
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt][g] = mfma16(a[nt][s], b[g][s], acc[nt][g]);
+                };
+                fetch(a0, b0, 0);
+                for (int kb = 0; kb < nkb; kb += 2) {
+                    if (kb + 1 < nkb) fetch(a1, b1, kb + 1);
+                    mma(a0, b0);
+                    if (kb + 1 < nkb) {
+                        if (kb + 2 < nkb) fetch(a0, b0, kb + 2);
+                        mma(a1, b1);
                     }
-                    wp += G * 64;
                 }
                 const int unit = ut * 16 + j;
 #pragma unroll
@@ -347,19 +360,19 @@ __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __
                         float h;
                         if constexpr (G == 4) {
                             if (cell == 0) {                                       // LSTM (torch gate order i f g o)
-                                const float ig = sigmoid_acc(acc[nt][0][r] + bq[u][0]), fg = sigmoid_acc(acc[nt][1][r] + bq[u][1]);
-                                const float gg = tanh_acc(acc[nt][2][r] + bq[u][2]), og = sigmoid_acc(acc[nt][3][r] + bq[u][3]);
+                                const float ig = sigmoid_f<FAST>(acc[nt][0][r] + bq[u][0]), fg = sigmoid_f<FAST>(acc[nt][1][r] + bq[u][1]);
+                                const float gg = tanh_f<FAST>(acc[nt][2][r] + bq[u][2]), og = sigmoid_f<FAST>(acc[nt][3][r] + bq[u][3]);
                                 const float c = fmaf(fg, state[u][nt][r], ig * gg);
                                 state[u][nt][r] = c;
-                                h = og * tanh_acc(c);
+                                h = og * tanh_f<FAST>(c);
                             } else {                                               // GRU (r z n)
-                                const float rg = sigmoid_acc(acc[nt][0][r] + bq[u][0]), zg = sigmoid_acc(acc[nt][1][r] + bq[u][1]);
-                                const float ng = tanh_acc(acc[nt][2][r] + bq[u][2] + rg * (acc[nt][3][r] + bq[u][3]));
+                                const float rg = sigmoid_f<FAST>(acc[nt][0][r] + bq[u][0]), zg = sigmoid_f<FAST>(acc[nt][1][r] + bq[u][1]);
+                                const float ng = tanh_f<FAST>(acc[nt][2][r] + bq[u][2] + rg * (acc[nt][3][r] + bq[u][3]));
                                 h = (1.f - zg) * ng + zg * state[u][nt][r];
                                 state[u][nt][r] = h;
                             }
                         } else {
-                            h = tanh_acc(acc[nt][0][r] + bq[u][0]);                // Elman, tanh
+                            h = tanh_f<FAST>(acc[nt][0][r] + bq[u][0]);            // Elman, tanh
                         }
                         nxt[sr * pitch + Fp + unit] = h;
                         const long long q = q0 + sr;
@@ -487,22 +500,29 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
     const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, pitch = Fp + Hp + 4;
     if (Hp / 16 > 4 * MAXUT) { dprnn_set_error("dprnn_wide_rnn_fwd: hidden_size %d > %d", H, 4 * MAXUT * 16); return -1; }
     // 32 sequences per workgroup when they fit the LDS and still fill the chip, else 16
-    int nt = 2;
-    if ((size_t)2 * 32 * pitch * sizeof(float) > 160 * 1024 || (long long)nseq * ndir < 32LL * dprnn_num_cus()) nt = 1;
+    // 16 sequences per workgroup: two workgroups per CU (two waves per SIMD) hide the weight-fragment and LDS latencies better than one
+    // 32-sequence workgroup halves the weight stream (F = H = 256, 64 x 3 s: 0.52 / 0.60 of the MFMA peak against 0.41 / 0.51);
+    // DPRNN_WIDE_NT=2 selects the 32-sequence form (diagnostics, tests)
+    int nt = 1;
+    if (const char* e = getenv("DPRNN_WIDE_NT")) { if (atoi(e) == 2) nt = 2; }
+    if ((size_t)2 * 32 * pitch * sizeof(float) > 160 * 1024) nt = 1;
     const size_t lds = (size_t)2 * 16 * nt * pitch * sizeof(float);
     if (lds > 160 * 1024) { dprnn_set_error("dprnn_wide_rnn_fwd: feature_size %d + hidden_size %d need %zu bytes of LDS (160 KB per CU)", F, H, lds); return -1; }
     const long long wp_dir = dprnn_wide_rnn_pack_floats(cell, F, H);
     const dim3 grid((nseq + 16 * nt - 1) / (16 * nt), ndir), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define WIDE_RNN(NT_, G_)                                                                                                                   \
+#define WIDE_RNN2(NT_, G_, FAST_)                                                                                                                 \
     do {                                                                                                                                    \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_rnn_kernel<NT_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_rnn_kernel<NT_, G_, FAST_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 160 * 1024) != hipSuccess) { dprnn_set_error("dprnn_wide_rnn_fwd: hipFuncSetAttribute"); return -2; }        \
-        hipLaunchKernelGGL((wide_rnn_kernel<NT_, G_>), grid, block, lds, st, cell, X, Wp, bv, Hout, F, H, nseq, T, (long long)inner_n,      \
+        hipLaunchKernelGGL((wide_rnn_kernel<NT_, G_, FAST_>), grid, block, lds, st, cell, X, Wp, bv, Hout, F, H, nseq, T, (long long)inner_n,      \
                            (long long)outer, (long long)inner, (long long)t_stride, ndir * H, wp_dir);                                      \
     } while (0)
+#define WIDE_RNN(NT_, G_) do { if (fast) WIDE_RNN2(NT_, G_, true); else WIDE_RNN2(NT_, G_, false); } while (0)
+    const bool fast = dprnn_get_fast_activations() != 0;        // v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), as the built kernels' default
     if (cell == 2) { if (nt == 2) WIDE_RNN(2, 1); else WIDE_RNN(1, 1); }
     else { if (nt == 2) WIDE_RNN(2, 4); else WIDE_RNN(1, 4); }
 #undef WIDE_RNN
+#undef WIDE_RNN2
     return dprnn_check_launch("wide_rnn_kernel");
 }
