@@ -58,16 +58,18 @@ int dprnn_wide_rnn_pack(int cell, const float* w_ih, const float* w_hh, const fl
 int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
                        int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream);
 
-/* out[m][o] = act(sum_k a(m,k) * W[o*ldw + k] + bias[o]) * mul[mrow(m)*ldm + o]
+/* out[m][o] = act(rscale[m] * sum_k a(m,k) * W[o*ldw + k] + bias[o] + ubias[u*O + o]) * mul[mrow(m)*ldm + o]
  *   a(m,k) = prelu(A[m*lda + k] * sc[u*K + k] + sh[u*K + k]), u = m / rows_per_utt (sc / sh NULL: no affine; prelu NULL: none, else
- *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, mul, stats optional;
+ *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, ubias, rscale, mul, stats optional;
+ *   ubias [U][O]: a bias per utterance (the embedding half of the 'cat' fusion's 1x1 conv, dprnn_spe.py:186-192); rscale [M]: a factor per
+ *   row (the 'att' fusion's frame weights, dprnn_spe.py:178-183,214-222: conv(x * r) = r * (W x) + b);
  *   mrow(m) = m when mul_rep == 1, else (m / (mul_L*mul_rep))*mul_L + m % mul_L (the encoder rows shared by the mul_rep speakers,
  *   dprnn.py:277);  stats[u] += (sum, sum of squares) of the outputs of utterance u = m / rows_per_utt in fp64.
  * Every Linear / 1x1 convolution of the path: bottleneck (dprnn.py:135-136), intra / inter Linear (:59,68), conv2d (:151), out / gate
  * (:153-154), end_conv1x1 (:156) and the decoder's per-frame taps (encoder_decoder.py:36-42). */
 int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, const float* sh, int64_t rows_per_utt, const float* prelu,
-                    const float* W, int ldw, const float* bias, int act, const float* mul, int64_t ldm, int64_t mul_L, int mul_rep,
-                    float* out, int64_t ldo, double* stats, int64_t M, int K, int O, void* stream);
+                    const float* W, int ldw, const float* bias, const float* ubias, const float* rscale, int act, const float* mul,
+                    int64_t ldm, int64_t mul_L, int mul_rep, float* out, int64_t ldo, double* stats, int64_t M, int K, int O, void* stream);
 
 /* X[m][c] += Z[m][c]*sc[u][c] + sh[u][c], u = m / rows_per_utt: the norm after a path's Linear and the residual (dprnn.py:90-92,98-99). */
 int dprnn_wide_norm_residual_fwd(float* X, const float* Z, const float* sc, const float* sh, int64_t M, int C, int64_t rows_per_utt,

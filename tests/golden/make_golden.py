@@ -103,6 +103,16 @@ CASES = [
     ("bss_wider_n128_h320_b1", "bss", dict(WIDE, input_size=128, hidden_size=320, n_repeats=1), 1, 257, 104, False, False),
     ("bss_wider_gru_f192", "bss", dict(WIDE, feature_size=192, hidden_size=192, rnn_type="GRU", norm_type="gLN", n_repeats=1), 2, 300, 105,
      False, False),
+    # ... and the speaker-conditioned classes with feature / hidden size above the build (input_size and the speaker encoder at the built
+    # widths: the speaker branch keeps the built kernels): one golden per fusion family, BatchNorm in eval and in train mode, both IRA passes
+    ("spe_wider256_cat", "spe", dict(WIDE, feature_size=256, hidden_size=256, fusion_type="cat", norm_type="ln"), 2, 300, 110, False, False),
+    ("spe_wider_f160_h200_att_bntrain", "spe", dict(WIDE, feature_size=160, hidden_size=200, fusion_type="att", norm_type="ln", n_repeats=1),
+     3, 301, 111, False, True),
+    ("spe_wider_f192_film_gln", "spe", dict(WIDE, feature_size=192, hidden_size=144, fusion_type="film", norm_type="gLN", n_repeats=1), 2, 300, 112,
+     False, False),
+    ("ira_wider256_cat", "ira", dict(WIDE, feature_size=256, hidden_size=256, fusion_type="cat", norm_type="ln", n_repeats=1), 2, 300, 113, False, False),
+    ("ira_wider_f144_mul", "ira", dict(WIDE, feature_size=144, hidden_size=160, fusion_type="mul", norm_type="ln", n_repeats=1), 2, 300, 114, False,
+     False),
 ]
 AUX_SAMPLES = {"ira_full_long_b1": 24000}       # reference-utterance length where it differs from the mixture's
 

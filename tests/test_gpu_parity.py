@@ -269,8 +269,8 @@ def test_headline_batch_b64_full_size():
 # every forward golden (grad_* are training steps).  Since round 4 that includes the widths BELOW the kernels' build -- the 14 "tiny"
 # fixtures (input_size 8, feature / hidden 16, speaker encoder 16 / 24 / 12) and the *_narrow_* ones: they run as zero-padded twins
 # (tss-with-dprnn_amd/padded.py), so they pin the HIP path too, not only the oracle.
-# (widths ABOVE the build, bss_wider_*, run on the any-width kernels whatever the mode: tests/test_gpu_wide.py)
-FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith(("grad_", "bss_wider"))]
+# (widths ABOVE the build, *_wider*, run on the any-width kernels whatever the mode: tests/test_gpu_wide.py)
+FORWARD_GOLDENS = [n for n in golden_names() if not n.startswith("grad_") and "_wider" not in n]
 
 
 # In the opt-in modes 0 and 1 a representative third runs by default -- every full-size golden, the wide ones that differ in kernel path

@@ -291,8 +291,53 @@ def test_limits_raise_and_name_themselves():
     with pytest.raises(NotImplementedError):                 # gradients at these widths: not built
         wide(x)
     spe = dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1).to(dev)
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="speaker-conditioned"):
+    with pytest.raises(NotImplementedError):                 # training of the speaker-conditioned classes at these widths: not built
         spe(x, x, torch.tensor(400.0))
+
+
+@pytest.mark.parametrize("name", golden_names("spe_wider") + golden_names("ira_wider"))
+def test_wider_speaker_conditioned_models_match_the_reference(name):
+    """DPRNNSpeTasNet / DPRNNSpeIRATasNet with feature / hidden size above the build (input_size and speaker encoder at the built widths):
+    speaker branch and fusion operands on the built kernels, DPRNN stack on the any-width ones; estimate and speaker logits against the
+    reference classes' outputs, BatchNorm in eval or (as the reference's Inferencer leaves it) train mode."""
+    from conftest import state_from_meta
+    g = load_golden(name)
+    m = g["meta"]
+    model, sd, _ = build_model(m["kind"], m["cfg"], m["seed"], _dev())
+    if m.get("bn_training"):
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.train()
+    with torch.no_grad():
+        out, logits = model(torch.from_numpy(g["mix"]).to(_dev()), torch.from_numpy(g["aux"]).to(_dev()), torch.tensor(float(g["aux_len"])))
+    assert out.shape == g["out"].shape
+    r, rl = rel_l2(out.cpu().numpy(), g["out"]), rel_l2(logits.cpu().numpy(), g["logits"])
+    assert r <= REL_TOL and rl <= REL_TOL, f"{name}: estimate rel-L2 {r:.3e}, logits {rl:.3e}"
+    print(f"{name}: rel-L2 vs reference {r:.2e} (logits {rl:.2e})")
+
+
+def test_wider_speaker_conditioned_entry_points():
+    """separate_many (equal-length buckets), forward_async, batch invariance for a wide DPRNN-Spe-IRA; what stays out raises by name."""
+    from tss_with_dprnn_amd import dprnn_spe, engine, inference
+    cfg = dict(feature_size=160, hidden_size=144, chunk_length=16, hop_length=8, n_repeats=1, fusion_type="film", norm_type="ln")
+    model, sd, cfg = build_model("ira", cfg, 7, _dev())
+    x = torch.from_numpy(make_mixture(3, 400, seed=9)).to(_dev())
+    a = torch.from_numpy(make_mixture(3, 350, seed=10)).to(_dev())
+    with torch.no_grad():
+        full, lg = model(x, a, torch.tensor(350.0))
+        one, lg1 = model(x[1:2], a[1:2], torch.tensor(350.0))
+        (out2, lg2), ticket = engine.forward_async(model, x, a, torch.tensor(350.0))
+    assert full.shape == (3, 400) and rel_l2(one[0].cpu().numpy(), full[1].cpu().numpy()) <= 2e-6
+    assert torch.equal(ticket.result()[0], full)
+    outs = inference.separate_many(model, [x[i] for i in range(3)], extra_inputs=[(a[i], 350.0) for i in range(3)])
+    for i in range(3):
+        assert rel_l2(outs[i][0].cpu().numpy(), full[i].cpu().numpy()) <= 2e-6
+    narrow_in = dprnn_spe.DPRNNSpeTasNet(48, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1).to(_dev())
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="input_size 64"):
+        narrow_in(x, a, torch.tensor(350.0))
+    wide_spk = dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1, O=256).to(_dev())
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="speaker encoder"):
+        wide_spk(x, a, torch.tensor(350.0))
 
 
 # ------------------------------------------------------------------------------------------------ separation-level entry points

@@ -144,8 +144,8 @@ SIGNATURES = {
     "dprnn_wide_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_wide_rnn_pack": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp],
     "dprnn_wide_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_fp],
-    "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64, c_i, c_i,
-                        c_fp],
+    "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64,
+                        c_i, c_i, c_fp],
     "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp],
     "dprnn_wide_ola_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }

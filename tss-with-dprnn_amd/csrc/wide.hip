@@ -112,7 +112,8 @@ constexpr int GP = 20;          // LDS pitch of a 16-float k block (floats): 16-
 template <int NB>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, long long rows_per_utt, const float* __restrict__ prelu,
-                                                        const float* __restrict__ W, int ldw, const float* __restrict__ bias, int act,
+                                                        const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                        const float* __restrict__ ubias, const float* __restrict__ rscale, int act,
                                                         const float* __restrict__ mul, long long ldm, long long mul_L, int mul_rep,
                                                         float* __restrict__ out, long long ldo, double* __restrict__ stats,
                                                         long long M, int K, int O, int vec) {
@@ -191,11 +192,15 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict_
         if (m >= M) continue;
         long long mrow = m;
         if (mul && mul_rep > 1) mrow = (m / (mul_L * mul_rep)) * mul_L + m % mul_L;
+        const float rs = rscale ? rscale[m] : 1.f;
+        const float* ub = ubias ? ubias + (m / rows_per_utt) * O : nullptr;
 #pragma unroll
         for (int t = 0; t < 4 * NB; ++t) {
             const int o = o0 + 16 * t + j;
             if (o >= O) continue;
-            float v = acc[t][r] + (bias ? bias[o] : 0.f);
+            float v = acc[t][r];
+            if (rscale) v *= rs;
+            v += (bias ? bias[o] : 0.f) + (ub ? ub[o] : 0.f);
             if (act == 1) v = relu_f(v);
             else if (act == 2) v = sigmoid_acc(v);
             else if (act == 3) v = tanh_acc(v);
@@ -452,8 +457,9 @@ extern "C" int dprnn_wide_ola_fwd(const float* U, float* frames, int B, int L, i
 }
 
 extern "C" int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, const float* sh, int64_t rows_per_utt, const float* prelu,
-                               const float* W, int ldw, const float* bias, int act, const float* mul, int64_t ldm, int64_t mul_L, int mul_rep,
-                               float* out, int64_t ldo, double* stats, int64_t M, int K, int O, void* stream) {
+                               const float* W, int ldw, const float* bias, const float* ubias, const float* rscale, int act, const float* mul,
+                               int64_t ldm, int64_t mul_L, int mul_rep, float* out, int64_t ldo, double* stats, int64_t M, int K, int O,
+                               void* stream) {
     WIDE_NULL(!A || !W || !out || ((sc == nullptr) != (sh == nullptr)), "dprnn_wide_gemm");
     if (M < 1 || K < 1 || O < 1 || lda < K || ldw < K || ldo < O || act < 0 || act > 3 || rows_per_utt < 1 || (mul && (ldm < O || mul_rep < 1 || mul_L < 1))) {
         dprnn_set_error("dprnn_wide_gemm: bad sizes M=%lld K=%d O=%d lda=%lld ldw=%d ldo=%lld act=%d", (long long)M, K, O, (long long)lda, ldw,
@@ -465,11 +471,11 @@ extern "C" int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, con
     const int vec = (K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)sc | (uintptr_t)sh) & 15) == 0) ? 1 : 0;
     if (O > 128)
         hipLaunchKernelGGL(wide_gemm_kernel<4>, dim3((unsigned)gm, (O + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, sc, sh,
-                           (long long)rows_per_utt, prelu, W, ldw, bias, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
+                           (long long)rows_per_utt, prelu, W, ldw, bias, ubias, rscale, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
                            stats, (long long)M, K, O, vec);
     else
         hipLaunchKernelGGL(wide_gemm_kernel<1>, dim3((unsigned)gm, (O + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long long)lda, sc, sh,
-                           (long long)rows_per_utt, prelu, W, ldw, bias, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
+                           (long long)rows_per_utt, prelu, W, ldw, bias, ubias, rscale, act, mul, (long long)ldm, (long long)mul_L, mul_rep, out, (long long)ldo,
                            stats, (long long)M, K, O, vec);
     return dprnn_check_launch("wide_gemm_kernel");
 }

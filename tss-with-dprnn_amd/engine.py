@@ -1189,6 +1189,12 @@ def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
 
 def spe_forward(model, wav, aux, aux_len, ira: bool = False, debug: Optional[dict] = None):
     wav, aux = check_input(wav), check_input(aux, "aux")
+    if _wider_than_built(model):
+        from . import wide
+        out = wide.spe_forward(model, wav, aux, aux_len, ira, debug)           # exact fp32: nothing to check afterwards
+        if getattr(_TLS, "want_ticket", False):
+            return out, ForwardTicket(wav.device, out, None, None, None, "DPRNNSpeTasNet.forward (any-width kernels)", [], [], None)
+        return out
     narrow = model
     model, tw = _twin(model)
     if tw is not None and _bn_training(model.separation):

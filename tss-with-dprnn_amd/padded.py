@@ -20,8 +20,8 @@ hold stay valid).  BatchNorm buffers a train-mode forward updates are written ba
 kernels run the twin as well -- the same element-count correction on the two sums of every global norm's backward
 (training._count_scale_red) -- and ``placed_parameters`` makes the twin's parameters differentiable functions of the narrow ones, so
 ``loss.backward()`` leaves each narrow parameter the real block of its twin's gradient (DPRNNTasNet, DPRNNSpeTasNet and
-DPRNNSpeIRATasNet: tests/golden/grad_*_narrow_*.npz hold the reference's gradients).  WIDER than built: DPRNNTasNet inference runs on
-the any-width kernels (wide.py, csrc/wide.hip); training and the speaker-conditioned classes at such widths raise here.
+DPRNNSpeIRATasNet: tests/golden/grad_*_narrow_*.npz hold the reference's gradients).  WIDER than built: inference runs on
+the any-width kernels (wide.py, csrc/wide.hip: all three model classes); training at such widths raises here.
 """
 from __future__ import annotations
 
@@ -102,9 +102,9 @@ class Twin:
             raise NotImplementedError(
                 "DPRNN MI355X path: widths above the kernels' build (input_size 64, feature_size / hidden_size 128; speaker encoder "
                 f"O 128, P 256, embeddings 128) are not supported by the fused / training kernels: got input_size {cfg['input_size']}, feature_size "
-                f"{cfg['feature_size']}, hidden_size {cfg['hidden_size']}.  (A DPRNNTasNet of any width runs its INFERENCE forward on the "
-                "any-width kernels, wide.py: call it under torch.no_grad(); training and the speaker-conditioned classes stop at the "
-                "built widths.)")
+                f"{cfg['feature_size']}, hidden_size {cfg['hidden_size']}.  (INFERENCE at such widths runs on the any-width kernels, wide.py -- "
+                "call the model under torch.no_grad(); the speaker-conditioned classes need input_size 64 and the built speaker encoder "
+                "there.  Training stops at the built widths.)")
         self.narrow_cfg = cfg
         wide = dict(cfg, input_size=N_BUILT, feature_size=F_BUILT, hidden_size=F_BUILT)
         for k, v in SPE_BUILT.items():

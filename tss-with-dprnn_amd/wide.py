@@ -9,8 +9,10 @@ It is the unfused form of the path: the norms are materialised between the launc
 costs about the 10 slab units per path the built kernels started from -- a model at these widths is supported, not tuned.
 
 No fallback: a missing library raises (``_lib.load_library``); what the kernels cannot hold (hidden_size above 512, or feature_size
-+ hidden_size beyond the LDS of a CU) raises NotImplementedError naming the limit.  Inference only (under autograd the mirror class
-raises), DPRNNTasNet only (the speaker-conditioned classes at these widths raise in ``padded.Twin``).
++ hidden_size beyond the LDS of a CU) raises NotImplementedError naming the limit.  Inference only (under autograd the mirror
+class raises).  DPRNNSpeTasNet / DPRNNSpeIRATasNet with feature_size / hidden_size above the build run here too when input_size and the
+speaker encoder keep the built widths (64; O 128, P 256, embeddings 128 -- every shipped YAML): speaker branch and fusion operands on the
+built kernels, the DPRNN stack on the any-width ones.
 """
 from __future__ import annotations
 
@@ -54,12 +56,12 @@ class _Launcher(E.Stage):
 
     def gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], M: int, K: int, O: int, *, sc=None, sh=None,
              rows_per_utt: int = 1, prelu=None, act: int = 0, mul=None, mul_L: int = 1, mul_rep: int = 1, stats=None,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, ldw: Optional[int] = None, ubias=None, rscale=None) -> torch.Tensor:
         if out is None:
             out = torch.empty(M, O, device=A.device, dtype=torch.float32)
         ldm = 0 if mul is None else mul.shape[-1]
-        self.call("dprnn_wide_gemm", E._p(A), K, E._p(sc), E._p(sh), rows_per_utt, E._p(prelu), E._p(W), K, E._p(bias), act, E._p(mul), ldm,
-                  mul_L, mul_rep, E._p(out), O, E._p(stats), M, K, O)
+        self.call("dprnn_wide_gemm", E._p(A), K, E._p(sc), E._p(sh), rows_per_utt, E._p(prelu), E._p(W), K if ldw is None else ldw, E._p(bias),
+                  E._p(ubias), E._p(rscale), act, E._p(mul), ldm, mul_L, mul_rep, E._p(out), O, E._p(stats), M, K, O)
         return out
 
     def norm_affine(self, stats_slot: torch.Tensor, norm, B: int, rows_per_utt: int, C: int):
@@ -231,6 +233,105 @@ def _forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None) -> tor
         wd = dec_w.view(N, geo.ks).t().contiguous()                      # [ks][N]
         taps = st.gemm(masked, wd, None, B * 2 * L, N, geo.ks)
         return E.decode(st, taps, geo, 2)
+
+
+def check_supported_spe(cfg: dict) -> None:
+    """The speaker-conditioned classes above the built widths: the DPRNN stack runs at any feature / hidden size; the speaker branch and the
+    fusions live on the encoder side of the bottleneck (N channels) and keep the built kernels, so input_size and the speaker encoder's
+    widths must be the build's (the shipped YAMLs' values)."""
+    check_supported(cfg)
+    E.check_supported_spe(dict(cfg, input_size=E.N_BUILT, feature_size=E.F_BUILT, hidden_size=E.F_BUILT))
+    if cfg["input_size"] != E.N_BUILT:
+        raise NotImplementedError(
+            f"DPRNN-Spe MI355X path (any-width kernels): a speaker-conditioned model wider than the build needs input_size {E.N_BUILT} (the speaker "
+            f"branch and the fusions run on the built kernels); got {cfg['input_size']}")
+
+
+def _spe_forward_impl(model, wav: torch.Tensor, aux: torch.Tensor, aux_len, ira: bool, debug: Optional[dict] = None):
+    """DPRNNSpeTasNet.forward (dprnn_spe.py:314-327) / DPRNNSpeIRATasNet.forward (dprnn_spe_ira.py:179-190) with feature_size / hidden_size
+    above the build: speaker branch and fusion operands on the built kernels in their exact-fp32 arithmetic (engine.speaker_embedding,
+    engine._fusion_operands, engine._att_row_scale), bottleneck 1x1 conv, DPRNN stack and mask head on the any-width kernels."""
+    cfg = model.cfg
+    check_supported_spe(cfg)
+    if aux.shape[0] != wav.shape[0]:
+        raise DprnnError("mixture and reference batch sizes differ")
+    dev = wav.device
+    N, F = cfg["input_size"], cfg["feature_size"]
+    ks, stride = cfg["kernel_size"], cfg["stride"]
+    with torch.cuda.device(dev), E.use_gemm_mode(0):
+        st = _Launcher(dev)
+        st.lib.dprnn_set_gemm_mode(0)
+        geo = E.make_geometry(wav.shape[0], wav.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+        geo_a = E.make_geometry(aux.shape[0], aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+        if geo.T_out < 2:
+            raise DprnnError("utterance too short")
+        B, L = geo.B, geo.L
+        sep = model.separation
+        se = sep.spk_encoder
+        enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
+        nb = 1 + 2 * len(sep.dprnn_blocks)
+        stats = torch.zeros((2 if ira else 1) * nb + 2, B, 2, device=dev, dtype=torch.float64)
+        aux_len_dev = E._aux_len_tensor(aux_len, B, dev)
+        # speaker embedding of the reference utterance (dprnn_spe.py:156-163)
+        sc_a, sh_a = E.bottleneck_affine(st, aux, enc_w, se[0], geo_a, stats[-1])
+        A0 = E.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], geo_a, gemm_mode=0, scale_slot=E.SLOT_AUX_BOTTLENECK).view(B * geo_a.L, E.F_BUILT)
+        v0 = E.speaker_embedding(st, sep, A0, B, geo_a.L, aux_len_dev, ks)
+        if debug is not None:
+            debug["emb"] = v0.clone()
+        enc = torch.empty(B * L, N, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_encoder_fwd", E._p(wav), E._p(enc_w), E._p(enc), B, geo.T, L, N, geo.ks, geo.stride)
+        conv = sep.bottleneck[1]
+        wb = E._param(conv.weight, "bottleneck.weight", dev)
+        if wb.shape[0] != F or wb.shape[1] < N:
+            raise DprnnError(f"bottleneck 1x1 conv weight {tuple(wb.shape)} does not fit {N} -> {F}")
+        bb = E._param(conv.bias, "bottleneck.bias", dev)
+        att = cfg["fusion_type"] == "att"
+
+        def separate(v, sc, sh, stats_block, first: bool):
+            """One separation pass conditioned on embedding v (dprnn_spe.py:165-229, 231-248) -> masked encoder rows [(b, spk, l)][N]."""
+            mul, add, row_bias = E._fusion_operands(st, sep, cfg, v)
+            if first:
+                sc, sh = E.bottleneck_affine(st, wav, enc_w, sep.bottleneck[0], geo, stats[0], mul, add)
+            elif mul is not None or add is not None:        # the cached norm output (dprnn_spe_ira.py:96): same sums, new fusion operands
+                g, b_, eps = E._norm_params(sep.bottleneck[0])
+                st.call("dprnn_bottleneck_prep", E._p(stats[0]), E._p(g), E._p(b_), eps, E._p(mul), E._p(add), E._p(sc), E._p(sh), B, L, N)
+            row_scale = E._att_row_scale(st, sep, cfg, wav, enc_w, geo, stats[0], mul) if att else None
+            Y = st.gemm(enc, wb, bb, B * L, N, F, sc=sc, sh=sh, rows_per_utt=L, ldw=wb.shape[1], ubias=row_bias, rscale=row_scale)
+            if debug is not None and first:
+                debug["bottleneck"] = Y.view(B, L, F).clone()
+            return _masks_from_frames(st, sep, Y, geo, stats_block, mul_enc=enc, debug=debug if first else None), sc, sh
+
+        masked, sc, sh = separate(v0, None, None, stats[:nb], True)
+        v_last = v0
+        if ira:
+            # second embedding from the first estimate d0 = mask0 * enc (dprnn_spe_ira.py:79-92), then the second pass
+            d0 = masked.view(B, 2, L, N)[:, 0].contiguous().view(B * L, N)
+            st.call("dprnn_rows_stats", E._p(d0), E._p(stats[-2]), B, L, N)
+            g0, b0, _ = E._norm_params(se[0])
+            sc_d = torch.empty(B, N, device=dev, dtype=torch.float32)
+            sh_d = torch.empty_like(sc_d)
+            st.call("dprnn_bottleneck_prep", E._p(stats[-2]), E._p(E._param(g0, "spk_encoder.0.weight", dev)), E._p(E._param(b0, "spk_encoder.0.bias", dev)),
+                    1e-5, 0, 0, E._p(sc_d), E._p(sh_d), B, L, N)
+            A0d = E._pointwise(st, d0, B * L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d, aff_stride=N, rows_per_utt=L)
+            v1 = E.speaker_embedding(st, sep, A0d, B, L, aux_len_dev, ks)
+            v1 = E._linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0, v1), dim=1).contiguous())
+            if debug is not None:
+                debug["v1"] = v1.clone()
+            del masked
+            masked, sc, sh = separate(v1, sc, sh, stats[nb: 2 * nb], False)
+            v_last = v1
+        logits = E._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, v_last)
+        wd = dec_w.view(N, geo.ks).t().contiguous()
+        taps = st.gemm(masked, wd, None, B * 2 * L, N, geo.ks)
+        est = E.decode(st, taps, geo, 1)                     # speaker 0 only (dprnn_spe.py:325)
+        return est[:, 0, :], logits
+
+
+def spe_forward(model, wav: torch.Tensor, aux: torch.Tensor, aux_len, ira: bool = False, debug: Optional[dict] = None):
+    wav, aux = E.check_input(wav), E.check_input(aux, "aux")
+    load_library()
+    return _spe_forward_impl(model, wav, aux, aux_len, ira, debug)
 
 
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> torch.Tensor:
