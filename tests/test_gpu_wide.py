@@ -363,3 +363,29 @@ def test_separator_level_forwards_at_any_width(over):
     assert rel_l2(got2.cpu().numpy(), want) <= REL_TOL
     with pytest.raises(NotImplementedError, match="inference-only"):
         model.separation(torch.from_numpy(enc).to(_dev()))
+
+
+@pytest.mark.parametrize("over,B,T", [(dict(kernel_size=16, stride=8, chunk_length=12, hop_length=6), 2, 1000),       # Conv-TasNet-style long filters
+                                      (dict(chunk_length=10, hop_length=10), 3, 157),                               # no overlap between chunks
+                                      (dict(chunk_length=7, hop_length=2), 2, 90),                                  # hop that does not divide the chunk
+                                      (dict(chunk_length=250, hop_length=125), 1, 3),                               # two encoder frames, one real chunk row
+                                      (dict(kernel_size=3, stride=1, chunk_length=8, hop_length=4, bidirectional=False), 2, 64)])
+def test_edge_geometries_against_the_cpu_oracle(over, B, T):
+    """Encoder filter lengths beyond the built path's 8 taps, hops equal to / not dividing the chunk, utterances of a few frames."""
+    model, sd, cfg = build_model("bss", dict(feature_size=144, hidden_size=136, n_repeats=1, **over), 17, _dev())
+    x = make_mixture(B, T, seed=T)
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
+    with torch.no_grad():
+        got = model(torch.from_numpy(x).to(_dev())).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) <= REL_TOL, rel_l2(got, want)
+
+
+def test_long_encoder_filters_at_the_built_widths_take_the_any_width_path():
+    """kernel_size 16 / stride 8 (Conv-TasNet's encoder) at 64 / 128 / 128: beyond the fused kernels' 8 taps, so the any-width kernels run it."""
+    model, sd, cfg = build_model("bss", dict(kernel_size=16, stride=8, chunk_length=20, hop_length=10, n_repeats=1), 19, _dev())
+    x = make_mixture(2, 4000, seed=5)
+    want = otc.tasnet_forward(otc.to_torch_state(sd), cfg, torch.from_numpy(x)).numpy()
+    with torch.no_grad():
+        got = model(torch.from_numpy(x).to(_dev())).cpu().numpy()
+    assert got.shape == want.shape and rel_l2(got, want) <= REL_TOL

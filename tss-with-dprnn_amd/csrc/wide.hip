@@ -130,8 +130,11 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict_
     f32x4 acc[4 * NB];
 #pragma unroll
     for (int t = 0; t < 4 * NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv[NB];
+    // the next k block's A and W words are requested right after this block's went to LDS, so their latency (HBM for A) runs under
+    // this block's 16 NB MFMAs per wave instead of in front of them
+    f32x4 av, wv[NB];
+    auto stage = [&](int k0) {
+        av = f32x4{0.f, 0.f, 0.f, 0.f};
         const int kq = k0 + lk;
         if (vec) {                                                // K, lda, ldw multiples of 4 and 16-byte aligned bases: whole 16-byte words
             if (a_ok && kq < K) {
@@ -170,12 +173,15 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[e] = av[e] >= 0.f ? av[e] : pw * av[e];
         }
-        if (sc && !(a_ok)) av = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    stage(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
         __syncthreads();                                          // the previous block's reads are done
         *reinterpret_cast<f32x4*>(&As[lr * GP + lk]) = av;
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Ws[(lr + 64 * i) * GP + lk]) = wv[i];
         __syncthreads();
+        if (k0 + 16 < K) stage(k0 + 16);
         const f32x4 a = *reinterpret_cast<const f32x4*>(&As[(16 * w + j) * GP + 4 * kk]);
 #pragma unroll
         for (int t = 0; t < 4 * NB; ++t) {

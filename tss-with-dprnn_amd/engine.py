@@ -1166,9 +1166,10 @@ def _twin(model):
 
 
 def _wider_than_built(model) -> bool:
-    """Wider than the fused kernels' build (padded.fits): such a DPRNNTasNet runs on the any-width kernels (wide.py)."""
+    """Beyond the fused kernels' build -- wider (padded.fits) or an encoder filter longer than KS_MAX taps (Conv-TasNet-style kernel_size 16):
+    such a model runs its inference forward on the any-width kernels (wide.py)."""
     from . import padded
-    return not padded.fits(model.cfg)
+    return not padded.fits(model.cfg) or model.cfg["kernel_size"] > KS_MAX
 
 
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):

@@ -240,7 +240,9 @@ def check_supported_spe(cfg: dict) -> None:
     fusions live on the encoder side of the bottleneck (N channels) and keep the built kernels, so input_size and the speaker encoder's
     widths must be the build's (the shipped YAMLs' values)."""
     check_supported(cfg)
-    E.check_supported_spe(dict(cfg, input_size=E.N_BUILT, feature_size=E.F_BUILT, hidden_size=E.F_BUILT))
+    E.check_supported_spe(dict(cfg, input_size=E.N_BUILT, feature_size=E.F_BUILT, hidden_size=E.F_BUILT, kernel_size=min(cfg["kernel_size"], E.KS_MAX)))
+    if cfg["kernel_size"] > E.KS_MAX:
+        raise NotImplementedError(f"DPRNN-Spe MI355X path (any-width kernels): the speaker branch's built kernels take kernel_size <= {E.KS_MAX}")
     if cfg["input_size"] != E.N_BUILT:
         raise NotImplementedError(
             f"DPRNN-Spe MI355X path (any-width kernels): a speaker-conditioned model wider than the build needs input_size {E.N_BUILT} (the speaker "
