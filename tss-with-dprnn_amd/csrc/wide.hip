@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void wide_rnn_pack_kernel(int cell, const floa
 // writes h_t into image nxt, x_{t+1} is copied into nxt at the start of the step; one barrier per step.  Wave w owns unit tiles
 // w, w+4, ...: the four gates of one (sequence, unit) meet in one lane, c / h state stays in registers.  Weights stream from L2
 // every step as 16-byte fragments (1 KB per wave instruction).
-constexpr int MAXUT = 8;        // unit tiles per wave: hidden_size <= 4 * 8 * 16 = 512
-template <int NT, int G, bool FAST>
+constexpr int MAXUT_WIDE = 8;   // unit tiles per wave: hidden_size <= 4 * 8 * 16 = 512; the 2-tile build (hidden_size <= 128) keeps the
+                                // registers of a narrow model's recurrence low enough for four workgroups per CU
+template <int NT, int G, bool FAST, int MAXUT>
 __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __restrict__ X, const float* __restrict__ WpAll,
                                                        const float* __restrict__ bvAll, float* __restrict__ Hout, int F, int H, int nseq, int T,
                                                        long long inner_n, long long outer, long long inner, long long t_stride, int ldh,
@@ -510,7 +511,7 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
         return -1;
     }
     const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, pitch = Fp + Hp + 4;
-    if (Hp / 16 > 4 * MAXUT) { dprnn_set_error("dprnn_wide_rnn_fwd: hidden_size %d > %d", H, 4 * MAXUT * 16); return -1; }
+    if (Hp / 16 > 4 * MAXUT_WIDE) { dprnn_set_error("dprnn_wide_rnn_fwd: hidden_size %d > %d", H, 4 * MAXUT_WIDE * 16); return -1; }
     // 32 sequences per workgroup when they fit the LDS and still fill the chip, else 16
     // 16 sequences per workgroup: two workgroups per CU (two waves per SIMD) hide the weight-fragment and LDS latencies better than one
     // 32-sequence workgroup halves the weight stream (F = H = 256, 64 x 3 s: 0.52 / 0.60 of the MFMA peak against 0.41 / 0.51);
@@ -523,18 +524,20 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
     const long long wp_dir = dprnn_wide_rnn_pack_floats(cell, F, H);
     const dim3 grid((nseq + 16 * nt - 1) / (16 * nt), ndir), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define WIDE_RNN2(NT_, G_, FAST_)                                                                                                                 \
+#define WIDE_RNN3(NT_, G_, FAST_, UT_)                                                                                                                 \
     do {                                                                                                                                    \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_rnn_kernel<NT_, G_, FAST_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_rnn_kernel<NT_, G_, FAST_, UT_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 160 * 1024) != hipSuccess) { dprnn_set_error("dprnn_wide_rnn_fwd: hipFuncSetAttribute"); return -2; }        \
-        hipLaunchKernelGGL((wide_rnn_kernel<NT_, G_, FAST_>), grid, block, lds, st, cell, X, Wp, bv, Hout, F, H, nseq, T, (long long)inner_n,      \
+        hipLaunchKernelGGL((wide_rnn_kernel<NT_, G_, FAST_, UT_>), grid, block, lds, st, cell, X, Wp, bv, Hout, F, H, nseq, T, (long long)inner_n,      \
                            (long long)outer, (long long)inner, (long long)t_stride, ndir * H, wp_dir);                                      \
     } while (0)
+#define WIDE_RNN2(NT_, G_, FAST_) do { if (Hp / 16 <= 8) WIDE_RNN3(NT_, G_, FAST_, 2); else WIDE_RNN3(NT_, G_, FAST_, MAXUT_WIDE); } while (0)
 #define WIDE_RNN(NT_, G_) do { if (fast) WIDE_RNN2(NT_, G_, true); else WIDE_RNN2(NT_, G_, false); } while (0)
     const bool fast = dprnn_get_fast_activations() != 0;        // v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), as the built kernels' default
     if (cell == 2) { if (nt == 2) WIDE_RNN(2, 1); else WIDE_RNN(1, 1); }
     else { if (nt == 2) WIDE_RNN(2, 4); else WIDE_RNN(1, 4); }
 #undef WIDE_RNN
 #undef WIDE_RNN2
+#undef WIDE_RNN3
     return dprnn_check_launch("wide_rnn_kernel");
 }

@@ -63,6 +63,9 @@ if DEFAULT_GEMM_MODE not in GEMM_MODES:
     raise DprnnError(f"DPRNN_GEMM_MODE={DEFAULT_GEMM_MODE}: the gate-GEMM modes are 0 (exact fp32 MFMA), 1 (three bf16 pieces) "
                      "and 3 (two f16 pieces, the default)")
 GEMM_MODE = DEFAULT_GEMM_MODE
+# DPRNNTasNet inference of a model narrower than the build: feature / hidden sizes up to this run natively on the any-width kernels (exact
+# fp32 MFMA arithmetic, work proportional to the real widths) instead of as a zero-padded twin on the 128-wide fused kernels.
+NARROW_NATIVE_MAX = int(os.environ.get("DPRNN_NARROW_NATIVE_MAX", "0"))
 SPLIT_ONE_GROUP = True      # split modes: SPLIT_GROUPS pipelines instead of STREAM_GROUPS (the wide kernels take one workgroup per CU)
 
 # What a forward does when the f16-pieces arithmetic met a value beyond its range: "fallback" = run the call again in mode 1
@@ -1104,7 +1107,7 @@ GRAPH_STATS = {"captures": 0, "replays": 0, "capture_failures": 0, "kept_eager_f
 # upper-case name is left out): LAUNCH_KNOBS change the launch sequence of a forward -- which kernels, tiles, streams, arithmetic --
 # and are therefore part of every captured graph's key; the others are constants, bookkeeping, or policy applied outside a capture.
 # A knob added to the module and forgotten here fails that test instead of replaying a stale graph.
-LAUNCH_KNOBS = ("STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
+LAUNCH_KNOBS = ("NARROW_NATIVE_MAX", "STREAM_GROUPS", "MIN_GROUP_BATCH", "FUSE_NORM", "SPLIT_ONE_GROUP", "SPLIT_GROUPS", "GROUP_SIZES", "SEQ_TILE", "SPLIT_WIDE_TILE_MARGIN",
                 "SPLIT_MIN_BATCH", "H_PIECES", "ADAPTIVE_SCALE", "GEMM_MODE", "SPLIT_STEP_US", "SPLIT_STEP_US_F16", "RAGGED_STREAMS", "RAGGED_AUX_BATCH", "RAGGED_GATE_BATCHED", "RAGGED_HEAD_CONV_BATCHED", "RAGGED_BN_FOLDS_ONCE",
                 "SATURATION_CHECK", "LIN_FOLD", "FOLD_SPLIT_MIN_FILL", "FOLD_SERIAL_MIN_FILL", "FOLD_TILES", "WIDE_TILE_MIN_FILL")
 OTHER_SETTINGS = ("F_BUILT", "N_BUILT", "KS_MAX", "PACK_PER_DIR", "PACK_PER_DIR_MAX", "CELL_ID", "GEMM_MODES", "DEFAULT_GEMM_MODE",
@@ -1167,9 +1170,13 @@ def _twin(model):
 
 def _wider_than_built(model) -> bool:
     """Beyond the fused kernels' build -- wider (padded.fits) or an encoder filter longer than KS_MAX taps (Conv-TasNet-style kernel_size 16):
-    such a model runs its inference forward on the any-width kernels (wide.py)."""
+    such a model runs its inference forward on the any-width kernels (wide.py).  So does a DPRNNTasNet NARROWER than the build whose
+    feature and hidden size are at most NARROW_NATIVE_MAX: its zero-padded twin would pay for 128-wide kernels."""
     from . import padded
-    return not padded.fits(model.cfg) or model.cfg["kernel_size"] > KS_MAX
+    cfg = model.cfg
+    if not padded.fits(cfg) or cfg["kernel_size"] > KS_MAX:
+        return True
+    return ("fusion_type" not in cfg and padded.needs_twin(cfg) and max(cfg["feature_size"], cfg["hidden_size"]) <= NARROW_NATIVE_MAX)
 
 
 def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None):
