@@ -54,7 +54,7 @@ int dprnn_wide_rnn_pack(int cell, const float* w_ih, const float* w_hh, const fl
  * bv + d*gates*roundup16(H)); input row of (sequence q, step t) = (q / inner_n)*outer + (q % inner_n)*inner + t*t_stride in rows of
  * F floats, output rows of ndir*H floats at the same index (forward | backward halves, as torch concatenates them).  Intra-chunk:
  * inner_n = 1, outer = K, t_stride = 1; inter-chunk: inner_n = K, outer = S*K, inner = 1, t_stride = K (dprnn.py:84,94).
- * hidden_size <= 512 and 2*16*(roundup16(F) + roundup16(H) + 4)*4 bytes of LDS <= 160 KB. */
+ * hidden_size <= 512 and 2*16*(roundup16(F) + roundup16(H) + 8)*4 bytes of LDS <= 160 KB. */
 int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
                        int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream);
 

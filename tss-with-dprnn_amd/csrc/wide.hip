@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void wide_ola_kernel(const float* __restrict__
 // a block is permuted (step s of lane group kk takes k = 4 kk + s) so that every lane reads its operands as one 16-byte LDS word.
 // NB = 4 (256 columns per workgroup) for the wide outputs: a 64-column tile does 16 FLOPs per byte it stages and would re-read the A rows
 // from HBM once per column tile (9.8 TB/s at the fp32 MFMA peak); at 256 columns the rows are read once and W (L2-resident) paces nothing.
-constexpr int GP = 20;          // LDS pitch of a 16-float k block (floats): 16-byte aligned, conflict-free for ds_read_b128
+constexpr int GP = 24;          // LDS pitch of a 16-float k block (floats): 16-byte aligned; pitch / 4 = 2 (mod 4) puts the 16 lanes of every
+                                // ds_read_b128 lane group on 16 different 4-bank slots (pitch 20: one 2-way conflict per group)
 template <int NB>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, long long rows_per_utt, const float* __restrict__ prelu,
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __
                                                        long long inner_n, long long outer, long long inner, long long t_stride, int ldh,
                                                        long long wp_dir_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, Kp = Fp + Hp, pitch = Kp + 4, nkb = Kp / 16, nut = Hp / 16;
+    const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, Kp = Fp + Hp, pitch = Kp + 8, nkb = Kp / 16, nut = Hp / 16;    // pitch / 4 = 2 (mod 4): see GP
     constexpr int NS = 16 * NT;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
     const int dir = blockIdx.y;
@@ -510,7 +511,7 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
         dprnn_set_error("dprnn_wide_rnn_fwd: bad sizes cell=%d ndir=%d F=%d H=%d nseq=%d T=%d", cell, ndir, F, H, nseq, T);
         return -1;
     }
-    const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, pitch = Fp + Hp + 4;
+    const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, pitch = Fp + Hp + 8;
     if (Hp / 16 > 4 * MAXUT_WIDE) { dprnn_set_error("dprnn_wide_rnn_fwd: hidden_size %d > %d", H, 4 * MAXUT_WIDE * 16); return -1; }
     // 32 sequences per workgroup when they fit the LDS and still fill the chip, else 16
     // 16 sequences per workgroup: two workgroups per CU (two waves per SIMD) hide the weight-fragment and LDS latencies better than one

@@ -39,7 +39,7 @@ def check_supported(cfg: dict) -> None:
         bad.append(f"rnn_type {cfg['rnn_type']!r}: torch.nn has LSTM, GRU and RNN recurrences")
     if H > H_MAX:
         bad.append(f"hidden_size {H} > {H_MAX} (four waves x eight 16-unit tiles hold a recurrence's state in registers)")
-    elif 2 * 16 * (_r16(F) + _r16(H) + 4) * 4 > LDS_BYTES:
+    elif 2 * 16 * (_r16(F) + _r16(H) + 8) * 4 > LDS_BYTES:
         bad.append(f"feature_size {F} + hidden_size {H}: two LDS images of 16 sequences x (x_t | h_t-1) exceed the 160 KB of a CU")
     if cfg["norm_type"] not in ("ln", "gLN"):
         bad.append(f"norm_type {cfg['norm_type']!r} (reference leaves the norms undefined, dprnn.py:72-77)")
