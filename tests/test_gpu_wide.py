@@ -389,3 +389,47 @@ def test_long_encoder_filters_at_the_built_widths_take_the_any_width_path():
     with torch.no_grad():
         got = model(torch.from_numpy(x).to(_dev())).cpu().numpy()
     assert got.shape == want.shape and rel_l2(got, want) <= REL_TOL
+
+
+@pytest.mark.parametrize("rnn_type,bidir,N,F,H", [("LSTM", True, 64, 256, 256), ("GRU", False, 96, 96, 80), ("RNN", True, 40, 133, 70)])
+def test_sub_module_forwards_at_any_width(rnn_type, bidir, N, F, H):
+    """SingleRNN.forward, DPRNNBlock.forward (dprnn.py:33-37, 79-99) and Encoder.forward (encoder_decoder.py:25-33) of models off the fused
+    kernels' build, against the reference's permutations written with stock torch modules on the CPU."""
+    model, _, cfg = build_model("bss", dict(input_size=N, feature_size=F, hidden_size=H, chunk_length=16, hop_length=8, n_repeats=1, rnn_type=rnn_type,
+                                            bidirectional=bidir, kernel_size=16 if N == 96 else 2), 77, _dev())
+    blk = model.separation.dprnn_blocks[0]
+
+    def cpu_rnn(single):
+        r = getattr(torch.nn, rnn_type)(F, H, num_layers=1, batch_first=True, bidirectional=single.bidirectional)
+        r.load_state_dict({k: v.cpu() for k, v in single.rnn.state_dict().items()})
+        return r
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((37, 21, F)).astype(np.float32))
+    with torch.no_grad():
+        got = blk.inter_rnn(x.to(_dev())).cpu().numpy()
+        want = cpu_rnn(blk.inter_rnn)(x)[0].numpy()
+    assert got.shape == want.shape and rel_l2(got, want) < 3e-6
+    B, K, S = 2, 16, 9
+    xb = torch.from_numpy(rng.standard_normal((B, F, K, S)).astype(np.float32))
+    nd = 2 if bidir else 1
+    with torch.no_grad():
+        got = blk(xb.to(_dev())).cpu().numpy()
+        intra, inter = cpu_rnn(blk.intra_rnn), cpu_rnn(blk.inter_rnn)
+        lin1 = torch.nn.Linear(2 * H, F); lin1.load_state_dict({k: v.cpu() for k, v in blk.intra_linear.state_dict().items()})
+        lin2 = torch.nn.Linear(nd * H, F); lin2.load_state_dict({k: v.cpu() for k, v in blk.inter_linear.state_dict().items()})
+        n1 = torch.nn.GroupNorm(1, F); n1.load_state_dict({k: v.cpu() for k, v in blk.intra_norm.state_dict().items()})
+        n2 = torch.nn.GroupNorm(1, F); n2.load_state_dict({k: v.cpu() for k, v in blk.inter_norm.state_dict().items()})
+        o = xb.transpose(1, -1).reshape(B * S, K, F)
+        o = lin1(intra(o)[0]).reshape(B, S, K, F).transpose(1, -1)
+        o = n1(o) + xb
+        y = o
+        o = o.transpose(1, 2).transpose(2, -1).reshape(B * K, S, F)
+        o = lin2(inter(o)[0]).reshape(B, K, S, F).transpose(1, -1).transpose(2, -1).contiguous()
+        want = (n2(o) + y).numpy()
+    assert got.shape == want.shape and rel_l2(got, want) < 5e-6, rel_l2(got, want)
+    if N != 64 or cfg["kernel_size"] > 8:
+        wav = torch.from_numpy(rng.standard_normal((3, 501)).astype(np.float32))
+        with torch.no_grad():
+            e = model.encoder(wav.to(_dev()))
+            want = torch.relu(torch.nn.functional.conv1d(wav[:, None, :], model.encoder.conv1d.weight.detach().cpu(), stride=model.encoder.conv1d.stride[0]))
+        assert e.shape == want.shape and rel_l2(e.cpu().numpy(), want.numpy()) < 1e-6

@@ -115,7 +115,10 @@ def _auxiliary_embedding_impl(sep, aux: torch.Tensor, aux_len) -> torch.Tensor:
 # changes between the reference's channels-first tensors and the kernels' channels-last rows are torch copies (plumbing).
 def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
     """SingleRNN.forward (dprnn.py:33-37): [n, T, F] batch-first -> [n, T, ndir*H], zero initial state."""
-    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[2] != E.F_BUILT or rnn.hidden_size != E.F_BUILT:
+    if rnn.rnn.input_size != E.F_BUILT or rnn.hidden_size != E.F_BUILT:          # off the fused kernels' build: the any-width kernels
+        from . import wide
+        return wide.single_rnn_forward(rnn, x)
+    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[2] != E.F_BUILT:
         raise DprnnError(f"SingleRNN input must be [sequences, steps, {E.F_BUILT}] with hidden_size {E.F_BUILT}")
     if not x.is_cuda or x.dtype != torch.float32:
         raise DprnnError("SingleRNN runs on float32 HIP tensors only (no CPU fallback)")
@@ -150,6 +153,9 @@ def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
 
 def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
     """DPRNNBlock.forward (dprnn.py:79-99): [B, F, K, S] -> [B, F, K, S]."""
+    if blk.intra_rnn.rnn.input_size != E.F_BUILT or blk.intra_rnn.hidden_size != E.F_BUILT:      # off the build: the any-width kernels
+        from . import wide
+        return wide.block_forward(blk, x)
     if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != E.F_BUILT:
         raise DprnnError(f"DPRNNBlock input must be [batch, {E.F_BUILT}, chunk_length, chunks]")
     if not x.is_cuda or x.dtype != torch.float32:
@@ -200,8 +206,9 @@ def encoder_forward(enc, wav: torch.Tensor) -> torch.Tensor:
     w = E._param(enc.conv1d.weight, "encoder.conv1d.weight", dev)
     N, _, ks = w.shape
     stride = enc.conv1d.stride[0]
-    if N != E.N_BUILT or ks > E.KS_MAX:
-        raise NotImplementedError(f"Encoder MI355X path: output_size must be {E.N_BUILT}, kernel_size <= {E.KS_MAX}")
+    if N != E.N_BUILT or ks > E.KS_MAX:                       # off the fused kernels' build: the any-width encoder kernel
+        from . import wide
+        return wide.encoder_forward(enc, wav)
     _no_grad_only("Encoder.forward", wav, module=enc)
     with torch.cuda.device(dev):
         st = E.Stage(dev)

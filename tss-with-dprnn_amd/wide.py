@@ -235,6 +235,72 @@ def _forward_impl(model, wav: torch.Tensor, debug: Optional[dict] = None) -> tor
         return E.decode(st, taps, geo, 2)
 
 
+def single_rnn_forward(rnn, x: torch.Tensor) -> torch.Tensor:
+    """SingleRNN.forward (dprnn.py:33-37) at any width: [n, T, F] batch-first -> [n, T, ndir*H], zero initial state."""
+    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.shape[2] != rnn.rnn.input_size:
+        raise DprnnError(f"SingleRNN input must be [sequences, steps, {rnn.rnn.input_size}]")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("SingleRNN runs on float32 HIP tensors only (no CPU fallback)")
+    E._no_grad_only("SingleRNN.forward", x, module=rnn)
+    dev = x.device
+    n, T, F = x.shape
+    H = rnn.hidden_size
+    kind = rnn.rnn.mode.split("_")[0]
+    check_supported(dict(feature_size=F, hidden_size=H, rnn_type=kind, norm_type="ln", activation_type="relu", hop_length=1, chunk_length=1))
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        xc = x.contiguous()
+        Wp, bv, ndir = _pack_rnn(st, rnn.rnn, CELL_ID[kind], F, H, dev)
+        out = torch.empty(n, T, ndir * H, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_rnn_fwd", CELL_ID[kind], E._p(xc), E._p(Wp), E._p(bv), E._p(out), ndir, F, H, n, T, 1, T, 0, 1)
+        return out
+
+
+def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
+    """DPRNNBlock.forward (dprnn.py:79-99) at any width: [B, F, K, S] -> [B, F, K, S]."""
+    F = blk.intra_rnn.rnn.input_size
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != F:
+        raise DprnnError(f"DPRNNBlock input must be [batch, {F}, chunk_length, chunks]")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise DprnnError("DPRNNBlock runs on float32 HIP tensors only (no CPU fallback)")
+    if not hasattr(blk, "intra_norm"):
+        raise DprnnError("DPRNNBlock without norms (norm_type neither 'ln' nor 'gLN'): the reference's forward fails too")
+    E._no_grad_only("DPRNNBlock.forward", x, module=blk)
+    dev = x.device
+    B, _, K, S = x.shape
+    H = blk.intra_rnn.hidden_size
+    kind = blk.intra_rnn.rnn.mode.split("_")[0]
+    check_supported(dict(feature_size=F, hidden_size=H, rnn_type=kind, norm_type="ln", activation_type="relu", hop_length=1, chunk_length=1))
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        geo = E.Geometry(B, 0, 0, K, 1, S, 1, 1, 0)
+        rows = geo.rows
+        X = x.permute(0, 3, 2, 1).contiguous().view(rows, F)                     # slab rows (b, s, k)
+        Hbuf = torch.empty(rows * 2 * H, device=dev, dtype=torch.float32)
+        Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
+        stats = torch.zeros(2, B, 2, device=dev, dtype=torch.float64)
+        cell = CELL_ID[kind]
+        _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[0], geo, F, H, cell, True)
+        _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[1], geo, F, H, cell, False)
+        return X.view(B, S, K, F).permute(0, 3, 2, 1).contiguous()
+
+
+def encoder_forward(enc, wav: torch.Tensor) -> torch.Tensor:
+    """Encoder.forward (encoder_decoder.py:25-33) with any filter count / length: [B, T] -> relu(conv1d) [B, N, L]."""
+    wav = E.check_input(wav)
+    dev = wav.device
+    w = E._param(enc.conv1d.weight, "encoder.conv1d.weight", dev)
+    N, _, ks = w.shape
+    stride = enc.conv1d.stride[0]
+    E._no_grad_only("Encoder.forward", wav, module=enc)
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        geo = E.make_geometry(wav.shape[0], wav.shape[1], N, 1, 1, ks, stride)
+        rows = torch.empty(geo.B * geo.L, N, device=dev, dtype=torch.float32)
+        st.call("dprnn_wide_encoder_fwd", E._p(wav), E._p(w), E._p(rows), geo.B, geo.T, geo.L, N, ks, stride)
+        return rows.view(geo.B, geo.L, N).transpose(1, 2).contiguous()
+
+
 def check_supported_spe(cfg: dict) -> None:
     """The speaker-conditioned classes above the built widths: the DPRNN stack runs at any feature / hidden size; the speaker branch and the
     fusions live on the encoder side of the bottleneck (N channels) and keep the built kernels, so input_size and the speaker encoder's
