@@ -506,3 +506,41 @@ def test_placed_parameters_hand_a_narrow_model_the_real_blocks_of_its_twins_grad
         assert where.numel() == prm.numel(), k
         want.reshape(-1)[(scratch.reshape(-1)[where] - 1.0).long()] = up[k].reshape(-1)[where]
         assert torch.equal(prm.grad, want), k
+
+
+def test_which_models_take_the_any_width_kernels_and_which_limits_raise(monkeypatch):
+    """Host-side routing of configurations off the fused kernels' build (engine._wider_than_built, engine._sep_off_build, wide.check_supported*):
+    wider models and long encoder filters go to wide.py, narrower ones stay zero-padded twins (unless NARROW_NATIVE_MAX says otherwise), the
+    speaker-conditioned classes go there only with feature / hidden size wide; every limit is a NotImplementedError that names itself."""
+    import tss_with_dprnn_amd as pkg
+    from tss_with_dprnn_amd import dprnn_spe, engine, wide
+    mk = lambda **kw: pkg.DPRNNTasNet(**dict(dict(input_size=64, chunk_length=16, n_repeats=1), **kw))
+    assert not engine._wider_than_built(mk())                                            # the build itself
+    assert engine._wider_than_built(mk(feature_size=256, hidden_size=256))
+    assert engine._wider_than_built(mk(hidden_size=129)) and engine._wider_than_built(mk(input_size=65))
+    assert engine._wider_than_built(mk(kernel_size=16))                                  # Conv-TasNet's encoder: beyond KS_MAX taps
+    narrow = mk(feature_size=64, hidden_size=48)
+    assert not engine._wider_than_built(narrow)                                          # a zero-padded twin ...
+    monkeypatch.setattr(engine, "NARROW_NATIVE_MAX", 64)
+    assert engine._wider_than_built(narrow) and not engine._wider_than_built(mk(feature_size=96, hidden_size=96))
+    monkeypatch.setattr(engine, "NARROW_NATIVE_MAX", 0)
+    spe = dprnn_spe.DPRNNSpeTasNet(64, feature_size=64, hidden_size=64, chunk_length=16, n_repeats=1)
+    monkeypatch.setattr(engine, "NARROW_NATIVE_MAX", 128)
+    assert not engine._wider_than_built(spe)                                             # ... the speaker-conditioned classes always
+    monkeypatch.setattr(engine, "NARROW_NATIVE_MAX", 0)
+    assert engine._sep_off_build(narrow.separation) and not engine._sep_off_build(mk().separation)
+    assert not engine.ragged_supported(mk(feature_size=256, hidden_size=256).separation)
+    ok = dict(feature_size=512, hidden_size=512, rnn_type="GRU", norm_type="gLN", activation_type="relu", hop_length=8, chunk_length=16)
+    wide.check_supported(ok)
+    for bad, what in ((dict(ok, hidden_size=528), "hidden_size 528"), (dict(ok, feature_size=1024), "160 KB"),
+                      (dict(ok, rnn_type="QRNN"), "rnn_type"), (dict(ok, hop_length=17), "hop_length")):
+        with pytest.raises(NotImplementedError, match=what):
+            wide.check_supported(bad)
+    wspe = dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1)
+    wide.check_supported_spe(wspe.cfg)
+    with pytest.raises(NotImplementedError, match="input_size 64"):
+        wide.check_supported_spe(dict(wspe.cfg, input_size=48))
+    with pytest.raises(NotImplementedError, match="speaker encoder"):
+        wide.check_supported_spe(dict(wspe.cfg, P=512))
+    with pytest.raises(NotImplementedError, match="kernel_size"):
+        wide.check_supported_spe(dict(wspe.cfg, kernel_size=16))
