@@ -58,6 +58,13 @@ int dprnn_wide_rnn_pack(int cell, const float* w_ih, const float* w_hh, const fl
 int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
                        int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream);
 
+/* The same recurrence over TILES of up to 16 sequences with their own step counts: utterances of different lengths in one launch (the
+ * inter-chunk path of a ragged batch: a tile = 16 chunk positions of one utterance, S_u steps; src/inferencers/inferencer.py:54-58 runs
+ * them one at a time).  desc[4*i .. 4*i+3] = {first row, steps, sequences (1..16), row step between sequences} (device int64); row of
+ * (tile sequence j, step t) = first + j*step_between + t*t_stride.  List the longest tiles first: their workgroups run longest. */
+int dprnn_wide_rnn_fwd_tiles(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H,
+                             const int64_t* desc, int ntiles, int64_t t_stride, void* stream);
+
 /* out[m][o] = act(rscale[m] * sum_k a(m,k) * W[o*ldw + k] + bias[o] + ubias[u*O + o]) * mul[mrow(m)*ldm + o]
  *   a(m,k) = prelu(A[m*lda + k] * sc[u*K + k] + sh[u*K + k]), u = m / rows_per_utt (sc / sh NULL: no affine; prelu NULL: none, else
  *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, ubias, rscale, mul, stats optional;

@@ -144,6 +144,7 @@ SIGNATURES = {
     "dprnn_wide_segment_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     "dprnn_wide_rnn_pack": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp],
     "dprnn_wide_rnn_fwd": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_fp],
+    "dprnn_wide_rnn_fwd_tiles": [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i64, c_fp],
     "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64,
                         c_i, c_i, c_fp],
     "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp],

@@ -285,7 +285,7 @@ template <int NT, int G, bool FAST, int MAXUT>
 __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __restrict__ X, const float* __restrict__ WpAll,
                                                        const float* __restrict__ bvAll, float* __restrict__ Hout, int F, int H, int nseq, int T,
                                                        long long inner_n, long long outer, long long inner, long long t_stride, int ldh,
-                                                       long long wp_dir_stride) {
+                                                       long long wp_dir_stride, const long long* __restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Fp = (F + 15) & ~15, Hp = (H + 15) & ~15, Kp = Fp + Hp, pitch = Kp + 8, nkb = Kp / 16, nut = Hp / 16;    // pitch / 4 = 2 (mod 4): see GP
     constexpr int NS = 16 * NT;
@@ -298,13 +298,25 @@ __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __
     float* img1 = lds + NS * pitch;
     for (int i = tid; i < 2 * NS * pitch; i += 256) lds[i] = 0.f;
     __syncthreads();
-    // row of (sequence q, time t): an intra-chunk sequence is K consecutive rows, an inter-chunk one strides over the chunks
-    auto seq_base = [&](long long q) { return (q / inner_n) * outer + (q % inner_n) * inner; };
+    // row of (sequence q, time t): an intra-chunk sequence is K consecutive rows, an inter-chunk one strides over the chunks.
+    // Tile descriptors (ragged batches: utterances of different lengths in one launch): {first row, steps, sequences, row step between
+    // sequences} per workgroup instead of the regular formula -- every tile has its own step count.
+    long long d_base = 0, d_inner = 0;
+    int d_valid = 0;
+    if (desc) {
+        const long long* d = desc + 4 * (long long)blockIdx.x;
+        d_base = d[0]; T = (int)d[1]; d_valid = (int)d[2]; d_inner = d[3];
+    }
+    auto seq_row0 = [&](int sr) -> long long {                  // first row of the tile's sequence sr, or -1 beyond the tile's last one
+        if (desc) return sr < d_valid ? d_base + sr * d_inner : -1;
+        const long long q = q0 + sr;
+        return q < nseq ? (q / inner_n) * outer + (q % inner_n) * inner : -1;
+    };
     auto load_x = [&](float* img, int t) {
         for (int sr = w; sr < NS; sr += 4) {
-            const long long q = q0 + sr;
-            if (q >= nseq) continue;
-            const float* src = X + (seq_base(q) + (long long)t * t_stride) * F;
+            const long long r0 = seq_row0(sr);
+            if (r0 < 0) continue;
+            const float* src = X + (r0 + (long long)t * t_stride) * F;
             for (int c = lane; c < F; c += 64) img[sr * pitch + c] = src[c];
         }
     };
@@ -388,8 +400,8 @@ __global__ __launch_bounds__(256) void wide_rnn_kernel(int cell, const float* __
                             h = tanh_f<FAST>(acc[nt][0][r] + bq[u][0]);            // Elman, tanh
                         }
                         nxt[sr * pitch + Fp + unit] = h;
-                        const long long q = q0 + sr;
-                        if (q < nseq && unit < H) Hout[(seq_base(q) + (long long)t * t_stride) * ldh + (long long)dir * H + unit] = h;
+                        const long long r0 = seq_row0(sr);
+                        if (r0 >= 0 && unit < H) Hout[(r0 + (long long)t * t_stride) * ldh + (long long)dir * H + unit] = h;
                     }
             }
         }
@@ -504,8 +516,8 @@ extern "C" int dprnn_wide_rnn_pack(int cell, const float* w_ih, const float* w_h
     return dprnn_check_launch("wide_rnn_pack_kernel");
 }
 
-extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
-                                  int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream) {
+static int wide_rnn_launch(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
+                           int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, const long long* desc, int ntiles, void* stream) {
     WIDE_NULL(!X || !Wp || !bv || !Hout, "dprnn_wide_rnn_fwd");
     if (cell < 0 || cell > 2 || ndir < 1 || ndir > 2 || F < 1 || H < 1 || nseq < 1 || T < 1 || inner_n < 1) {
         dprnn_set_error("dprnn_wide_rnn_fwd: bad sizes cell=%d ndir=%d F=%d H=%d nseq=%d T=%d", cell, ndir, F, H, nseq, T);
@@ -519,18 +531,18 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
     // DPRNN_WIDE_NT=2 selects the 32-sequence form (diagnostics, tests)
     int nt = 1;
     if (const char* e = getenv("DPRNN_WIDE_NT")) { if (atoi(e) == 2) nt = 2; }
-    if ((size_t)2 * 32 * pitch * sizeof(float) > 160 * 1024) nt = 1;
+    if ((size_t)2 * 32 * pitch * sizeof(float) > 160 * 1024 || desc) nt = 1;
     const size_t lds = (size_t)2 * 16 * nt * pitch * sizeof(float);
     if (lds > 160 * 1024) { dprnn_set_error("dprnn_wide_rnn_fwd: feature_size %d + hidden_size %d need %zu bytes of LDS (160 KB per CU)", F, H, lds); return -1; }
     const long long wp_dir = dprnn_wide_rnn_pack_floats(cell, F, H);
-    const dim3 grid((nseq + 16 * nt - 1) / (16 * nt), ndir), block(256);
+    const dim3 grid(desc ? ntiles : (nseq + 16 * nt - 1) / (16 * nt), ndir), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define WIDE_RNN3(NT_, G_, FAST_, UT_)                                                                                                                 \
     do {                                                                                                                                    \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_rnn_kernel<NT_, G_, FAST_, UT_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 160 * 1024) != hipSuccess) { dprnn_set_error("dprnn_wide_rnn_fwd: hipFuncSetAttribute"); return -2; }        \
         hipLaunchKernelGGL((wide_rnn_kernel<NT_, G_, FAST_, UT_>), grid, block, lds, st, cell, X, Wp, bv, Hout, F, H, nseq, T, (long long)inner_n,      \
-                           (long long)outer, (long long)inner, (long long)t_stride, ndir * H, wp_dir);                                      \
+                           (long long)outer, (long long)inner, (long long)t_stride, ndir * H, wp_dir, desc);                                \
     } while (0)
 #define WIDE_RNN2(NT_, G_, FAST_) do { if (Hp / 16 <= 8) WIDE_RNN3(NT_, G_, FAST_, 2); else WIDE_RNN3(NT_, G_, FAST_, MAXUT_WIDE); } while (0)
 #define WIDE_RNN(NT_, G_) do { if (fast) WIDE_RNN2(NT_, G_, true); else WIDE_RNN2(NT_, G_, false); } while (0)
@@ -541,4 +553,15 @@ extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, con
 #undef WIDE_RNN2
 #undef WIDE_RNN3
     return dprnn_check_launch("wide_rnn_kernel");
+}
+
+extern "C" int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H, int nseq, int T,
+                                  int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, void* stream) {
+    return wide_rnn_launch(cell, X, Wp, bv, Hout, ndir, F, H, nseq, T, inner_n, outer, inner, t_stride, nullptr, 0, stream);
+}
+
+extern "C" int dprnn_wide_rnn_fwd_tiles(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H,
+                                        const int64_t* desc, int ntiles, int64_t t_stride, void* stream) {
+    if (!desc || ntiles < 1) { dprnn_set_error("dprnn_wide_rnn_fwd_tiles: no tiles"); return -1; }
+    return wide_rnn_launch(cell, X, Wp, bv, Hout, ndir, F, H, ntiles, 1, 1, 0, 0, t_stride, reinterpret_cast<const long long*>(desc), ntiles, stream);
 }

@@ -151,17 +151,23 @@ def _masks_from_frames(st: _Launcher, sep, Y: torch.Tensor, geo, stats: torch.Te
         if debug is not None:
             debug[f"block{i}"] = X.view(B, S, K, F).clone()
     del Z
-    # mask head (dprnn.py:172-186): PReLU + conv2d, overlap-add, tanh x sigmoid gate, end 1x1 conv + activation
+    return _head(st, sep, cfg, X, Hbuf, geo, mul_enc)
+
+
+def _head(st: _Launcher, sep, cfg: dict, X: torch.Tensor, Hbuf: torch.Tensor, geo, mul_enc: Optional[torch.Tensor]) -> torch.Tensor:
+    """Mask head (dprnn.py:172-186) on the slab rows X [B*S*K][F]: PReLU + conv2d, overlap-add, tanh x sigmoid gate, end 1x1 conv +
+    activation (x the encoder rows when given) -> rows [(b*2 + spk)*L + l][N].  Hbuf: scratch of at least rows x 2F floats."""
+    dev = X.device
+    N, F = cfg["input_size"], cfg["feature_size"]
+    B, L, K, P, S, rows = geo.B, geo.L, geo.K, geo.P, geo.S, geo.rows
     w2 = E._param(sep.conv2d.weight, "conv2d.weight", dev)
     nspk = w2.shape[0] // F
     if nspk != 2 or tuple(w2.shape[:2]) != (2 * F, F):
         raise DprnnError(f"conv2d weight {tuple(w2.shape)}, expected ({2 * F}, {F}, 1, 1)")
     U = Hbuf[: rows * 2 * F].view(rows, 2 * F)
     st.gemm(X, w2, E._param(sep.conv2d.bias, "conv2d.bias", dev), rows, F, 2 * F, prelu=E._param(sep.prelu.weight, "prelu.weight", dev), out=U)
-    del X
     frames = torch.empty(B * nspk * L, F, device=dev, dtype=torch.float32)
     st.call("dprnn_wide_ola_fwd", E._p(U), E._p(frames), B, L, K, P, S, F, nspk)
-    del U, Hbuf
     M2 = B * nspk * L
     t_out = st.gemm(frames, E._param(sep.out[0].weight, "out.weight", dev), E._param(sep.out[0].bias, "out.bias", dev), M2, F, F, act=3)
     V = st.gemm(frames, E._param(sep.gate[0].weight, "gate.weight", dev), E._param(sep.gate[0].bias, "gate.bias", dev), M2, F, F, act=2, mul=t_out)
@@ -410,15 +416,105 @@ def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> to
     return _forward_impl(model, wav, debug)
 
 
+RAGGED_MAX_SLAB_BYTES = 48 << 30          # slab rows x (F + 2 max(F, H) + F) floats of one ragged batch (X, the recurrence output, Z)
+
+
+def _ragged_batch(model, wavs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Utterances of DIFFERENT lengths through one recurrence launch per DPRNN path and direction set (batch-of-one semantics each: the
+    reference evaluates them one at a time, inferencer.py:54-58).  The slabs [S_u][K][F] are concatenated: the intra-chunk recurrence sees
+    sum(S_u) sequences of K steps; the inter-chunk one gets a tile descriptor per (utterance, 16 chunk positions) with its own step count
+    S_u (dprnn_wide_rnn_fwd_tiles); everything per-utterance by nature (global norms, Linear + its sums, mask head) is launched per
+    utterance on that utterance's rows -- a few per cent of the work."""
+    import numpy as np
+    cfg = model.cfg
+    check_supported(cfg)
+    dev = wavs[0].device
+    N, F, H = cfg["input_size"], cfg["feature_size"], cfg["hidden_size"]
+    K, P = cfg["chunk_length"], cfg["hop_length"]
+    cell = CELL_ID[cfg["rnn_type"]]
+    sep = model.separation
+    blocks = list(sep.dprnn_blocks)
+    U = len(wavs)
+    with torch.cuda.device(dev):
+        st = _Launcher(dev)
+        geos = [E.make_geometry(1, int(w.numel()), N, K, P, cfg["kernel_size"], cfg["stride"]) for w in wavs]
+        for g in geos:
+            if g.T_out < 2:
+                raise DprnnError("utterance too short")
+        rows = np.array([g.rows for g in geos], dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+        total = int(starts[-1])
+        enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
+        X = torch.empty(total, F, device=dev, dtype=torch.float32)
+        stats = torch.zeros(1 + 2 * len(blocks), U, 2, device=dev, dtype=torch.float64)
+        encs = []
+        for u, (w, g) in enumerate(zip(wavs, geos)):
+            enc = torch.empty(g.L, N, device=dev, dtype=torch.float32)
+            st.call("dprnn_wide_encoder_fwd", E._p(w), E._p(enc_w), E._p(enc), 1, g.T, g.L, N, g.ks, g.stride)
+            Y = _frames_from_rows(st, sep, enc, 1, g.L, stats[0, u:u + 1])
+            st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(X[starts[u]: starts[u + 1]]), 1, g.L, K, P, g.S, F)
+            encs.append(enc)
+        # inter-chunk tiles: 16 chunk positions of one utterance, S_u steps, rows K apart; longest first
+        desc = []
+        for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
+            for k0 in range(0, K, 16):
+                desc.append((int(starts[u]) + k0, geos[u].S, min(16, K - k0), 1))
+        desc_dev = torch.from_numpy(np.asarray(desc, dtype=np.int64)).to(dev)
+        n_intra = int(sum(g.S for g in geos))
+        Hbuf = torch.empty(total * 2 * max(H, F), device=dev, dtype=torch.float32)
+        Z = torch.empty(total, F, device=dev, dtype=torch.float32)
+        for i, blk in enumerate(blocks):
+            for j, (single, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
+                                                            (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
+                Wp, bv, ndir = _pack_rnn(st, single.rnn, cell, F, H, dev)
+                Hout = Hbuf[: total * ndir * H].view(total, ndir * H)
+                if intra:
+                    st.call("dprnn_wide_rnn_fwd", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, n_intra, K, 1, K, 0, 1)
+                else:
+                    st.call("dprnn_wide_rnn_fwd_tiles", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, E._p(desc_dev), len(desc), K)
+                w = E._param(lin.weight, "linear.weight", dev)
+                b = E._param(lin.bias, "linear.bias", dev)
+                slot = stats[1 + 2 * i + j]
+                for u in range(U):
+                    r0, r1, n = int(starts[u]), int(starts[u + 1]), int(rows[u])
+                    st.gemm(Hout[r0:r1], w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Z[r0:r1])
+                    sc, sh = st.norm_affine(slot[u:u + 1], norm, 1, n, F)
+                    st.call("dprnn_wide_norm_residual_fwd", E._p(X[r0:r1]), E._p(Z[r0:r1]), E._p(sc), E._p(sh), n, F, n)
+        del Z
+        scfg = _sep_cfg(sep)
+        wd = dec_w.view(N, geos[0].ks).t().contiguous()
+        outs = []
+        for u, g in enumerate(geos):
+            masked = _head(st, sep, scfg, X[starts[u]: starts[u + 1]], Hbuf, g, encs[u])
+            taps = st.gemm(masked, wd, None, 2 * g.L, N, g.ks)
+            outs.append(E.decode(st, taps, g, 2)[0])
+        return outs
+
+
 def tasnet_forward_ragged(model, wavs: List[torch.Tensor]) -> List[torch.Tensor]:
-    """Utterances of different lengths, batch-of-one semantics each (inferencer.py:40-60): equal lengths share a launch sequence."""
-    by_len = {}
-    for i, w in enumerate(wavs):
-        by_len.setdefault(int(w.numel()), []).append(i)
+    """Utterances of different lengths, batch-of-one semantics each (inferencer.py:40-60): ragged batches as large as RAGGED_MAX_SLAB_BYTES
+    allows, in the order given (pass them sorted by length for short tails)."""
+    load_library()
+    cfg = model.cfg
+    F, H = cfg["feature_size"], cfg["hidden_size"]
+    per_row = 4 * (2 * F + 2 * max(F, H))
     outs: List[Optional[torch.Tensor]] = [None] * len(wavs)
-    for _, idx in sorted(by_len.items()):
-        batch = torch.stack([wavs[i].reshape(-1) for i in idx])
-        res = tasnet_forward(model, batch)
-        for j, i in enumerate(idx):
-            outs[i] = res[j]
+    batch: List[int] = []
+    used = 0
+    def flush():
+        if batch:
+            with torch.no_grad():                              # an inference entry point, like engine.tasnet_forward_ragged
+                res = _ragged_batch(model, [E.check_input(wavs[i].reshape(1, -1)).reshape(-1) for i in batch])
+            for i, o in zip(batch, res):
+                outs[i] = o
+    for i, w in enumerate(wavs):
+        g = E.make_geometry(1, int(w.numel()), cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
+        need = g.rows * per_row
+        if batch and used + need > RAGGED_MAX_SLAB_BYTES:
+            flush()
+            batch, used = [], 0
+        batch.append(i)
+        used += need
+    flush()
     return outs
