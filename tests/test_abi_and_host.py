@@ -530,7 +530,7 @@ def test_which_models_take_the_any_width_kernels_and_which_limits_raise(monkeypa
     monkeypatch.setattr(engine, "NARROW_NATIVE_MAX", 0)
     assert engine._sep_off_build(narrow.separation) and not engine._sep_off_build(mk().separation)
     assert engine.ragged_supported(mk(feature_size=256, hidden_size=256, rnn_type="GRU").separation)       # wide.tasnet_forward_ragged: any cell
-    assert not engine.ragged_supported(dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1).separation)
+    assert engine.ragged_supported(dprnn_spe.DPRNNSpeTasNet(64, feature_size=256, hidden_size=256, chunk_length=16, n_repeats=1).separation)
     ok = dict(feature_size=512, hidden_size=512, rnn_type="GRU", norm_type="gLN", activation_type="relu", hop_length=8, chunk_length=16)
     wide.check_supported(ok)
     for bad, what in ((dict(ok, hidden_size=528), "hidden_size 528"), (dict(ok, feature_size=1024), "160 KB"),

@@ -368,6 +368,29 @@ def test_ragged_batches_of_a_wider_model(over, monkeypatch):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("kind,fusion,bn_train", [("spe", "att", True), ("ira", "cat", False), ("ira", "film", True)])
+def test_ragged_batches_of_wider_speaker_conditioned_models(kind, fusion, bn_train):
+    """Mixtures AND reference utterances of different lengths (inferencer_spe.py:20-54): speaker branch, fusion and bottleneck per utterance,
+    the DPRNN stack of every pass as one ragged slab; estimate and logits equal each utterance's batch-of-one forward."""
+    from tss_with_dprnn_amd import inference
+    cfg = dict(feature_size=160, hidden_size=144, chunk_length=16, hop_length=8, n_repeats=1, fusion_type=fusion, norm_type="ln")
+    model, sd, cfg = build_model(kind, cfg, 43, _dev())
+    if bn_train:
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.train()
+    lens = [900, 333, 1501, 420, 700, 333, 1200, 250]
+    alens = [400, 377, 350, 500, 377, 420, 333, 390]
+    wavs = [torch.from_numpy(make_mixture(1, n, seed=70 + i)[0]).to(_dev()) for i, n in enumerate(lens)]
+    auxs = [torch.from_numpy(make_mixture(1, n, seed=90 + i)[0]).to(_dev()) for i, n in enumerate(alens)]
+    outs = inference.separate_many(model, wavs, extra_inputs=[(a, float(n)) for a, n in zip(auxs, alens)])
+    for i, n in enumerate(lens):
+        with torch.no_grad():
+            est, logits = model(wavs[i][None], auxs[i][None], torch.tensor(float(alens[i])))
+        assert outs[i][0].shape == (n,) and rel_l2(outs[i][0].cpu().numpy(), est[0].cpu().numpy()) <= 2e-6, i
+        assert rel_l2(outs[i][1].cpu().numpy(), logits[0].cpu().numpy()) <= 2e-6, i
+
+
 # ------------------------------------------------------------------------------------------------ separation-level entry points
 @pytest.mark.parametrize("over", [dict(feature_size=256, hidden_size=256), dict(input_size=96, feature_size=160, hidden_size=200, norm_type="gLN",
                                                                                 activation_type="relu"),

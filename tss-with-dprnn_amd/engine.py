@@ -1294,6 +1294,9 @@ def tasnet_forward_ragged(model, wavs):
 def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
     for w in wavs:
         check_input(w.reshape(1, -1))
+    if _wider_than_built(model):
+        from . import wide
+        return wide.spe_forward_ragged(model, wavs, auxs, aux_lens, ira)
     narrow = model
     model, tw = _twin(model)
     if tw is not None and _bn_training(model.separation):

@@ -76,8 +76,9 @@ def ragged_supported(sep) -> bool:
     from . import padded
     wide = sep.input_size > padded.N_BUILT or sep.feature_size > padded.F_BUILT or any(
         b.intra_rnn.rnn.hidden_size > padded.F_BUILT for b in sep.dprnn_blocks)
-    if wide:                     # the any-width kernels batch ragged DPRNNTasNet forwards themselves (wide.tasnet_forward_ragged), any cell
-        return not hasattr(sep, "spk_encoder")
+    if wide:                     # the any-width kernels batch ragged forwards themselves (wide.tasnet_forward_ragged / spe_forward_ragged), any cell;
+        # a speaker encoder with BatchNorm in train mode included (one utterance after the other through the speaker branch, in order)
+        return True
     return E.current_mode() in (1, 3) and all(b.intra_rnn.rnn.mode == "LSTM" and b.inter_rnn.rnn.mode == "LSTM" for b in sep.dprnn_blocks)
 
 

@@ -419,102 +419,233 @@ def tasnet_forward(model, wav: torch.Tensor, debug: Optional[dict] = None) -> to
 RAGGED_MAX_SLAB_BYTES = 48 << 30          # slab rows x (F + 2 max(F, H) + F) floats of one ragged batch (X, the recurrence output, Z)
 
 
+class _RaggedSlab:
+    """The concatenated slabs [S_u][K][F] of utterances of different lengths and the launches that run over all of them at once."""
+
+    def __init__(self, st: _Launcher, sep, geos):
+        import numpy as np
+        self.st, self.sep, self.geos = st, sep, geos
+        self.cfg = _sep_cfg(sep)
+        check_supported(self.cfg)
+        self.F, self.H, self.K = self.cfg["feature_size"], self.cfg["hidden_size"], self.cfg["chunk_length"]
+        self.cell = CELL_ID[self.cfg["rnn_type"]]
+        dev = st.device
+        self.rows = [g.rows for g in geos]
+        self.starts = np.concatenate([[0], np.cumsum(np.array(self.rows, dtype=np.int64))]).astype(np.int64)
+        self.total = int(self.starts[-1])
+        self.n_intra = int(sum(g.S for g in geos))
+        # inter-chunk tiles: 16 chunk positions of one utterance, S_u steps, rows K apart; longest first (their workgroups run longest)
+        desc = []
+        for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
+            for k0 in range(0, self.K, 16):
+                desc.append((int(self.starts[u]) + k0, geos[u].S, min(16, self.K - k0), 1))
+        self.n_tiles = len(desc)
+        self.desc = torch.from_numpy(np.asarray(desc, dtype=np.int64)).to(dev)
+        F, H = self.F, self.H
+        self.X = torch.empty(self.total, F, device=dev, dtype=torch.float32)
+        self.Hbuf = torch.empty(self.total * 2 * max(H, F), device=dev, dtype=torch.float32)
+        self.Z = torch.empty(self.total, F, device=dev, dtype=torch.float32)
+
+    def rows_of(self, t: torch.Tensor, u: int) -> torch.Tensor:
+        return t[int(self.starts[u]): int(self.starts[u + 1])]
+
+    def segment(self, u: int, Y: torch.Tensor) -> None:
+        g = self.geos[u]
+        self.st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(self.rows_of(self.X, u)), 1, g.L, g.K, g.P, g.S, self.F)
+
+    def blocks(self) -> None:
+        """All DPRNN blocks over the slab: one recurrence launch per path, the Linear / norm / residual per utterance (its sums are its own)."""
+        st, F, H, K, dev = self.st, self.F, self.H, self.K, self.st.device
+        U = len(self.geos)
+        blocks = list(self.sep.dprnn_blocks)
+        stats = torch.zeros(2 * len(blocks), U, 2, device=dev, dtype=torch.float64)
+        for i, blk in enumerate(blocks):
+            for j, (single, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
+                                                            (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
+                Wp, bv, ndir = _pack_rnn(st, single.rnn, self.cell, F, H, dev)
+                Hout = self.Hbuf[: self.total * ndir * H].view(self.total, ndir * H)
+                if intra:
+                    st.call("dprnn_wide_rnn_fwd", self.cell, E._p(self.X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, self.n_intra, K, 1, K, 0, 1)
+                else:
+                    st.call("dprnn_wide_rnn_fwd_tiles", self.cell, E._p(self.X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, E._p(self.desc),
+                            self.n_tiles, K)
+                w = E._param(lin.weight, "linear.weight", dev)
+                b = E._param(lin.bias, "linear.bias", dev)
+                slot = stats[2 * i + j]
+                for u in range(U):
+                    n = self.rows[u]
+                    Xu, Zu = self.rows_of(self.X, u), self.rows_of(self.Z, u)
+                    st.gemm(self.rows_of(Hout, u), w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Zu)
+                    sc, sh = st.norm_affine(slot[u:u + 1], norm, 1, n, F)
+                    st.call("dprnn_wide_norm_residual_fwd", E._p(Xu), E._p(Zu), E._p(sc), E._p(sh), n, F, n)
+
+    def head(self, u: int, enc: torch.Tensor) -> torch.Tensor:
+        """Mask head of utterance u x its encoder rows -> [(spk, l)][N]."""
+        return _head(self.st, self.sep, self.cfg, self.rows_of(self.X, u), self.Hbuf, self.geos[u], enc)
+
+
+def _ragged_geometries(cfg: dict, wavs):
+    geos = [E.make_geometry(1, int(w.numel()), cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"]) for w in wavs]
+    for g in geos:
+        if g.T_out < 2:
+            raise DprnnError("utterance too short")
+    return geos
+
+
 def _ragged_batch(model, wavs: List[torch.Tensor]) -> List[torch.Tensor]:
     """Utterances of DIFFERENT lengths through one recurrence launch per DPRNN path and direction set (batch-of-one semantics each: the
     reference evaluates them one at a time, inferencer.py:54-58).  The slabs [S_u][K][F] are concatenated: the intra-chunk recurrence sees
     sum(S_u) sequences of K steps; the inter-chunk one gets a tile descriptor per (utterance, 16 chunk positions) with its own step count
     S_u (dprnn_wide_rnn_fwd_tiles); everything per-utterance by nature (global norms, Linear + its sums, mask head) is launched per
     utterance on that utterance's rows -- a few per cent of the work."""
-    import numpy as np
     cfg = model.cfg
     check_supported(cfg)
     dev = wavs[0].device
-    N, F, H = cfg["input_size"], cfg["feature_size"], cfg["hidden_size"]
-    K, P = cfg["chunk_length"], cfg["hop_length"]
-    cell = CELL_ID[cfg["rnn_type"]]
+    N = cfg["input_size"]
     sep = model.separation
-    blocks = list(sep.dprnn_blocks)
-    U = len(wavs)
     with torch.cuda.device(dev):
         st = _Launcher(dev)
-        geos = [E.make_geometry(1, int(w.numel()), N, K, P, cfg["kernel_size"], cfg["stride"]) for w in wavs]
-        for g in geos:
-            if g.T_out < 2:
-                raise DprnnError("utterance too short")
-        rows = np.array([g.rows for g in geos], dtype=np.int64)
-        starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-        total = int(starts[-1])
+        geos = _ragged_geometries(cfg, wavs)
         enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
         dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
-        X = torch.empty(total, F, device=dev, dtype=torch.float32)
-        stats = torch.zeros(1 + 2 * len(blocks), U, 2, device=dev, dtype=torch.float64)
+        slab = _RaggedSlab(st, sep, geos)
+        stats0 = torch.zeros(len(wavs), 2, device=dev, dtype=torch.float64)
         encs = []
         for u, (w, g) in enumerate(zip(wavs, geos)):
             enc = torch.empty(g.L, N, device=dev, dtype=torch.float32)
             st.call("dprnn_wide_encoder_fwd", E._p(w), E._p(enc_w), E._p(enc), 1, g.T, g.L, N, g.ks, g.stride)
-            Y = _frames_from_rows(st, sep, enc, 1, g.L, stats[0, u:u + 1])
-            st.call("dprnn_wide_segment_fwd", E._p(Y), E._p(X[starts[u]: starts[u + 1]]), 1, g.L, K, P, g.S, F)
+            slab.segment(u, _frames_from_rows(st, sep, enc, 1, g.L, stats0[u:u + 1]))
             encs.append(enc)
-        # inter-chunk tiles: 16 chunk positions of one utterance, S_u steps, rows K apart; longest first
-        desc = []
-        for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
-            for k0 in range(0, K, 16):
-                desc.append((int(starts[u]) + k0, geos[u].S, min(16, K - k0), 1))
-        desc_dev = torch.from_numpy(np.asarray(desc, dtype=np.int64)).to(dev)
-        n_intra = int(sum(g.S for g in geos))
-        Hbuf = torch.empty(total * 2 * max(H, F), device=dev, dtype=torch.float32)
-        Z = torch.empty(total, F, device=dev, dtype=torch.float32)
-        for i, blk in enumerate(blocks):
-            for j, (single, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
-                                                            (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
-                Wp, bv, ndir = _pack_rnn(st, single.rnn, cell, F, H, dev)
-                Hout = Hbuf[: total * ndir * H].view(total, ndir * H)
-                if intra:
-                    st.call("dprnn_wide_rnn_fwd", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, n_intra, K, 1, K, 0, 1)
-                else:
-                    st.call("dprnn_wide_rnn_fwd_tiles", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, E._p(desc_dev), len(desc), K)
-                w = E._param(lin.weight, "linear.weight", dev)
-                b = E._param(lin.bias, "linear.bias", dev)
-                slot = stats[1 + 2 * i + j]
-                for u in range(U):
-                    r0, r1, n = int(starts[u]), int(starts[u + 1]), int(rows[u])
-                    st.gemm(Hout[r0:r1], w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Z[r0:r1])
-                    sc, sh = st.norm_affine(slot[u:u + 1], norm, 1, n, F)
-                    st.call("dprnn_wide_norm_residual_fwd", E._p(X[r0:r1]), E._p(Z[r0:r1]), E._p(sc), E._p(sh), n, F, n)
-        del Z
-        scfg = _sep_cfg(sep)
+        slab.blocks()
         wd = dec_w.view(N, geos[0].ks).t().contiguous()
         outs = []
         for u, g in enumerate(geos):
-            masked = _head(st, sep, scfg, X[starts[u]: starts[u + 1]], Hbuf, g, encs[u])
-            taps = st.gemm(masked, wd, None, 2 * g.L, N, g.ks)
+            taps = st.gemm(slab.head(u, encs[u]), wd, None, 2 * g.L, N, g.ks)
             outs.append(E.decode(st, taps, g, 2)[0])
         return outs
+
+
+def _spe_ragged_batch(model, wavs, auxs, aux_lens, ira: bool):
+    """DPRNNSpeTasNet / DPRNNSpeIRATasNet over mixtures and reference utterances of different lengths -> [(estimate [T_out_u], logits)]:
+    speaker branch, fusion operands and bottleneck per utterance (batch-of-one semantics, BatchNorm statistics of the speaker branch
+    included, in order: inferencer_spe.py:27-32), the DPRNN stack of every pass as one ragged slab."""
+    cfg = model.cfg
+    check_supported_spe(cfg)
+    dev = wavs[0].device
+    N, F = cfg["input_size"], cfg["feature_size"]
+    ks, stride = cfg["kernel_size"], cfg["stride"]
+    sep = model.separation
+    se = sep.spk_encoder
+    att = cfg["fusion_type"] == "att"
+    U = len(wavs)
+    with torch.cuda.device(dev), E.use_gemm_mode(0):
+        st = _Launcher(dev)
+        st.lib.dprnn_set_gemm_mode(0)
+        geos = _ragged_geometries(cfg, wavs)
+        enc_w = E._param(model.encoder.conv1d.weight, "encoder.conv1d.weight", dev)
+        dec_w = E._param(model.decoder.weight, "decoder.weight", dev)
+        conv = sep.bottleneck[1]
+        wb = E._param(conv.weight, "bottleneck.weight", dev)
+        bb = E._param(conv.bias, "bottleneck.bias", dev)
+        stats = torch.zeros(3, U, 2, device=dev, dtype=torch.float64)          # encoder sums of the mixture, of the reference, of d0
+        wav2 = [w.reshape(1, -1) for w in wavs]
+        encs, v0s, scsh, alens = [], [], [], []
+        for u, g in enumerate(geos):
+            aux = E.check_input(auxs[u].reshape(1, -1), "aux")
+            ga = E.make_geometry(1, aux.shape[1], N, cfg["chunk_length"], cfg["hop_length"], ks, stride)
+            alen = E._aux_len_tensor(aux_lens[u], 1, dev)
+            sc_a, sh_a = E.bottleneck_affine(st, aux, enc_w, se[0], ga, stats[1, u:u + 1])
+            A0 = E.bottleneck_frames(st, aux, enc_w, sc_a, sh_a, se[1], ga, gemm_mode=0, scale_slot=E.SLOT_AUX_BOTTLENECK).view(ga.L, E.F_BUILT)
+            v0s.append(E.speaker_embedding(st, sep, A0, 1, ga.L, alen, ks))
+            alens.append(alen)
+            enc = torch.empty(g.L, N, device=dev, dtype=torch.float32)
+            st.call("dprnn_wide_encoder_fwd", E._p(wav2[u]), E._p(enc_w), E._p(enc), 1, g.T, g.L, N, g.ks, g.stride)
+            encs.append(enc)
+            scsh.append(None)
+
+        def one_pass(vs, first: bool):
+            slab = _RaggedSlab(st, sep, geos)
+            for u, g in enumerate(geos):
+                mul, add, row_bias = E._fusion_operands(st, sep, cfg, vs[u])
+                if first:
+                    scsh[u] = E.bottleneck_affine(st, wav2[u], enc_w, sep.bottleneck[0], g, stats[0, u:u + 1], mul, add)
+                elif mul is not None or add is not None:        # the cached norm output (dprnn_spe_ira.py:96): same sums, new fusion operands
+                    gm, bt, eps = E._norm_params(sep.bottleneck[0])
+                    st.call("dprnn_bottleneck_prep", E._p(stats[0, u:u + 1]), E._p(gm), E._p(bt), eps, E._p(mul), E._p(add), E._p(scsh[u][0]),
+                            E._p(scsh[u][1]), 1, g.L, N)
+                row_scale = E._att_row_scale(st, sep, cfg, wav2[u], enc_w, g, stats[0, u:u + 1], mul) if att else None
+                Y = st.gemm(encs[u], wb, bb, g.L, N, F, sc=scsh[u][0], sh=scsh[u][1], rows_per_utt=g.L, ldw=wb.shape[1], ubias=row_bias,
+                            rscale=row_scale)
+                slab.segment(u, Y)
+            slab.blocks()
+            return [slab.head(u, encs[u]) for u in range(U)]
+
+        masked = one_pass(v0s, True)
+        vlast = v0s
+        if ira:
+            v1s = []
+            g0, b0, _ = E._norm_params(se[0])
+            g0, b0 = E._param(g0, "spk_encoder.0.weight", dev), E._param(b0, "spk_encoder.0.bias", dev)
+            for u, g in enumerate(geos):
+                d0 = masked[u][: g.L]                                                # speaker 0's rows: mask_0 x enc (dprnn_spe_ira.py:79-92)
+                st.call("dprnn_rows_stats", E._p(d0), E._p(stats[2, u:u + 1]), 1, g.L, N)
+                sc_d = torch.empty(1, N, device=dev, dtype=torch.float32)
+                sh_d = torch.empty_like(sc_d)
+                st.call("dprnn_bottleneck_prep", E._p(stats[2, u:u + 1]), E._p(g0), E._p(b0), 1e-5, 0, 0, E._p(sc_d), E._p(sh_d), 1, g.L, N)
+                A0d = E._pointwise(st, d0, g.L, N, se[1].weight, se[1].bias, 128, in_scale=sc_d, in_shift=sh_d, aff_stride=N, rows_per_utt=g.L)
+                v1 = E.speaker_embedding(st, sep, A0d, 1, g.L, alens[u], ks)
+                v1s.append(E._linear_small(st, sep.aux_linear.weight, sep.aux_linear.bias, torch.cat((v0s[u], v1), dim=1).contiguous()))
+            del masked
+            masked = one_pass(v1s, False)
+            vlast = v1s
+        wd = dec_w.view(N, geos[0].ks).t().contiguous()
+        outs = []
+        for u, g in enumerate(geos):
+            logits = E._linear_small(st, sep.pred_linear.weight, sep.pred_linear.bias, vlast[u])
+            taps = st.gemm(masked[u], wd, None, 2 * g.L, N, g.ks)
+            outs.append((E.decode(st, taps, g, 1)[0, 0, :], logits[0]))
+        return outs
+
+
+def _ragged_chunks(cfg: dict, wavs, passes_held: int = 1):
+    """Indices of the utterances of each ragged batch, in the order given: as many as RAGGED_MAX_SLAB_BYTES of slab (X, recurrence output, Z) hold."""
+    F, H = cfg["feature_size"], cfg["hidden_size"]
+    per_row = 4 * (2 * F + 2 * max(F, H)) * passes_held
+    chunks, batch, used = [], [], 0
+    for i, w in enumerate(wavs):
+        g = E.make_geometry(1, int(w.numel()), cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
+        need = g.rows * per_row
+        if batch and used + need > RAGGED_MAX_SLAB_BYTES:
+            chunks.append(batch)
+            batch, used = [], 0
+        batch.append(i)
+        used += need
+    if batch:
+        chunks.append(batch)
+    return chunks
+
+
+def spe_forward_ragged(model, wavs, auxs, aux_lens, ira: bool = False):
+    """The speaker-conditioned classes over utterances of different lengths (inferencer_spe.py:20-54), list of (estimate, logits)."""
+    load_library()
+    outs: List = [None] * len(wavs)
+    for idx in _ragged_chunks(model.cfg, wavs):
+        with torch.no_grad():
+            res = _spe_ragged_batch(model, [E.check_input(wavs[i].reshape(1, -1)).reshape(-1) for i in idx], [auxs[i] for i in idx],
+                                    [aux_lens[i] for i in idx], ira)
+        for i, o in zip(idx, res):
+            outs[i] = o
+    return outs
 
 
 def tasnet_forward_ragged(model, wavs: List[torch.Tensor]) -> List[torch.Tensor]:
     """Utterances of different lengths, batch-of-one semantics each (inferencer.py:40-60): ragged batches as large as RAGGED_MAX_SLAB_BYTES
     allows, in the order given (pass them sorted by length for short tails)."""
     load_library()
-    cfg = model.cfg
-    F, H = cfg["feature_size"], cfg["hidden_size"]
-    per_row = 4 * (2 * F + 2 * max(F, H))
     outs: List[Optional[torch.Tensor]] = [None] * len(wavs)
-    batch: List[int] = []
-    used = 0
-    def flush():
-        if batch:
-            with torch.no_grad():                              # an inference entry point, like engine.tasnet_forward_ragged
-                res = _ragged_batch(model, [E.check_input(wavs[i].reshape(1, -1)).reshape(-1) for i in batch])
-            for i, o in zip(batch, res):
-                outs[i] = o
-    for i, w in enumerate(wavs):
-        g = E.make_geometry(1, int(w.numel()), cfg["input_size"], cfg["chunk_length"], cfg["hop_length"], cfg["kernel_size"], cfg["stride"])
-        need = g.rows * per_row
-        if batch and used + need > RAGGED_MAX_SLAB_BYTES:
-            flush()
-            batch, used = [], 0
-        batch.append(i)
-        used += need
-    flush()
+    for idx in _ragged_chunks(model.cfg, wavs):
+        with torch.no_grad():                              # an inference entry point, like engine.tasnet_forward_ragged
+            res = _ragged_batch(model, [E.check_input(wavs[i].reshape(1, -1)).reshape(-1) for i in idx])
+        for i, o in zip(idx, res):
+            outs[i] = o
     return outs
