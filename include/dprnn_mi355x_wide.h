@@ -65,6 +65,22 @@ int dprnn_wide_rnn_fwd(int cell, const float* X, const float* Wp, const float* b
 int dprnn_wide_rnn_fwd_tiles(int cell, const float* X, const float* Wp, const float* bv, float* Hout, int ndir, int F, int H,
                              const int64_t* desc, int ntiles, int64_t t_stride, void* stream);
 
+/* ---- LSTM recurrence in the f16-pieces arithmetic (csrc/wide_f16.hip): every fp32 operand as two f16 pieces of a power-of-two multiple of
+ * itself, a product = three v_mfma_f32_16x16x32_f16 (fp32 accumulate, 22+ operand bits), 64 sequences per 8-wave workgroup.  Ranges are by
+ * construction: dprnn_wide_absmax leaves max |.| over the finite elements (as float bits; zero the word first) of the slab the launch
+ * reads in amax[0] and of W_ih / W_hh of direction d in amax[1 + 2 d] / amax[2 + 2 d]; dprnn_wide_lstm_pack_f16 derives the direction's
+ * scales from them (scal[4 d .. 4 d + 3], device floats) and writes the weight fragments (dprnn_wide_lstm_pack_f16_words(F, H) 16-byte
+ * words per direction at Wp + d * words) and the bias sums bv[d][4 * roundup16(H)]; dprnn_wide_lstm_f16_fwd is dprnn_wide_rnn_fwd /
+ * dprnn_wide_rnn_fwd_tiles (desc != NULL: tiles of up to 64 sequences) for LSTM cells.  64 * (2 * (roundup32(F) + roundup32(H)) + 16) * 2
+ * bytes of LDS <= 160 KB; hidden_size <= 256 in this build. */
+int dprnn_wide_absmax(const float* A, int64_t n, void* out_bits, void* stream);
+int64_t dprnn_wide_lstm_pack_f16_words(int F, int H);
+int dprnn_wide_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int F, int H, int dir,
+                             const void* amax_bits, float* scal, void* Wp, float* bv, void* stream);
+int dprnn_wide_lstm_f16_fwd(const float* X, const void* Wp, const float* bv, const float* scal, float* Hout, int ndir, int F, int H,
+                            int nseq, int T, int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, const int64_t* desc,
+                            int ntiles, void* stream);
+
 /* out[m][o] = act(rscale[m] * sum_k a(m,k) * W[o*ldw + k] + bias[o] + ubias[u*O + o]) * mul[mrow(m)*ldm + o]
  *   a(m,k) = prelu(A[m*lda + k] * sc[u*K + k] + sh[u*K + k]), u = m / rows_per_utt (sc / sh NULL: no affine; prelu NULL: none, else
  *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, ubias, rscale, mul, stats optional;

@@ -130,6 +130,36 @@ def test_recurrence_against_torch(kind, F, H, bidir, intra):
     assert _rel(out.view(B, S, K, -1), want.contiguous()) <= 3e-6
 
 
+@pytest.mark.parametrize("F,H,bidir", [(256, 256, True), (160, 200, True), (133, 131, False), (40, 16, True)])
+@pytest.mark.parametrize("intra", [True, False])
+def test_f16_pieces_lstm_recurrence_against_torch(F, H, bidir, intra):
+    """dprnn_wide_absmax + dprnn_wide_lstm_pack_f16 + dprnn_wide_lstm_f16_fwd (csrc/wide_f16.hip: two f16 pieces per operand, three products,
+    64 sequences per workgroup, scales from the measured maxima) against torch's LSTM on the CPU; inputs 50 x larger than unit scale in one
+    half of the sequences, tiny in the other (the launch's one activation scale has to serve both)."""
+    from tss_with_dprnn_amd import wide
+    assert wide.f16_recurrence(0, F, H)
+    B, S, K = 3, 7, 23
+    rnn = _torch_rnn("LSTM", F, H, bidir, 5)
+    X = torch.randn(B, S, K, F, generator=torch.Generator().manual_seed(9))
+    X[0] *= 50.0
+    X[2] *= 1e-3
+    with torch.no_grad():
+        if intra:
+            want = rnn(X.view(B * S, K, F))[0].reshape(B, S, K, -1)
+        else:
+            want = rnn(X.permute(0, 2, 1, 3).reshape(B * K, S, F))[0].reshape(B, K, S, -1).permute(0, 2, 1, 3)
+    st = _stage()
+    dev = _dev()
+    Xd = X.to(dev).contiguous().view(B * S * K, F)
+    ndir = 2 if bidir else 1
+    Hbuf = torch.full((B * S * K * ndir * H,), float("nan"), device=dev)
+    addr = (B * S, K, 1, K, 0, 1) if intra else (B * K, S, K, S * K, 1, K)
+    out, nd = wide._recurrence(st, rnn.to(dev), 0, Xd, B * S * K, Hbuf, F, H, addr)
+    torch.cuda.synchronize()
+    assert nd == ndir and torch.isfinite(out).all()
+    assert _rel(out.view(B, S, K, -1), want.contiguous()) <= 3e-6
+
+
 def test_recurrence_with_32_sequence_tiles(monkeypatch):
     """The 32-sequence workgroups (DPRNN_WIDE_NT=2: half the weight stream, one workgroup per CU; the default is 16), and a count that
     is no multiple of 32."""

@@ -16,6 +16,7 @@ built kernels, the DPRNN stack on the any-width ones.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -24,12 +25,25 @@ from ._lib import DprnnError, load_library
 from . import engine as E
 
 CELL_ID = {"LSTM": 0, "GRU": 1, "RNN": 2}
+# LSTM recurrences in the f16-pieces arithmetic (csrc/wide_f16.hip: three f16 MFMAs per product, 64 sequences per workgroup, scales from the
+# measured maxima of the launch's operands) where its LDS image and register budget hold the model; DPRNN_WIDE_F16=0: fp32 MFMA everywhere.
+WIDE_F16 = os.environ.get("DPRNN_WIDE_F16", "1") != "0"
 H_MAX = 512                 # csrc/wide.hip: MAXUT = 8 unit tiles per wave, 4 waves
 LDS_BYTES = 160 * 1024
 
 
 def _r16(n: int) -> int:
     return (n + 15) // 16 * 16
+
+
+def _r32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def f16_recurrence(cell: int, F: int, H: int) -> bool:
+    """Whether this recurrence runs in the f16-pieces arithmetic: LSTM, hidden_size <= 256 (c and h_t of two unit tiles per wave), one
+    64-sequence image of piece pairs within the 160 KB of a CU."""
+    return WIDE_F16 and cell == 0 and _r16(H) <= 256 and 64 * (2 * (_r32(F) + _r32(H)) + 16) * 2 + 512 <= LDS_BYTES
 
 
 def check_supported(cfg: dict) -> None:
@@ -88,17 +102,49 @@ def _pack_rnn(st: _Launcher, rnn: torch.nn.Module, cell: int, F: int, H: int, de
     return Wp, bv, ndir
 
 
+def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf: torch.Tensor, F: int, H: int, addr, tiles=None):
+    """SingleRNN.forward over the slab rows X [rows][F] -> (Hout [rows][ndir*H] inside Hbuf, ndir).  addr = (nseq, T, inner_n, outer, inner,
+    t_stride) of dprnn_wide_rnn_fwd; tiles (ragged inter-chunk path) = {16: (desc, n), 64: (desc, n)} tile descriptors instead."""
+    dev = X.device
+    ndir = 2 if rnn.bidirectional else 1
+    Hout = Hbuf[: rows * ndir * H].view(rows, ndir * H)
+    if f16_recurrence(cell, F, H):
+        amax = torch.zeros(1 + 2 * ndir, device=dev, dtype=torch.int32)
+        st.call("dprnn_wide_absmax", E._p(X), rows * F, E._p(amax))
+        words = int(st.lib.dprnn_wide_lstm_pack_f16_words(F, H))
+        Wp = torch.empty(ndir, words * 4, device=dev, dtype=torch.int32)
+        bv = torch.empty(ndir, 4 * _r16(H), device=dev, dtype=torch.float32)
+        scal = torch.empty(ndir, 4, device=dev, dtype=torch.float32)
+        for d in range(ndir):
+            sfx = "_reverse" if d else ""
+            w = [E._param(getattr(rnn, f"{n}_l0{sfx}"), f"rnn.{n}_l0{sfx}", dev) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            st.call("dprnn_wide_absmax", E._p(w[0]), w[0].numel(), E._p(amax[1 + 2 * d:]))
+            st.call("dprnn_wide_absmax", E._p(w[1]), w[1].numel(), E._p(amax[2 + 2 * d:]))
+            st.call("dprnn_wide_lstm_pack_f16", E._p(w[0]), E._p(w[1]), E._p(w[2]), E._p(w[3]), F, H, d, E._p(amax), E._p(scal), E._p(Wp[d]), E._p(bv[d]))
+        if tiles is None:
+            st.call("dprnn_wide_lstm_f16_fwd", E._p(X), E._p(Wp), E._p(bv), E._p(scal), E._p(Hout), ndir, F, H, *addr, 0, 0)
+        else:
+            desc, n = tiles[64]
+            st.call("dprnn_wide_lstm_f16_fwd", E._p(X), E._p(Wp), E._p(bv), E._p(scal), E._p(Hout), ndir, F, H, n, 1, 1, 0, 0, addr[5], E._p(desc), n)
+        return Hout, ndir
+    Wp, bv, ndir = _pack_rnn(st, rnn, cell, F, H, dev)
+    if tiles is None:
+        st.call("dprnn_wide_rnn_fwd", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, *addr)
+    else:
+        desc, n = tiles[16]
+        st.call("dprnn_wide_rnn_fwd_tiles", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, E._p(desc), n, addr[5])
+    return Hout, ndir
+
+
 def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int, H: int, cell: int, intra: bool):
     """One half of DPRNNBlock.forward (dprnn.py:83-92 intra, :94-99 inter): X += norm(Linear(RNN(X))) in place."""
     dev = X.device
     rows = geo.rows
-    Wp, bv, ndir = _pack_rnn(st, single.rnn, cell, F, H, dev)
     if intra:       # B*S sequences of K steps, consecutive rows
-        nseq, T, inner_n, outer, inner, t_stride = geo.B * geo.S, geo.K, 1, geo.K, 0, 1
+        addr = (geo.B * geo.S, geo.K, 1, geo.K, 0, 1)
     else:           # B*K sequences of S steps, K rows apart
-        nseq, T, inner_n, outer, inner, t_stride = geo.B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K
-    Hout = Hbuf[: rows * ndir * H].view(rows, ndir * H)
-    st.call("dprnn_wide_rnn_fwd", cell, E._p(X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, nseq, T, inner_n, outer, inner, t_stride)
+        addr = (geo.B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K)
+    Hout, ndir = _recurrence(st, single.rnn, cell, X, rows, Hbuf, F, H, addr)
     w = E._param(lin.weight, "linear.weight", dev)
     if tuple(w.shape) != (F, ndir * H):
         raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(F, ndir * H)}")
@@ -435,12 +481,13 @@ class _RaggedSlab:
         self.total = int(self.starts[-1])
         self.n_intra = int(sum(g.S for g in geos))
         # inter-chunk tiles: 16 chunk positions of one utterance, S_u steps, rows K apart; longest first (their workgroups run longest)
-        desc = []
-        for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
-            for k0 in range(0, self.K, 16):
-                desc.append((int(self.starts[u]) + k0, geos[u].S, min(16, self.K - k0), 1))
-        self.n_tiles = len(desc)
-        self.desc = torch.from_numpy(np.asarray(desc, dtype=np.int64)).to(dev)
+        self.tiles = {}
+        for width in (16, 64):          # 16 positions per tile for the fp32 kernel, 64 for the f16-pieces one
+            desc = []
+            for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
+                for k0 in range(0, self.K, width):
+                    desc.append((int(self.starts[u]) + k0, geos[u].S, min(width, self.K - k0), 1))
+            self.tiles[width] = (torch.from_numpy(np.asarray(desc, dtype=np.int64)).to(dev), len(desc))
         F, H = self.F, self.H
         self.X = torch.empty(self.total, F, device=dev, dtype=torch.float32)
         self.Hbuf = torch.empty(self.total * 2 * max(H, F), device=dev, dtype=torch.float32)
@@ -462,13 +509,10 @@ class _RaggedSlab:
         for i, blk in enumerate(blocks):
             for j, (single, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
                                                             (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
-                Wp, bv, ndir = _pack_rnn(st, single.rnn, self.cell, F, H, dev)
-                Hout = self.Hbuf[: self.total * ndir * H].view(self.total, ndir * H)
                 if intra:
-                    st.call("dprnn_wide_rnn_fwd", self.cell, E._p(self.X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, self.n_intra, K, 1, K, 0, 1)
+                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (self.n_intra, K, 1, K, 0, 1))
                 else:
-                    st.call("dprnn_wide_rnn_fwd_tiles", self.cell, E._p(self.X), E._p(Wp), E._p(bv), E._p(Hout), ndir, F, H, E._p(self.desc),
-                            self.n_tiles, K)
+                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (0, 0, 1, 0, 0, K), self.tiles)
                 w = E._param(lin.weight, "linear.weight", dev)
                 b = E._param(lin.bias, "linear.bias", dev)
                 slot = stats[2 * i + j]
