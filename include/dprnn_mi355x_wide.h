@@ -94,9 +94,10 @@ int dprnn_wide_gemm(const float* A, int64_t lda, const float* sc, const float* s
                     const float* W, int ldw, const float* bias, const float* ubias, const float* rscale, int act, const float* mul,
                     int64_t ldm, int64_t mul_L, int mul_rep, float* out, int64_t ldo, double* stats, int64_t M, int K, int O, void* stream);
 
-/* X[m][c] += Z[m][c]*sc[u][c] + sh[u][c], u = m / rows_per_utt: the norm after a path's Linear and the residual (dprnn.py:90-92,98-99). */
+/* X[m][c] += Z[m][c]*sc[u][c] + sh[u][c], u = m / rows_per_utt: the norm after a path's Linear and the residual (dprnn.py:90-92,98-99).
+ * amax_bits (optional, as dprnn_wide_absmax: zero it first) receives max |X| of the result -- the next recurrence's activation scale. */
 int dprnn_wide_norm_residual_fwd(float* X, const float* Z, const float* sc, const float* sh, int64_t M, int C, int64_t rows_per_utt,
-                                 void* stream);
+                                 void* amax_bits, void* stream);
 
 /* DPRNN._overlap_add (dprnn.py:203-217) of U [B*S*K][nspk*C] (conv2d output, speaker-major channels: the reshape of dprnn.py:176)
  * -> frames [(b*nspk + spk)*L + l][C]. */

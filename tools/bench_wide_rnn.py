@@ -28,3 +28,17 @@ for name, args in (("intra", (B * geo.S, geo.K, 1, geo.K, 0, 1)), ("inter", (B *
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"{name}: F={F} H={H} B={B} nseq={args[0]} T={args[1]}: {dt * 1e3:.2f} ms  {flop / dt / 1e12:.1f} TFLOP/s ({flop / dt / 157.3e12:.3f} of fp32 MFMA peak)  NT env={os.environ.get('DPRNN_WIDE_NT', '-')}")
+if wide.f16_recurrence(0, F, H):
+    Hbuf = out.view(-1)
+    for name, args in (("intra", (B * geo.S, geo.K, 1, geo.K, 0, 1)), ("inter", (B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K))):
+        for _ in range(2):
+            wide._recurrence(st, rnn, 0, X, geo.rows, Hbuf, F, H, args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            wide._recurrence(st, rnn, 0, X, geo.rows, Hbuf, F, H, args)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"{name}, f16 pieces (absmax + pack + dprnn_wide_lstm_f16_fwd): {dt * 1e3:.2f} ms  {flop / dt / 1e12:.1f} TFLOP/s algorithmic "
+              f"({flop / dt / 833.3e12:.3f} of the f16-pieces ceiling 2500 / 3)")

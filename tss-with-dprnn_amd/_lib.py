@@ -150,7 +150,7 @@ SIGNATURES = {
     "dprnn_wide_lstm_f16_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_fp, c_i, c_fp],
     "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64,
                         c_i, c_i, c_fp],
-    "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp],
+    "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp, c_fp],
     "dprnn_wide_ola_fwd": [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }
 _VOID = {

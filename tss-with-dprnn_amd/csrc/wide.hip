@@ -76,11 +76,21 @@ __global__ __launch_bounds__(256) void wide_segment_kernel(const float* __restri
 
 // ---- X += Z sc[u] + sh[u]     (dprnn.py:90-92, 98-99)
 __global__ __launch_bounds__(256) void wide_norm_residual_kernel(float* __restrict__ X, const float* __restrict__ Z, const float* __restrict__ sc,
-                                                                 const float* __restrict__ sh, long long total, int C, long long rows_per_utt) {
+                                                                 const float* __restrict__ sh, long long total, int C, long long rows_per_utt,
+                                                                 unsigned* __restrict__ amax) {
+    float m = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C); const long long row = i / C;
         const long long u = row / rows_per_utt;
-        X[i] = X[i] + fmaf(Z[i], sc[u * C + c], sh[u * C + c]);
+        const float v = X[i] + fmaf(Z[i], sc[u * C + c], sh[u * C + c]);
+        X[i] = v;
+        const float a = fabsf(v);
+        if (a < 3.0e38f) m = fmaxf(m, a);
+    }
+    if (amax) {                                               // max |x| over the finite elements: the next recurrence's activation scale (wide_f16.hip)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
     }
 }
 
@@ -456,12 +466,12 @@ extern "C" int dprnn_wide_segment_fwd(const float* Y, float* X, int B, int L, in
 }
 
 extern "C" int dprnn_wide_norm_residual_fwd(float* X, const float* Z, const float* sc, const float* sh, int64_t M, int C, int64_t rows_per_utt,
-                                            void* stream) {
+                                            void* amax_bits, void* stream) {
     WIDE_NULL(!X || !Z || !sc || !sh, "dprnn_wide_norm_residual_fwd");
     if (M < 1 || C < 1 || rows_per_utt < 1) { dprnn_set_error("dprnn_wide_norm_residual_fwd: bad sizes"); return -1; }
     const long long total = (long long)M * C;
     hipLaunchKernelGGL(wide_norm_residual_kernel, dim3(grid_cap(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, X, Z, sc, sh, total, C,
-                       (long long)rows_per_utt);
+                       (long long)rows_per_utt, static_cast<unsigned*>(amax_bits));
     return dprnn_check_launch("wide_norm_residual_kernel");
 }
 

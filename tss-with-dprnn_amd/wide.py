@@ -102,7 +102,8 @@ def _pack_rnn(st: _Launcher, rnn: torch.nn.Module, cell: int, F: int, H: int, de
     return Wp, bv, ndir
 
 
-def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf: torch.Tensor, F: int, H: int, addr, tiles=None):
+def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf: torch.Tensor, F: int, H: int, addr, tiles=None,
+                amax_x: Optional[torch.Tensor] = None):
     """SingleRNN.forward over the slab rows X [rows][F] -> (Hout [rows][ndir*H] inside Hbuf, ndir).  addr = (nseq, T, inner_n, outer, inner,
     t_stride) of dprnn_wide_rnn_fwd; tiles (ragged inter-chunk path) = {16: (desc, n), 64: (desc, n)} tile descriptors instead."""
     dev = X.device
@@ -110,7 +111,10 @@ def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf:
     Hout = Hbuf[: rows * ndir * H].view(rows, ndir * H)
     if f16_recurrence(cell, F, H):
         amax = torch.zeros(1 + 2 * ndir, device=dev, dtype=torch.int32)
-        st.call("dprnn_wide_absmax", E._p(X), rows * F, E._p(amax))
+        if amax_x is not None:      # max |X| left by the launch that wrote X (dprnn_wide_norm_residual_fwd)
+            amax[0:1].copy_(amax_x)
+        else:
+            st.call("dprnn_wide_absmax", E._p(X), rows * F, E._p(amax))
         words = int(st.lib.dprnn_wide_lstm_pack_f16_words(F, H))
         Wp = torch.empty(ndir, words * 4, device=dev, dtype=torch.int32)
         bv = torch.empty(ndir, 4 * _r16(H), device=dev, dtype=torch.float32)
@@ -136,21 +140,24 @@ def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf:
     return Hout, ndir
 
 
-def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int, H: int, cell: int, intra: bool):
-    """One half of DPRNNBlock.forward (dprnn.py:83-92 intra, :94-99 inter): X += norm(Linear(RNN(X))) in place."""
+def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int, H: int, cell: int, intra: bool, amax_in=None):
+    """One half of DPRNNBlock.forward (dprnn.py:83-92 intra, :94-99 inter): X += norm(Linear(RNN(X))) in place.  amax_in: max |X| as float
+    bits when the writer of X left it; returns that word for the X this path leaves (the next path's activation scale)."""
     dev = X.device
     rows = geo.rows
     if intra:       # B*S sequences of K steps, consecutive rows
         addr = (geo.B * geo.S, geo.K, 1, geo.K, 0, 1)
     else:           # B*K sequences of S steps, K rows apart
         addr = (geo.B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K)
-    Hout, ndir = _recurrence(st, single.rnn, cell, X, rows, Hbuf, F, H, addr)
+    Hout, ndir = _recurrence(st, single.rnn, cell, X, rows, Hbuf, F, H, addr, amax_x=amax_in)
     w = E._param(lin.weight, "linear.weight", dev)
     if tuple(w.shape) != (F, ndir * H):
         raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(F, ndir * H)}")
     st.gemm(Hout, w, E._param(lin.bias, "linear.bias", dev), rows, ndir * H, F, rows_per_utt=geo.S * geo.K, stats=stats_slot, out=Z)
     sc, sh = st.norm_affine(stats_slot, norm, geo.B, geo.S * geo.K, F)
-    st.call("dprnn_wide_norm_residual_fwd", E._p(X), E._p(Z), E._p(sc), E._p(sh), rows, F, geo.S * geo.K)
+    amax_out = torch.zeros(1, device=dev, dtype=torch.int32) if f16_recurrence(cell, F, H) else None
+    st.call("dprnn_wide_norm_residual_fwd", E._p(X), E._p(Z), E._p(sc), E._p(sh), rows, F, geo.S * geo.K, E._p(amax_out))
+    return amax_out
 
 
 def _sep_cfg(sep) -> dict:
@@ -191,9 +198,10 @@ def _masks_from_frames(st: _Launcher, sep, Y: torch.Tensor, geo, stats: torch.Te
     # the recurrence output and the mask head's conv2d output share one block ([rows][2 H] then [rows][2 F])
     Hbuf = torch.empty(rows * 2 * max(H, F), device=dev, dtype=torch.float32)
     Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
+    amax = None
     for i, blk in enumerate(blocks):
-        _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[1 + 2 * i], geo, F, H, cell, True)
-        _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[2 + 2 * i], geo, F, H, cell, False)
+        amax = _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[1 + 2 * i], geo, F, H, cell, True, amax)
+        amax = _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[2 + 2 * i], geo, F, H, cell, False, amax)
         if debug is not None:
             debug[f"block{i}"] = X.view(B, S, K, F).clone()
     del Z
@@ -332,8 +340,8 @@ def block_forward(blk, x: torch.Tensor) -> torch.Tensor:
         Z = torch.empty(rows, F, device=dev, dtype=torch.float32)
         stats = torch.zeros(2, B, 2, device=dev, dtype=torch.float64)
         cell = CELL_ID[kind]
-        _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[0], geo, F, H, cell, True)
-        _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[1], geo, F, H, cell, False)
+        amax = _path(st, blk.intra_rnn, blk.intra_linear, blk.intra_norm, X, Hbuf, Z, stats[0], geo, F, H, cell, True)
+        _path(st, blk.inter_rnn, blk.inter_linear, blk.inter_norm, X, Hbuf, Z, stats[1], geo, F, H, cell, False, amax)
         return X.view(B, S, K, F).permute(0, 3, 2, 1).contiguous()
 
 
@@ -506,13 +514,16 @@ class _RaggedSlab:
         U = len(self.geos)
         blocks = list(self.sep.dprnn_blocks)
         stats = torch.zeros(2 * len(blocks), U, 2, device=dev, dtype=torch.float64)
+        f16 = f16_recurrence(self.cell, F, H)
+        amax = None
         for i, blk in enumerate(blocks):
             for j, (single, lin, norm, intra) in enumerate(((blk.intra_rnn, blk.intra_linear, blk.intra_norm, True),
                                                             (blk.inter_rnn, blk.inter_linear, blk.inter_norm, False))):
                 if intra:
-                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (self.n_intra, K, 1, K, 0, 1))
+                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (self.n_intra, K, 1, K, 0, 1), amax_x=amax)
                 else:
-                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (0, 0, 1, 0, 0, K), self.tiles)
+                    Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (0, 0, 1, 0, 0, K), self.tiles, amax_x=amax)
+                amax = torch.zeros(1, device=dev, dtype=torch.int32) if f16 else None
                 w = E._param(lin.weight, "linear.weight", dev)
                 b = E._param(lin.bias, "linear.bias", dev)
                 slot = stats[2 * i + j]
@@ -521,7 +532,7 @@ class _RaggedSlab:
                     Xu, Zu = self.rows_of(self.X, u), self.rows_of(self.Z, u)
                     st.gemm(self.rows_of(Hout, u), w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Zu)
                     sc, sh = st.norm_affine(slot[u:u + 1], norm, 1, n, F)
-                    st.call("dprnn_wide_norm_residual_fwd", E._p(Xu), E._p(Zu), E._p(sc), E._p(sh), n, F, n)
+                    st.call("dprnn_wide_norm_residual_fwd", E._p(Xu), E._p(Zu), E._p(sc), E._p(sh), n, F, n, E._p(amax))
 
     def head(self, u: int, enc: torch.Tensor) -> torch.Tensor:
         """Mask head of utterance u x its encoder rows -> [(spk, l)][N]."""
