@@ -81,6 +81,14 @@ int dprnn_wide_lstm_f16_fwd(const float* X, const void* Wp, const float* bv, con
                             int nseq, int T, int64_t inner_n, int64_t outer, int64_t inner, int64_t t_stride, const int64_t* desc,
                             int ntiles, void* stream);
 
+/* The Linear after a recurrence (dprnn.py:59,68) in the same arithmetic: W (O x K, ldw) packed once into f16-piece fragments with the scale from
+ * its measured maximum (amax_bits: dprnn_wide_absmax of W), the rows A (|a| <= a_bound: 1 for an LSTM's h) split on their way into LDS;
+ * out[m][o] = sum_k A[m][k] W[o][k] + bias[o], stats as dprnn_wide_gemm.  Wp: dprnn_wide_linear_pack_f16_words(K, O) 16-byte words, scal: 2 floats. */
+int64_t dprnn_wide_linear_pack_f16_words(int K, int O);
+int dprnn_wide_linear_pack_f16(const float* W, int ldw, int K, int O, const void* amax_bits, float a_bound, void* Wp, float* scal, void* stream);
+int dprnn_wide_linear_f16(const float* A, int64_t lda, const void* Wp, const float* scal, const float* bias, float* out, int64_t ldo,
+                          double* stats, int64_t rows_per_utt, int64_t M, int K, int O, void* stream);
+
 /* out[m][o] = act(rscale[m] * sum_k a(m,k) * W[o*ldw + k] + bias[o] + ubias[u*O + o]) * mul[mrow(m)*ldm + o]
  *   a(m,k) = prelu(A[m*lda + k] * sc[u*K + k] + sh[u*K + k]), u = m / rows_per_utt (sc / sh NULL: no affine; prelu NULL: none, else
  *   one device float: nn.PReLU(), dprnn.py:150,172);  act: 0 none, 1 relu, 2 sigmoid, 3 tanh;  bias, ubias, rscale, mul, stats optional;

@@ -160,6 +160,32 @@ def test_f16_pieces_lstm_recurrence_against_torch(F, H, bidir, intra):
     assert _rel(out.view(B, S, K, -1), want.contiguous()) <= 3e-6
 
 
+@pytest.mark.parametrize("M,K,O,rows_per_utt", [(1000, 512, 256, 250), (777, 400, 133, 5), (64, 32, 16, 64), (5000, 262, 300, 1250)])
+def test_f16_pieces_linear_against_torch(M, K, O, rows_per_utt):
+    """dprnn_wide_linear_pack_f16 + dprnn_wide_linear_f16: the Linear after an LSTM recurrence (rows in (-1, 1)) in two f16 pieces per operand,
+    three products, with the fp64 norm sums of its outputs."""
+    from tss_with_dprnn_amd import wide
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.tanh(torch.randn(M, K, generator=g) * 2.0).to(_dev())
+    lin = torch.nn.Linear(K, O)
+    with torch.no_grad():
+        lin.weight.mul_(3.0)
+    lin = lin.to(_dev())
+    st = _stage()
+    Wp, scal, b = wide._pack_linear_f16(st, lin, K, O, _dev())
+    B = (M + rows_per_utt - 1) // rows_per_utt
+    stats = torch.zeros(B, 2, dtype=torch.float64, device=_dev())
+    out = torch.full((M, O), float("nan"), device=_dev())
+    st.call("dprnn_wide_linear_f16", _p(A), K, _p(Wp), _p(scal), _p(b), _p(out), O, _p(stats), rows_per_utt, M, K, O)
+    want = (A.double() @ lin.weight.double().t() + lin.bias.double()).float()
+    assert torch.isfinite(out).all() and _rel(out, want) <= 1e-6
+    y = out.double()
+    s = torch.zeros(B, 2, dtype=torch.float64, device=_dev())
+    idx = (torch.arange(M, device=_dev()) // rows_per_utt)
+    s[:, 0].index_add_(0, idx, y.sum(1)); s[:, 1].index_add_(0, idx, (y * y).sum(1))
+    assert torch.allclose(stats, s, rtol=1e-5, atol=2e-3)
+
+
 def test_recurrence_with_32_sequence_tiles(monkeypatch):
     """The 32-sequence workgroups (DPRNN_WIDE_NT=2: half the weight stream, one workgroup per CU; the default is 16), and a count that
     is no multiple of 32."""

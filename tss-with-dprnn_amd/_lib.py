@@ -148,6 +148,8 @@ SIGNATURES = {
     "dprnn_wide_absmax": [c_fp, c_i64, c_fp, c_fp],
     "dprnn_wide_lstm_pack_f16": [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dprnn_wide_lstm_f16_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_fp, c_i, c_fp],
+    "dprnn_wide_linear_pack_f16": [c_fp, c_i, c_i, c_i, c_fp, c_f, c_fp, c_fp, c_fp],
+    "dprnn_wide_linear_f16": [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_i64, c_i64, c_i, c_i, c_fp],
     "dprnn_wide_gemm": [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_i64, c_fp, c_i64,
                         c_i, c_i, c_fp],
     "dprnn_wide_norm_residual_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i, c_i64, c_fp, c_fp],
@@ -180,6 +182,7 @@ _SPECIAL = {
     "dprnn_lin_pack_floats": ([], c_i64),
     "dprnn_wide_rnn_pack_floats": ([c_i, c_i, c_i], c_i64),
     "dprnn_wide_lstm_pack_f16_words": ([c_i, c_i], c_i64),
+    "dprnn_wide_linear_pack_f16_words": ([c_i, c_i], c_i64),
     "dprnn_rnn_lin_state_floats": ([c_i, c_i], c_i64),
     "dprnn_rnn_pack_bwd_floats": ([c_i], c_i64),
     "dprnn_rnn_bwd_gradmax_offset": ([c_i], c_i64),

@@ -225,6 +225,150 @@ __global__ __launch_bounds__(512) void wide_lstm_f16_kernel(const float* __restr
     }
 }
 
+// ---- the Linear after a recurrence (dprnn.py:59,68,88,97) in the same arithmetic: out[m][o] = sum_k A[m][k] W[o][k] + bias[o], A = recurrence
+// output rows (|a| <= a_bound, 1 for an LSTM's h: scale 2^13 / a_bound's exponent, no measurement needed), W as pre-packed f16-piece
+// fragments.  Weight fragments of one 32-k block and one group of up to 256 output columns: Wp[((cg*nkb + kb)*16 + ct)*2 + piece][lane],
+// lane (j, kk) = W[cg*256 + ct*16 + j][kb*32 + 8 kk + i] 2^ew; scal[0] = 2^ea, scal[1] = 1 / (2^ea 2^ew).
+__global__ __launch_bounds__(256) void wide_linear_pack_f16_kernel(const float* __restrict__ W, int ldw, int K, int O, const unsigned* __restrict__ amax,
+                                                                   float a_bound, u32x4* __restrict__ Wp, float* __restrict__ scal, long long nfrag) {
+    const int nkb = (K + 31) / 32;
+    int ew = 0, ea = 0;
+    { const float m = __uint_as_float(amax[0]); if (m > 0.f && m < 3.0e38f) frexpf(m, &ew); ew = 14 - (ew < -100 ? -100 : ew > 100 ? 100 : ew); }
+    frexpf(a_bound, &ea);                                       // a_bound < 2^ea: |a| 2^(14 - ea) stays below 2^14
+    ea = 14 - ea;
+    const float sw = ldexpf(1.f, ew);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = ldexpf(1.f, ea); scal[1] = ldexpf(1.f, -ea - ew); }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nfrag; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63); long long r = i >> 6;
+        const int ct = (int)(r & 15); r >>= 4;
+        const int kb = (int)(r % nkb); const int cg = (int)(r / nkb);
+        const int o = cg * 256 + ct * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            pieces((o < O && k < K) ? W[(long long)o * ldw + k] * sw : 0.f, hi[e], lo[e]);
+        }
+        u32x4 whi, wlo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            whi[e] = (unsigned)__builtin_bit_cast(unsigned short, hi[2 * e]) | ((unsigned)__builtin_bit_cast(unsigned short, hi[2 * e + 1]) << 16);
+            wlo[e] = (unsigned)__builtin_bit_cast(unsigned short, lo[2 * e]) | ((unsigned)__builtin_bit_cast(unsigned short, lo[2 * e + 1]) << 16);
+        }
+        const long long base = ((((long long)cg * nkb + kb) * 16 + ct) * 2) * 64 + lane;
+        Wp[base] = whi;
+        Wp[base + 64] = wlo;
+    }
+}
+
+// 16 NW rows x 256 columns per workgroup of NW waves (wave w: rows 16 w .. 16 w + 15, all column tiles); per 32-k block the A rows are split
+// into pieces on their way into LDS (row pitch 80 halves: hi 32 | lo 32 | pad) and the block's weight fragments are copied into LDS as they
+// are; the next block's global words are requested before this block's 48 MFMAs per wave.
+constexpr int LP = 80;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wide_linear_f16_kernel(const float* __restrict__ A, long long lda, const u32x4* __restrict__ Wp,
+                                                                  const float* __restrict__ scal, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, long long ldo, double* __restrict__ stats,
+                                                                  long long rows_per_utt, long long M, int K, int O) {
+    constexpr int BM = 16 * NW, NTH = 64 * NW, WPT = 2048 / NTH;            // 2048 16-byte words of weight fragments per block
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * LP];
+    __shared__ __attribute__((aligned(16))) u32x4 Wl[2048];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int cg = blockIdx.y, o0 = cg * 256;
+    const int nkb = (K + 31) / 32;
+    const float sa = scal[0], inv = scal[1];
+    const int lr = tid >> 2, lk = (tid & 3) * 8;                 // this thread stages (row lr, k lk .. lk + 7) of the A tile
+    const long long am = m0 + lr;
+    const bool a_ok = am < M;
+    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const u32x4* wsrc = Wp + ((long long)cg * nkb) * 2048 + tid;
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a0, a1;
+    u32x4 wv[WPT];
+    auto stage = [&](int kb) {
+        a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0;
+        const int k = kb * 32 + lk;
+        if (a_ok) {
+            const float* src = A + am * lda + k;
+            if (vec) {
+                if (k < K) a0 = *reinterpret_cast<const f32x4*>(src);
+                if (k + 4 < K) a1 = *reinterpret_cast<const f32x4*>(src + 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (k + e < K) a0[e] = src[e]; if (k + 4 + e < K) a1[e] = src[4 + e]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wv[i] = wsrc[(long long)kb * 2048 + i * NTH];
+    };
+    stage(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        {
+            _Float16 hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pieces(a0[e] * sa, hi[e], lo[e]); pieces(a1[e] * sa, hi[4 + e], lo[4 + e]); }
+            u32x4 whi, wlo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                whi[e] = (unsigned)__builtin_bit_cast(unsigned short, hi[2 * e]) | ((unsigned)__builtin_bit_cast(unsigned short, hi[2 * e + 1]) << 16);
+                wlo[e] = (unsigned)__builtin_bit_cast(unsigned short, lo[2 * e]) | ((unsigned)__builtin_bit_cast(unsigned short, lo[2 * e + 1]) << 16);
+            }
+            *reinterpret_cast<u32x4*>(&As[lr * LP + lk]) = whi;
+            *reinterpret_cast<u32x4*>(&As[lr * LP + 32 + lk]) = wlo;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) Wl[tid + i * NTH] = wv[i];
+        __syncthreads();
+        if (kb + 1 < nkb) stage(kb + 1);
+        const u32x4 ahi = *reinterpret_cast<const u32x4*>(&As[(16 * w + j) * LP + 8 * kk]);
+        const u32x4 alo = *reinterpret_cast<const u32x4*>(&As[(16 * w + j) * LP + 32 + 8 * kk]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const u32x4 bhi = Wl[(t * 2) * 64 + lane], blo = Wl[(t * 2 + 1) * 64 + lane];
+            acc[t] = mfma_f16(ahi, bhi, acc[t]);
+            acc[t] = mfma_f16(ahi, blo, acc[t]);
+            acc[t] = mfma_f16(alo, bhi, acc[t]);
+        }
+    }
+    float rs1[4] = {0.f, 0.f, 0.f, 0.f}, rs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + 16 * w + 4 * kk + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int o = o0 + 16 * t + j;
+            if (o >= O) continue;
+            const float v = fmaf(acc[t][r], inv, bias ? bias[o] : 0.f);
+            out[m * ldo + o] = v;
+            rs1[r] += v; rs2[r] = fmaf(v, v, rs2[r]);
+        }
+    }
+    if (stats) {
+        const long long mf = m0 + 16 * w, ml = (mf + 15 < M ? mf + 15 : M - 1);
+        if (mf < M) {
+            if (mf / rows_per_utt == ml / rows_per_utt) {
+                const double s1 = wave_sum((double)(rs1[0] + rs1[1] + rs1[2] + rs1[3]));
+                const double s2 = wave_sum((double)(rs2[0] + rs2[1] + rs2[2] + rs2[3]));
+                if (lane == 0) { const long long u = mf / rows_per_utt; atomicAdd(&stats[2 * u], s1); atomicAdd(&stats[2 * u + 1], s2); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a1s = rs1[r], a2s = rs2[r];
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) { a1s += __shfl_xor(a1s, d, 64); a2s += __shfl_xor(a2s, d, 64); }
+                    const long long m = mf + 4 * kk + r;
+                    if (j == 0 && m < M) { const long long u = m / rows_per_utt; atomicAdd(&stats[2 * u], (double)a1s); atomicAdd(&stats[2 * u + 1], (double)a2s); }
+                }
+            }
+        }
+    }
+}
+
 inline unsigned grid_cap(long long n, int per_block, long long cap) {
     long long g = (n + per_block - 1) / per_block;
     if (g > cap) g = cap;
@@ -295,4 +439,31 @@ extern "C" int dprnn_wide_lstm_f16_fwd(const float* X, const void* Wp, const flo
     if (fast) WF_LAUNCH(2, true); else WF_LAUNCH(2, false);
 #undef WF_LAUNCH
     return dprnn_check_launch("wide_lstm_f16_kernel");
+}
+
+extern "C" int64_t dprnn_wide_linear_pack_f16_words(int K, int O) {
+    if (K < 1 || O < 1) return -1;
+    return (long long)((O + 255) / 256) * ((K + 31) / 32) * 2048;
+}
+
+extern "C" int dprnn_wide_linear_pack_f16(const float* W, int ldw, int K, int O, const void* amax_bits, float a_bound, void* Wp, float* scal,
+                                          void* stream) {
+    WF_NULL(!W || !amax_bits || !Wp || !scal, "dprnn_wide_linear_pack_f16");
+    const long long words = dprnn_wide_linear_pack_f16_words(K, O);
+    if (words < 0 || ldw < K || !(a_bound > 0.f)) { dprnn_set_error("dprnn_wide_linear_pack_f16: K=%d O=%d ldw=%d a_bound=%g", K, O, ldw, (double)a_bound); return -1; }
+    const long long nfrag = words / 2;
+    hipLaunchKernelGGL(wide_linear_pack_f16_kernel, dim3(grid_cap(nfrag, 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, ldw, K, O,
+                       static_cast<const unsigned*>(amax_bits), a_bound, static_cast<u32x4*>(Wp), scal, nfrag);
+    return dprnn_check_launch("wide_linear_pack_f16_kernel");
+}
+
+extern "C" int dprnn_wide_linear_f16(const float* A, int64_t lda, const void* Wp, const float* scal, const float* bias, float* out, int64_t ldo,
+                                     double* stats, int64_t rows_per_utt, int64_t M, int K, int O, void* stream) {
+    WF_NULL(!A || !Wp || !scal || !out, "dprnn_wide_linear_f16");
+    if (M < 1 || K < 1 || O < 1 || lda < K || ldo < O || rows_per_utt < 1) { dprnn_set_error("dprnn_wide_linear_f16: bad sizes M=%lld K=%d O=%d", (long long)M, K, O); return -1; }
+    const long long gm = (M + 63) / 64;
+    if (gm > 0x7fffffffLL) { dprnn_set_error("dprnn_wide_linear_f16: M too large"); return -1; }
+    hipLaunchKernelGGL(wide_linear_f16_kernel<4>, dim3((unsigned)gm, (O + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, (long long)lda,
+                       static_cast<const u32x4*>(Wp), scal, bias, out, (long long)ldo, stats, (long long)rows_per_utt, (long long)M, K, O);
+    return dprnn_check_launch("wide_linear_f16_kernel");
 }

@@ -140,6 +140,19 @@ def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf:
     return Hout, ndir
 
 
+def _pack_linear_f16(st: _Launcher, lin, K: int, O: int, dev):
+    """The Linear after an LSTM recurrence as f16-piece fragments (its rows are h: |a| < 1)."""
+    w = E._param(lin.weight, "linear.weight", dev)
+    if tuple(w.shape) != (O, K):
+        raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(O, K)}")
+    amax = torch.zeros(1, device=dev, dtype=torch.int32)
+    st.call("dprnn_wide_absmax", E._p(w), w.numel(), E._p(amax))
+    Wp = torch.empty(int(st.lib.dprnn_wide_linear_pack_f16_words(K, O)) * 4, device=dev, dtype=torch.int32)
+    scal = torch.empty(2, device=dev, dtype=torch.float32)
+    st.call("dprnn_wide_linear_pack_f16", E._p(w), K, K, O, E._p(amax), 1.0, E._p(Wp), E._p(scal))
+    return Wp, scal, E._param(lin.bias, "linear.bias", dev)
+
+
 def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int, H: int, cell: int, intra: bool, amax_in=None):
     """One half of DPRNNBlock.forward (dprnn.py:83-92 intra, :94-99 inter): X += norm(Linear(RNN(X))) in place.  amax_in: max |X| as float
     bits when the writer of X left it; returns that word for the X this path leaves (the next path's activation scale)."""
@@ -150,10 +163,15 @@ def _path(st: _Launcher, single, lin, norm, X, Hbuf, Z, stats_slot, geo, F: int,
     else:           # B*K sequences of S steps, K rows apart
         addr = (geo.B * geo.K, geo.S, geo.K, geo.S * geo.K, 1, geo.K)
     Hout, ndir = _recurrence(st, single.rnn, cell, X, rows, Hbuf, F, H, addr, amax_x=amax_in)
-    w = E._param(lin.weight, "linear.weight", dev)
-    if tuple(w.shape) != (F, ndir * H):
-        raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(F, ndir * H)}")
-    st.gemm(Hout, w, E._param(lin.bias, "linear.bias", dev), rows, ndir * H, F, rows_per_utt=geo.S * geo.K, stats=stats_slot, out=Z)
+    if f16_recurrence(cell, F, H):
+        Wp, scal, b = _pack_linear_f16(st, lin, ndir * H, F, dev)
+        st.call("dprnn_wide_linear_f16", E._p(Hout), ndir * H, E._p(Wp), E._p(scal), E._p(b), E._p(Z), F, E._p(stats_slot), geo.S * geo.K, rows,
+                ndir * H, F)
+    else:
+        w = E._param(lin.weight, "linear.weight", dev)
+        if tuple(w.shape) != (F, ndir * H):
+            raise DprnnError(f"Linear after the recurrence: weight {tuple(w.shape)}, expected {(F, ndir * H)}")
+        st.gemm(Hout, w, E._param(lin.bias, "linear.bias", dev), rows, ndir * H, F, rows_per_utt=geo.S * geo.K, stats=stats_slot, out=Z)
     sc, sh = st.norm_affine(stats_slot, norm, geo.B, geo.S * geo.K, F)
     amax_out = torch.zeros(1, device=dev, dtype=torch.int32) if f16_recurrence(cell, F, H) else None
     st.call("dprnn_wide_norm_residual_fwd", E._p(X), E._p(Z), E._p(sc), E._p(sh), rows, F, geo.S * geo.K, E._p(amax_out))
@@ -524,13 +542,20 @@ class _RaggedSlab:
                 else:
                     Hout, ndir = _recurrence(st, single.rnn, self.cell, self.X, self.total, self.Hbuf, F, H, (0, 0, 1, 0, 0, K), self.tiles, amax_x=amax)
                 amax = torch.zeros(1, device=dev, dtype=torch.int32) if f16 else None
-                w = E._param(lin.weight, "linear.weight", dev)
-                b = E._param(lin.bias, "linear.bias", dev)
+                if f16:
+                    Wpl, scl, b = _pack_linear_f16(st, lin, ndir * H, F, dev)
+                else:
+                    w = E._param(lin.weight, "linear.weight", dev)
+                    b = E._param(lin.bias, "linear.bias", dev)
                 slot = stats[2 * i + j]
                 for u in range(U):
                     n = self.rows[u]
                     Xu, Zu = self.rows_of(self.X, u), self.rows_of(self.Z, u)
-                    st.gemm(self.rows_of(Hout, u), w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Zu)
+                    if f16:
+                        st.call("dprnn_wide_linear_f16", E._p(self.rows_of(Hout, u)), ndir * H, E._p(Wpl), E._p(scl), E._p(b), E._p(Zu), F,
+                                E._p(slot[u:u + 1]), n, n, ndir * H, F)
+                    else:
+                        st.gemm(self.rows_of(Hout, u), w, b, n, ndir * H, F, rows_per_utt=n, stats=slot[u:u + 1], out=Zu)
                     sc, sh = st.norm_affine(slot[u:u + 1], norm, 1, n, F)
                     st.call("dprnn_wide_norm_residual_fwd", E._p(Xu), E._p(Zu), E._p(sc), E._p(sh), n, F, n, E._p(amax))
 
