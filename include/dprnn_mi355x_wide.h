@@ -5,8 +5,9 @@
  * The kernels of dprnn_mi355x.h are built for input_size 64, feature_size = hidden_size 128 (every shipped YAML); the reference's
  * constructors take any width (src/models/dprnn.py:117-120, 234-239).  Narrower models run on those kernels as zero-padded twins;
  * WIDER ones (feature_size or hidden_size above 128, input_size above 64) run on the entry points below: the same channels-last
- * row layout ([rows][C] fp32, C a run-time argument), fp32 operands on the fp32 MFMA, the norms materialised between the launches
- * instead of folded into the next loader.  Conventions as in dprnn_mi355x.h: device pointers to contiguous fp32 unless stated,
+ * row layout ([rows][C] fp32, C a run-time argument), the norms materialised between the launches instead of folded into the next loader;
+ * fp32 operands on the fp32 MFMA, and the f16-pieces arithmetic (dprnn_wide_lstm_f16_fwd, dprnn_wide_linear_f16) for LSTM recurrences and the
+ * Linear after them.  Conventions as in dprnn_mi355x.h: device pointers to contiguous fp32 unless stated,
  * `stream` is a hipStream_t passed as void*, asynchronous, 0 on success, dprnn_last_error() says what failed.
  * No torch types cross this boundary.  One forward is (tss-with-dprnn_amd/wide.py):
  *

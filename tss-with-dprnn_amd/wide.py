@@ -4,9 +4,11 @@ The fused kernels behind ``engine.tasnet_forward`` are built for input_size 64, 
 narrower models run on them as zero-padded twins (``padded.py``).  The reference's constructors take any width (dprnn.py:117-120,
 234-239): a DPRNNTasNet with feature_size / hidden_size above 128 or input_size above 64 runs here, on the any-width kernels of
 ``csrc/wide.hip`` (C ABI: ``include/dprnn_mi355x_wide.h``) -- the same channels-last rows with the channel count a run-time
-argument, fp32 operands on the fp32 MFMA, every width (multiples of 16 or not), LSTM / GRU / RNN cells, one or two directions.
+argument, every width (multiples of 16 or not), LSTM / GRU / RNN cells, one or two directions; fp32 operands on the fp32 MFMA, and for LSTM
+recurrences up to hidden_size 256 and the Linear after them the f16-pieces arithmetic of the built kernels with its ranges by construction
+(``csrc/wide_f16.hip``: scales from the measured maxima of a launch's operands, so there is no saturation flag and no repeat).
 It is the unfused form of the path: the norms are materialised between the launches and the Linear is a launch of its own, so it
-costs about the 10 slab units per path the built kernels started from -- a model at these widths is supported, not tuned.
+costs about the 10 slab units per path the built kernels started from.
 
 No fallback: a missing library raises (``_lib.load_library``); what the kernels cannot hold (hidden_size above 512, or feature_size
 + hidden_size beyond the LDS of a CU) raises NotImplementedError naming the limit.  Inference only (under autograd the mirror
