@@ -3,7 +3,7 @@
 # any-width path's evidence at F = H = 256 (bench, kernel trace, PMC traffic)
 set -o pipefail
 export TMPDIR=/tmp
-O=gpurun_out/r05f4; mkdir -p $O
+O=gpurun_out/r05f5; mkdir -p $O
 ( time timeout -k 10 1000 python -m pytest tests -x -q -m gpu --durations=15 ) > $O/gpu_tests.txt 2>&1 || { tail -40 $O/gpu_tests.txt; exit 1; }
 grep -E "passed|failed|real" $O/gpu_tests.txt
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1 || { tail $O/smoke.txt; exit 1; }
@@ -11,7 +11,7 @@ tail -2 $O/smoke.txt
 ( time timeout -k 10 900 python bench.py ) > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r05f4/bench.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/r05f5/bench.json').read().strip().splitlines()[-1])
 print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'], 'kernel_ms', d['roofline']['kernel_ms'], 'traffic', d['roofline']['traffic'])
 print('exact', d['exact_fp32']['value'], 'cpu', d['cpu_baseline']['value'])
 oc=d['other_configs']
