@@ -72,8 +72,8 @@ int dprnn_wide_rnn_fwd_tiles(int cell, const float* X, const float* Wp, const fl
  * reads in amax[0] and of W_ih / W_hh of direction d in amax[1 + 2 d] / amax[2 + 2 d]; dprnn_wide_lstm_pack_f16 derives the direction's
  * scales from them (scal[4 d .. 4 d + 3], device floats) and writes the weight fragments (dprnn_wide_lstm_pack_f16_words(F, H) 16-byte
  * words per direction at Wp + d * words) and the bias sums bv[d][4 * roundup16(H)]; dprnn_wide_lstm_f16_fwd is dprnn_wide_rnn_fwd /
- * dprnn_wide_rnn_fwd_tiles (desc != NULL: tiles of up to 64 sequences) for LSTM cells.  64 * (2 * (roundup32(F) + roundup32(H)) + 16) * 2
- * bytes of LDS <= 160 KB; hidden_size <= 256 in this build. */
+ * dprnn_wide_rnn_fwd_tiles (desc != NULL: tiles of up to ns sequences) for LSTM cells; ns = 64 sequences per workgroup up to hidden_size 256,
+ * 32 up to 512.  ns * (2 * (roundup32(F) + roundup32(H)) + 16) * 2 bytes of LDS <= 160 KB. */
 int dprnn_wide_absmax(const float* A, int64_t n, void* out_bits, void* stream);
 int64_t dprnn_wide_lstm_pack_f16_words(int F, int H);
 int dprnn_wide_lstm_pack_f16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int F, int H, int dir,

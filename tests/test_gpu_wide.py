@@ -130,7 +130,7 @@ def test_recurrence_against_torch(kind, F, H, bidir, intra):
     assert _rel(out.view(B, S, K, -1), want.contiguous()) <= 3e-6
 
 
-@pytest.mark.parametrize("F,H,bidir", [(256, 256, True), (160, 200, True), (133, 131, False), (40, 16, True)])
+@pytest.mark.parametrize("F,H,bidir", [(256, 256, True), (160, 200, True), (133, 131, False), (40, 16, True), (128, 320, True), (512, 512, False)])
 @pytest.mark.parametrize("intra", [True, False])
 def test_f16_pieces_lstm_recurrence_against_torch(F, H, bidir, intra):
     """dprnn_wide_absmax + dprnn_wide_lstm_pack_f16 + dprnn_wide_lstm_f16_fwd (csrc/wide_f16.hip: two f16 pieces per operand, three products,

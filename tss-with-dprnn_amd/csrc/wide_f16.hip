@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void wide_lstm_pack_f16_kernel(const float* __
 // [64][hi pieces of (x_t | h_t-1) | lo pieces | pad] in halves; a step is: gate GEMM of every owned unit tile from the image (A operand: two
 // 16-byte words per lane and 32-k block) + cell update with h_t kept in registers -> barrier -> h_t pieces and x_t+1 pieces into the
 // image -> barrier.  Wave w owns unit tiles w, w + 8, ...: the four gates of one (sequence, unit) meet in one lane, c in registers.
-template <int MAXUT, bool FAST>
+template <int MAXUT, bool FAST, int NT>
 __global__ __launch_bounds__(512) void wide_lstm_f16_kernel(const float* __restrict__ X, const u32x4* __restrict__ WpAll, const float* __restrict__ bvAll,
                                                             const float* __restrict__ scalAll, float* __restrict__ Hout, int F, int H, int nseq, int T,
                                                             long long inner_n, long long outer, long long inner, long long t_stride, int ldh,
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void wide_lstm_f16_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) _Float16 img[];
     const int Fp = (F + 31) & ~31, Hp = (H + 31) & ~31, Kp = Fp + Hp, nkb = Kp / 32, Hu = (H + 15) & ~15, nut = Hu / 16;
     const int pitch = 2 * Kp + 16;                            // halves per row: hi | lo | 8 dwords of pad (dword pitch / 4 = 2 mod 4)
-    constexpr int NS = 64, NT = 4, NW = 8;
+    constexpr int NS = 16 * NT, NW = 8;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
     const int dir = blockIdx.y;
     const u32x4* Wp = WpAll + (long long)dir * wp_dir_words;
@@ -418,25 +418,29 @@ extern "C" int dprnn_wide_lstm_f16_fwd(const float* X, const void* Wp, const flo
         return -1;
     }
     const int Fp = (F + 31) & ~31, Hp = (H + 31) & ~31, Hu = (H + 15) & ~15;
-    const size_t lds = (size_t)64 * (2 * (Fp + Hp) + 16) * sizeof(_Float16);
-    if (lds + 512 > 160 * 1024) {        // + the 64 row bases
+    // 64 sequences per workgroup with two unit tiles per wave (hidden_size <= 256); 32 with four (<= 512): c, h_t and the accumulators of a wave
+    // have to fit its 256 registers
+    const int ns = Hu / 16 <= 16 ? 64 : 32;
+    const size_t lds = (size_t)ns * (2 * (Fp + Hp) + 16) * sizeof(_Float16);
+    if (lds + 512 > 160 * 1024) {        // + the row bases
         dprnn_set_error("dprnn_wide_lstm_f16_fwd: feature_size %d + hidden_size %d need %zu bytes of LDS (160 KB per CU)", F, H, lds);
         return -1;
     }
-    if (Hu / 16 > 8 * 2) { dprnn_set_error("dprnn_wide_lstm_f16_fwd: hidden_size %d > 256 (c and h_t of two unit tiles per wave fill the registers)", H); return -1; }
+    if (Hu / 16 > 8 * 4) { dprnn_set_error("dprnn_wide_lstm_f16_fwd: hidden_size %d > 512", H); return -1; }
     const long long words = dprnn_wide_lstm_pack_f16_words(F, H);
-    const dim3 grid(desc ? ntiles : (nseq + 63) / 64, ndir), block(512);
+    const dim3 grid(desc ? ntiles : (nseq + ns - 1) / ns, ndir), block(512);
     const bool fast = dprnn_get_fast_activations() != 0;
     hipStream_t st = (hipStream_t)stream;
-#define WF_LAUNCH(UT_, FAST_)                                                                                                               \
+#define WF_LAUNCH(UT_, FAST_, NT_)                                                                                                              \
     do {                                                                                                                                    \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_lstm_f16_kernel<UT_, FAST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_lstm_f16_kernel<UT_, FAST_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess) { dprnn_set_error("dprnn_wide_lstm_f16_fwd: hipFuncSetAttribute"); return -2; }     \
-        hipLaunchKernelGGL((wide_lstm_f16_kernel<UT_, FAST_>), grid, block, lds, st, X, static_cast<const u32x4*>(Wp), bv, scal, Hout, F, H, \
+        hipLaunchKernelGGL((wide_lstm_f16_kernel<UT_, FAST_, NT_>), grid, block, lds, st, X, static_cast<const u32x4*>(Wp), bv, scal, Hout, F, H, \
                            nseq, T, (long long)inner_n, (long long)outer, (long long)inner, (long long)t_stride, ndir * H, words,            \
                            reinterpret_cast<const long long*>(desc));                                                                       \
     } while (0)
-    if (fast) WF_LAUNCH(2, true); else WF_LAUNCH(2, false);
+    if (ns == 64) { if (fast) WF_LAUNCH(2, true, 4); else WF_LAUNCH(2, false, 4); }
+    else { if (fast) WF_LAUNCH(4, true, 2); else WF_LAUNCH(4, false, 2); }
 #undef WF_LAUNCH
     return dprnn_check_launch("wide_lstm_f16_kernel");
 }

@@ -5,7 +5,7 @@ narrower models run on them as zero-padded twins (``padded.py``).  The reference
 234-239): a DPRNNTasNet with feature_size / hidden_size above 128 or input_size above 64 runs here, on the any-width kernels of
 ``csrc/wide.hip`` (C ABI: ``include/dprnn_mi355x_wide.h``) -- the same channels-last rows with the channel count a run-time
 argument, every width (multiples of 16 or not), LSTM / GRU / RNN cells, one or two directions; fp32 operands on the fp32 MFMA, and for LSTM
-recurrences up to hidden_size 256 and the Linear after them the f16-pieces arithmetic of the built kernels with its ranges by construction
+recurrences and the Linear after them the f16-pieces arithmetic of the built kernels with its ranges by construction
 (``csrc/wide_f16.hip``: scales from the measured maxima of a launch's operands, so there is no saturation flag and no repeat).
 It is the unfused form of the path: the norms are materialised between the launches and the Linear is a launch of its own, so it
 costs about the 10 slab units per path the built kernels started from.
@@ -42,10 +42,15 @@ def _r32(n: int) -> int:
     return (n + 31) // 32 * 32
 
 
+def f16_tile(H: int) -> int:
+    """Sequences per workgroup of the f16-pieces recurrence: 64 with two unit tiles per wave (hidden_size <= 256), 32 with four (<= 512)."""
+    return 64 if _r16(H) <= 256 else 32
+
+
 def f16_recurrence(cell: int, F: int, H: int) -> bool:
-    """Whether this recurrence runs in the f16-pieces arithmetic: LSTM, hidden_size <= 256 (c and h_t of two unit tiles per wave), one
-    64-sequence image of piece pairs within the 160 KB of a CU."""
-    return WIDE_F16 and cell == 0 and _r16(H) <= 256 and 64 * (2 * (_r32(F) + _r32(H)) + 16) * 2 + 512 <= LDS_BYTES
+    """Whether this recurrence runs in the f16-pieces arithmetic: LSTM, hidden_size <= 512, one image of piece pairs of f16_tile(H) sequences
+    within the 160 KB of a CU."""
+    return WIDE_F16 and cell == 0 and _r16(H) <= 512 and f16_tile(H) * (2 * (_r32(F) + _r32(H)) + 16) * 2 + 512 <= LDS_BYTES
 
 
 def check_supported(cfg: dict) -> None:
@@ -107,7 +112,7 @@ def _pack_rnn(st: _Launcher, rnn: torch.nn.Module, cell: int, F: int, H: int, de
 def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf: torch.Tensor, F: int, H: int, addr, tiles=None,
                 amax_x: Optional[torch.Tensor] = None):
     """SingleRNN.forward over the slab rows X [rows][F] -> (Hout [rows][ndir*H] inside Hbuf, ndir).  addr = (nseq, T, inner_n, outer, inner,
-    t_stride) of dprnn_wide_rnn_fwd; tiles (ragged inter-chunk path) = {16: (desc, n), 64: (desc, n)} tile descriptors instead."""
+    t_stride) of dprnn_wide_rnn_fwd; tiles (ragged inter-chunk path) = {tile width: (desc, n)} tile descriptors instead."""
     dev = X.device
     ndir = 2 if rnn.bidirectional else 1
     Hout = Hbuf[: rows * ndir * H].view(rows, ndir * H)
@@ -130,7 +135,7 @@ def _recurrence(st: _Launcher, rnn, cell: int, X: torch.Tensor, rows: int, Hbuf:
         if tiles is None:
             st.call("dprnn_wide_lstm_f16_fwd", E._p(X), E._p(Wp), E._p(bv), E._p(scal), E._p(Hout), ndir, F, H, *addr, 0, 0)
         else:
-            desc, n = tiles[64]
+            desc, n = tiles[f16_tile(H)]
             st.call("dprnn_wide_lstm_f16_fwd", E._p(X), E._p(Wp), E._p(bv), E._p(scal), E._p(Hout), ndir, F, H, n, 1, 1, 0, 0, addr[5], E._p(desc), n)
         return Hout, ndir
     Wp, bv, ndir = _pack_rnn(st, rnn, cell, F, H, dev)
@@ -510,7 +515,7 @@ class _RaggedSlab:
         self.n_intra = int(sum(g.S for g in geos))
         # inter-chunk tiles: 16 chunk positions of one utterance, S_u steps, rows K apart; longest first (their workgroups run longest)
         self.tiles = {}
-        for width in (16, 64):          # 16 positions per tile for the fp32 kernel, 64 for the f16-pieces one
+        for width in (16, 32, 64):      # 16 positions per tile for the fp32 kernel, 64 / 32 for the f16-pieces one
             desc = []
             for u in np.argsort(-np.array([g.S for g in geos]), kind="stable"):
                 for k0 in range(0, self.K, width):
