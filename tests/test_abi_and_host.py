@@ -432,6 +432,33 @@ def test_every_engine_setting_is_classified_for_the_graph_key():
     assert not set(engine.LAUNCH_KNOBS) & set(engine.OTHER_SETTINGS)
 
 
+def test_engine_settings_block_checks_names_and_restores():
+    """engine.settings(**knobs): the named settings hold inside the block and are back afterwards (also when the block raises); an
+    unknown name raises instead of creating an attribute nobody reads; a launch knob changed by the block changes launch_knobs()
+    -- the part of every captured graph's key -- so the block cannot replay a graph captured outside it."""
+    import pytest
+    from tss_with_dprnn_amd import engine
+    before = engine.current_settings()
+    assert set(engine.LAUNCH_KNOBS) <= set(before)
+    key0 = engine.launch_knobs()
+    with engine.settings(GEMM_MODE=0, STREAM_GROUPS=2, GRAPHS=False):
+        assert (engine.GEMM_MODE, engine.STREAM_GROUPS, engine.GRAPHS) == (0, 2, False)
+        assert engine.launch_knobs() != key0
+    assert engine.current_settings() == before and engine.launch_knobs() == key0
+    with pytest.raises(RuntimeError):
+        with engine.settings(LIN_FOLD="off"):
+            assert engine.LIN_FOLD == "off"
+            raise RuntimeError("inside")
+    assert engine.current_settings() == before
+    with pytest.raises(engine.DprnnError, match="no such setting"):
+        with engine.settings(STREAM_GROUP=2):
+            pass
+    assert not hasattr(engine, "STREAM_GROUP")
+    with pytest.raises(engine.DprnnError):                      # constants of the build are not settings
+        with engine.settings(F_BUILT=256):
+            pass
+
+
 def test_padded_twin_places_every_block_and_scales_every_global_norm():
     """padded.Twin (CPU: construction and parameter placement only; the arithmetic is checked on the GPU against the narrow goldens): every
     value of the narrow model appears in the twin exactly once and everything else is zero; gate blocks of the RNN weights, direction

@@ -1133,6 +1133,35 @@ def launch_knobs() -> tuple:
         ("rowgemm_grid", lib.dprnn_get_rowgemm_grid()))
 
 
+# names `settings` may change: every launch knob, and the policy / bookkeeping settings that are not constants of the build
+_SETTABLE = set(LAUNCH_KNOBS) | {"ON_SATURATION", "PIN_AFTER_FALLBACKS", "PROFILE", "GRAPHS", "GRAPH_CACHE_MAX"}
+
+
+def current_settings() -> dict:
+    """{name: value} of everything `settings` accepts (a snapshot: mutable values are copied one level deep)."""
+    g = globals()
+    return {k: (dict(g[k]) if isinstance(g[k], dict) else list(g[k]) if isinstance(g[k], list) else g[k]) for k in sorted(_SETTABLE)}
+
+
+@contextlib.contextmanager
+def settings(**values):
+    """`with engine.settings(GEMM_MODE=0, STREAM_GROUPS=2): ...` -- engine settings for the forwards inside the block, put back on the
+    way out whatever happens.  The one place that checks the NAME: an unknown name raises instead of creating a module attribute
+    nobody reads (assigning `engine.NAME = v` directly stays possible -- bench.py and the sweeps do -- and has no such check).  The
+    launch knobs are part of every captured graph's key (launch_knobs), so a block with other knobs never replays a graph captured
+    outside it.  Process-wide like the assignments it replaces: not for two threads with different settings at once."""
+    unknown = sorted(set(values) - _SETTABLE)
+    if unknown:
+        raise DprnnError(f"engine.settings: no such setting {unknown}; known: {sorted(_SETTABLE)}")
+    g = globals()
+    before = {k: g[k] for k in values}
+    g.update(values)
+    try:
+        yield
+    finally:
+        g.update(before)
+
+
 # ------------------------------------------------------------------------------------------------ guarded entry points
 # What the model classes call.  Each runs its forward with saturation detection (see _guarded) and, should the f16-pieces
 # arithmetic have met a value beyond its range, again in mode 1 (three bf16 pieces: no range assumption).
