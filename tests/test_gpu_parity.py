@@ -91,7 +91,7 @@ def test_batch_invariance_and_determinism():
     _close(one[0].cpu().numpy(), full[3].cpu().numpy(), "batch invariance")
 
 
-@pytest.mark.parametrize("B,T", [(1, 24000), (3, 9000)])
+@pytest.mark.parametrize("B,T", [(1, 24000), pytest.param(3, 9000, marks=pytest.mark.slow)])      # (3, 9000): 11 s of CPU oracle between B = 1 and the B = 64 case below
 def test_against_cpu_oracle_shipped_config(B, T):
     """Full-width, full-depth model vs the torch-CPU oracle on fresh seeded input."""
     model, sd, cfg = build_model("bss", dict(), 123, _dev())
@@ -424,7 +424,7 @@ def test_values_beyond_the_f16_range_fall_back_to_bf16_pieces(kind, where):
     print(f"{kind} / {where}: flags {flags}, rel-L2 vs CPU oracle after the fall-back {r:.2e}")
 
 
-@pytest.mark.parametrize("where", ["residual_stream", "bottleneck"])
+@pytest.mark.parametrize("where", ["residual_stream", pytest.param("bottleneck", marks=pytest.mark.slow)])      # 12-14 s each: the second site by -m "gpu and slow"
 def test_a_model_beyond_the_default_range_pays_the_repeat_once(where):
     """Round 4 (unbounded affine gains, dprnn.py:76-77): a norm gain of 3000 puts the residual stream / the bottleneck rows beyond
     |x| = 4062.  The FIRST forward saturates and is repeated in mode 1; it leaves its maxima in the model's activation-scale
