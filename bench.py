@@ -76,6 +76,8 @@ def parse_args(argv=None):
                          "pieces, six products (fp32-equivalent, no range assumption); 0 = exact fp32 MFMA")
     ap.add_argument("--rowgemm-grid", type=int, default=None, help="workgroups of the HBM-bound f16 row GEMMs (dprnn_set_rowgemm_grid)")
     ap.add_argument("--min-group", type=int, default=None, help="smallest utterance group (engine.MIN_GROUP_BATCH)")
+    ap.add_argument("--no-standalone", action="store_true", help="skip roofline.standalone (the dominant launch shapes timed alone on the chip, ~4 s): "
+                    "under rocprofv3 its launches would mix into the per-kernel averages of the forward's own")
     ap.add_argument("--group-sizes", type=str, default="", help="experiment: explicit utterance-group sizes, e.g. 20,18,14,12")
     ap.add_argument("--seq-tile-intra", type=int, default=0)
     ap.add_argument("--serial-tile-intra", type=int, default=0, help="seq_tile of the direction-serial launches (engine.SEQ_TILE['serial_intra'])")
@@ -582,7 +584,7 @@ def main():
                              f"a second pass of {prof_steps} eager forwards of the same batch right after the timed region, which replays a "
                              "captured HIP graph (no place for events inside a graph)")
     n_groups = head_roof["concurrent_streams"]
-    if rank == 0 and world == 1 and args.gemm_mode == 3 and head_roof["linear_folded_in"] and n_groups == 2 and B % 2 == 0 and not args.group_sizes:
+    if rank == 0 and world == 1 and args.gemm_mode == 3 and head_roof["linear_folded_in"] and n_groups == 2 and B % 2 == 0 and not args.group_sizes and not args.no_standalone:
         # the same kernel without the other pipeline's launches beside it, measured live (~4 s); never inside the timed region
         try:
             sa = standalone_folded_launches(engine, dev, B // n_groups, geo.S, geo.K, lib.dprnn_num_cus())
