@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-parameter gradient errors of one tests/golden/grad_*.npz case, in network order (debugging aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from conftest import build_model, load_golden

@@ -15,7 +15,7 @@ scaling, and the same with subnormals flushed (what the hardware would do if the
 tools/probes/mfma_f16_denorm.hip)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dprnn_numpy as onp
 from oracle.sisdr import si_sdr
 from tss_with_dprnn_amd.synthetic import full_cfg, make_mixture, make_sources, make_state

@@ -572,3 +572,39 @@ def test_which_models_take_the_any_width_kernels_and_which_limits_raise(monkeypa
         wide.check_supported_spe(dict(wspe.cfg, P=512))
     with pytest.raises(NotImplementedError, match="kernel_size"):
         wide.check_supported_spe(dict(wspe.cfg, kernel_size=16))
+
+
+def test_only_test_infrastructure_imports_the_oracle():
+    """oracle/ is the checker: tests/ (its studies included), __graft_entry__.smoke() / build()'s import check and
+    bench.py's cpu_baseline leg may import it; the package, the tools and everything else may not."""
+    import ast
+    allowed = {"bench.py": {"cpu_baseline"}, "__graft_entry__.py": {"build", "smoke"}}
+    skip_dirs = {".git", "gpurun_out", "tests", "oracle", "__pycache__", "build"}
+    offenders = []
+    for top, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in skip_dirs]
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(top, f)
+            rel = os.path.relpath(path, ROOT)
+            tree = ast.parse(open(path, encoding="utf-8").read(), filename=rel)
+
+            def names(node):
+                if isinstance(node, ast.Import):
+                    return [a.name for a in node.names]
+                if isinstance(node, ast.ImportFrom) and node.level == 0:
+                    return [node.module or ""]
+                return []
+
+            def walk(node, fn):
+                for child in ast.iter_child_nodes(node):
+                    inner = child.name if isinstance(child, (ast.FunctionDef, ast.AsyncFunctionDef)) and fn is None else fn
+                    for n in names(child):
+                        if n == "oracle" or n.startswith("oracle."):
+                            if inner not in allowed.get(rel, ()):
+                                offenders.append(f"{rel}:{child.lineno} ({inner or 'module level'})")
+                    walk(child, inner)
+
+            walk(tree, None)
+    assert not offenders, offenders

@@ -49,7 +49,7 @@ FUSE_NORM = True
 #   3 (default) = every fp32 operand as a sum of TWO f16 pieces of a power-of-two multiple of it (activations x 2^4, weights x
 #                 a per-matrix 2^e that puts max|W| in [2^13, 2^14)): 22+ operand bits, three cross products on the f16 MFMA
 #                 with fp32 accumulation, the dropped product v2 w2 ~ 2^-24 |v||w| -- one fp32 product rounding
-#                 (recur_split.h; tools/split_precision_study.py) -- in the recurrence, the Linear after it, the bottleneck and the
+#                 (recur_split.h; tests/studies/split_precision_study.py) -- in the recurrence, the Linear after it, the bottleneck and the
 #                 mask head.  f16 has 5 exponent bits: |x| > 4062 does not fit 2^4 x.  Every conversion site raises a device flag
 #                 when that happens (dprnn_saturation_begin / _flags); every forward checks the flags before it returns and, if
 #                 one is set, runs again in mode 1 (_guarded below) -- a clamped value never reaches the caller;
